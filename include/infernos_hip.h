@@ -1,0 +1,137 @@
+/*
+ * infernos_hip.h -- C ABI of libinfernos_hip.so, the MI355X (gfx950) implementation of
+ * the Infernos per-call speech hot path.
+ *
+ * The reference (sippy/Infernos) has no FFI of its own: the path is reached through
+ * duck-typed Python classes.  Every entry point below names the
+ * reference interface it sits underneath (file:line under the reference tree); the
+ * Python classes in infernos_amd/ keep the reference's names and call these through
+ * ctypes on raw device pointers (torch.Tensor.data_ptr()) and the caller's hipStream_t.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative IFH_E* code on failure; the text of
+ *     the last failure on the calling thread is ifh_last_error().
+ *   - all pointers are DEVICE pointers unless the parameter name ends in _host.
+ *   - `stream` is a hipStream_t passed as void*; NULL is the legacy default stream.
+ *   - nothing is allocated, freed or synchronised inside a launch function (graph-capture
+ *     safe) unless the comment says "host sync".
+ *   - no ownership crosses the boundary; handles are created/destroyed explicitly.
+ *   - bf16 tensors are raw uint16_t bit patterns.
+ */
+#ifndef INFERNOS_HIP_H
+#define INFERNOS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IFH_OK 0
+#define IFH_EINVAL (-1)   /* bad argument */
+#define IFH_EHIP (-2)     /* HIP runtime error (text in ifh_last_error) */
+#define IFH_ENOMEM (-3)
+
+typedef void *ifh_stream_t;
+
+const char *ifh_last_error(void);
+int ifh_version(void);                 /* 10000*major + 100*minor + patch */
+int ifh_device_count(void);            /* does not initialise a context */
+
+/* ---------------------------------------------------------------------------------
+ * G.711 mu-law          replaces Core/Codecs/G711.py:7-47
+ * ------------------------------------------------------------------------------- */
+/* _ulaw_to_pcm_ct / _pcm_to_ulaw_ct (G711.py:7-19): the two tables, computed on the host
+ * by the same closed form the kernels use. out256_host: int16[256]; out65536_host: u8[65536]. */
+int ifh_g711_tables_host(int16_t *out256_host, uint8_t *out65536_host);
+/* G711Codec.decode (G711.py:34-42), resample=False: u8[n] -> f32[n] = lut[u]/32767.0f */
+int ifh_g711_decode_u8_f32(const uint8_t *in, float *out, int64_t n, ifh_stream_t stream);
+/* G711Codec.encode (G711.py:25-32): f32[n] -> u8[n] */
+int ifh_g711_encode_f32_u8(const float *in, uint8_t *out, int64_t n, ifh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Sinc resampler        replaces Core/AudioChunk.py:19-24 + config/InfernGlobals.py:23-26
+ *                        (torchaudio.transforms.Resample(orig, new), sinc_interp_hann)
+ * ------------------------------------------------------------------------------- */
+typedef struct ifh_resampler *ifh_resampler_t;
+int ifh_resample_create(int orig_sr, int new_sr, ifh_resampler_t *out);       /* host sync */
+int ifh_resample_destroy(ifh_resampler_t h);
+/* taps_host[new_r*ntaps] float32; returns geometry (orig_r/new_r are gcd-reduced) */
+int ifh_resample_info(ifh_resampler_t h, int *orig_r, int *new_r, int *ntaps, int *width,
+                      float *taps_host /* may be NULL */);
+int64_t ifh_resample_out_len(ifh_resampler_t h, int64_t in_len);              /* ceil(new*L/orig) */
+/* N independent rows: in[r*in_stride .. +len_r), out[r*out_stride .. +out_len(len_r)).
+ * lens may be NULL (every row has max_len samples).  Zero padding at both row ends, as
+ * torchaudio does for a whole chunk. */
+int ifh_resample_run(ifh_resampler_t h, const float *in, int64_t in_stride, const int32_t *lens,
+                     int64_t max_len, int nrows, float *out, int64_t out_stride, ifh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Per-tick ingest       replaces RTP/InfernRTPIngest.py:98 -> Core/VAD/SileroVAD.py:27-35
+ *                        (VADChannel.ingest: byte FIFO -> 768-sample decoded windows) fused
+ *                        with G711Codec.decode and a streaming 8k->16k resample.
+ * One call = one 20 ms tick of n calls.  State arrays are indexed by slot[i]:
+ *   fifo      u8  [ncap][IFH_FIFO_CAP]   pending encoded bytes
+ *   fifo_len  i32 [ncap]
+ *   win       f32 [ncap][768]            last completed decoded window (8 kHz)
+ *   win_ready i32 [ncap]                 set to 1 when `win` was refreshed by this tick
+ *   hist      f32 [ncap][16]             last 15 decoded samples (streaming resample carry)
+ * Outputs for this tick, row i = call slot[i]:
+ *   pcm8k  f32 [n][160]   decoded frame
+ *   pcm16k f32 [n][320]   streaming resample; sample k of tick t is y[2*(160*t-8)+k] of the
+ *                         whole-stream resample (8-sample look-ahead delay), bit-identical taps
+ * ------------------------------------------------------------------------------- */
+#define IFH_FIFO_CAP 1024
+#define IFH_VAD_WINDOW 768
+int ifh_ingest_tick(const uint8_t *frames /* [n][160] */, const int32_t *slot, int n,
+                    uint8_t *fifo, int32_t *fifo_len, float *win, int32_t *win_ready, float *hist,
+                    float *pcm8k, float *pcm16k, ifh_resampler_t rs8to16, ifh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * VAD                   replaces Core/VAD/SileroVADUtils.py:105-130 (hysteresis FSM) and
+ *                        Core/VAD/SileroVAD.py:81-112 (chunk assembly), batched on device.
+ * The speech-probability model itself (Silero v3.1 JIT, third party, weights not
+ * obtainable offline) is pluggable: callers pass prob[n].  ifh_vad_energy_prob is the
+ * documented stand-in used by the benchmarks.
+ * Per-slot state (SoA, indexed by slot[i]):
+ *   st_i64 [ncap][4]  = {triggered, temp_end, current_sample, active_start(-1 = None)}
+ *   buf_len i32[ncap] ; abuf f32 [ncap][IFH_ABUF_CAP]  (VADChannel.active_buffer)
+ * Per-call-of-this-function outputs, row i:
+ *   ev i64 [n][8] = {kind(0 none,1 start,2 end), pos, active(0/1) AFTER this window,
+ *                    n_emit (0,1), emit_ipos, emit_len, err(0 ok / 1 = the reference's
+ *                    assert at SileroVAD.py:89/95-98 would have fired), 0}
+ *   emit f32 [ncap][IFH_EMIT_CAP] : the emitted VadAudioChunk audio (8 kHz) for slot[i]
+ * ------------------------------------------------------------------------------- */
+#define IFH_ABUF_CAP (240000 + 768)
+#define IFH_EMIT_CAP 240000
+int ifh_vad_energy_prob(const float *win /* [ncap][768] */, const int32_t *slot, int n,
+                        float *prob /* [n] */, ifh_stream_t stream);
+/* FSM only (VADIteratorB.__call__): updates st_i64[slot][0..2]; ev2 i64 [n][2] = {kind, pos} */
+int ifh_vad_fsm_step(const float *prob /* [n] */, const int32_t *slot, int n, int window, int sample_rate,
+                     double threshold, int64_t *st_i64, int64_t *ev2, ifh_stream_t stream);
+/* FSM + chunk assembly for one 768-sample window per listed call */
+int ifh_vad_step(const float *win /* [ncap][768] */, const float *prob /* [n] */, const int32_t *slot,
+                 int n, int sample_rate, double threshold, int64_t *st_i64, int32_t *buf_len, float *abuf,
+                 int64_t *ev, float *emit, ifh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * Whisper log-mel       replaces Cluster/InfernSTTWorker.py:114 (WhisperProcessor ->
+ *                        WhisperFeatureExtractor, transformers feature_extraction_whisper.py:135-168)
+ * audio f32 rows of `stride` samples, lens[b] valid samples (zero beyond, truncated to 480000);
+ * out [B][n_mel][3000] f32 (out_bf16=0) or bf16 (out_bf16=1).  n_mel is 80 or 128.
+ * workspace: ifh_logmel_workspace_floats() floats, any contents (per-utterance max; plus
+ * the f32 staging plane when the output is bf16).
+ * ------------------------------------------------------------------------------- */
+typedef struct ifh_logmel *ifh_logmel_t;
+int ifh_logmel_create(int n_mel, ifh_logmel_t *out);                           /* host sync */
+int ifh_logmel_destroy(ifh_logmel_t h);
+int ifh_logmel_filters_host(ifh_logmel_t h, float *out201xnmel_host);          /* [201][n_mel] */
+int64_t ifh_logmel_workspace_floats(ifh_logmel_t h, int nbatch, int out_bf16);  /* B (+ B*n_mel*3000 if bf16) */
+int ifh_logmel_run(ifh_logmel_t h, const float *audio, int64_t stride, const int32_t *lens, int nbatch,
+                   void *out, int out_bf16, float *workspace, ifh_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INFERNOS_HIP_H */

@@ -1,0 +1,97 @@
+"""ctypes binding of libinfernos_hip.so (include/infernos_hip.h).
+
+The product has no CPU fallback: if the shared library is missing, or a compute entry
+point is reached without a HIP device, a RuntimeError is raised.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libinfernos_hip.so')
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+_vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+
+# name -> (restype, argtypes); mirrors include/infernos_hip.h one to one
+SIGNATURES = {
+    'ifh_last_error': (ctypes.c_char_p, []),
+    'ifh_version': (_i, []),
+    'ifh_device_count': (_i, []),
+    'ifh_g711_tables_host': (_i, [_vp, _vp]),
+    'ifh_g711_decode_u8_f32': (_i, [_vp, _vp, _i64, _vp]),
+    'ifh_g711_encode_f32_u8': (_i, [_vp, _vp, _i64, _vp]),
+    'ifh_resample_create': (_i, [_i, _i, ctypes.POINTER(_vp)]),
+    'ifh_resample_destroy': (_i, [_vp]),
+    'ifh_resample_info': (_i, [_vp, c_i32p, c_i32p, c_i32p, c_i32p, _vp]),
+    'ifh_resample_out_len': (_i64, [_vp, _i64]),
+    'ifh_resample_run': (_i, [_vp, _vp, _i64, _vp, _i64, _i, _vp, _i64, _vp]),
+    'ifh_ingest_tick': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'ifh_vad_energy_prob': (_i, [_vp, _vp, _i, _vp, _vp]),
+    'ifh_vad_fsm_step': (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp]),
+    'ifh_vad_step': (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'ifh_logmel_create': (_i, [_i, ctypes.POINTER(_vp)]),
+    'ifh_logmel_destroy': (_i, [_vp]),
+    'ifh_logmel_filters_host': (_i, [_vp, _vp]),
+    'ifh_logmel_workspace_floats': (_i64, [_vp, _i, _i]),
+    'ifh_logmel_run': (_i, [_vp, _vp, _i64, _vp, _i, _vp, _i, _vp, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class InfernosHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise InfernosHipError(
+                        'libinfernos_hip.so is missing (%s): run `python -c "import __graft_entry__ as g; g.build()"`; '
+                        'there is no CPU fallback' % LIB_PATH)
+                L = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(L, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = L
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = lib().ifh_last_error()
+        raise InfernosHipError('%s failed (%d): %s' % (what or 'libinfernos_hip', rc, (msg or b'').decode()))
+    return rc
+
+
+def require_device(device=None):
+    """torch.device of the HIP GPU to run on; raises when there is none."""
+    import torch
+    if not torch.cuda.is_available():
+        raise InfernosHipError('infernos_amd: no HIP device is visible; the speech path has no CPU fallback')
+    if device is None or str(device) in ('cuda', 'hip'):
+        return torch.device('cuda', torch.cuda.current_device())
+    d = torch.device(device)
+    if d.type != 'cuda':
+        raise InfernosHipError('infernos_amd: device %r is not a HIP GPU; the speech path has no CPU fallback' % (device,))
+    return d
+
+
+def stream_ptr(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    """Raw device (or host) pointer of a contiguous torch tensor / None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'tensor must be contiguous'
+    return ctypes.c_void_p(t.data_ptr())

