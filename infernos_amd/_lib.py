@@ -55,6 +55,10 @@ def lib():
                     raise InfernosHipError(
                         'libinfernos_hip.so is missing (%s): run `python -c "import __graft_entry__ as g; g.build()"`; '
                         'there is no CPU fallback' % LIB_PATH)
+                # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import torch
+                # first so that ONE HIP runtime is shared by torch (memory, streams) and the
+                # kernels here; two runtimes in a process do not see each other's context.
+                import torch  # noqa: F401
                 L = ctypes.CDLL(LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(L, name)

@@ -46,6 +46,8 @@ class Resampler:
         x = audio.to(device=self.device, dtype=torch.float32)
         shape = x.shape
         L = shape[-1] if x.dim() else 0
+        if L == 0:
+            return torch.zeros(shape, dtype=torch.float32, device=self.device)
         x2 = x.reshape(-1, L).contiguous()
         olen = self.out_len(L)
         out = torch.empty((x2.size(0), olen), dtype=torch.float32, device=self.device)

@@ -93,6 +93,8 @@ def resample(x, orig, new):
     k, width, o, n = sinc_kernel(orig, new)
     L = x.shape[-1]
     out_len = int(math.ceil(n * L / o))
+    if L == 0:
+        return np.zeros(x.shape[:-1] + (0,), np.float32)
     flat = x.reshape(-1, L)
     out = np.empty((flat.shape[0], out_len), np.float32)
     for r in range(flat.shape[0]):
