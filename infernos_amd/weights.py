@@ -1,0 +1,105 @@
+"""Model weights for the speech engines: HF-format state dicts in, device tensors out.
+
+The engines consume state dicts with the key names/shapes of the checkpoints the reference
+loads (HelloSippyRTPipe.py:164-178: microsoft/speecht5_tts, microsoft/speecht5_hifigan,
+sobomax/speecht5-rt.post_vocoder.v2; InfernSTTWorker.py:25: openai/whisper-*).  No
+checkpoint is reachable offline, so benchmarks and tests use `synth_state_dict`: seeded
+random tensors with exactly those names and shapes (schema captured from the reference's
+model classes into tests/golden/nn_schema.json and mirrored in SCHEMA_FILE).
+"""
+import json
+import math
+import os
+import zlib
+
+import torch
+
+SCHEMA_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'nn_schema.json')
+
+FAMILIES = ('speecht5_tts', 'hifigan', 'amendment', 'whisper_tiny', 'whisper_base')
+
+
+def load_schema():
+    with open(SCHEMA_FILE) as f:
+        return json.load(f)
+
+
+def _std_for(name, shape):
+    """Initialisation scale keeping activations O(1) through the deep stacks."""
+    if len(shape) < 2:
+        return None
+    if name.endswith('pe_k.weight'):
+        return 0.1
+    if 'embed_tokens' in name or 'embed_positions' in name:
+        return 0.5 if 'embed_tokens' in name else 0.1
+    if name.startswith('upsampler.') or '.upsampler.' in name:      # ConvTranspose1d [in, out, k], stride 4
+        fan = shape[0] * shape[2] / 4.0
+        return 1.0 / math.sqrt(fan)
+    fan_in = 1
+    for s in shape[1:]:
+        fan_in *= s
+    gain = 1.0
+    if 'resblocks' in name or name.startswith('resblock.'):
+        gain = 0.6
+    if 'post_conv' in name:
+        gain = 2.0
+    return gain / math.sqrt(fan_in)
+
+
+def synth_tensor(name, shape, dtype, seed):
+    g = torch.Generator(device='cpu')
+    g.manual_seed((seed * 1000003 + zlib.crc32(name.encode())) & 0x7FFFFFFF)
+    shape = tuple(shape)
+    if dtype == 'int64':
+        return torch.zeros(shape, dtype=torch.int64)
+    leaf = name.rsplit('.', 1)[-1]
+    norm_like = ('layer_norm' in name or 'batch_norm' in name or 'layernorm' in name)
+    if leaf == 'alpha':
+        return torch.ones(shape)
+    if leaf == 'running_var':
+        return 1.0 + 0.2 * torch.rand(shape, generator=g)
+    if leaf == 'running_mean':
+        return 0.1 * torch.randn(shape, generator=g)
+    if name == 'mean':
+        return 0.1 * torch.randn(shape, generator=g)
+    if name == 'scale':
+        return 1.0 + 0.1 * torch.rand(shape, generator=g)
+    if norm_like and leaf == 'weight':
+        return 1.0 + 0.1 * torch.randn(shape, generator=g)
+    if leaf == 'bias' or len(shape) < 2:
+        return 0.05 * torch.randn(shape, generator=g)
+    return _std_for(name, shape) * torch.randn(shape, generator=g)
+
+
+def synth_state_dict(family: str, seed: int = 0, stop_bias=None):
+    """Seeded random HF-format state dict (CPU, float32) for one model family.
+    stop_bias: value for speech_decoder_postnet.prob_out.bias (e.g. -20 disables the stop
+    head)."""
+    schema = load_schema()[family]
+    sd = {}
+    for name in sorted(schema):
+        shape, dtype = schema[name]
+        sd[name] = synth_tensor(name, shape, dtype, seed)
+    if family.startswith('whisper'):
+        sd['proj_out.weight'] = sd['model.decoder.embed_tokens.weight']      # tied
+        sd['model.encoder.embed_positions.weight'] = whisper_sinusoids(*schema['model.encoder.embed_positions.weight'][0])
+    if stop_bias is not None and 'speech_decoder_postnet.prob_out.bias' in sd:
+        sd['speech_decoder_postnet.prob_out.bias'] = torch.full_like(sd['speech_decoder_postnet.prob_out.bias'], stop_bias)
+    return sd
+
+
+def whisper_sinusoids(length, channels, max_timescale=10000.0):
+    inc = math.log(max_timescale) / (channels // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(channels // 2))
+    st = torch.arange(length).view(-1, 1) * inv.view(1, -1)
+    return torch.cat([st.sin(), st.cos()], dim=1)
+
+
+def scaled_positional_table(max_len, dim):
+    """SpeechT5ScaledPositionalEncoding.pe (non-persistent buffer, so not in checkpoints)."""
+    pe = torch.zeros(max_len, dim)
+    pos = torch.arange(0, max_len).unsqueeze(1).float()
+    div = torch.exp(torch.arange(0, dim, 2, dtype=torch.int64).float() * -(math.log(10000.0) / dim))
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe

@@ -1,0 +1,231 @@
+"""Golden vectors for the neural rows: run the REFERENCE's own code
+(HelloSippyRTPipe.infer / unbatch_and_dispatch, InfernSTTWorker.process_batch) on the
+third-party engines it uses (transformers), with the seeded synthetic weights of
+infernos_amd.weights loaded into those engines.  Imported by tools/gen_golden.py.
+"""
+import contextlib
+import io
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def _ids_processor(text, return_tensors='pt'):
+    return {'input_ids': torch.tensor([[int(t) for t in text.split()]], dtype=torch.long)}
+
+
+def _make_pipe(sd_t5, sd_voc, sd_amd, half):
+    import HelloSippyTTSRT.HelloSippyRTPipe as mod
+    from HelloSippyTTSRT.HelloSippyRT import AmendmentNetwork1, AmendmentNetwork1Config
+    from transformers import SpeechT5ForTextToSpeech, SpeechT5Config, SpeechT5HifiGan, SpeechT5HifiGanConfig
+    from config.InfernGlobals import InfernGlobals
+    if not half:
+        mod.maybe_half = lambda x: x
+    else:
+        import importlib
+        importlib.reload(mod)
+    pp = object.__new__(mod.HelloSippyRTPipe)
+    pp.cuda_lock = InfernGlobals().torcher
+    pp.processor = _ids_processor
+    model = SpeechT5ForTextToSpeech(SpeechT5Config())
+    model.load_state_dict(sd_t5, strict=True)
+    voc = SpeechT5HifiGan(SpeechT5HifiGanConfig())
+    voc.load_state_dict(sd_voc, strict=True)
+    amd = AmendmentNetwork1(AmendmentNetwork1Config())
+    amd.load_state_dict(sd_amd, strict=True)
+    if half:
+        model, voc, amd = mod.maybe_half(model), mod.maybe_half(voc), mod.maybe_half(amd)
+    pp.model, pp.vocoder, pp.chunker = model.eval(), voc.eval(), amd.eval()
+    pp.resampler = None
+    pp.output_sr = 16000
+    return mod, pp
+
+
+def _run_tts(sd_t5, sd_voc, sd_amd, texts, speakers, ncalls, half, seed):
+    mod, pp = _make_pipe(sd_t5, sd_voc, sd_amd, half)
+    masks = []
+    real_bernoulli = torch.bernoulli
+
+    def rec_bernoulli(inp, p=None, **kw):
+        m = real_bernoulli(inp, p=p, **kw)
+        masks.append(m[-1].to(torch.uint8).clone())
+        return m
+    dispatched = [[] for _ in texts]
+    reqs = []
+    for i, (t, s) in enumerate(zip(texts, speakers)):
+        def disp(chunk, i=i):
+            dispatched[i].append(None if chunk is None else chunk.float().numpy().copy())
+        reqs.append(mod.HelloSippyPlayRequest(None, t, s, disp))
+    torch.manual_seed(seed)
+    torch.bernoulli = rec_bernoulli
+    try:
+        with torch.no_grad():
+            states = [mod.HelloSippyPipeState(pp, r) for r in reqs]
+            st = mod.HelloSippyPipeStateBatched(states, pp)
+            enc = st.encoder_last_hidden_state.float().clone()
+            audios, more, bookkeeping = [], [], []
+            for c in range(ncalls):
+                pp.infer(st)
+                audios.append(st.audio.float().clone())
+                bookkeeping.append({'idx': int(st.idx), 'starts_at': st.starts_at.tolist(), 'ends_at': st.ends_at.tolist()})
+                with contextlib.redirect_stdout(io.StringIO()):
+                    more.append(bool(pp.unbatch_and_dispatch(st)))
+    finally:
+        torch.bernoulli = real_bernoulli
+    m = torch.stack(masks).view(ncalls, 16, 2, 256).numpy()
+    return dict(enc=enc, audios=audios, more=more, book=bookkeeping, masks=m, dispatched=dispatched,
+                maxlen=st.maxlen, pre_frames=st.pre_frames.float().clone())
+
+
+def gen_tts():
+    from infernos_amd.weights import synth_state_dict
+    from oracle import nn as onn
+    sd_voc = synth_state_dict('hifigan', 0)
+    sd_amd = synth_state_dict('amendment', 0)
+    texts = ['5 17 33 8 21 60 4', '9 10 11 12 13 14 15 16 17 18 19 70', '44 45 46 47 48 49 50 51 52']
+    g = torch.Generator().manual_seed(2000)
+    speakers = [torch.randn(1, 512, generator=g) for _ in texts]
+    out = {}
+    meta = {'source': 'HelloSippyTTSRT/HelloSippyRTPipe.py:71-121,191-259 run on transformers 5.15.0 modules holding '
+                      'infernos_amd.weights.synth_state_dict(seed 0) weights', 'texts': texts, 'speaker_seed': 2000}
+    # ---- scenario A: stop head disabled (prob_out.bias=-20), 2 calls, fp32 and the reference's bf16
+    sdA = synth_state_dict('speecht5_tts', 0, stop_bias=-20.0)
+    A = _run_tts(sdA, sd_voc, sd_amd, texts, speakers, 2, half=False, seed=3000)
+    Ab = _run_tts(sdA, sd_voc, sd_amd, texts, speakers, 2, half=True, seed=3000)
+    assert np.array_equal(A['masks'], Ab['masks'])
+    out['A_masks'] = np.packbits(A['masks'], axis=-1)
+    out['A_enc_slice'] = A['enc'][:, :, :16].numpy()
+    for c in range(2):
+        out['A_audio_%d' % c] = A['audios'][c][:, ::8].numpy()
+        out['A_audio_bf16_%d' % c] = Ab['audios'][c][:, ::8].numpy()
+    meta['A'] = {'book': A['book'], 'more': A['more'], 'maxlen': A['maxlen'],
+                 'dispatch_lens': [[None if d is None else int(d.size) for d in ch] for ch in A['dispatched']],
+                 'enc_sum': float(A['enc'].double().sum()), 'audio_abs_mean': [float(a.abs().mean()) for a in A['audios']],
+                 'bf16_vs_fp32_max_abs': [float((a - b).abs().max()) for a, b in zip(A['audios'], Ab['audios'])],
+                 'bf16_vs_fp32_rel_l2': [float((a - b).norm() / a.norm()) for a, b in zip(A['audios'], Ab['audios'])]}
+    # first dispatched chunk of each row == audio[startoff:]
+    out['A_first_dispatch_0'] = A['dispatched'][0][0][::8]
+    # ---- oracle cross-check while we are here (printed, also asserted in tests)
+    ids = [torch.tensor([[int(t) for t in s.split()]]) for s in texts]
+    T = max(i.size(1) for i in ids)
+    inp = torch.cat([torch.nn.functional.pad(i, (0, T - i.size(1))) for i in ids])
+    msk = torch.cat([torch.nn.functional.pad(torch.ones_like(i), (0, T - i.size(1))) for i in ids]).int()
+    st = onn.TTSState(sdA, inp, msk, torch.cat(speakers))
+    print('enc diff', float((st.enc - A['enc']).abs().max()))
+    stages = {}
+    for c in range(2):
+        a = onn.tts_infer(sdA, sd_voc, sd_amd, st, torch.from_numpy(A['masks'][c]), stages=stages)
+        print('call', c, 'audio diff', float((a - A['audios'][c]).abs().max()), 'scale', float(a.abs().mean()),
+              'voc scale', float(stages['vocoder'].abs().mean()), 'mel scale', float(stages['postnet'].abs().mean()))
+        if c == 0:
+            out['A_postnet_0'] = stages['postnet'].numpy()
+            out['A_vocoder_0'] = stages['vocoder'][:, ::16].numpy()
+    # ---- scenario B: natural stop head (random weights stop early) -> dispatch bookkeeping
+    sdB = synth_state_dict('speecht5_tts', 0)
+    Bx = _run_tts(sdB, sd_voc, sd_amd, texts, speakers, 3, half=False, seed=3001)
+    out['B_masks'] = np.packbits(Bx['masks'], axis=-1)
+    meta['B'] = {'book': Bx['book'], 'more': Bx['more'], 'maxlen': Bx['maxlen'],
+                 'dispatch_lens': [[None if d is None else int(d.size) for d in ch] for ch in Bx['dispatched']]}
+    for i, ch in enumerate(Bx['dispatched']):
+        for j, d in enumerate(ch):
+            if d is not None:
+                out['B_disp_%d_%d' % (i, j)] = d[::8]
+    np.savez_compressed(os.path.join(GOLD, 'tts.npz'), **out)
+    import json
+    json.dump(meta, open(os.path.join(GOLD, 'tts_meta.json'), 'w'), indent=1, sort_keys=True)
+    print('wrote tts.npz / tts_meta.json', meta['A']['bf16_vs_fp32_rel_l2'], meta['B']['book'])
+
+
+def gen_whisper():
+    import json
+    import types
+    from transformers import WhisperConfig, WhisperForConditionalGeneration, WhisperFeatureExtractor
+    from infernos_amd.weights import synth_state_dict
+    from Cluster.InfernSTTWorker import InfernSTTWorker
+    from Cluster.InfernBatchedWorker import InfernBatchedWorker
+    from Cluster.STTSession import STTRequest
+    from Core.AudioChunk import AudioChunk
+    from oracle import nn as onn, dsp
+    sys.path.insert(0, HERE)
+    from gen_golden import synth_utterance
+    sd = synth_state_dict('whisper_tiny', 0)
+    model = WhisperForConditionalGeneration(WhisperConfig())
+    missing = model.load_state_dict(sd, strict=True)
+    model.eval()
+    fe = WhisperFeatureExtractor()
+    PROMPT = [50258, 50259, 50359, 50363]     # <|startoftranscript|><|en|><|transcribe|><|notimestamps|> (multilingual ids)
+    NOSPEECH = 50362
+
+    class Tok:
+        pad_token_id = 50257
+
+        def convert_tokens_to_ids(self, toks):
+            if isinstance(toks, str):
+                return NOSPEECH
+            return list(PROMPT[:len(toks)])
+
+    class Proc:
+        tokenizer = Tok()
+
+        def __call__(self, audios, sampling_rate=None, return_tensors='pt'):
+            return fe(audios, sampling_rate=sampling_rate, return_tensors=return_tensors)
+
+        def batch_decode(self, seqs, skip_special_tokens=True):
+            return [' '.join(str(int(t)) for t in s) for s in seqs]
+    w = object.__new__(InfernSTTWorker)
+    InfernBatchedWorker.__init__(w)
+    w.model, w.processor, w.device = model, Proc(), 'cpu'
+    w.no_speech_token_id = NOSPEECH
+    from functools import partial
+    w.process_audios = partial(w.processor, return_tensors='pt')
+    w.infer_and_decode = w.infer_and_decode_torch
+    auds = [dsp.resample(synth_utterance(1000 + i, 10.0), 8000, 16000) for i in range(2)]
+    results = []
+    wis = []
+    for a in auds:
+        ch = AudioChunk(torch.from_numpy(a), 16000)
+        ch.audio = ch.audio.numpy()
+        req = STTRequest(ch, None, 'en')
+        req.max_ns_prob = -1.0            # every no-speech prob is above it -> early return, no generate()
+        wis.append((req, lambda result: results.append(result), None))
+    w.process_batch(wis)
+    nsp = [float(r.no_speech_prob) for r in results]
+    # engine-level pins (HF forward with the reference's prompt layout)
+    mel = torch.from_numpy(fe(auds, sampling_rate=16000, return_tensors='np').input_features)
+    prompt = torch.tensor([PROMPT, PROMPT])
+    with torch.no_grad():
+        fo = model(input_features=mel, decoder_input_ids=prompt)
+        enc = fo.encoder_last_hidden_state
+        logits = fo.logits
+        # manual greedy, 8 tokens
+        toks = prompt.clone()
+        outs = []
+        for s in range(8):
+            lg = model(input_features=mel, decoder_input_ids=toks).logits[:, -1]
+            nxt = lg.argmax(-1)
+            outs.append(nxt)
+            toks = torch.cat([toks, nxt[:, None]], 1)
+    greedy = torch.stack(outs, 1)
+    o_toks, o_first, o_l0, o_enc = onn.whisper_greedy(sd, mel, prompt, 8, 6)
+    print('whisper enc diff', float((o_enc - enc).abs().max()), 'logit diff', float((o_first - logits[:, -1]).abs().max()),
+          'tokens equal', bool((o_toks == greedy).all()), 'nsp', nsp,
+          float(torch.softmax(o_l0, -1)[0, NOSPEECH]))
+    np.savez_compressed(os.path.join(GOLD, 'whisper.npz'), enc_slice=enc[:, ::25, :32].numpy(),
+                        first_logits_slice=logits[:, -1, ::97].numpy(), logits0_slice=logits[:, 0, ::97].numpy(),
+                        greedy=greedy.numpy())
+    json.dump({'source': 'Cluster/InfernSTTWorker.py:77-92,109-123 (process_batch -> infer_and_decode_torch early-return '
+                         'path) on transformers 5.15.0 WhisperForConditionalGeneration(WhisperConfig()) holding '
+                         'synth_state_dict(whisper_tiny, 0); greedy tokens from the same engine',
+               'prompt': PROMPT, 'no_speech_id': NOSPEECH, 'no_speech_prob': nsp, 'audio_seeds': [1000, 1001],
+               'enc_sum': float(enc.double().sum()), 'first_logits_max': [float(x) for x in logits[:, -1].max(-1).values]},
+              open(os.path.join(GOLD, 'whisper_meta.json'), 'w'), indent=1, sort_keys=True)
+    print('wrote whisper.npz')
+
+
+SECTIONS = {'tts': gen_tts, 'whisper': gen_whisper}
