@@ -131,6 +131,101 @@ int64_t ifh_logmel_workspace_floats(ifh_logmel_t h, int nbatch, int out_bf16);  
 int ifh_logmel_run(ifh_logmel_t h, const float *audio, int64_t stride, const int32_t *lens, int nbatch,
                    void *out, int out_bf16, float *workspace, ifh_stream_t stream);
 
+
+/* ---------------------------------------------------------------------------------
+ * Dense building blocks of the speech models (bf16 storage, fp32 accumulate).  These sit
+ * under the third-party engines the reference calls from
+ *   Cluster/InfernSTTWorker.py:61-107   (Whisper encoder/decoder; CTranslate2 / HF)
+ *   HelloSippyTTSRT/HelloSippyRTPipe.py:111-115,196-237 (SpeechT5, HiFi-GAN; HF transformers)
+ *   HelloSippyTTSRT/HelloSippyRT.py:219-237 (AmendmentNetwork1)
+ * ------------------------------------------------------------------------------- */
+#define IFH_ACT_NONE 0
+#define IFH_ACT_RELU 1
+#define IFH_ACT_GELU 2      /* exact erf form */
+#define IFH_ACT_TANH 3
+#define IFH_ACT_LRELU 4     /* slope = act_slope */
+#define IFH_ACT_SIGMOID 5
+
+/* One implicit-GEMM launch on the matrix cores: Linear, Conv1d, or one phase of a
+ * ConvTranspose1d, channels-last.
+ *   out[b][t*ostride+ooff][n] (+)= scale * ( mask_n( act( bias[n] + sum_{tap,ci} w[n][tap][ci] *
+ *        pre(x[b][t*stride - pad + tap*dil][ci]) ) ) + resid )
+ * x rows outside [0,t_in) read as zero (after pre()).  pre() = LeakyReLU(pre_slope), 1.0 = identity.
+ * Element strides: x row r of batch b is x + b*x_bstride + r*lda; out/resid likewise with
+ * (out_bstride, ldc) / (resid_bstride, resid_ld; both 0 broadcast one row).  cin % 8 == 0. */
+typedef struct ifh_conv_desc {
+    const void *x;          /* bf16 */
+    int64_t x_bstride;
+    int32_t lda;
+    int32_t cin, taps, stride, dil, pad;
+    int32_t t_in, t_out, nbatch;
+    const void *w;          /* bf16 [n][taps][cin] */
+    int32_t n;
+    const float *bias;      /* [n] or NULL */
+    const uint8_t *colmask; /* [n] or NULL: keep ? 2*v : 0  (SpeechT5 prenet dropout, p = 0.5) */
+    float pre_slope;
+    int32_t act;
+    float act_slope;
+    const void *resid;      /* bf16 or NULL */
+    int64_t resid_bstride;
+    int32_t resid_ld;
+    float out_scale;
+    int32_t accumulate;     /* add the previous contents of out */
+    void *out;              /* bf16, or f32 when out_f32 */
+    int32_t out_f32;
+    int64_t out_bstride;
+    int32_t ldc, ostride, ooff;
+} ifh_conv_desc;
+int ifh_conv_bf16(const ifh_conv_desc *desc, ifh_stream_t stream);
+
+/* y = LayerNorm(x (+ resid)) * gamma + beta; rows of `dim` bf16, dim <= 1024, dim % 4 == 0 */
+int ifh_layernorm_bf16(const void *x, const void *resid, const float *gamma, const float *beta, void *out,
+                       int rows, int dim, float eps, ifh_stream_t stream);
+/* in [nbatch][rows][cols] (f32 if in_f32 else bf16) -> out bf16 [nbatch][cols][rows] */
+int ifh_transpose_to_bf16(const void *in, int in_f32, void *out, int nbatch, int rows, int cols, ifh_stream_t stream);
+
+/* Non-causal multi-head attention, head_dim 64, q pre-scaled.  Element strides (batch, token);
+ * head h lives at +64*h.  key_len[b] (>=1) masks keys >= key_len; relbias f32
+ * [nbatch][tq][nheads][nrel] adds relbias[q][clip(q-k, -nrel/2, nrel/2-1) + nrel/2]. */
+typedef struct ifh_attn_desc {
+    const void *q, *k, *v;
+    void *out;
+    int64_t q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
+    int32_t nbatch, nheads, head_dim, tq, tk;
+    const int32_t *key_len;
+    const float *relbias;
+    int32_t nrel;
+} ifh_attn_desc;
+int ifh_attn_prefill_bf16(const ifh_attn_desc *desc, ifh_stream_t stream);
+/* one query token per (batch, head) against a KV cache of key_len[b] (or max_keys) entries */
+int ifh_attn_decode_bf16(const void *q, int64_t q_bs, const void *k, const void *v, int64_t kv_bs, int64_t kv_ts,
+                         void *out, int64_t o_bs, const int32_t *key_len, int max_keys, int nbatch, int nheads,
+                         int head_dim, ifh_stream_t stream);
+
+/* out[i] = table[ids[i]] + pos_table[pos0 + i % seq_len] (pos_table may be NULL); bf16, dim % 8 == 0 */
+int ifh_embed_bf16(const int32_t *ids, const void *table, const void *pos_table, int pos0, int seq_len, int dim,
+                   int n, void *out, ifh_stream_t stream);
+/* per row of f32 logits: argmax (first on ties) and/or softmax probability of pick_token */
+int ifh_argmax_pick_f32(const float *logits, int64_t ld, int vocab, int nrows, int pick_token, int32_t *argmax_out,
+                        float *pick_prob_out, ifh_stream_t stream);
+
+/* ---- TTS streaming glue, HelloSippyRTPipe.infer (HelloSippyRTPipe.py:191-240) ---- */
+/* stop rule (:227-228) on the 2 stop logits per utterance; ends_at int64[n] */
+int ifh_tts_stop_update(const float *prob_logits, int64_t *ends_at, int n, int idx, int minlen, int maxlen,
+                        float threshold, int ends_inc, ifh_stream_t stream);
+/* carry + 4 overlapped 12-frame chunks (:231-235): pre_frames bf16 [B][4][80] (updated), post bf16
+ * [B][32][80] -> voc_in bf16 [4B][12][80] normalised by (x-mean)/scale, amd_mel bf16 [4B][12][80] =
+ * channels-last form of the chunk re-viewed as [80][12] (HelloSippyRT.py:224) */
+int ifh_tts_chunks_bf16(void *pre_frames, const void *post, const float *mean, const float *scale, void *voc_in,
+                        void *amd_mel, int nbatch, ifh_stream_t stream);
+/* HiFi-GAN tail: LeakyReLU(slope) -> Conv1d(32->1,k7,p3) -> tanh; x bf16 [nrows][t][32] -> bf16 [nrows][t] */
+int ifh_hifigan_post_bf16(const void *x, const float *w7x32, float bias, void *audio, int nrows, int t, float slope,
+                          ifh_stream_t stream);
+/* AmendmentNetwork1 tail + chunk un-stacking: post bf16 [4B][8][256], audio bf16 [4B][3072] -> out bf16 [B][8192] */
+int ifh_amend_final_bf16(const void *post, const void *audio, void *out, int nbatch, ifh_stream_t stream);
+/* rows / max(||row||, 1e-12) (F.normalize) written with leading dimension ld_out */
+int ifh_l2norm_rows_bf16(const void *x, int dim, int nrows, void *out, int ld_out, ifh_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,44 @@ SIGNATURES = {
     'ifh_logmel_run': (_i, [_vp, _vp, _i64, _vp, _i, _vp, _i, _vp, _vp]),
 }
 
+
+
+class ConvDesc(ctypes.Structure):
+    """ifh_conv_desc (include/infernos_hip.h)"""
+    _fields_ = [('x', _vp), ('x_bstride', _i64), ('lda', ctypes.c_int32),
+                ('cin', ctypes.c_int32), ('taps', ctypes.c_int32), ('stride', ctypes.c_int32), ('dil', ctypes.c_int32),
+                ('pad', ctypes.c_int32), ('t_in', ctypes.c_int32), ('t_out', ctypes.c_int32), ('nbatch', ctypes.c_int32),
+                ('w', _vp), ('n', ctypes.c_int32), ('bias', _vp), ('colmask', _vp), ('pre_slope', _f),
+                ('act', ctypes.c_int32), ('act_slope', _f), ('resid', _vp), ('resid_bstride', _i64),
+                ('resid_ld', ctypes.c_int32), ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp),
+                ('out_f32', ctypes.c_int32), ('out_bstride', _i64), ('ldc', ctypes.c_int32), ('ostride', ctypes.c_int32),
+                ('ooff', ctypes.c_int32)]
+
+
+class AttnDesc(ctypes.Structure):
+    """ifh_attn_desc (include/infernos_hip.h)"""
+    _fields_ = [('q', _vp), ('k', _vp), ('v', _vp), ('out', _vp),
+                ('q_bs', _i64), ('q_ts', _i64), ('k_bs', _i64), ('k_ts', _i64), ('v_bs', _i64), ('v_ts', _i64),
+                ('o_bs', _i64), ('o_ts', _i64),
+                ('nbatch', ctypes.c_int32), ('nheads', ctypes.c_int32), ('head_dim', ctypes.c_int32),
+                ('tq', ctypes.c_int32), ('tk', ctypes.c_int32), ('key_len', _vp), ('relbias', _vp), ('nrel', ctypes.c_int32)]
+
+
+SIGNATURES.update({
+    'ifh_conv_bf16': (_i, [ctypes.POINTER(ConvDesc), _vp]),
+    'ifh_layernorm_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    'ifh_transpose_to_bf16': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
+    'ifh_attn_prefill_bf16': (_i, [ctypes.POINTER(AttnDesc), _vp]),
+    'ifh_attn_decode_bf16': (_i, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),
+    'ifh_embed_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    'ifh_argmax_pick_f32': (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
+    'ifh_tts_stop_update': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    'ifh_tts_chunks_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    'ifh_hifigan_post_bf16': (_i, [_vp, _vp, _f, _vp, _i, _i, _f, _vp]),
+    'ifh_amend_final_bf16': (_i, [_vp, _vp, _vp, _i, _vp]),
+    'ifh_l2norm_rows_bf16': (_i, [_vp, _i, _i, _vp, _i, _vp]),
+})
+
 _lib = None
 _lock = threading.Lock()
 

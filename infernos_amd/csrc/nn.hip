@@ -1,0 +1,431 @@
+// nn.hip -- dense building blocks of the speech models on gfx950:
+//   * k_igemm: bf16 implicit-GEMM on the matrix cores (v_mfma_f32_16x16x32_bf16) covering
+//     Linear, Conv1d (any taps/stride/dilation, channels-last) and the phases of
+//     ConvTranspose1d, with fused input LeakyReLU and a fused epilogue (bias, activation,
+//     dropout column mask, residual, scale, accumulate).
+//   * k_layernorm: wave-per-row LayerNorm with optional fused residual add.
+//   * k_transpose: [B][R][C] -> [B][C][R] with cast to bf16 (layout glue).
+// The MFMA is issued "swapped" (A = weight rows, B = activation rows) so that a lane ends
+// up holding 4 consecutive output channels of one output row -> 8/16-byte stores.
+#include <math.h>
+
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace ifh {
+
+struct IgemmParams {
+    const uint16_t *x;
+    int64_t x_bstride;
+    int lda;
+    int Cin, taps, stride, dil, pad;
+    int T_in, T_out, nbatch;
+    const uint16_t *w;
+    int K, N;
+    const float *bias;
+    const uint8_t *colmask;
+    float pre_slope;
+    int act;
+    float act_slope;
+    const uint16_t *resid;
+    int64_t resid_bstride;
+    int resid_ld;
+    float out_scale;
+    int accumulate;
+    void *out;
+    int out_f32;
+    int64_t out_bstride;
+    int ldc, ostride, ooff;
+    int vec_ok;
+};
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_TANH = 3, ACT_LRELU = 4, ACT_SIGMOID = 5 };
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope)
+{
+    switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.0f);
+    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case ACT_TANH: return tanhf(v);
+    case ACT_LRELU: return v > 0.0f ? v : v * slope;
+    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+    }
+}
+
+__device__ __forceinline__ uint4 lrelu8(uint4 v, float slope)
+{
+    uint32_t *u = reinterpret_cast<uint32_t *>(&v);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
+        lo = lo > 0.0f ? lo : lo * slope;
+        hi = hi > 0.0f ? hi : hi * slope;
+        u[i] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    }
+    return v;
+}
+
+template <int BM, int BN, int WGM, bool PRE>
+__global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
+{
+    constexpr int WGN = 4 / WGM;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int LD = 40;  // 32 + 8 pad (80-byte rows)
+    constexpr int AV = BM * 4 / 256, BV = (BN * 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) uint16_t As[BM * LD];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid % WGM, wn = wid / WGM;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int M = p.nbatch * p.T_out;
+    const bool uniform_tap = (p.Cin & 31) == 0;
+
+    // per-thread activation-row descriptors (fixed over the K loop)
+    const uint16_t *arow[AV];
+    int abase_t[AV];
+    bool avalid[AV];
+#pragma unroll
+    for (int i = 0; i < AV; i++) {
+        const int v = tid + 256 * i;
+        const int m = m0 + (v >> 2);
+        avalid[i] = m < M;
+        const int mm = avalid[i] ? m : 0;
+        const int b = mm / p.T_out, t = mm - b * p.T_out;
+        arow[i] = p.x + (int64_t)b * p.x_bstride;
+        abase_t[i] = t * p.stride - p.pad;
+    }
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[AV], rb[BV];
+    auto load_tiles = [&](int k0) {
+        int tap_u = 0, ci_u = 0;
+        if (uniform_tap) {
+            tap_u = k0 / p.Cin;
+            ci_u = k0 - tap_u * p.Cin;
+        }
+#pragma unroll
+        for (int i = 0; i < AV; i++) {
+            const int v = tid + 256 * i;
+            const int k = k0 + (v & 3) * 8;
+            int tap, ci;
+            if (uniform_tap) {
+                tap = tap_u;
+                ci = ci_u + (v & 3) * 8;
+            } else {
+                tap = k / p.Cin;
+                ci = k - tap * p.Cin;
+            }
+            const int tin = abase_t[i] + tap * p.dil;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (avalid[i] && k < p.K && tin >= 0 && tin < p.T_in) {
+                val = *reinterpret_cast<const uint4 *>(arow[i] + (int64_t)tin * p.lda + ci);
+                if (PRE) val = lrelu8(val, p.pre_slope);
+            }
+            ra[i] = val;
+        }
+#pragma unroll
+        for (int i = 0; i < BV; i++) {
+            const int v = tid + 256 * i;
+            const int n = n0 + (v >> 2);
+            const int k = k0 + (v & 3) * 8;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (v < BN * 4 && n < p.N && k < p.K) val = *reinterpret_cast<const uint4 *>(p.w + (int64_t)n * p.K + k);
+            rb[i] = val;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < AV; i++) {
+            const int v = tid + 256 * i;
+            *reinterpret_cast<uint4 *>(&As[(v >> 2) * LD + (v & 3) * 8]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BV; i++) {
+            const int v = tid + 256 * i;
+            if (v < BN * 4) *reinterpret_cast<uint4 *>(&Bs[(v >> 2) * LD + (v & 3) * 8]) = rb[i];
+        }
+    };
+
+    const int nk = (p.K + 31) / 32;
+    load_tiles(0);
+    const int fr = lane & 15, fg = lane >> 4;
+    for (int kt = 0; kt < nk; kt++) {
+        store_tiles();
+        __syncthreads();
+        if (kt + 1 < nk) load_tiles((kt + 1) * 32);
+        bf16x8_t fa[NT], fb[MT];
+#pragma unroll
+        for (int i = 0; i < NT; i++)
+            fa[i] = *reinterpret_cast<const bf16x8_t *>(&Bs[(wn * WN + i * 16 + fr) * LD + fg * 8]);
+#pragma unroll
+        for (int j = 0; j < MT; j++)
+            fb[j] = *reinterpret_cast<const bf16x8_t *>(&As[(wm * WM + j * 16 + fr) * LD + fg * 8]);
+#pragma unroll
+        for (int i = 0; i < NT; i++)
+#pragma unroll
+            for (int j = 0; j < MT; j++)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds D[n = 4*fg + r][m = fr] of each 16x16 tile
+#pragma unroll
+    for (int j = 0; j < MT; j++) {
+        const int m = m0 + wm * WM + j * 16 + fr;
+        if (m >= M) continue;
+        const int b = m / p.T_out, t = m - b * p.T_out;
+        const int64_t orow = (int64_t)t * p.ostride + p.ooff;
+        const int64_t obase = (int64_t)b * p.out_bstride + orow * p.ldc;
+        const int64_t rbase = (int64_t)b * p.resid_bstride + orow * p.resid_ld;
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int n = n0 + wn * WN + i * 16 + 4 * fg;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float a = acc[i][j][r];
+                const int nn = n + r;
+                if (nn < p.N) {
+                    if (p.bias) a += p.bias[nn];
+                    a = apply_act(a, p.act, p.act_slope);
+                    if (p.colmask) a = p.colmask[nn] ? a * 2.0f : 0.0f;
+                    if (p.resid) a += bf16_to_f32(p.resid[rbase + nn]);
+                    a *= p.out_scale;
+                }
+                v[r] = a;
+            }
+            if (p.vec_ok && n + 3 < p.N) {
+                if (p.out_f32) {
+                    float *o = reinterpret_cast<float *>(p.out) + obase + n;
+                    float4 prev = make_float4(0, 0, 0, 0);
+                    if (p.accumulate) prev = *reinterpret_cast<const float4 *>(o);
+                    *reinterpret_cast<float4 *>(o) = make_float4(v[0] + prev.x, v[1] + prev.y, v[2] + prev.z, v[3] + prev.w);
+                } else {
+                    uint16_t *o = reinterpret_cast<uint16_t *>(p.out) + obase + n;
+                    if (p.accumulate) {
+                        const uint2 pv = *reinterpret_cast<const uint2 *>(o);
+                        v[0] += __uint_as_float(pv.x << 16);
+                        v[1] += __uint_as_float(pv.x & 0xffff0000u);
+                        v[2] += __uint_as_float(pv.y << 16);
+                        v[3] += __uint_as_float(pv.y & 0xffff0000u);
+                    }
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2 *>(o) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (n + r >= p.N) break;
+                    if (p.out_f32) {
+                        float *o = reinterpret_cast<float *>(p.out) + obase + n + r;
+                        *o = v[r] + (p.accumulate ? *o : 0.0f);
+                    } else {
+                        uint16_t *o = reinterpret_cast<uint16_t *>(p.out) + obase + n + r;
+                        *o = f32_to_bf16(v[r] + (p.accumulate ? bf16_to_f32(*o) : 0.0f));
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- LayerNorm: one wave per row, optional residual add first; D <= 1024, D % 4 == 0
+__global__ __launch_bounds__(256) void k_layernorm(const uint16_t *__restrict__ x, const uint16_t *__restrict__ resid,
+                                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                   uint16_t *__restrict__ out, int rows, int D, float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const uint16_t *xr = x + (int64_t)row * D;
+    const uint16_t *rr = resid ? resid + (int64_t)row * D : nullptr;
+    float v[4][4];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int e = lane * 4 + 256 * i;
+        if (e < D) {
+            const uint2 a = *reinterpret_cast<const uint2 *>(xr + e);
+            v[i][0] = __uint_as_float(a.x << 16);
+            v[i][1] = __uint_as_float(a.x & 0xffff0000u);
+            v[i][2] = __uint_as_float(a.y << 16);
+            v[i][3] = __uint_as_float(a.y & 0xffff0000u);
+            if (rr) {
+                const uint2 c = *reinterpret_cast<const uint2 *>(rr + e);
+                v[i][0] += __uint_as_float(c.x << 16);
+                v[i][1] += __uint_as_float(c.x & 0xffff0000u);
+                v[i][2] += __uint_as_float(c.y << 16);
+                v[i][3] += __uint_as_float(c.y & 0xffff0000u);
+            }
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        } else {
+            v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.0f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int e = lane * 4 + 256 * i;
+        if (e < D) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float d = v[i][r] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    uint16_t *orow = out + (int64_t)row * D;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int e = lane * 4 + 256 * i;
+        if (e < D) {
+            const float4 g = *reinterpret_cast<const float4 *>(gamma + e);
+            const float4 bt = *reinterpret_cast<const float4 *>(beta + e);
+            const float o0 = (v[i][0] - mean) * rstd * g.x + bt.x, o1 = (v[i][1] - mean) * rstd * g.y + bt.y;
+            const float o2 = (v[i][2] - mean) * rstd * g.z + bt.z, o3 = (v[i][3] - mean) * rstd * g.w + bt.w;
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(o0) | ((uint32_t)f32_to_bf16(o1) << 16);
+            pk.y = (uint32_t)f32_to_bf16(o2) | ((uint32_t)f32_to_bf16(o3) << 16);
+            *reinterpret_cast<uint2 *>(orow + e) = pk;
+        }
+    }
+}
+
+// ---- transpose the last two dims, cast to bf16: in [B][R][C] (f32 or bf16) -> out [B][C][R]
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void k_transpose(const void *__restrict__ in, uint16_t *__restrict__ out, int R, int C)
+{
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        float v = 0.0f;
+        if (r < R && c < C) {
+            const int64_t idx = ((int64_t)b * R + r) * C + c;
+            v = IN_F32 ? reinterpret_cast<const float *>(in)[idx] : bf16_to_f32(reinterpret_cast<const uint16_t *>(in)[idx]);
+        }
+        tile[k][tx] = v;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (r < R && c < C) out[((int64_t)b * C + c) * R + r] = f32_to_bf16(tile[tx][k]);
+    }
+}
+
+template <int BM, int BN, int WGM>
+static void launch_igemm(const IgemmParams &p, bool pre, hipStream_t st)
+{
+    const int M = p.nbatch * p.T_out;
+    dim3 grid((M + BM - 1) / BM, (p.N + BN - 1) / BN);
+    if (pre)
+        hipLaunchKernelGGL((k_igemm<BM, BN, WGM, true>), grid, dim3(256), 0, st, p);
+    else
+        hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false>), grid, dim3(256), 0, st, p);
+}
+
+}  // namespace ifh
+
+using namespace ifh;
+
+extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(d);
+    IFH_CHECK_ARG(d->x && d->w && d->out);
+    IFH_CHECK_ARG(d->nbatch >= 0 && d->t_out >= 0);
+    if (d->nbatch == 0 || d->t_out == 0) return IFH_OK;
+    IFH_CHECK_ARG(d->cin > 0 && d->cin % 8 == 0 && d->taps >= 1 && d->stride >= 1 && d->dil >= 1);
+    IFH_CHECK_ARG(d->lda % 8 == 0 && d->x_bstride % 8 == 0 && (((uintptr_t)d->x) & 15) == 0 && (((uintptr_t)d->w) & 15) == 0);
+    IFH_CHECK_ARG(d->n > 0 && d->t_in > 0 && d->ldc > 0 && d->ostride >= 1 && d->ooff >= 0);
+    IFH_CHECK_ARG(d->act >= 0 && d->act <= 5);
+    IgemmParams p;
+    p.x = (const uint16_t *)d->x;
+    p.x_bstride = d->x_bstride;
+    p.lda = d->lda;
+    p.Cin = d->cin;
+    p.taps = d->taps;
+    p.stride = d->stride;
+    p.dil = d->dil;
+    p.pad = d->pad;
+    p.T_in = d->t_in;
+    p.T_out = d->t_out;
+    p.nbatch = d->nbatch;
+    p.w = (const uint16_t *)d->w;
+    p.K = d->taps * d->cin;
+    p.N = d->n;
+    p.bias = d->bias;
+    p.colmask = d->colmask;
+    p.pre_slope = d->pre_slope;
+    p.act = d->act;
+    p.act_slope = d->act_slope;
+    p.resid = (const uint16_t *)d->resid;
+    p.resid_bstride = d->resid_bstride;
+    p.resid_ld = d->resid_ld;
+    p.out_scale = d->out_scale;
+    p.accumulate = d->accumulate;
+    p.out = d->out;
+    p.out_f32 = d->out_f32;
+    p.out_bstride = d->out_bstride;
+    p.ldc = d->ldc;
+    p.ostride = d->ostride;
+    p.ooff = d->ooff;
+    const int esz = d->out_f32 ? 4 : 2;
+    p.vec_ok = (d->ldc % 4 == 0) && (d->out_bstride % 4 == 0) && ((((uintptr_t)d->out) % (4 * esz)) == 0);
+    const bool pre = d->pre_slope != 1.0f;
+    const int64_t M = (int64_t)d->nbatch * d->t_out;
+    IFH_CHECK_ARG(M < (1ll << 31));
+    hipStream_t st = as_stream(stream);
+    if (d->n <= 32)
+        launch_igemm<128, 32, 4>(p, pre, st);
+    else if (M <= 64)
+        launch_igemm<64, 32, 2>(p, pre, st);
+    else if (d->n <= 64)
+        launch_igemm<128, 64, 2>(p, pre, st);
+    else
+        launch_igemm<128, 128, 2>(p, pre, st);
+    IFH_LAUNCH_CHECK("conv_bf16");
+    return IFH_OK;
+}
+
+extern "C" int ifh_layernorm_bf16(const void *x, const void *resid, const float *gamma, const float *beta, void *out,
+                                  int rows, int dim, float eps, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(rows >= 0);
+    if (rows == 0) return IFH_OK;
+    IFH_CHECK_ARG(x && gamma && beta && out && dim > 0 && dim <= 1024 && dim % 4 == 0);
+    hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), (const uint16_t *)x,
+                       (const uint16_t *)resid, gamma, beta, (uint16_t *)out, rows, dim, eps);
+    IFH_LAUNCH_CHECK("layernorm");
+    return IFH_OK;
+}
+
+extern "C" int ifh_transpose_to_bf16(const void *in, int in_f32, void *out, int nbatch, int rows, int cols,
+                                     ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(nbatch >= 0 && rows >= 0 && cols >= 0);
+    if (nbatch == 0 || rows == 0 || cols == 0) return IFH_OK;
+    IFH_CHECK_ARG(in && out && nbatch < 65536);
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32, nbatch);
+    if (in_f32)
+        hipLaunchKernelGGL(k_transpose<true>, grid, dim3(256), 0, as_stream(stream), in, (uint16_t *)out, rows, cols);
+    else
+        hipLaunchKernelGGL(k_transpose<false>, grid, dim3(256), 0, as_stream(stream), in, (uint16_t *)out, rows, cols);
+    IFH_LAUNCH_CHECK("transpose");
+    return IFH_OK;
+}

@@ -1,0 +1,218 @@
+"""SpeechT5 text encoder, streaming speech decoder and postnet on the HIP device.
+
+Replaces the transformers SpeechT5ForTextToSpeech modules the reference drives from
+HelloSippyTTSRT/HelloSippyRTPipe.py:111-115 (encoder, once per batch) and :196-230 (16
+decoder steps + postnet per infer() call).  Architecture per modeling_speecht5.py (v5.15.0):
+post-LN layers, q pre-scaled by 64^-0.5 (folded into the q weights here), relative position
+bias in the encoder, always-on prenet dropout whose Bernoulli(0.5) keep-masks are an explicit
+input (one [2][256] pair per decoder step, shared across the batch as in the reference).
+Only the last time row of the prenet is computed per step: rows are independent given the
+mask row, so this equals the reference's prenet-over-history followed by [:, -1:].
+"""
+import math
+
+import torch
+
+from .. import _lib, ops
+from ..ops import ACT_GELU, ACT_RELU, ACT_TANH, BF16
+from ..weights import scaled_positional_table
+
+D, H, FF = 768, 12, 3072
+QS = 64 ** -0.5
+
+
+def _ln(sd, p, dev):
+    return sd[p + '.weight'].float().contiguous().to(dev), sd[p + '.bias'].float().contiguous().to(dev)
+
+
+class SpeechT5:
+    n_dec_layers = 6
+
+    def __init__(self, sd, device, max_steps=640):
+        self.device = dev = _lib.require_device(device)
+        self.max_steps = max_steps
+        E = 'speecht5.encoder.'
+        alpha_e = float(sd[E + 'prenet.encode_positions.alpha'])
+        self.tok = sd[E + 'prenet.embed_tokens.weight'].to(BF16).contiguous().to(dev)
+        self.pe_enc = (alpha_e * scaled_positional_table(450, D)).to(BF16).contiguous().to(dev)
+        W = E + 'wrapped_encoder.'
+        self.enc_ln = _ln(sd, W + 'layer_norm', dev)
+        self.pe_k = ops.w_linear(sd[W + 'embed_positions.pe_k.weight'], dev)            # [320,64]
+        self.enc_layers = []
+        i = 0
+        while (W + 'layers.%d.attention.q_proj.weight' % i) in sd:
+            L = W + 'layers.%d.' % i
+            A = L + 'attention.'
+            wqkv = torch.cat([sd[A + 'q_proj.weight'].float() * QS, sd[A + 'k_proj.weight'].float(), sd[A + 'v_proj.weight'].float()])
+            bqkv = torch.cat([sd[A + 'q_proj.bias'].float() * QS, sd[A + 'k_proj.bias'].float(), sd[A + 'v_proj.bias'].float()])
+            self.enc_layers.append(dict(
+                wqkv=ops.w_linear(wqkv, dev), bqkv=ops.w_bias(bqkv, dev),
+                wo=ops.w_linear(sd[A + 'out_proj.weight'], dev), bo=ops.w_bias(sd[A + 'out_proj.bias'], dev),
+                ln1=_ln(sd, L + 'layer_norm', dev),
+                w1=ops.w_linear(sd[L + 'feed_forward.intermediate_dense.weight'], dev),
+                b1=ops.w_bias(sd[L + 'feed_forward.intermediate_dense.bias'], dev),
+                w2=ops.w_linear(sd[L + 'feed_forward.output_dense.weight'], dev),
+                b2=ops.w_bias(sd[L + 'feed_forward.output_dense.bias'], dev),
+                ln2=_ln(sd, L + 'final_layer_norm', dev)))
+            i += 1
+        P = 'speecht5.decoder.prenet.'
+        self.p0 = (ops.w_linear(sd[P + 'layers.0.weight'], dev), ops.w_bias(sd[P + 'layers.0.bias'], dev))
+        self.p1 = (ops.w_linear(sd[P + 'layers.1.weight'], dev), ops.w_bias(sd[P + 'layers.1.bias'], dev))
+        self.pf = (ops.w_linear(sd[P + 'final_layer.weight'], dev), ops.w_bias(sd[P + 'final_layer.bias'], dev))
+        self.ps = (ops.w_linear(sd[P + 'speaker_embeds_layer.weight'], dev), ops.w_bias(sd[P + 'speaker_embeds_layer.bias'], dev))
+        alpha_d = float(sd[P + 'encode_positions.alpha'])
+        self.pe_dec = (alpha_d * scaled_positional_table(4000, D)).to(BF16).contiguous().to(dev)
+        Wd = 'speecht5.decoder.wrapped_decoder.'
+        self.dec_layers = []
+        for i in range(self.n_dec_layers):
+            L = Wd + 'layers.%d.' % i
+            S, C = L + 'self_attn.', L + 'encoder_attn.'
+            self.dec_layers.append(dict(
+                wq=ops.w_linear(sd[S + 'q_proj.weight'], dev, QS), bq=ops.w_bias(sd[S + 'q_proj.bias'], dev, QS),
+                wkv=ops.w_linear(torch.cat([sd[S + 'k_proj.weight'].float(), sd[S + 'v_proj.weight'].float()]), dev),
+                bkv=ops.w_bias(torch.cat([sd[S + 'k_proj.bias'].float(), sd[S + 'v_proj.bias'].float()]), dev),
+                wo=ops.w_linear(sd[S + 'out_proj.weight'], dev), bo=ops.w_bias(sd[S + 'out_proj.bias'], dev),
+                ln1=_ln(sd, L + 'self_attn_layer_norm', dev),
+                cwq=ops.w_linear(sd[C + 'q_proj.weight'], dev, QS), cbq=ops.w_bias(sd[C + 'q_proj.bias'], dev, QS),
+                cwkv=ops.w_linear(torch.cat([sd[C + 'k_proj.weight'].float(), sd[C + 'v_proj.weight'].float()]), dev),
+                cbkv=ops.w_bias(torch.cat([sd[C + 'k_proj.bias'].float(), sd[C + 'v_proj.bias'].float()]), dev),
+                cwo=ops.w_linear(sd[C + 'out_proj.weight'], dev), cbo=ops.w_bias(sd[C + 'out_proj.bias'], dev),
+                ln2=_ln(sd, L + 'encoder_attn_layer_norm', dev),
+                w1=ops.w_linear(sd[L + 'feed_forward.intermediate_dense.weight'], dev),
+                b1=ops.w_bias(sd[L + 'feed_forward.intermediate_dense.bias'], dev),
+                w2=ops.w_linear(sd[L + 'feed_forward.output_dense.weight'], dev),
+                b2=ops.w_bias(sd[L + 'feed_forward.output_dense.bias'], dev),
+                ln3=_ln(sd, L + 'final_layer_norm', dev)))
+        O = 'speech_decoder_postnet.'
+        self.feat = (ops.w_linear(sd[O + 'feat_out.weight'], dev), ops.w_bias(sd[O + 'feat_out.bias'], dev))
+        self.prob = (ops.w_linear(sd[O + 'prob_out.weight'], dev), ops.w_bias(sd[O + 'prob_out.bias'], dev))
+        self.postnet = []
+        for i in range(5):                  # fold eval-mode BatchNorm into the (bias-free) conv
+            b = O + 'layers.%d.batch_norm.' % i
+            s = sd[b + 'weight'].float() / torch.sqrt(sd[b + 'running_var'].float() + 1e-5)
+            shift = sd[b + 'bias'].float() - sd[b + 'running_mean'].float() * s
+            self.postnet.append((ops.w_conv(sd[O + 'layers.%d.conv.weight' % i], dev, scale_per_out=s), shift.contiguous().to(dev)))
+
+    # ---- text encoder (HelloSippyRTPipe.py:111-115) -------------------------------------------
+    def encode(self, input_ids: torch.Tensor, lens: torch.Tensor) -> torch.Tensor:
+        """input_ids int32 [B,T] (right-padded), lens int32 [B] -> bf16 [B,T,768]"""
+        dev = self.device
+        Bn, T = input_ids.shape
+        rows = Bn * T
+        e = lambda *s, dt=BF16: torch.empty(s, dtype=dt, device=dev)
+        ids = input_ids.to(dev, torch.int32).contiguous()
+        lens = lens.to(dev, torch.int32).contiguous()
+        x, t1 = e(rows, D), e(rows, D)
+        ops.embed(ids, self.tok, self.pe_enc, t1, n=rows, dim=D, pos0=0, seq_len=T)
+        ops.layernorm(t1, *self.enc_ln, x, rows, D)
+        qkv, att, ff = e(rows, 3 * D), e(rows, D), e(rows, FF)
+        rel = e(rows, H, 320, dt=torch.float32)
+        for L in self.enc_layers:
+            ops.linear(x, L['wqkv'], L['bqkv'], qkv, rows=rows, k=D, n=3 * D)
+            # relative position bias table R[b,t,h,:] = q_h . pe_k^T  (q already scaled)
+            ops.conv(qkv, self.pe_k, None, rel, nbatch=rows, t_in=H, t_out=H, cin=64, n=320, lda=64, x_bstride=3 * D)
+            ops.attn_prefill(qkv, qkv, qkv, att, nbatch=Bn, nheads=H, tq=T, tk=T, k_off=D, v_off=2 * D,
+                             q_ts=3 * D, k_ts=3 * D, v_ts=3 * D, o_ts=D, key_len=lens, relbias=rel, nrel=320)
+            ops.linear(att, L['wo'], L['bo'], t1, rows=rows, k=D, n=D, resid=x)
+            ops.layernorm(t1, *L['ln1'], x, rows, D)
+            ops.linear(x, L['w1'], L['b1'], ff, rows=rows, k=D, n=FF, act=ACT_GELU)
+            ops.linear(ff, L['w2'], L['b2'], t1, rows=rows, k=FF, n=D, resid=x)
+            ops.layernorm(t1, *L['ln2'], x, rows, D)
+        return x.view(Bn, T, D)
+
+
+class TTSBatchState:
+    """Device-resident HelloSippyPipeStateBatched (HelloSippyRTPipe.py:81-121)."""
+
+    def __init__(self, model: SpeechT5, input_ids, lens, speakers):
+        dev = model.device
+        self.B, self.T = input_ids.shape
+        B, T = self.B, self.T
+        self.enc_len = lens.to(dev, torch.int32).contiguous()
+        self.enc = model.encode(input_ids, lens)
+        self.maxlen = int(T * 20.0 / 2)
+        self.minlen = 0
+        self.idx = 0
+        e = lambda *s, dt=BF16: torch.empty(s, dtype=dt, device=dev)
+        # cross-attention K|V of every decoder layer, computed once
+        self.cross = []
+        for L in model.dec_layers:
+            kv = e(B * T, 2 * D)
+            ops.linear(self.enc, L['cwkv'], L['cbkv'], kv, rows=B * T, k=D, n=2 * D)
+            self.cross.append(kv)
+        self.smax = min(model.max_steps, self.maxlen + 32)
+        self.self_kv = [torch.zeros((B, self.smax, 2 * D), dtype=BF16, device=dev) for _ in model.dec_layers]
+        self.spec = torch.zeros((B, 33, 80), dtype=BF16, device=dev)       # frame 0 = carried last frame
+        self.cat = torch.zeros((B, D + 512), dtype=BF16, device=dev)
+        spk = speakers.to(dev, BF16).contiguous().view(B, 512)
+        _lib.check(_lib.lib().ifh_l2norm_rows_bf16(ops._addr(spk), 512, B, ops._addr(self.cat, D), D + 512,
+                                                   _lib.stream_ptr(dev)), 'ifh_l2norm_rows_bf16')
+        self.pre_frames = torch.zeros((B, 4, 80), dtype=BF16, device=dev)
+        self.starts_at = torch.full((B,), 1, dtype=torch.int64, device=dev)
+        self.ends_at = torch.full((B,), -1, dtype=torch.int64, device=dev)
+        self.post = e(B, 32, 80)
+        self.audio = None
+        # scratch
+        self.h1, self.h2, self.x = e(B, 256), e(B, 256), e(B, D)
+        self.q, self.att, self.t1, self.ff = e(B, D), e(B, D), e(B, D), e(B, FF)
+        self.plog = e(B, 2, dt=torch.float32)
+        self.pn = [e(B, 32, 256), e(B, 32, 256)]
+
+
+def decoder_steps(model: SpeechT5, st: TTSBatchState, masks: torch.Tensor, nsteps=16, threshold=0.5):
+    """The while-loop of HelloSippyRTPipe.infer (:195-229).  masks uint8 [nsteps,2,256] on device."""
+    dev = model.device
+    B, T = st.B, st.T
+    assert st.idx + nsteps <= st.smax, 'decoder step budget exceeded'
+    for s in range(nsteps):
+        pos = st.idx
+        # prenet on the last produced frame (frame 2s of the call buffer)
+        ops.linear(st.spec, *model.p0, st.h1, rows=B, k=80, n=256, x_off=2 * s * 80, lda=33 * 80, act=ACT_RELU,
+                   colmask=masks, colmask_off=(s * 2) * 256)
+        ops.linear(st.h1, *model.p1, st.h2, rows=B, k=256, n=256, act=ACT_RELU, colmask=masks, colmask_off=(s * 2 + 1) * 256)
+        ops.linear(st.h2, *model.pf, st.cat, rows=B, k=256, n=D, ldc=D + 512, resid=model.pe_dec, resid_off=pos * D,
+                   resid_ld=0, resid_bstride=0)
+        ops.linear(st.cat, *model.ps, st.x, rows=B, k=D + 512, n=D, act=ACT_RELU)
+        x = st.x
+        for li, L in enumerate(model.dec_layers):
+            kv = st.self_kv[li]
+            ops.linear(x, L['wq'], L['bq'], st.q, rows=B, k=D, n=D)
+            ops.conv(x, L['wkv'], L['bkv'], kv, nbatch=B, t_in=1, t_out=1, cin=D, n=2 * D, out_bstride=st.smax * 2 * D,
+                     ldc=2 * D, ooff=pos)
+            ops.attn_decode(st.q, kv, kv, st.att, nbatch=B, nheads=H, max_keys=pos + 1, q_bs=D, kv_bs=st.smax * 2 * D,
+                            kv_ts=2 * D, o_bs=D, v_off=D)
+            ops.linear(st.att, L['wo'], L['bo'], st.t1, rows=B, k=D, n=D, resid=x)
+            ops.layernorm(st.t1, *L['ln1'], st.x, B, D)
+            ops.linear(st.x, L['cwq'], L['cbq'], st.q, rows=B, k=D, n=D)
+            ck = st.cross[li]
+            ops.attn_decode(st.q, ck, ck, st.att, nbatch=B, nheads=H, max_keys=T, q_bs=D, kv_bs=T * 2 * D, kv_ts=2 * D,
+                            o_bs=D, v_off=D, key_len=st.enc_len)
+            ops.linear(st.att, L['cwo'], L['cbo'], st.t1, rows=B, k=D, n=D, resid=st.x)
+            ops.layernorm(st.t1, *L['ln2'], st.x, B, D)
+            ops.linear(st.x, L['w1'], L['b1'], st.ff, rows=B, k=D, n=FF, act=ACT_GELU)
+            ops.linear(st.ff, L['w2'], L['b2'], st.t1, rows=B, k=FF, n=D, resid=st.x)
+            ops.layernorm(st.t1, *L['ln3'], st.x, B, D)
+            x = st.x
+        # two new mel frames -> frames 2s+1, 2s+2 ; stop logits
+        ops.linear(x, *model.feat, st.spec, rows=B, k=D, n=160, out_off=(2 * s + 1) * 80, ldc=33 * 80)
+        ops.linear(x, *model.prob, st.plog, rows=B, k=D, n=2)
+        _lib.check(_lib.lib().ifh_tts_stop_update(ops._addr(st.plog), ops._addr(st.ends_at), B, pos, st.minlen, st.maxlen,
+                                                  threshold, 2, _lib.stream_ptr(dev)), 'ifh_tts_stop_update')
+        st.idx += 1
+
+
+def postnet(model: SpeechT5, st: TTSBatchState):
+    """speech_decoder_postnet.postnet on the 32 new frames (:230) -> st.post bf16 [B,32,80]"""
+    B = st.B
+    src, lda, off, cin = st.spec, 80, 80, 80
+    for i, (w, shift) in enumerate(model.postnet):
+        last = i == 4
+        out = st.post if last else st.pn[i % 2]
+        cout = 80 if last else 256
+        ops.conv(src, w, shift, out, nbatch=B, t_in=32, t_out=32, cin=cin, n=cout, taps=5, pad=2, x_off=off,
+                 x_bstride=(33 * 80 if i == 0 else 32 * cin), lda=cin, act=(0 if last else ACT_TANH),
+                 resid=(st.spec if last else None), resid_off=(80 if last else 0), resid_ld=80, resid_bstride=33 * 80)
+        src, off, cin = out, 0, cout
+    # carry the last produced frame into slot 0 for the next call
+    st.spec[:, 0, :].copy_(st.spec[:, 32, :])
+    return st.post

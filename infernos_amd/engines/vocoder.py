@@ -1,0 +1,134 @@
+"""HiFi-GAN vocoder + AmendmentNetwork1 on the HIP device.
+
+Replaces `self.vocoder(spectrogram)` / `self.chunker(spectrogram, audio)` at
+HelloSippyTTSRT/HelloSippyRTPipe.py:236-237 (transformers SpeechT5HifiGan,
+modeling_speecht5.py:2954-3064; AmendmentNetwork1, HelloSippyRT.py:181-237).  Every
+convolution is one ifh_conv_bf16 launch (implicit GEMM on the matrix cores) with LeakyReLU
+fused on the operand load and bias/residual/3-way-mean fused in the epilogue; the transposed
+convolutions run as 4 two-tap phases.
+"""
+import torch
+
+from .. import _lib, ops
+from ..ops import ACT_LRELU, ACT_NONE, BF16
+
+
+class HifiGan:
+    def __init__(self, sd, device):
+        self.device = dev = _lib.require_device(device)
+        self.mean = sd['mean'].float().to(dev)
+        self.scale = sd['scale'].float().to(dev)
+        self.pre_w, self.pre_b = ops.w_conv(sd['conv_pre.weight'], dev), ops.w_bias(sd['conv_pre.bias'], dev)
+        self.up = [(ops.w_convT_phases(sd['upsampler.%d.weight' % i], dev), ops.w_bias(sd['upsampler.%d.bias' % i], dev))
+                   for i in range(4)]
+        self.res = []
+        for i in range(4):
+            lvl = []
+            for j, k in enumerate((3, 7, 11)):
+                R = 'resblocks.%d.' % (i * 3 + j)
+                lvl.append([(ops.w_conv(sd[R + 'convs1.%d.weight' % d], dev), ops.w_bias(sd[R + 'convs1.%d.bias' % d], dev),
+                             ops.w_conv(sd[R + 'convs2.%d.weight' % d], dev), ops.w_bias(sd[R + 'convs2.%d.bias' % d], dev))
+                            for d in range(3)])
+            self.res.append(lvl)
+        self.post_w = sd['conv_post.weight'].float()[0].t().contiguous().to(dev)     # [7][32]
+        self.post_b = float(sd['conv_post.bias'].float()[0])
+        self._bufs = {}
+
+    def _buffers(self, n, t0):
+        key = (n, t0)
+        if key not in self._bufs:
+            dev = self.device
+            b = {'x0': torch.empty((n, t0, 512), dtype=BF16, device=dev)}
+            t, c = t0, 512
+            for i in range(4):
+                t, c = t * 4, c // 2
+                for nm in ('u', 'h', 'r0', 'r1', 'xn'):
+                    b['%s%d' % (nm, i)] = torch.empty((n, t, c), dtype=BF16, device=dev)
+            b['audio'] = torch.empty((n, t), dtype=BF16, device=dev)
+            self._bufs = {key: b}          # keep one shape resident
+        return self._bufs[key]
+
+    def __call__(self, voc_in: torch.Tensor) -> torch.Tensor:
+        """voc_in bf16 [N, T, 80], already (x-mean)/scale normalised -> bf16 [N, 256*T]"""
+        n, t0, _ = voc_in.shape
+        B = self._buffers(n, t0)
+        ops.conv(voc_in, self.pre_w, self.pre_b, B['x0'], nbatch=n, t_in=t0, t_out=t0, cin=80, n=512, taps=7, pad=3)
+        prev, t, c = B['x0'], t0, 512
+        for i in range(4):
+            phases, ub = self.up[i]
+            u = B['u%d' % i]
+            for r, (w, pad) in enumerate(phases):
+                ops.conv(prev, w, ub, u, nbatch=n, t_in=t, t_out=t, cin=c, n=c // 2, taps=2, pad=pad, pre_slope=0.1,
+                         ostride=4, ooff=r)
+            t, c = t * 4, c // 2
+            h, xn = B['h%d' % i], B['xn%d' % i]
+            rbuf = (B['r0%d' % i], B['r1%d' % i])
+            for j, k in enumerate((3, 7, 11)):
+                cur = u
+                for di, d in enumerate((1, 3, 5)):
+                    w1, b1, w2, b2 = self.res[i][j][di]
+                    ops.conv(cur, w1, b1, h, nbatch=n, t_in=t, t_out=t, cin=c, n=c, taps=k, dil=d, pad=(k * d - d) // 2,
+                             pre_slope=0.1)
+                    if di < 2:
+                        nxt = rbuf[di]
+                        ops.conv(h, w2, b2, nxt, nbatch=n, t_in=t, t_out=t, cin=c, n=c, taps=k, pad=(k - 1) // 2,
+                                 pre_slope=0.1, resid=cur)
+                        cur = nxt
+                    else:       # last dilation: fold the /3 mean over the three resblocks into the epilogue
+                        ops.conv(h, w2, b2, xn, nbatch=n, t_in=t, t_out=t, cin=c, n=c, taps=k, pad=(k - 1) // 2,
+                                 pre_slope=0.1, resid=cur, scale=1.0 / 3.0, accumulate=(j > 0))
+            prev = xn
+        audio = B['audio']
+        _lib.check(_lib.lib().ifh_hifigan_post_bf16(ops._addr(prev), ops._addr(self.post_w), self.post_b, ops._addr(audio),
+                                                    n, t, 0.01, _lib.stream_ptr(self.device)), 'ifh_hifigan_post_bf16')
+        return audio
+
+
+class Amendment:
+    """AmendmentNetwork1 (HelloSippyRT.py:181-237) for 12-frame chunks."""
+
+    def __init__(self, sd, device):
+        self.device = dev = _lib.require_device(device)
+        g = lambda k: sd[k]
+        self.pm_w, self.pm_b = ops.w_conv(g('conv_pre_m.weight'), dev), ops.w_bias(g('conv_pre_m.bias'), dev)
+        self.pa_w, self.pa_b = ops.w_conv(g('conv_pre_a.weight'), dev), ops.w_bias(g('conv_pre_a.bias'), dev)
+        self.up = [(ops.w_convT_phases(g('upsampler.%d.weight' % i), dev), ops.w_bias(g('upsampler.%d.bias' % i), dev))
+                   for i in range(2)]
+        self.r1_w, self.r1_b = ops.w_conv(g('resblock.conv1.weight'), dev), ops.w_bias(g('resblock.conv1.bias'), dev)
+        self.r2_w, self.r2_b = ops.w_conv(g('resblock.conv2.weight'), dev), ops.w_bias(g('resblock.conv2.bias'), dev)
+        self.po_w, self.po_b = ops.w_conv(g('post_conv.weight'), dev), ops.w_bias(g('post_conv.bias'), dev)
+        self._bufs = {}
+
+    def _buffers(self, n):
+        if n not in self._bufs:
+            dev = self.device
+            e = lambda *s: torch.empty(s, dtype=BF16, device=dev)
+            self._bufs = {n: dict(a_cl=e(n, 12, 256), cat=e(n, 12, 192), u0=e(n, 48, 128), u1=e(n, 192, 64),
+                                  h=e(n, 192, 64), r=e(n, 192, 64), post=e(n, 8, 256))}
+        return self._bufs[n]
+
+    def __call__(self, amd_mel: torch.Tensor, audio: torch.Tensor, out: torch.Tensor, nbatch: int):
+        """amd_mel bf16 [4B,12,80] (ifh_tts_chunks_bf16 output), audio bf16 [4B,3072] -> out bf16 [B,8192]"""
+        n = audio.size(0)
+        assert n == 4 * nbatch and audio.size(1) == 3072
+        B = self._buffers(n)
+        ops.transpose_to_bf16(audio, B['a_cl'], n, 256, 12)                      # audio.view(N,256,12) -> [N,12,256]
+        ops.conv(amd_mel, self.pm_w, self.pm_b, B['cat'], nbatch=n, t_in=12, t_out=12, cin=80, n=32, taps=3, pad=1, ldc=192)
+        ops.conv(B['a_cl'], self.pa_w, self.pa_b, B['cat'], nbatch=n, t_in=12, t_out=12, cin=256, n=160, taps=3, pad=1,
+                 ldc=192, out_off=32)
+        prev, t, c = B['cat'], 12, 192
+        for i, co in enumerate((128, 64)):
+            phases, ub = self.up[i]
+            u = B['u%d' % i]
+            for r, (w, pad) in enumerate(phases):
+                ops.conv(prev, w, ub, u, nbatch=n, t_in=t, t_out=t, cin=c, n=co, taps=2, pad=pad, pre_slope=0.01,
+                         ostride=4, ooff=r)
+            prev, t, c = u, t * 4, co
+        ops.conv(prev, self.r1_w, self.r1_b, B['h'], nbatch=n, t_in=192, t_out=192, cin=64, n=64, taps=3, pad=1, pre_slope=0.01)
+        ops.conv(B['h'], self.r2_w, self.r2_b, B['r'], nbatch=n, t_in=192, t_out=192, cin=64, n=64, taps=3, dil=3, pad=3,
+                 pre_slope=0.01, resid=prev)
+        ops.conv(B['r'], self.po_w, self.po_b, B['post'], nbatch=n, t_in=192, t_out=8, cin=64, n=256, taps=8, stride=24,
+                 pad=0, pre_slope=0.01, act=ACT_LRELU, act_slope=0.01)
+        _lib.check(_lib.lib().ifh_amend_final_bf16(ops._addr(B['post']), ops._addr(audio), ops._addr(out), nbatch,
+                                                   _lib.stream_ptr(self.device)), 'ifh_amend_final_bf16')
+        return out

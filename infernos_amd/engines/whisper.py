@@ -1,0 +1,174 @@
+"""Whisper encoder/decoder with greedy search on the HIP device.
+
+Replaces the engines behind Cluster/InfernSTTWorker.py:61-107 (CTranslate2
+`Whisper.generate`, or the HF/ipex torch path): conv front-end, pre-LN transformer encoder,
+KV-cached decoder, tied output projection, greedy argmax and the no-speech probability
+(softmax of the first-position logits at <|nospeech|>, InfernSTTWorker.py:89-90).
+Architecture per transformers modeling_whisper.py (v5.15.0).  The decode loop runs entirely
+on the device (argmax feeds the next embedding lookup; no host sync per token).
+"""
+import torch
+
+from .. import _lib, ops
+from ..ops import ACT_GELU, BF16
+
+QS = 64 ** -0.5
+N_CTX = 1500
+
+
+def _ln(sd, p, dev):
+    return sd[p + '.weight'].float().contiguous().to(dev), sd[p + '.bias'].float().contiguous().to(dev)
+
+
+class Whisper:
+    def __init__(self, sd, device, max_batch=64, max_tokens=448):
+        self.device = dev = _lib.require_device(device)
+        E, Dc = 'model.encoder.', 'model.decoder.'
+        self.d = d = sd[E + 'conv1.weight'].shape[0]
+        self.n_mel = sd[E + 'conv1.weight'].shape[1]
+        self.h = d // 64
+        self.ff = sd[E + 'layers.0.fc1.weight'].shape[0]
+        self.vocab = sd[Dc + 'embed_tokens.weight'].shape[0]
+        self.max_tokens = min(max_tokens, sd[Dc + 'embed_positions.weight'].shape[0])
+        self.c1 = (ops.w_conv(sd[E + 'conv1.weight'], dev), ops.w_bias(sd[E + 'conv1.bias'], dev))
+        self.c2 = (ops.w_conv(sd[E + 'conv2.weight'], dev), ops.w_bias(sd[E + 'conv2.bias'], dev))
+        self.enc_pos = sd[E + 'embed_positions.weight'].to(BF16).contiguous().to(dev)
+        self.enc_layers, self.dec_layers = [], []
+        zero_k = torch.zeros(d)
+
+        def attn(prefix, fused_qkv):
+            q = (sd[prefix + 'q_proj.weight'].float() * QS, sd[prefix + 'q_proj.bias'].float() * QS)
+            k = (sd[prefix + 'k_proj.weight'].float(), zero_k)                 # k_proj has no bias
+            v = (sd[prefix + 'v_proj.weight'].float(), sd[prefix + 'v_proj.bias'].float())
+            out = dict(wo=ops.w_linear(sd[prefix + 'out_proj.weight'], dev), bo=ops.w_bias(sd[prefix + 'out_proj.bias'], dev))
+            if fused_qkv:
+                out['wqkv'] = ops.w_linear(torch.cat([q[0], k[0], v[0]]), dev)
+                out['bqkv'] = ops.w_bias(torch.cat([q[1], k[1], v[1]]), dev)
+            else:
+                out['wq'], out['bq'] = ops.w_linear(q[0], dev), ops.w_bias(q[1], dev)
+                out['wkv'] = ops.w_linear(torch.cat([k[0], v[0]]), dev)
+                out['bkv'] = ops.w_bias(torch.cat([k[1], v[1]]), dev)
+            return out
+        i = 0
+        while (E + 'layers.%d.fc1.weight' % i) in sd:
+            L = E + 'layers.%d.' % i
+            lay = attn(L + 'self_attn.', True)
+            lay.update(ln1=_ln(sd, L + 'self_attn_layer_norm', dev), ln2=_ln(sd, L + 'final_layer_norm', dev),
+                       w1=ops.w_linear(sd[L + 'fc1.weight'], dev), b1=ops.w_bias(sd[L + 'fc1.bias'], dev),
+                       w2=ops.w_linear(sd[L + 'fc2.weight'], dev), b2=ops.w_bias(sd[L + 'fc2.bias'], dev))
+            self.enc_layers.append(lay)
+            i += 1
+        self.enc_ln = _ln(sd, E + 'layer_norm', dev)
+        i = 0
+        while (Dc + 'layers.%d.fc1.weight' % i) in sd:
+            L = Dc + 'layers.%d.' % i
+            lay = {'self': attn(L + 'self_attn.', False), 'cross': attn(L + 'encoder_attn.', False)}
+            lay.update(ln1=_ln(sd, L + 'self_attn_layer_norm', dev), ln2=_ln(sd, L + 'encoder_attn_layer_norm', dev),
+                       ln3=_ln(sd, L + 'final_layer_norm', dev),
+                       w1=ops.w_linear(sd[L + 'fc1.weight'], dev), b1=ops.w_bias(sd[L + 'fc1.bias'], dev),
+                       w2=ops.w_linear(sd[L + 'fc2.weight'], dev), b2=ops.w_bias(sd[L + 'fc2.bias'], dev))
+            self.dec_layers.append(lay)
+            i += 1
+        self.dec_ln = _ln(sd, Dc + 'layer_norm', dev)
+        self.tok = sd[Dc + 'embed_tokens.weight'].to(BF16).contiguous().to(dev)        # also the tied proj_out
+        self.dec_pos = sd[Dc + 'embed_positions.weight'].to(BF16).contiguous().to(dev)
+        self._enc_bufs = {}
+        self._dec_bufs = {}
+
+    # ---- encoder ------------------------------------------------------------------------------
+    def encode(self, mel: torch.Tensor) -> torch.Tensor:
+        """mel [B, n_mel, 3000] f32 or bf16 (ifh_logmel_run layout) -> bf16 [B, 1500, d]"""
+        dev, d, H, FF = self.device, self.d, self.h, self.ff
+        Bn = mel.size(0)
+        if Bn not in self._enc_bufs:
+            e = lambda *s: torch.empty(s, dtype=BF16, device=dev)
+            rows = Bn * N_CTX
+            self._enc_bufs = {Bn: dict(mt=e(Bn, 3000, self.n_mel), c1=e(Bn, 3000, d), x=e(rows, d), hn=e(rows, d),
+                                       qkv=e(rows, 3 * d), att=e(rows, d), ff=e(rows, FF), out=e(rows, d))}
+        b = self._enc_bufs[Bn]
+        rows = Bn * N_CTX
+        ops.transpose_to_bf16(mel.contiguous(), b['mt'], Bn, self.n_mel, 3000)
+        ops.conv(b['mt'], *self.c1, b['c1'], nbatch=Bn, t_in=3000, t_out=3000, cin=self.n_mel, n=d, taps=3, pad=1, act=ACT_GELU)
+        ops.conv(b['c1'], *self.c2, b['x'], nbatch=Bn, t_in=3000, t_out=N_CTX, cin=d, n=d, taps=3, stride=2, pad=1,
+                 act=ACT_GELU, resid=self.enc_pos, resid_ld=d, resid_bstride=0)
+        x = b['x']
+        for L in self.enc_layers:
+            ops.layernorm(x, *L['ln1'], b['hn'], rows, d)
+            ops.linear(b['hn'], L['wqkv'], L['bqkv'], b['qkv'], rows=rows, k=d, n=3 * d)
+            ops.attn_prefill(b['qkv'], b['qkv'], b['qkv'], b['att'], nbatch=Bn, nheads=H, tq=N_CTX, tk=N_CTX, k_off=d,
+                             v_off=2 * d, q_ts=3 * d, k_ts=3 * d, v_ts=3 * d, o_ts=d)
+            ops.linear(b['att'], L['wo'], L['bo'], x, rows=rows, k=d, n=d, resid=x)
+            ops.layernorm(x, *L['ln2'], b['hn'], rows, d)
+            ops.linear(b['hn'], L['w1'], L['b1'], b['ff'], rows=rows, k=d, n=FF, act=ACT_GELU)
+            ops.linear(b['ff'], L['w2'], L['b2'], x, rows=rows, k=FF, n=d, resid=x)
+        ops.layernorm(x, *self.enc_ln, b['out'], rows, d)
+        return b['out'].view(Bn, N_CTX, d)
+
+    # ---- decoder ------------------------------------------------------------------------------
+    def _dec(self, Bn):
+        if Bn not in self._dec_bufs:
+            dev, d = self.device, self.d
+            e = lambda *s, dt=BF16: torch.empty(s, dtype=dt, device=dev)
+            self._dec_bufs = {Bn: dict(
+                cross=[e(Bn * N_CTX, 2 * d) for _ in self.dec_layers],
+                kv=[torch.zeros((Bn, self.max_tokens, 2 * d), dtype=BF16, device=dev) for _ in self.dec_layers],
+                x=e(Bn, d), hn=e(Bn, d), q=e(Bn, d), att=e(Bn, d), ff=e(Bn, self.ff),
+                logits=e(Bn, self.vocab, dt=torch.float32))}
+        return self._dec_bufs[Bn]
+
+    def decoder_step(self, ids: torch.Tensor, ids_off: int, ids_stride_ok: bool, pos: int, bufs, Bn: int):
+        """One token per sequence at position pos; ids int32 buffer, row-contiguous column view
+        is not needed: the caller passes a dense int32[B] tensor (ids_off selects a column block)."""
+        d, H = self.d, self.h
+        x = bufs['x']
+        _lib.check(_lib.lib().ifh_embed_bf16(ops._addr(ids, ids_off), ops._addr(self.tok), ops._addr(self.dec_pos), pos, 1,
+                                             d, Bn, ops._addr(x), _lib.stream_ptr(self.device)), 'ifh_embed_bf16')
+        smax = self.max_tokens
+        for li, L in enumerate(self.dec_layers):
+            S, C = L['self'], L['cross']
+            kv = bufs['kv'][li]
+            ops.layernorm(x, *L['ln1'], bufs['hn'], Bn, d)
+            ops.linear(bufs['hn'], S['wq'], S['bq'], bufs['q'], rows=Bn, k=d, n=d)
+            ops.conv(bufs['hn'], S['wkv'], S['bkv'], kv, nbatch=Bn, t_in=1, t_out=1, cin=d, n=2 * d,
+                     out_bstride=smax * 2 * d, ldc=2 * d, ooff=pos)
+            ops.attn_decode(bufs['q'], kv, kv, bufs['att'], nbatch=Bn, nheads=H, max_keys=pos + 1, q_bs=d,
+                            kv_bs=smax * 2 * d, kv_ts=2 * d, o_bs=d, v_off=d)
+            ops.linear(bufs['att'], S['wo'], S['bo'], x, rows=Bn, k=d, n=d, resid=x)
+            ops.layernorm(x, *L['ln2'], bufs['hn'], Bn, d)
+            ops.linear(bufs['hn'], C['wq'], C['bq'], bufs['q'], rows=Bn, k=d, n=d)
+            ck = bufs['cross'][li]
+            ops.attn_decode(bufs['q'], ck, ck, bufs['att'], nbatch=Bn, nheads=H, max_keys=N_CTX, q_bs=d,
+                            kv_bs=N_CTX * 2 * d, kv_ts=2 * d, o_bs=d, v_off=d)
+            ops.linear(bufs['att'], C['wo'], C['bo'], x, rows=Bn, k=d, n=d, resid=x)
+            ops.layernorm(x, *L['ln3'], bufs['hn'], Bn, d)
+            ops.linear(bufs['hn'], L['w1'], L['b1'], bufs['ff'], rows=Bn, k=d, n=self.ff, act=ACT_GELU)
+            ops.linear(bufs['ff'], L['w2'], L['b2'], x, rows=Bn, k=self.ff, n=d, resid=x)
+        ops.layernorm(x, *self.dec_ln, bufs['hn'], Bn, d)
+        ops.linear(bufs['hn'], self.tok, None, bufs['logits'], rows=Bn, k=d, n=self.vocab)
+        return bufs['logits']
+
+    def generate(self, enc: torch.Tensor, prompts: torch.Tensor, n_new: int, no_speech_id=None, keep_logits=False):
+        """Greedy decode exactly n_new tokens after the prompt.
+        enc bf16 [B,1500,d]; prompts int32 [B,P] -> (tokens int32 [B,n_new] on device,
+        no_speech_prob f32 [B] or None, first_logits f32 [B,V] (after the whole prompt) if keep_logits)."""
+        dev, d = self.device, self.d
+        Bn, P = prompts.shape
+        assert P + n_new <= self.max_tokens
+        bufs = self._dec(Bn)
+        for li, L in enumerate(self.dec_layers):
+            C = L['cross']
+            ops.linear(enc, C['wkv'], C['bkv'], bufs['cross'][li], rows=Bn * N_CTX, k=d, n=2 * d)
+        # token matrix, column-major so that each step's ids are a dense int32[B] block
+        toks = torch.zeros((P + n_new, Bn), dtype=torch.int32, device=dev)
+        toks[:P] = prompts.to(dev, torch.int32).t()
+        nsp = torch.empty(Bn, dtype=torch.float32, device=dev) if no_speech_id is not None else None
+        first = None
+        for pos in range(P + n_new - 1):
+            logits = self.decoder_step(toks, pos * Bn, True, pos, bufs, Bn)
+            if pos == 0 and nsp is not None:
+                ops.argmax_pick(logits, vocab=self.vocab, nrows=Bn, pick_token=no_speech_id, pick_prob_out=nsp)
+            if pos >= P - 1:
+                if pos == P - 1 and keep_logits:
+                    first = logits.clone()
+                ops.argmax_pick(logits, vocab=self.vocab, nrows=Bn, argmax_out=toks, out_off=(pos + 1) * Bn)
+        return toks[P:].t().contiguous(), nsp, first

@@ -1,0 +1,137 @@
+"""Tensor-level wrappers over the dense C-ABI entry points (ifh_conv_bf16, ifh_layernorm_bf16,
+ifh_attn_*).  torch tensors are used only as device memory; every FLOP happens in
+libinfernos_hip.so.  All activations are bf16, channels-last.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import AttnDesc, ConvDesc
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_LRELU, ACT_SIGMOID = range(6)
+BF16 = torch.bfloat16
+
+
+def _addr(t, off=0):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr() + off * t.element_size())
+
+
+def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=1, pad=0,
+         x_off=0, lda=None, x_bstride=None, act=ACT_NONE, act_slope=0.0, pre_slope=1.0, colmask=None, colmask_off=0,
+         resid=None, resid_off=0, resid_ld=None, resid_bstride=None, scale=1.0, accumulate=False,
+         out_off=0, ldc=None, out_bstride=None, ostride=1, ooff=0):
+    """One implicit-GEMM launch (see ifh_conv_desc).  Strides default to dense [nbatch][t][c]."""
+    d = ConvDesc()
+    lda = cin if lda is None else lda
+    ldc = n if ldc is None else ldc
+    d.x, d.x_bstride, d.lda = _addr(x, x_off), (t_in * lda if x_bstride is None else x_bstride), lda
+    d.cin, d.taps, d.stride, d.dil, d.pad = cin, taps, stride, dil, pad
+    d.t_in, d.t_out, d.nbatch = t_in, t_out, nbatch
+    d.w, d.n = _addr(w), n
+    d.bias, d.colmask = _addr(bias), _addr(colmask, colmask_off)
+    d.pre_slope, d.act, d.act_slope = pre_slope, act, act_slope
+    d.resid = _addr(resid, resid_off)
+    d.resid_ld = ldc if resid_ld is None else resid_ld
+    d.resid_bstride = (t_out * ostride * d.resid_ld if resid_bstride is None else resid_bstride)
+    d.out_scale, d.accumulate = scale, int(accumulate)
+    d.out, d.out_f32 = _addr(out, out_off), int(out.dtype == torch.float32)
+    d.out_bstride = (t_out * ostride * ldc if out_bstride is None else out_bstride)
+    d.ldc, d.ostride, d.ooff = ldc, ostride, ooff
+    _lib.check(_lib.lib().ifh_conv_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_conv_bf16')
+    return out
+
+
+def linear(x, w, bias, out, *, rows, k, n, **kw):
+    """out[rows, n] = epi(x[rows, k] @ w[n, k]^T + bias)"""
+    return conv(x, w, bias, out, nbatch=1, t_in=rows, t_out=rows, cin=k, n=n, **kw)
+
+
+def layernorm(x, gamma, beta, out, rows, dim, resid=None, eps=1e-5):
+    _lib.check(_lib.lib().ifh_layernorm_bf16(_addr(x), _addr(resid), _addr(gamma), _addr(beta), _addr(out), rows, dim,
+                                             eps, _lib.stream_ptr(out.device)), 'ifh_layernorm_bf16')
+    return out
+
+
+def transpose_to_bf16(x, out, nbatch, rows, cols):
+    _lib.check(_lib.lib().ifh_transpose_to_bf16(_addr(x), int(x.dtype == torch.float32), _addr(out), nbatch, rows, cols,
+                                                _lib.stream_ptr(out.device)), 'ifh_transpose_to_bf16')
+    return out
+
+
+def attn_prefill(q, k, v, out, *, nbatch, nheads, tq, tk, q_off=0, k_off=0, v_off=0, q_ts, k_ts, v_ts, o_ts,
+                 q_bs=None, k_bs=None, v_bs=None, o_bs=None, key_len=None, relbias=None, nrel=0):
+    d = AttnDesc()
+    d.q, d.k, d.v, d.out = _addr(q, q_off), _addr(k, k_off), _addr(v, v_off), _addr(out)
+    d.q_ts, d.k_ts, d.v_ts, d.o_ts = q_ts, k_ts, v_ts, o_ts
+    d.q_bs = tq * q_ts if q_bs is None else q_bs
+    d.k_bs = tk * k_ts if k_bs is None else k_bs
+    d.v_bs = tk * v_ts if v_bs is None else v_bs
+    d.o_bs = tq * o_ts if o_bs is None else o_bs
+    d.nbatch, d.nheads, d.head_dim, d.tq, d.tk = nbatch, nheads, 64, tq, tk
+    d.key_len, d.relbias, d.nrel = _addr(key_len), _addr(relbias), nrel
+    _lib.check(_lib.lib().ifh_attn_prefill_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_attn_prefill_bf16')
+    return out
+
+
+def attn_decode(q, k, v, out, *, nbatch, nheads, max_keys, q_bs, kv_bs, kv_ts, o_bs, k_off=0, v_off=0, key_len=None):
+    _lib.check(_lib.lib().ifh_attn_decode_bf16(_addr(q), q_bs, _addr(k, k_off), _addr(v, v_off), kv_bs, kv_ts, _addr(out),
+                                               o_bs, _addr(key_len), max_keys, nbatch, nheads, 64,
+                                               _lib.stream_ptr(out.device)), 'ifh_attn_decode_bf16')
+    return out
+
+
+def embed(ids, table, pos_table, out, *, n, dim, pos0=0, seq_len=1):
+    _lib.check(_lib.lib().ifh_embed_bf16(_addr(ids), _addr(table), _addr(pos_table), pos0, seq_len, dim, n, _addr(out),
+                                         _lib.stream_ptr(out.device)), 'ifh_embed_bf16')
+    return out
+
+
+def argmax_pick(logits, *, vocab, nrows, ld=None, argmax_out=None, pick_token=0, pick_prob_out=None, out_off=0):
+    _lib.check(_lib.lib().ifh_argmax_pick_f32(_addr(logits), vocab if ld is None else ld, vocab, nrows, pick_token,
+                                              _addr(argmax_out, out_off), _addr(pick_prob_out),
+                                              _lib.stream_ptr(logits.device)), 'ifh_argmax_pick_f32')
+
+
+# ---- weight preparation (host side, once per model load) -----------------------------------
+def w_linear(w, device, scale=None):
+    w = w.float()
+    if scale is not None:
+        w = w * scale
+    return w.to(BF16).contiguous().to(device)
+
+
+def w_bias(b, device, scale=None, n=None):
+    if b is None:
+        return torch.zeros(n, dtype=torch.float32, device=device)
+    b = b.float()
+    if scale is not None:
+        b = b * scale
+    return b.contiguous().to(device)
+
+
+def w_conv(w, device, scale_per_out=None):
+    """Conv1d weight [Cout, Cin, k] -> bf16 [Cout][k][Cin]"""
+    w = w.float()
+    if scale_per_out is not None:
+        w = w * scale_per_out[:, None, None]
+    return w.permute(0, 2, 1).to(BF16).contiguous().to(device)
+
+
+def w_convT_phases(w, device):
+    """ConvTranspose1d(k=8, stride=4, padding=2) weight [Cin, Cout, 8] -> 4 phase weights
+    bf16 [Cout][2][Cin] and their left pads.  Output o = 4q + r takes input q-1 (tap k=r+6) and q
+    (k=r+2) for r in {0,1}; q (k=r+2) and q+1 (k=r-2) for r in {2,3}."""
+    w = w.float()
+    assert w.size(2) == 8
+    phases = []
+    for r in range(4):
+        if r < 2:
+            k0, k1, pad = r + 6, r + 2, 1
+        else:
+            k0, k1, pad = r + 2, r - 2, 0
+        wr = torch.stack([w[:, :, k0].t(), w[:, :, k1].t()], dim=1)     # [Cout][2][Cin]
+        phases.append((wr.to(BF16).contiguous().to(device), pad))
+    return phases

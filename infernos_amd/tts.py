@@ -1,0 +1,345 @@
+"""Text-to-speech plugin surface: HelloSippyRTPipe (+ request/state types), InfernTTSWorker,
+TTSRequest / TTSSndDispatch / TTSSession.
+
+Interface of HelloSippyTTSRT/HelloSippyRTPipe.py:47-272, Cluster/InfernTTSWorker.py:56-105 and
+Cluster/TTSSession.py:41-141.  `infer()` runs the whole 512 ms chunk (16 decoder steps,
+postnet, carry+chunking, HiFi-GAN, AmendmentNetwork1, optional 16k->8k resample) as HIP
+kernels; `unbatch_and_dispatch()` reproduces the reference's offset arithmetic and hands each
+live session a 1-D CPU tensor, then None at the end of the utterance.
+"""
+import uuid
+import weakref
+from functools import partial
+from time import monotonic
+from typing import Dict, List, Optional, Tuple, Union
+from uuid import UUID, uuid4
+
+import torch
+
+from . import _lib, ops
+from .audio import AudioChunk, get_resampler
+from .engines.speecht5 import SpeechT5, TTSBatchState, decoder_steps, postnet
+from .engines.vocoder import Amendment, HifiGan
+from .muxer import ASMarkerGeneric, ASMarkerNewSent, ASMarkerSentDoneCB
+from .torcher import InfernGlobals
+from .workers import InfernBatchedWorker
+
+
+class SessCmd:
+    pass
+
+
+class SessSyncCmd(SessCmd):
+    def __init__(self, sessions):
+        self.live = tuple(sorted(sessions.keys()))
+
+
+class SessDispatchCmd(SessCmd):
+    session: uuid.UUID
+
+    def __init__(self, session_id: uuid.UUID):
+        self.session = session_id
+
+
+class HelloSippyPlayRequest(SessDispatchCmd):
+    def __init__(self, session_id: uuid.UUID, text: str, speaker: torch.Tensor, dispatch: callable):
+        self.text, self.speaker, self.dispatch = text, speaker, dispatch
+        super().__init__(session_id)
+
+
+class HelloSippyPipeState:
+    """Per-utterance inputs (HelloSippyRTPipe.py:59-79): token ids, speaker x-vector."""
+
+    def __init__(self, pp: 'HelloSippyRTPipe', req: HelloSippyPlayRequest):
+        self.session, self.dispatch = req.session, req.dispatch
+        text = req.text if pp.cleanup_text is None else pp.cleanup_text(req.text)
+        self.inputs = pp.processor(text=text, return_tensors='pt')['input_ids']
+        self.speaker_embeddings = req.speaker
+        self.encoder_attention_mask = torch.ones_like(self.inputs, dtype=torch.int)
+
+
+class HelloSippyPipeStateBatched:
+    """Batch of utterances frozen at process_batch entry (HelloSippyRTPipe.py:81-121)."""
+
+    def __init__(self, states: List[HelloSippyPipeState], pp: 'HelloSippyRTPipe'):
+        self.dispatch = [s.dispatch for s in states]
+        self.sessions = [s.session for s in states]
+        T = max(s.inputs.size(1) for s in states)
+        ids = torch.zeros((len(states), T), dtype=torch.int32)        # right-padded with 0 like the reference
+        lens = torch.zeros(len(states), dtype=torch.int32)
+        for i, s in enumerate(states):
+            n = s.inputs.size(1)
+            ids[i, :n] = s.inputs[0].to(torch.int32)
+            lens[i] = n
+        spk = torch.cat([s.speaker_embeddings.reshape(1, 512).float() for s in states])
+        with torch.cuda.device(pp.device):
+            self.dev = TTSBatchState(pp.model, ids, lens, spk)
+        self.starts_at_host = [pp.post_nframes // 2] * len(states)
+        self.audio = None
+
+    # attribute views the reference exposes
+    idx = property(lambda self: self.dev.idx)
+    maxlen = property(lambda self: self.dev.maxlen)
+    minlen = property(lambda self: self.dev.minlen)
+    ends_at = property(lambda self: self.dev.ends_at)
+    starts_at = property(lambda self: self.dev.starts_at)
+    encoder_last_hidden_state = property(lambda self: self.dev.enc)
+
+
+class DeviceMaskSource:
+    """Bernoulli(0.5) keep-masks for the always-on prenet dropout, one [2][256] pair per decoder
+    step, drawn on the device from a seeded generator."""
+
+    def __init__(self, device, seed=0):
+        self.gen = torch.Generator(device=device)
+        self.gen.manual_seed(seed)
+        self.device = device
+
+    def __call__(self, nsteps):
+        return torch.randint(0, 2, (nsteps, 2, 256), dtype=torch.uint8, device=self.device, generator=self.gen)
+
+
+class HelloSippyRTPipe:
+    minlenratio: float = 0.0
+    maxlenratio: float = 20.0
+    threshold: float = 0.5
+    chunk_size: int = 8
+    pre_nframes: int = 2
+    post_nframes: int = 2
+    model_sr: int = 16000
+    output_sr: int = 16000
+    default_model = 'microsoft/speecht5_tts'
+    cleanup_text: Optional[callable] = None
+
+    def __init__(self, device, model=default_model, get_processor: Optional[callable] = None, output_sr: int = output_sr,
+                 weights: Optional[Dict[str, dict]] = None, processor=None, speaker_embeddings=None, mask_source=None, **kwa):
+        self.cuda_lock = InfernGlobals().torcher
+        self.cleanup_text = kwa.get('cleanup_text', self.cleanup_text)
+        self.device = dev = _lib.require_device(device)
+        if weights is None:
+            weights = load_pretrained_weights(model)
+        if processor is None:
+            processor = load_pretrained_processor(model, get_processor, dev)
+        self.processor = processor
+        with self.cuda_lock, torch.cuda.device(dev):
+            self.model = SpeechT5(weights['speecht5_tts'], dev)
+            self.vocoder = HifiGan(weights['hifigan'], dev)
+            self.chunker = Amendment(weights['amendment'], dev)
+        self.speaker_embeddings = speaker_embeddings if speaker_embeddings is not None else load_xvectors()
+        self.resampler = get_resampler(self.model_sr, output_sr, str(dev)) if self.model_sr != output_sr else None
+        self.output_sr = output_sr
+        self.mask_source = mask_source if mask_source is not None else DeviceMaskSource(dev)
+
+    def infer(self, state: HelloSippyPipeStateBatched) -> None:
+        st = state.dev
+        dev = self.device
+        with self.cuda_lock, torch.cuda.device(dev):
+            masks = self.mask_source(self.chunk_size * 4 // 2).to(dev).contiguous()
+            decoder_steps(self.model, st, masks, nsteps=self.chunk_size * 4 // 2, threshold=self.threshold)
+            post = postnet(self.model, st)
+            B = st.B
+            voc_in = torch.empty((4 * B, 12, 80), dtype=torch.bfloat16, device=dev)
+            amd_mel = torch.empty((4 * B, 12, 80), dtype=torch.bfloat16, device=dev)
+            _lib.check(_lib.lib().ifh_tts_chunks_bf16(ops._addr(st.pre_frames), ops._addr(post), ops._addr(self.vocoder.mean),
+                                                      ops._addr(self.vocoder.scale), ops._addr(voc_in), ops._addr(amd_mel), B,
+                                                      _lib.stream_ptr(dev)), 'ifh_tts_chunks_bf16')
+            audio = self.vocoder(voc_in)
+            out = torch.empty((B, 8192), dtype=torch.bfloat16, device=dev)
+            self.chunker(amd_mel, audio, out, B)
+            state.stage = dict(post=post, voc_in=voc_in, vocoder=audio)
+            if self.resampler is not None:
+                out = self.resampler(out.float()).to(torch.bfloat16)
+            st.audio = state.audio = out
+
+    def unbatch_and_dispatch(self, state: HelloSippyPipeStateBatched):
+        """HelloSippyRTPipe.py:242-259.  One D2H of the audio batch and of ends_at, then the
+        reference's per-row slicing; returns False once every utterance has ended."""
+        sr_rr = self.model_sr // self.output_sr
+        idx = state.idx
+        end_idx = idx - 1
+        stepsize = 256 * 2 // sr_rr
+        with self.cuda_lock:
+            audio = state.audio.cpu()
+            ends = state.ends_at.cpu().tolist()
+            for i, dispatch in [(i, d) for i, d in enumerate(state.dispatch) if d is not None]:
+                asize = audio[i].size(0)
+                startoff = max(0, asize - ((idx - state.starts_at_host[i]) * stepsize))
+                ends_at = ends[i]
+                endoff = min(asize, asize - (((idx - ends_at) * stepsize) if ends_at >= 0 else 0))
+                assert startoff <= endoff
+                if startoff != endoff:
+                    dispatch(audio[i][startoff:endoff].clone())
+                if ends_at >= 0 and ends_at <= end_idx:
+                    dispatch(None)
+                    state.dispatch[i] = None
+            if all(e >= 0 and e <= end_idx for e in ends):
+                return False
+        return True
+
+    def get_rand_voice_id(self):
+        return torch.randint(0, len(self.speaker_embeddings), (1,)).item()
+
+    def get_rand_voice(self):
+        s_index = self.get_rand_voice_id()
+        return (self.speaker_embeddings[s_index], s_index)
+
+    def get_voice(self, s_index: int):
+        return self.speaker_embeddings[s_index]
+
+
+def load_pretrained_weights(model_name):
+    """Checkpoints the reference loads (HelloSippyRTPipe.py:164-178).  Needs the HF hub."""
+    from transformers import SpeechT5ForTextToSpeech, SpeechT5HifiGan
+    from huggingface_hub import hf_hub_download
+    from safetensors.torch import load_file
+    tts = SpeechT5ForTextToSpeech.from_pretrained(model_name).state_dict()
+    voc = SpeechT5HifiGan.from_pretrained('microsoft/speecht5_hifigan').state_dict()
+    amd = load_file(hf_hub_download('sobomax/speecht5-rt.post_vocoder.v2', 'model.safetensors'))
+    return {'speecht5_tts': tts, 'hifigan': voc, 'amendment': amd}
+
+
+def load_pretrained_processor(model_name, get_processor, device):
+    from transformers import SpeechT5Processor
+    if get_processor is not None:
+        return get_processor(device, model_name)
+    return SpeechT5Processor.from_pretrained(model_name)
+
+
+def load_xvectors():
+    from datasets import load_dataset
+    ds = load_dataset('Matthijs/cmu-arctic-xvectors', split='validation')
+    return [torch.tensor(ed['xvector'], device='cpu').unsqueeze(0) for ed in sorted(ds, key=lambda x: x['filename'])]
+
+
+class cleanup_text_eu:
+    """Transliteration of accented characters before tokenisation (InfernTTSWorker.py:22-35)."""
+    pairs = ('ÄE ÆE ÇC ÉE ÍI ÓO ÖE ÜY ßS àa áa ãa äe åa ëe íi ïi ðo ñn òo óo ôo öu úu üy ýy Āa āa ăa ąa ćc ČC čc ďd ĐD ęe ěe '
+             'ğg İI ОO ŁL ńn ňn ŌO ōo őo řr ŚS śs ŞS şs ŠS šs ūu źz ŻZ ŽZ ǐi șs țt ùu').replace('Āa', 'ĀA').split()
+    table = str.maketrans(''.join(p[0] for p in pairs), ''.join(p[1] for p in pairs))
+
+    def __call__(self, text):
+        return text.translate(self.table)
+
+
+lang2model = {'en': {'cleanup_text': cleanup_text_eu()},
+              'it': {'model': 'Sandiago21/speecht5_finetuned_voxpopuli_it', 'cleanup_text': cleanup_text_eu()},
+              'es': {'model': 'Sandiago21/speecht5_finetuned_facebook_voxpopuli_spanish', 'cleanup_text': cleanup_text_eu()},
+              'fr': {'model': 'Sandiago21/speecht5_finetuned_facebook_voxpopuli_french', 'cleanup_text': cleanup_text_eu()},
+              'de': {'model': 'JFuellem/speecht5_finetuned_voxpopuli_de', 'cleanup_text': cleanup_text_eu()},
+              'pt': {'model': 'evertonaleixo/speecht5_finetuned_fleurs_ptbr', 'cleanup_text': cleanup_text_eu()},
+              'ru': {'model': 'zaebee/speecht5_tts_common_ru'}}
+
+
+class InfernTTSWorker(InfernBatchedWorker):
+    max_batch_size: int = 8
+    debug = False
+    tts_engine: HelloSippyRTPipe
+    output_sr: int
+
+    def __init__(self, lang, output_sr, device=None, **engine_kwa):
+        super().__init__()
+        kwa = dict(lang2model[lang])
+        kwa.update(engine_kwa)
+        self.tts_engine = HelloSippyRTPipe(_lib.require_device(device), output_sr=output_sr, **kwa)
+        self.output_sr = output_sr
+
+    def process_batch(self, wis: List[HelloSippyPlayRequest]):
+        new_states = [HelloSippyPipeState(self.tts_engine, r) for r in wis]
+        state = HelloSippyPipeStateBatched(new_states, self.tts_engine)
+        while True:
+            try:
+                self.tts_engine.infer(state)
+            except RuntimeError as e:
+                self.handle_runtime_error(e, wis, state)
+                raise
+            if not self.tts_engine.unbatch_and_dispatch(state):
+                break
+
+    def handle_runtime_error(self, e, wis, state):
+        print(f'InfernTTSWorker.handle_runtime_error: {e}')
+
+    def get_voice(self, *args):
+        return self.tts_engine.get_voice(*args)
+
+    def get_rand_voice(self):
+        return self.tts_engine.get_rand_voice()
+
+    def get_rand_voice_id(self):
+        return self.tts_engine.get_rand_voice_id()
+
+
+class TTSRequest:
+    def __init__(self, text: Union[str, List[str], Tuple[str]], speaker_id: Optional[int] = None,
+                 done_cb: Optional[callable] = None):
+        self.text, self.speaker_id, self.done_cb = text, speaker_id, done_cb
+
+
+class TTSSndDispatch:
+    debug: bool = False
+    cancelled: bool = False
+    cleanup_cb: Optional[callable] = None
+
+    def __init__(self, soundout: callable, output_sr: int, done_cb: Optional[callable]):
+        self.id = uuid4()
+        self.soundout, self.output_sr, self.done_cb = soundout, output_sr, done_cb
+
+    def _end_marker(self):
+        return ASMarkerNewSent() if self.done_cb is None else ASMarkerSentDoneCB(self.done_cb, sync=True)
+
+    def cancel(self):
+        self.cancelled = True
+        self.soundout(chunk=self._end_marker())
+        if self.cleanup_cb is not None:
+            self.cleanup_cb()
+
+    def sound_dispatch(self, chunk):
+        if self.cancelled:
+            return
+        finished = chunk is None
+        if finished:
+            chunk = self._end_marker()
+        elif not isinstance(chunk, ASMarkerGeneric):
+            assert chunk.size(0) > 0
+            chunk = AudioChunk(chunk, self.output_sr)
+        self.soundout(chunk=chunk)
+        if finished and self.cleanup_cb is not None:
+            self.cleanup_cb()
+
+
+class TTSSession:
+    debug = False
+
+    def __init__(self, tts: InfernTTSWorker, tts_actr):
+        self.id = uuid4()
+        self.tts, self.tts_actr = tts, tts_actr
+        self.active_req: Dict[UUID, TTSSndDispatch] = {}
+
+    def start(self, soundout: callable):
+        self.soundout = soundout
+
+    def say(self, req: TTSRequest) -> UUID:
+        if req.speaker_id is not None:
+            speaker = self.tts.get_voice(req.speaker_id)
+        else:
+            speaker, req.speaker_id = self.tts.get_rand_voice()
+        if isinstance(req.text, str):
+            req.text = (req.text,)
+        text, done_cb = req.text[0], req.done_cb
+        if len(req.text) > 1:          # chain the remaining sentences through the actor (TTSSession.py:113-115)
+            req.text = list(req.text)[1:]
+            done_cb = partial(self.tts_actr.tts_session_say.remote, rgen_id=self.id, req=req)
+        trd = TTSSndDispatch(self.soundout, self.tts.output_sr, done_cb)
+        trd.cleanup_cb = partial(self.active_req.pop, trd.id, None)
+        self.active_req[trd.id] = trd
+        self.tts.infer(HelloSippyPlayRequest(self.id, text, speaker, trd.sound_dispatch))
+        return trd.id
+
+    def stop_saying(self, rsay_id: UUID):
+        trd = self.active_req.get(rsay_id)
+        if trd is None:
+            return False
+        trd.cancel()
+        return True
+
+    def stop(self):
+        pass

@@ -1,0 +1,319 @@
+"""GPU parity tests for the neural rows (a13, a15-a18): kernels and engines,
+through the C ABI, against plain-PyTorch fp32 references / the oracle (oracle/nn.py) and the
+fixtures captured from the reference's own runs.
+
+Tolerances: kernels store bf16 and accumulate in fp32, like the reference's bf16 TTS stack
+(HelloSippyRTPipe.py:57 maybe_half).  The bar for whole-pipeline outputs is "no further from
+the fp32 oracle than the reference's own bf16 run" (measured in the fixture: ~2e-2 relative
+L2 on the audio); unit kernels are held to bf16 rounding of the result."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nn as onn  # noqa: E402  (checker only)
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope='module')
+def dev(built_lib):
+    from infernos_amd import _lib
+    return _lib.require_device('cuda:0')
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def bfr(x):
+    """round-trip through bf16 (what the kernels see)"""
+    return x.to(BF).float()
+
+
+# ---- implicit GEMM ---------------------------------------------------------------------------------
+@pytest.mark.parametrize('case', [
+    dict(B=3, T=12, cin=80, cout=512, k=7, pad=3),                      # conv_pre (K=560, not a multiple of 32)
+    dict(B=2, T=48, cin=256, cout=256, k=11, dil=5, pad=25, pre=0.1),   # resblock conv, dilated
+    dict(B=2, T=200, cin=64, cout=64, k=3, dil=3, pad=3, pre=0.01, resid=True),
+    dict(B=5, T=3072 // 8, cin=32, cout=32, k=7, pad=3, pre=0.1, resid=True, scale=1 / 3, accumulate=True),
+    dict(B=2, T=301, cin=80, cout=384, k=3, pad=1, act='gelu'),         # whisper conv1 (ragged M)
+    dict(B=2, T=300, cin=384, cout=384, k=3, pad=1, stride=2, act='gelu'),
+    dict(B=3, T=192, cin=64, cout=256, k=8, pad=0, stride=24, pre=0.01, act='lrelu'),   # amendment post_conv
+    dict(B=4, T=32, cin=80, cout=256, k=5, pad=2, act='tanh'),
+    dict(B=1, T=70, cin=768, cout=3072, k=1, act='gelu'),               # linear
+    dict(B=1, T=3, cin=768, cout=160, k=1),                             # tiny M
+    dict(B=1, T=64, cin=384, cout=1003, k=1, f32=True),                 # ragged N, f32 out (logits-like)
+    dict(B=1, T=130, cin=256, cout=256, k=1, act='relu', colmask=True),
+])
+def test_conv_kernel_matches_torch(dev, case):
+    from infernos_amd import ops
+    c = dict(dil=1, stride=1, pad=0, pre=1.0, act=None, resid=False, scale=1.0, accumulate=False, f32=False, colmask=False)
+    c.update(case)
+    g = torch.Generator().manual_seed(hash(str(sorted(case.items()))) & 0xffff)
+    B, T, cin, cout, k = c['B'], c['T'], c['cin'], c['cout'], c['k']
+    x = bfr(torch.randn(B, T, cin, generator=g))
+    w = bfr(torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.1
+    t_out = (T + 2 * c['pad'] - c['dil'] * (k - 1) - 1) // c['stride'] + 1
+    xin = F.leaky_relu(x, c['pre']) if c['pre'] != 1.0 else x
+    xin = bfr(xin)
+    ref = F.conv1d(xin.transpose(1, 2), w, bias, stride=c['stride'], padding=c['pad'], dilation=c['dil']).transpose(1, 2)
+    act = {None: lambda v: v, 'gelu': F.gelu, 'tanh': torch.tanh, 'relu': F.relu,
+           'lrelu': lambda v: F.leaky_relu(v, 0.01)}[c['act']]
+    ref = act(ref)
+    mask = None
+    if c['colmask']:
+        mask = (torch.rand(cout, generator=g) < 0.5).to(torch.uint8)
+        ref = torch.where(mask[None, None, :] == 1, ref * 2, torch.zeros_like(ref))
+    resid = bfr(torch.randn(B, t_out, cout, generator=g)) if c['resid'] else None
+    if resid is not None:
+        ref = ref + resid
+    ref = ref * c['scale']
+    prev = bfr(torch.randn(B, t_out, cout, generator=g)) if c['accumulate'] else None
+    if prev is not None:
+        ref = ref + prev
+    out = (prev.clone() if prev is not None else torch.zeros(B, t_out, cout)).to(dev, torch.float32 if c['f32'] else BF)
+    actc = {None: 0, 'relu': 1, 'gelu': 2, 'tanh': 3, 'lrelu': 4}[c['act']]
+    ops.conv(x.to(dev, BF), ops.w_conv(w, dev), bias.to(dev), out, nbatch=B, t_in=T, t_out=t_out, cin=cin, n=cout, taps=k,
+             stride=c['stride'], dil=c['dil'], pad=c['pad'], pre_slope=c['pre'], act=actc, act_slope=0.01,
+             colmask=None if mask is None else mask.to(dev), resid=None if resid is None else resid.to(dev, BF),
+             scale=c['scale'], accumulate=c['accumulate'])
+    got = out.float().cpu()
+    tol = 3e-3 if c['f32'] else 1.2e-2
+    err = (got - ref).abs().max() / (ref.abs().max() + 1e-6)
+    assert err < tol, (case, float(err), rel_l2(got, ref))
+    assert rel_l2(got, ref) < (1e-3 if c['f32'] else 5e-3)
+
+
+def test_conv_transpose_phases_match_torch(dev):
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, T, cin, cout = 3, 13, 128, 64
+    x = bfr(torch.randn(B, T, cin, generator=g))
+    w = bfr(torch.randn(cin, cout, 8, generator=g) / (cin * 2) ** 0.5)
+    bias = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv_transpose1d(bfr(F.leaky_relu(x, 0.1)).transpose(1, 2), w, bias, stride=4, padding=2).transpose(1, 2)
+    out = torch.zeros(B, 4 * T, cout, dtype=BF, device=dev)
+    for r, (wr, pad) in enumerate(ops.w_convT_phases(w, dev)):
+        ops.conv(x.to(dev, BF), wr, bias.to(dev), out, nbatch=B, t_in=T, t_out=T, cin=cin, n=cout, taps=2, pad=pad,
+                 pre_slope=0.1, ostride=4, ooff=r)
+    assert rel_l2(out.float().cpu(), ref) < 5e-3
+
+
+def test_layernorm_and_transpose(dev):
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(6)
+    for rows, D in ((7, 768), (130, 384), (5, 512)):
+        x, r = bfr(torch.randn(rows, D, generator=g) * 3), bfr(torch.randn(rows, D, generator=g))
+        gm, bt = torch.randn(D, generator=g), torch.randn(D, generator=g)
+        out = torch.empty(rows, D, dtype=BF, device=dev)
+        ops.layernorm(x.to(dev, BF), gm.to(dev), bt.to(dev), out, rows, D, resid=r.to(dev, BF))
+        ref = F.layer_norm(x + r, (D,), gm, bt, 1e-5)
+        assert (out.float().cpu() - ref).abs().max() < 4e-2 and rel_l2(out.float().cpu(), ref) < 4e-3
+    x = torch.randn(3, 80, 301, generator=g)
+    o = torch.empty(3, 301, 80, dtype=BF, device=dev)
+    ops.transpose_to_bf16(x.to(dev), o, 3, 80, 301)
+    assert torch.equal(o.cpu(), x.transpose(1, 2).to(BF))
+
+
+# ---- attention -----------------------------------------------------------------------------------
+def test_attention_prefill_matches_torch(dev):
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(7)
+    for (B, H, T, use_rel, lens) in ((2, 6, 200, False, None), (3, 12, 37, True, [37, 5, 20]), (1, 8, 1500, False, None)):
+        D = H * 64
+        qkv = bfr(torch.randn(B, T, 3 * D, generator=g))
+        q, k, v = (qkv[..., i * D:(i + 1) * D].reshape(B, T, H, 64).transpose(1, 2) for i in range(3))
+        q = q * 0.125
+        qkv_dev = qkv.clone()
+        qkv_dev[..., :D] = bfr(qkv[..., :D] * 0.125)
+        q = qkv_dev[..., :D].reshape(B, T, H, 64).transpose(1, 2)
+        w = q @ k.transpose(-1, -2)
+        rel = None
+        if use_rel:
+            rel = torch.randn(B, T, H, 320, generator=g)
+            pos = (torch.arange(T)[:, None] - torch.arange(T)[None, :]).clamp(-160, 159) + 160
+            w = w + torch.gather(rel.permute(0, 2, 1, 3), 3, pos[None, None].expand(B, H, T, T))
+        kl = None
+        if lens is not None:
+            kl = torch.tensor(lens, dtype=torch.int32)
+            m = torch.arange(T)[None, :] < kl[:, None]
+            w = w.masked_fill(~m[:, None, None, :], float('-inf'))
+        ref = (torch.softmax(w, -1) @ v).transpose(1, 2).reshape(B, T, D)
+        out = torch.empty(B, T, D, dtype=BF, device=dev)
+        ops.attn_prefill(qkv_dev.to(dev, BF), qkv_dev.to(dev, BF), qkv_dev.to(dev, BF), out, nbatch=B, nheads=H, tq=T, tk=T,
+                         k_off=D, v_off=2 * D, q_ts=3 * D, k_ts=3 * D, v_ts=3 * D, o_ts=D,
+                         key_len=None if kl is None else kl.to(dev), relbias=None if rel is None else rel.to(dev), nrel=320)
+        got = out.float().cpu()
+        assert rel_l2(got, ref) < 1e-2, (B, H, T, rel_l2(got, ref))
+
+
+def test_attention_decode_matches_torch(dev):
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(8)
+    B, H, S, SM = 5, 12, 77, 100
+    D = H * 64
+    q = bfr(torch.randn(B, D, generator=g) * 0.3)
+    kv = bfr(torch.randn(B, SM, 2 * D, generator=g))
+    lens = torch.tensor([77, 1, 64, 65, 30], dtype=torch.int32)
+    out = torch.empty(B, D, dtype=BF, device=dev)
+    ops.attn_decode(q.to(dev, BF), kv.to(dev, BF), kv.to(dev, BF), out, nbatch=B, nheads=H, max_keys=S, q_bs=D,
+                    kv_bs=SM * 2 * D, kv_ts=2 * D, o_bs=D, v_off=D, key_len=lens.to(dev))
+    for b in range(B):
+        n = int(lens[b])
+        kk = kv[b, :n, :D].reshape(n, H, 64).transpose(0, 1)
+        vv = kv[b, :n, D:].reshape(n, H, 64).transpose(0, 1)
+        a = torch.softmax(q[b].view(H, 1, 64) @ kk.transpose(-1, -2), -1) @ vv
+        assert rel_l2(out[b].float().cpu(), a.reshape(D)) < 1e-2
+
+
+# ---- vocoder / amendment ------------------------------------------------------------------------
+def test_hifigan_and_amendment_match_oracle(dev):
+    from infernos_amd.engines.vocoder import Amendment, HifiGan
+    from infernos_amd.weights import synth_state_dict
+    from infernos_amd import _lib, ops
+    sd_v, sd_a = synth_state_dict('hifigan', 0), synth_state_dict('amendment', 0)
+    g = torch.Generator().manual_seed(9)
+    Bn = 3
+    pre = bfr(torch.randn(Bn, 4, 80, generator=g) * 0.8)
+    post = bfr(torch.randn(Bn, 32, 80, generator=g) * 0.8)
+    S = torch.cat((pre, post), 1)
+    chunks = torch.cat([S[:, 8 * i:8 * i + 12] for i in range(4)], 0)
+    with torch.no_grad():
+        ref_voc = onn.hifigan(sd_v, chunks)
+        ref_out = onn.amendment(sd_a, chunks, ref_voc)
+        ref_audio = torch.cat(ref_out.split(Bn, 0), 1)
+    voc, amd = HifiGan(sd_v, dev), Amendment(sd_a, dev)
+    pf = pre.to(dev, BF).contiguous()
+    voc_in = torch.empty(4 * Bn, 12, 80, dtype=BF, device=dev)
+    amd_mel = torch.empty(4 * Bn, 12, 80, dtype=BF, device=dev)
+    _lib.check(_lib.lib().ifh_tts_chunks_bf16(ops._addr(pf), ops._addr(post.to(dev, BF).contiguous()), ops._addr(voc.mean),
+                                              ops._addr(voc.scale), ops._addr(voc_in), ops._addr(amd_mel), Bn,
+                                              _lib.stream_ptr(dev)))
+    assert torch.equal(pf.cpu().float(), S[:, -4:])
+    exp_in = ((chunks - sd_v['mean']) / sd_v['scale'])
+    assert (voc_in.float().cpu() - exp_in).abs().max() < 2e-2
+    assert torch.equal(amd_mel.float().cpu(), chunks.reshape(4 * Bn, 80, 12).transpose(1, 2))
+    audio = voc(voc_in)
+    e_voc = rel_l2(audio.float().cpu(), ref_voc)
+    assert e_voc < 2.5e-2, e_voc
+    out = torch.empty(Bn, 8192, dtype=BF, device=dev)
+    amd(amd_mel, audio, out, Bn)
+    e_out = rel_l2(out.float().cpu(), ref_audio)
+    assert e_out < 3e-2, e_out
+    print('hifigan rel_l2 %.3e, amended rel_l2 %.3e' % (e_voc, e_out))
+
+
+# ---- SpeechT5 + full infer ---------------------------------------------------------------------
+def _tts_inputs(meta):
+    ids = [torch.tensor([[int(t) for t in s.split()]]) for s in meta['texts']]
+    T = max(i.size(1) for i in ids)
+    inp = torch.cat([F.pad(i, (0, T - i.size(1))) for i in ids])
+    msk = torch.cat([F.pad(torch.ones_like(i), (0, T - i.size(1))) for i in ids]).int()
+    g = torch.Generator().manual_seed(meta['speaker_seed'])
+    spk = torch.cat([torch.randn(1, 512, generator=g) for _ in ids])
+    return inp, msk, spk
+
+
+class _IdsProcessor:
+    def __call__(self, text, return_tensors='pt'):
+        return {'input_ids': torch.tensor([[int(t) for t in text.split()]], dtype=torch.long)}
+
+
+class _FixedMasks:
+    def __init__(self, masks, dev):
+        self.m, self.i, self.dev = masks, 0, dev
+
+    def __call__(self, nsteps):
+        m = torch.from_numpy(self.m[self.i]).to(self.dev)
+        self.i += 1
+        return m
+
+
+def test_tts_pipe_matches_reference_run(dev, golden_dir):
+    """HelloSippyRTPipe.infer / unbatch_and_dispatch on the device vs the fixture from the
+    reference's own run (fp32 and its bf16), same weights, same dropout masks."""
+    from infernos_amd.tts import HelloSippyPipeState, HelloSippyPipeStateBatched, HelloSippyPlayRequest, HelloSippyRTPipe
+    from infernos_amd.weights import synth_state_dict
+    g = np.load(os.path.join(golden_dir, 'tts.npz'))
+    meta = json.load(open(os.path.join(golden_dir, 'tts_meta.json')))
+    for key, stop_bias, ncalls in (('A', -20.0, 2), ('B', None, 3)):
+        W = {'speecht5_tts': synth_state_dict('speecht5_tts', 0, stop_bias=stop_bias),
+             'hifigan': synth_state_dict('hifigan', 0), 'amendment': synth_state_dict('amendment', 0)}
+        masks = np.unpackbits(g[key + '_masks'], axis=-1)
+        pp = HelloSippyRTPipe(dev, weights=W, processor=_IdsProcessor(), speaker_embeddings=[],
+                              mask_source=_FixedMasks(masks, dev))
+        inp, msk, spk = _tts_inputs(meta)
+        got = [[] for _ in meta['texts']]
+        reqs = [HelloSippyPlayRequest(None, t, spk[i:i + 1], (lambda c, i=i: got[i].append(c)))
+                for i, t in enumerate(meta['texts'])]
+        st = HelloSippyPipeStateBatched([HelloSippyPipeState(pp, r) for r in reqs], pp)
+        assert st.maxlen == meta[key]['maxlen']
+        if key == 'A':
+            enc = st.encoder_last_hidden_state.float().cpu()
+            lens = msk.sum(1)
+            for b in range(enc.size(0)):
+                e = rel_l2(enc[b, :lens[b], :16], torch.from_numpy(g['A_enc_slice'][b, :lens[b]]))
+                assert e < 2e-2, ('encoder', b, e)
+        for c in range(ncalls):
+            pp.infer(st)
+            bk = meta[key]['book'][c]
+            assert st.idx == bk['idx'] and st.ends_at.cpu().tolist() == bk['ends_at'], (key, c, st.ends_at.cpu().tolist())
+            if key == 'A':
+                a = st.audio.float().cpu()[:, ::8]
+                ref32, refbf = torch.from_numpy(g['A_audio_%d' % c]), torch.from_numpy(g['A_audio_bf16_%d' % c])
+                e_dev, e_ref = rel_l2(a, ref32), rel_l2(refbf, ref32)
+                print('call %d: device-vs-fp32 rel_l2 %.3e ; reference-bf16-vs-fp32 %.3e' % (c, e_dev, e_ref))
+                assert e_dev < max(1.5 * e_ref, 3e-2), (c, e_dev, e_ref)
+                if c == 0:
+                    e_post = rel_l2(st.stage['post'].float().cpu(), torch.from_numpy(g['A_postnet_0']))
+                    assert e_post < 2e-2, e_post
+            more = pp.unbatch_and_dispatch(st)
+            assert more == meta[key]['more'][c]
+        lens = [[None if d is None else int(d.numel()) for d in ch] for ch in got]
+        assert lens == meta[key]['dispatch_lens'], key
+        for ch in got:
+            for d in ch:
+                assert d is None or (d.dim() == 1 and not d.is_cuda and d.numel() > 0)
+        if key == 'A':
+            assert rel_l2(got[0][0].float()[::8], torch.from_numpy(g['A_first_dispatch_0'])) < 5e-2
+
+
+# ---- Whisper ---------------------------------------------------------------------------------------
+def test_whisper_matches_oracle_and_reference_fixture(dev, golden_dir):
+    from infernos_amd.engines.whisper import Whisper
+    from infernos_amd.features import WhisperLogMel
+    from infernos_amd.synth import synth_utterance
+    from infernos_amd.audio import get_resampler
+    from infernos_amd.weights import synth_state_dict
+    g = np.load(os.path.join(golden_dir, 'whisper.npz'))
+    meta = json.load(open(os.path.join(golden_dir, 'whisper_meta.json')))
+    sd = synth_state_dict('whisper_tiny', 0)
+    model = Whisper(sd, dev)
+    rs = get_resampler(8000, 16000, str(dev))
+    x8 = torch.from_numpy(np.stack([synth_utterance(s, 10.0) for s in meta['audio_seeds']])).to(dev)
+    mel = WhisperLogMel(80, dev)(rs(x8))
+    enc = model.encode(mel)
+    e_enc = rel_l2(enc.float().cpu()[:, ::25, :32], torch.from_numpy(g['enc_slice']))
+    assert e_enc < 3e-2, e_enc
+    prompt = torch.tensor([meta['prompt']] * 2, dtype=torch.int32)
+    toks, nsp, first = model.generate(enc, prompt, 8, no_speech_id=meta['no_speech_id'], keep_logits=True)
+    ref_first = torch.from_numpy(g['first_logits_slice'])
+    e_log = rel_l2(first.cpu()[:, ::97], ref_first)
+    assert e_log < 5e-2, e_log
+    with torch.no_grad():
+        o_toks, o_first, o_l0, o_enc = onn.whisper_greedy(sd, mel.float().cpu(), prompt.long(), 8, 6)
+    assert rel_l2(enc.float().cpu(), o_enc) < 3e-2
+    # greedy tokens: must agree wherever the oracle's top-1 margin exceeds the logit error
+    agree = (toks.cpu() == o_toks.int())
+    print('whisper: enc rel_l2 %.3e logits rel_l2 %.3e token agreement %s' % (e_enc, e_log, agree.tolist()))
+    assert agree[:, 0].all() or float((o_first.topk(2).values[:, 0] - o_first.topk(2).values[:, 1]).min()) < 0.05
+    assert np.array_equal(o_toks.numpy(), g['greedy'])
+    np.testing.assert_allclose(nsp.cpu().numpy(), meta['no_speech_prob'], rtol=0.5)
