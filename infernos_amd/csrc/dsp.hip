@@ -419,7 +419,7 @@ extern "C" int ifh_ingest_tick(const uint8_t *frames, const int32_t *slot, int n
 namespace ifh {
 
 // Stand-in for the Silero v3.1 network (third party, weights unavailable offline):
-// p = sigmoid(0.5 * (10*log10(mean(x^2) + 1e-10) + 40)).  One wave per window.
+// p = sigmoid(0.5 * (10*log10(mean(x^2) + 1e-10) + 30)).  One wave per window.
 __global__ __launch_bounds__(64) void k_vad_energy_prob(const float *__restrict__ win,
                                                         const int32_t *__restrict__ slot, float *__restrict__ prob)
 {
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(64) void k_vad_energy_prob(const float *__restrict_
     acc = wave_sum(acc);
     if (t == 0) {
         const float db = 10.0f * log10f(acc / (float)IFH_VAD_WINDOW + 1e-10f);
-        prob[i] = 1.0f / (1.0f + expf(-0.5f * (db + 40.0f)));
+        prob[i] = 1.0f / (1.0f + expf(-0.5f * (db + 30.0f)));
     }
 }
 

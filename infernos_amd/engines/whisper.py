@@ -147,19 +147,25 @@ class Whisper:
         ops.linear(bufs['hn'], self.tok, None, bufs['logits'], rows=Bn, k=d, n=self.vocab)
         return bufs['logits']
 
-    def generate(self, enc: torch.Tensor, prompts: torch.Tensor, n_new: int, no_speech_id=None, keep_logits=False):
-        """Greedy decode exactly n_new tokens after the prompt.
+    def generate(self, enc: torch.Tensor, prompts: torch.Tensor, n_new: int, no_speech_id=None, keep_logits=False,
+                 eos_id=None, check_every=16, early_exit_nsp=None):
+        """Greedy decode up to n_new tokens after the prompt.
         enc bf16 [B,1500,d]; prompts int32 [B,P] -> (tokens int32 [B,n_new] on device,
-        no_speech_prob f32 [B] or None, first_logits f32 [B,V] (after the whole prompt) if keep_logits)."""
+        no_speech_prob f32 [B] or None, first_logits f32 [B,V] (after the whole prompt) if keep_logits).
+        eos_id: stop once every row has produced it (checked every `check_every` tokens; rows are
+        padded with eos).  early_exit_nsp: per-row max no-speech probabilities; if every row is
+        above its limit nothing is generated (tokens None), as InfernSTTWorker.py:91-92 does."""
         dev, d = self.device, self.d
         Bn, P = prompts.shape
-        assert P + n_new <= self.max_tokens
+        n_new = min(n_new, self.max_tokens - P)
         bufs = self._dec(Bn)
         for li, L in enumerate(self.dec_layers):
             C = L['cross']
             ops.linear(enc, C['wkv'], C['bkv'], bufs['cross'][li], rows=Bn * N_CTX, k=d, n=2 * d)
         # token matrix, column-major so that each step's ids are a dense int32[B] block
         toks = torch.zeros((P + n_new, Bn), dtype=torch.int32, device=dev)
+        if eos_id is not None:
+            toks[P:] = eos_id
         toks[:P] = prompts.to(dev, torch.int32).t()
         nsp = torch.empty(Bn, dtype=torch.float32, device=dev) if no_speech_id is not None else None
         first = None
@@ -167,8 +173,16 @@ class Whisper:
             logits = self.decoder_step(toks, pos * Bn, True, pos, bufs, Bn)
             if pos == 0 and nsp is not None:
                 ops.argmax_pick(logits, vocab=self.vocab, nrows=Bn, pick_token=no_speech_id, pick_prob_out=nsp)
+                if early_exit_nsp is not None:
+                    lim = torch.tensor(early_exit_nsp, dtype=torch.float32)
+                    if bool((nsp.cpu() > lim).all()):
+                        return None, nsp, None
             if pos >= P - 1:
                 if pos == P - 1 and keep_logits:
                     first = logits.clone()
                 ops.argmax_pick(logits, vocab=self.vocab, nrows=Bn, argmax_out=toks, out_off=(pos + 1) * Bn)
+                done = pos - (P - 1) + 1
+                if eos_id is not None and done % check_every == 0 and done < n_new:
+                    if bool((toks[P:P + done] == eos_id).any(0).all()):
+                        break
         return toks[P:].t().contiguous(), nsp, first

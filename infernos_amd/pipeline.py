@@ -1,0 +1,196 @@
+"""Batched per-GPU serving loop for N concurrent calls -- the MI355X counterpart of the
+reference's per-call Python threads (RTP/InfernRTPIngest.py:135-150 -> SileroVADWorker ->
+STTSession/InfernSTTWorker -> app (T2T stub) -> TTSSession/InfernTTSWorker -> G711 encode,
+SURVEY.md section 3).  One instance owns one GPU and a fixed set of calls (sticky sharding,
+SURVEY.md 8e); every stage processes all of its calls in one batch of HIP kernels.
+
+Stages of one utterance cycle (`step`):
+  ingest : T ticks of [N,160] mu-law frames -> ifh_ingest_tick; each completed 768-sample
+           window -> VAD probability (pluggable; stand-in) -> ifh_vad_step -> VadAudioChunks
+  stt    : per call merge chunks (VadAudioChunk.append) -> 8k->16k resample -> log-mel ->
+           Whisper encoder -> greedy decode (fixed token budget)
+  t2t    : identity stub on token ids (BASELINE config 3 calls it "T2T stub")
+  tts    : SpeechT5 encoder once, then n_infer x HelloSippyRTPipe.infer (16 decoder steps,
+           postnet, HiFi-GAN, amendment, 16k->8k), trimmed per the reference's dispatch offsets,
+           mu-law encoded -> [N, bytes] for the RTP side.
+"""
+import ctypes
+from typing import List
+
+import torch
+
+from . import _lib, ops
+from .audio import VadAudioChunk, get_resampler
+from .codecs import G711Codec
+from .frontend import CallTable
+from .vad import ABUF_CAP, EMIT_CAP, WINDOW
+
+
+class BatchedVAD:
+    """SileroVADWorker's device tables for a fixed set of N calls, stepped for all calls at once."""
+
+    def __init__(self, ncalls, device, model=None, input_sr=8000, threshold=0.5):
+        self.device = dev = _lib.require_device(device)
+        self.n, self.input_sr, self.threshold = ncalls, input_sr, threshold
+        self.model = model
+        self.slot = torch.arange(ncalls, dtype=torch.int32, device=dev)
+        self.st = torch.zeros((ncalls, 4), dtype=torch.int64, device=dev)
+        self.st[:, 3] = -1
+        self.blen = torch.zeros(ncalls, dtype=torch.int32, device=dev)
+        self.abuf = torch.zeros((ncalls, ABUF_CAP), dtype=torch.float32, device=dev)
+        self.emit = torch.empty((ncalls, EMIT_CAP), dtype=torch.float32, device=dev)
+        self.ev = torch.empty((ncalls, 8), dtype=torch.int64, device=dev)
+        self.prob = torch.empty(ncalls, dtype=torch.float32, device=dev)
+
+    def step(self, win: torch.Tensor) -> List[VadAudioChunk]:
+        """win f32 [N,768] (CallTable.win).  Returns [(call, VadAudioChunk)] emitted by this window."""
+        dev, L = self.device, _lib.lib()
+        if self.model is None:
+            _lib.check(L.ifh_vad_energy_prob(_lib.ptr(win), _lib.ptr(self.slot), self.n, _lib.ptr(self.prob),
+                                             _lib.stream_ptr(dev)), 'ifh_vad_energy_prob')
+            prob = self.prob
+        else:
+            prob = self.model(win, self.input_sr).to(dev, torch.float32).contiguous()
+        _lib.check(L.ifh_vad_step(_lib.ptr(win), _lib.ptr(prob), _lib.ptr(self.slot), self.n, self.input_sr,
+                                  float(self.threshold), _lib.ptr(self.st), _lib.ptr(self.blen), _lib.ptr(self.abuf),
+                                  _lib.ptr(self.ev), _lib.ptr(self.emit), _lib.stream_ptr(dev)), 'ifh_vad_step')
+        ev = self.ev.cpu()                       # one host sync per window batch, like the reference's .tolist()
+        if bool(ev[:, 6].any()):
+            raise AssertionError('VAD buffer invariant violated (SileroVAD.py:89/95-98)')
+        out = []
+        for i in torch.nonzero(ev[:, 3]).flatten().tolist():
+            out.append((i, VadAudioChunk(self.emit[i, :int(ev[i, 5])].clone(), self.input_sr, int(ev[i, 4]))))
+        return out
+
+
+class SpeechPipeline:
+    def __init__(self, ncalls: int, device=None, whisper_family='whisper_tiny', seed=0, n_text=64, n_infer=10,
+                 n_new_tokens=32, tts_output_sr=8000, weights=None):
+        from .engines.whisper import Whisper
+        from .features import WhisperLogMel
+        from .tts import HelloSippyRTPipe
+        from .weights import synth_state_dict
+        self.device = dev = _lib.require_device(device)
+        self.n, self.n_text, self.n_infer, self.n_new = ncalls, n_text, n_infer, n_new_tokens
+        with torch.cuda.device(dev):
+            self.calls = CallTable(ncalls, dev)
+            self.vad = BatchedVAD(ncalls, dev)
+            self.codec = G711Codec().to(dev)
+            self.up = get_resampler(8000, 16000, str(dev))
+            w = weights or {}
+            self.whisper = Whisper(w.get(whisper_family) or synth_state_dict(whisper_family, seed), dev)
+            self.logmel = WhisperLogMel(self.whisper.n_mel, dev)
+            tw = {k: (w.get(k) or synth_state_dict(k, seed, **({'stop_bias': -20.0} if k == 'speecht5_tts' else {})))
+                  for k in ('speecht5_tts', 'hifigan', 'amendment')}
+            self.tts = HelloSippyRTPipe(dev, weights=tw, processor=_NoProcessor(), speaker_embeddings=[],
+                                        output_sr=tts_output_sr)
+        self.slots = torch.arange(ncalls, dtype=torch.int32, device=dev)
+        self.prompt = torch.tensor([[50258, 50259, 50359, 50363]] * ncalls, dtype=torch.int32)
+        g = torch.Generator().manual_seed(2000 + seed)
+        self.speakers = torch.randn(ncalls, 512, generator=g)
+        self.text_ids = torch.randint(4, 80, (ncalls, n_text), generator=g, dtype=torch.int32)
+        self.pcm8k = torch.empty((ncalls, 160), dtype=torch.float32, device=dev)
+        self.pcm16k = torch.empty((ncalls, 320), dtype=torch.float32, device=dev)
+
+    # ---- stage 1 -----------------------------------------------------------------------------
+    def ingest(self, frames: torch.Tensor):
+        """frames u8 [T,N,160] on the device -> per-call list of VadAudioChunk"""
+        T = frames.size(0)
+        chunks = [[] for _ in range(self.n)]
+        nbytes = int(self.calls.fifo_len[0]) if T else 0
+        for t in range(T):
+            self.calls.tick(frames[t], self.slots, self.pcm8k, self.pcm16k)
+            nbytes += 160
+            if nbytes >= WINDOW:                 # every stream completes its window on the same tick
+                nbytes -= WINDOW
+                for i, ch in self.vad.step(self.calls.win):
+                    chunks[i].append(ch)
+        return chunks
+
+    # ---- stage 2 -----------------------------------------------------------------------------
+    def stt(self, chunks):
+        """-> (tokens int32 [N, n_new] device, no_speech_prob f32 [N] device, audio seconds per call)"""
+        dev = self.device
+        merged = []
+        for lst in chunks:
+            if not lst:
+                merged.append(torch.zeros(0, device=dev))
+                continue
+            head = lst[0]
+            for nxt in lst[1:]:
+                if nxt.tpos() + nxt.duration() - head.tpos() < 32.0:
+                    head.append(nxt)
+            merged.append(head.audio)
+        lens8 = torch.tensor([m.numel() for m in merged], dtype=torch.int32)
+        L8 = max(int(lens8.max()), 1)
+        x8 = torch.zeros((self.n, L8), dtype=torch.float32, device=dev)
+        for i, m in enumerate(merged):
+            x8[i, :m.numel()] = m
+        x16 = self.up(x8, lens=lens8)
+        lens16 = (lens8 * 2).to(dev)
+        mel = self.logmel(x16, lens=lens16)
+        enc = self.whisper.encode(mel)
+        toks, nsp, _ = self.whisper.generate(enc, self.prompt, self.n_new, no_speech_id=50362)
+        return toks, nsp, (lens8.float() / 8000.0)
+
+    # ---- stage 3 -----------------------------------------------------------------------------
+    def synthesize(self, text_ids=None):
+        """-> (ulaw u8 [N, n_infer*A] device, valid sample count per call) with A = 8192/(16000/output_sr)"""
+        from .tts import HelloSippyPipeStateBatched
+        dev, pp = self.device, self.tts
+        ids = self.text_ids if text_ids is None else text_ids
+        state = _make_state(pp, ids, self.speakers)
+        A = 8192 // (pp.model_sr // pp.output_sr)
+        stepsize = 512 // (pp.model_sr // pp.output_sr)
+        out = torch.empty((self.n, self.n_infer * A), dtype=torch.uint8, device=dev)
+        valid = torch.zeros(self.n, dtype=torch.int64)
+        spans = []
+        for c in range(self.n_infer):
+            pp.infer(state)
+            idx = state.idx
+            ends = state.ends_at.cpu().tolist()                  # the per-call sync the reference also has (.item())
+            pcm = state.audio.float().contiguous()
+            enc = out[:, c * A:(c + 1) * A]
+            tmp = torch.empty((self.n, A), dtype=torch.uint8, device=dev)
+            _lib.check(_lib.lib().ifh_g711_encode_f32_u8(_lib.ptr(pcm), _lib.ptr(tmp), pcm.numel(), _lib.stream_ptr(dev)),
+                       'ifh_g711_encode_f32_u8')
+            enc.copy_(tmp)
+            row = []
+            for i in range(self.n):
+                s = max(0, A - (idx - 1) * stepsize)
+                e = min(A, A - ((idx - ends[i]) * stepsize if ends[i] >= 0 else 0))
+                row.append((s, max(s, e)))
+                valid[i] += max(0, e - s)
+            spans.append(row)
+            if all(e >= 0 and e <= idx - 1 for e in ends):
+                break
+        return out, valid, spans
+
+    def step(self, frames: torch.Tensor):
+        chunks = self.ingest(frames)
+        toks, nsp, secs = self.stt(chunks)
+        # T2T stub: identity on token ids; the TTS text is the fixed synthetic utterance
+        ulaw, valid, spans = self.synthesize()
+        return dict(tokens=toks, no_speech_prob=nsp, stt_seconds=secs, ulaw=ulaw, tts_samples=valid, spans=spans,
+                    chunks=[[(c.ipos, c.audio.numel()) for c in lst] for lst in chunks])
+
+
+class _NoProcessor:
+    def __call__(self, text=None, return_tensors='pt'):
+        raise RuntimeError('SpeechPipeline feeds token ids directly; no tokenizer is available offline')
+
+
+def _make_state(pp, ids, speakers):
+    """HelloSippyPipeStateBatched from token ids (bypasses the tokenizer)."""
+    from .tts import HelloSippyPipeStateBatched
+
+    class _S:
+        pass
+    states = []
+    for i in range(ids.size(0)):
+        s = _S()
+        s.session, s.dispatch = None, None
+        s.inputs = ids[i:i + 1].long()
+        s.speaker_embeddings = speakers[i:i + 1]
+        states.append(s)
+    return HelloSippyPipeStateBatched(states, pp)

@@ -1,0 +1,76 @@
+"""Multi-GPU sharding of concurrent calls: one process per GPU (torch.distributed, backend
+"nccl" = RCCL over xGMI on ROCm; "gloo" for the CPU tests), sticky call -> rank assignment,
+models replicated, no collective on the model path.
+
+The only exchange step is the ingress/egress of the batch: the ingress rank holds the
+mu-law frame matrix of every call and scatters each rank's rows; ranks return their encoded
+output rows by gather.  Messages are small (160 B per call per tick), so whole utterance
+blocks are moved in one collective each way rather than one per tick.
+"""
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_total: int, world: int) -> List[range]:
+    """Contiguous, balanced call ranges per rank (first n_total % world ranks get one more)."""
+    q, r = divmod(n_total, world)
+    out, lo = [], 0
+    for k in range(world):
+        hi = lo + q + (1 if k < r else 0)
+        out.append(range(lo, hi))
+        lo = hi
+    return out
+
+
+def scatter_frames(frames_all: Optional[torch.Tensor], n_total: int, t: int, device, src: int = 0) -> torch.Tensor:
+    """frames_all u8 [T, n_total, 160] on rank `src` (None elsewhere) -> this rank's [T, n_local, 160]."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    bounds = shard_bounds(n_total, world)
+    mine = torch.empty((t, len(bounds[rank]), 160), dtype=torch.uint8, device=device)
+    if world == 1:
+        mine.copy_(frames_all)
+        return mine
+    if max(len(b) for b in bounds) == min(len(b) for b in bounds):
+        parts = None
+        if rank == src:
+            parts = [frames_all[:, b.start:b.stop].contiguous() for b in bounds]
+        dist.scatter(mine, parts, src=src)
+    else:                                   # ragged: point-to-point
+        if rank == src:
+            reqs = []
+            for k, b in enumerate(bounds):
+                part = frames_all[:, b.start:b.stop].contiguous()
+                if k == src:
+                    mine.copy_(part)
+                else:
+                    reqs.append(dist.isend(part, dst=k))
+            for r in reqs:
+                r.wait()
+        else:
+            dist.recv(mine, src=src)
+    return mine
+
+
+def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[torch.Tensor]:
+    """local [n_local, W] -> [n_total, W] on rank dst (None elsewhere)."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if world == 1:
+        return local
+    bounds = shard_bounds(n_total, world)
+    W = local.size(1)
+    if max(len(b) for b in bounds) == min(len(b) for b in bounds):
+        outs = [torch.empty((len(b), W), dtype=local.dtype, device=local.device) for b in bounds] if rank == dst else None
+        dist.gather(local.contiguous(), outs, dst=dst)
+        return torch.cat(outs) if rank == dst else None
+    if rank == dst:
+        full = torch.empty((n_total, W), dtype=local.dtype, device=local.device)
+        for k, b in enumerate(bounds):
+            if k == dst:
+                full[b.start:b.stop] = local
+            else:
+                dist.recv(full[b.start:b.stop], src=k)
+        return full
+    dist.send(local.contiguous(), dst=dst)
+    return None

@@ -133,3 +133,100 @@ class STTSession:
             self._drain_locked(deliver)
         for cb, r in deliver:
             cb(result=r)
+
+
+# =========================================================================================
+# InfernSTTWorker (Cluster/InfernSTTWorker.py:16-134) on the HIP device
+# =========================================================================================
+import torch  # noqa: E402
+
+from . import _lib  # noqa: E402
+from .workers import InfernBatchedWorker  # noqa: E402
+
+
+class InfernSTTWorker(InfernBatchedWorker):
+    """Whisper STT worker.  `infer((STTRequest, text_cb, context))`; results are delivered from
+    the worker thread, in item order, exactly once per item (InfernSTTWorker.py:118-123).
+
+    max_batch_size is the reference's tuning knob (4 there); the MI355X default is 64 because a
+    batch is one set of large GEMMs here.  Constructor extras (all optional): `weights` (HF-format
+    state dict; default: download `model_name`), `tokenizer` (needs convert_tokens_to_ids / decode;
+    default: WhisperTokenizer.from_pretrained), `max_new_tokens`."""
+    max_batch_size: int = 64
+    max_chunk_duration: float = 32.0
+    sample_rate: int = 16000
+    debug = False
+
+    def __init__(self, device: str, model_name: str = 'openai/whisper-large-v3', weights=None, tokenizer=None,
+                 max_new_tokens: int = 224, fixed_new_tokens=None):
+        super().__init__()
+        from .engines.whisper import Whisper
+        from .features import WhisperLogMel
+        self.device = dev = _lib.require_device(device)
+        if weights is None:
+            from transformers import WhisperForConditionalGeneration
+            weights = WhisperForConditionalGeneration.from_pretrained(model_name).state_dict()
+        if tokenizer is None:
+            from transformers import WhisperTokenizer
+            tokenizer = WhisperTokenizer.from_pretrained(model_name)
+        self.tokenizer = tokenizer
+        with torch.cuda.device(dev):
+            self.model = Whisper(weights, dev)
+            self.logmel = WhisperLogMel(self.model.n_mel, dev)
+        self.no_speech_token_id = tokenizer.convert_tokens_to_ids('<|nospeech|>')
+        self.eos_token_id = getattr(tokenizer, 'eos_token_id', None)
+        self.max_new_tokens = max_new_tokens
+        self.fixed_new_tokens = fixed_new_tokens
+        self._prompt_cache = {}
+
+    def get_prompt(self, options):
+        """[<|startoftranscript|>, <|lang|>, <|mode|>, (<|notimestamps|>)] per request (:125-134)."""
+        if options not in self._prompt_cache:
+            self._prompt_cache[options] = tuple(
+                self.tokenizer.convert_tokens_to_ids(['<|startoftranscript|>', f'<|{lang}|>', f'<|{mode}|>'] +
+                                                     ([] if ts else ['<|notimestamps|>'])) for lang, mode, ts in options)
+        return self._prompt_cache[options]
+
+    def transcribe_batch(self, audios, prompts, max_nsps):
+        """audios: list of 1-D float tensors/arrays @16 kHz -> [(text, no_speech_prob, token_ids)]"""
+        dev = self.device
+        B = len(audios)
+        with torch.cuda.device(dev):
+            lens = torch.tensor([min(len(a), 480000) for a in audios], dtype=torch.int32)
+            L = max(int(lens.max()), 1)
+            x = torch.zeros((B, L), dtype=torch.float32, device=dev)
+            for i, a in enumerate(audios):
+                a = torch.as_tensor(a)
+                x[i, :lens[i]] = a[:lens[i]].to(dev, torch.float32)
+            mel = self.logmel(x, lens=lens.to(dev))
+            enc = self.model.encode(mel)
+            P = max(len(p) for p in prompts)
+            assert all(len(p) == P for p in prompts), 'prompts of one batch must have equal length'
+            pr = torch.tensor(prompts, dtype=torch.int32)
+            n_new = self.fixed_new_tokens or self.max_new_tokens
+            toks, nsp, _ = self.model.generate(enc, pr, n_new, no_speech_id=self.no_speech_token_id,
+                                               eos_id=None if self.fixed_new_tokens else self.eos_token_id,
+                                               early_exit_nsp=max_nsps)
+            nsp = nsp.cpu().tolist()
+            if toks is None:            # every row above its max_ns_prob (InfernSTTWorker.py:91-92)
+                return [('', p, []) for p in nsp]
+            toks = toks.cpu().tolist()
+        out = []
+        for row, p in zip(toks, nsp):
+            if self.eos_token_id is not None and not self.fixed_new_tokens and self.eos_token_id in row:
+                row = row[:row.index(self.eos_token_id)]
+            out.append((self.tokenizer.decode(row, skip_special_tokens=True), p, row))
+        return out
+
+    def process_batch(self, wis):
+        assert all(wi[0].chunk.samplerate == self.sample_rate for wi in wis)
+        audios = [wi[0].chunk.audio for wi in wis]
+        prompts = self.get_prompt(tuple((wi[0].lang, wi[0].mode, wi[0].timestamps) for wi in wis))
+        max_nsps = [wi[0].max_ns_prob for wi in wis]
+        results = self.transcribe_batch(audios, [list(p) for p in prompts], max_nsps)
+        for (req, text_cb, ctx), (text, nsp, toks) in zip(wis, results):
+            if len(text) > 0 and text[0] == ' ':
+                text = text[1:]
+            if ctx is not None:
+                ctx[:] = (ctx + toks)[:-224]
+            text_cb(result=STTResult(text=text, no_speech_prob=nsp, req=req))

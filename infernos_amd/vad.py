@@ -57,7 +57,7 @@ class VADBatchFromList(VADBatchState):
 
 
 class EnergyVADModel:
-    """Stand-in speech-probability model: p = sigmoid(0.5*(10*log10(mean(x^2)+1e-10)+40))."""
+    """Stand-in speech-probability model: p = sigmoid(0.5*(10*log10(mean(x^2)+1e-10)+30))."""
 
     def __init__(self, device=None):
         self.device = _lib.require_device(device)

@@ -1,0 +1,65 @@
+"""GPU: the batched serving loop (infernos_amd.pipeline) end to end on a few calls, checked
+against the oracle stage by stage on the same intermediate data."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dsp as odsp, nn as onn  # noqa: E402
+
+
+def test_pipeline_cycle_small(built_lib):
+    from infernos_amd import _lib
+    from infernos_amd.codecs import G711Codec
+    from infernos_amd.pipeline import SpeechPipeline
+    from infernos_amd.synth import synth_utterance
+    from infernos_amd.weights import synth_state_dict
+    dev = _lib.require_device('cuda:0')
+    N = 3
+    pipe = SpeechPipeline(N, dev, n_infer=2, n_new_tokens=6)
+    x = np.stack([synth_utterance(1000 + i, 10.0) for i in range(N)])
+    ulaw = odsp.g711_encode(x)
+    frames = torch.from_numpy(np.ascontiguousarray(ulaw.reshape(N, 500, 160).transpose(1, 0, 2))).to(dev)
+    chunks = pipe.ingest(frames)
+    pcm = odsp.g711_decode(ulaw)
+    for i in range(N):
+        assert len(chunks[i]) >= 1
+        tot = sum(c.audio.numel() for c in chunks[i])
+        assert 6.5 * 8000 < tot < 9.5 * 8000, tot
+        for c in chunks[i]:
+            # chunk audio is the decoded stream at [ipos, ipos+len) -- except its first 240 samples (the 30 ms
+            # start pad), which the reference takes from the stale head of its idle buffer (SileroVAD.py:90,101-102)
+            a = c.audio.cpu().numpy()
+            assert np.array_equal(a[240:], pcm[i, c.ipos + 240:c.ipos + a.size])
+    spans = [[(c.ipos, c.audio.numel()) for c in lst] for lst in chunks]
+    pipe_merged = []
+    for lst in chunks:                           # what pipe.stt merges (VadAudioChunk.append semantics)
+        lo = lst[0].ipos
+        m = np.zeros(lst[-1].ipos + lst[-1].audio.numel() - lo, np.float32)
+        for c in lst:
+            m[c.ipos - lo:c.ipos - lo + c.audio.numel()] = c.audio.cpu().numpy()
+        pipe_merged.append(m)
+    toks, nsp, secs = pipe.stt(chunks)
+    assert toks.shape == (N, 6) and nsp.shape == (N,)
+    # oracle on the same merged audio
+    sd = synth_state_dict('whisper_tiny', 0)
+    for i in range(N):
+        lo = spans[i][0][0]
+        hi = spans[i][-1][0] + spans[i][-1][1]
+        merged = np.zeros(hi - lo, np.float32)
+        for (p, n) in spans[i]:
+            merged[p - lo:p - lo + n] = pcm[i, p:p + n]
+        merged = pipe_merged[i]
+        assert abs(float(secs[i]) - merged.size / 8000.0) < 1e-6
+        mel = torch.from_numpy(odsp.logmel(odsp.resample(merged, 8000, 16000)))[None]
+        with torch.no_grad():
+            o_toks, o_first, _, _ = onn.whisper_greedy(sd, mel, pipe.prompt[:1].long(), 6, 6)
+        margin = float(o_first.topk(2).values[0, 0] - o_first.topk(2).values[0, 1])
+        if margin > 0.05:
+            assert int(toks[i, 0]) == int(o_toks[0, 0]), (i, toks[i].tolist(), o_toks.tolist())
+    ul, valid, sp = pipe.synthesize()
+    assert ul.shape == (N, 2 * 4096) and ul.dtype == torch.uint8
+    assert valid.tolist() == [2 * 4096 - 256] * N          # the first call drops its first 256 samples @8 kHz
+    audio = odsp.g711_decode(ul.cpu().numpy())
+    assert np.isfinite(audio).all() and 1e-4 < np.abs(audio).mean() < 0.5
