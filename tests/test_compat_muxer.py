@@ -1,0 +1,72 @@
+"""CPU: compat aliases and the output muxer against the trace captured from the reference."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+
+def test_compat_install_aliases():
+    import infernos_amd.compat as compat
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k.split('.')[0] in ('Core', 'Cluster', 'HelloSippyTTSRT', 'config', 'safetorch')}
+    try:
+        compat.install()
+        from Core.Codecs.G711 import G711Codec
+        from Cluster.STTSession import STTSession
+        from HelloSippyTTSRT.HelloSippyRTPipe import HelloSippyRTPipe
+        from config.InfernGlobals import InfernGlobals
+        import infernos_amd.codecs, infernos_amd.stt, infernos_amd.tts
+        assert G711Codec is infernos_amd.codecs.G711Codec and STTSession is infernos_amd.stt.STTSession
+        assert HelloSippyRTPipe is infernos_amd.tts.HelloSippyRTPipe
+        assert InfernGlobals() is InfernGlobals() and InfernGlobals().torcher is not None
+        assert G711Codec.rtpmap() == 'rtpmap:0 PCMU/8000' and G711Codec().silence(2) == b'\xff\xff'
+        assert G711Codec().e2d_frames(160, 16000) == 320 and G711Codec().d2e_frames(768, 8000) == 768
+    finally:
+        for k in [k for k in sys.modules if k.split('.')[0] in ('Core', 'Cluster', 'HelloSippyTTSRT', 'config', 'safetorch')]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
+
+
+def test_torcher_lock_and_timeout():
+    import pytest
+    from infernos_amd.torcher import InfernTorcher, InfernTorcherDeadlock
+    t = InfernTorcher()
+    with t:
+        pass
+    assert t.nlocks == 1 and 0.0 <= t.load() <= 1.0
+    t.timeout = 0.05
+    t.acquire()
+    with pytest.raises(InfernTorcherDeadlock):
+        t.acquire()
+    t.release()
+
+
+def test_output_muxer_trace(golden_dir):
+    from infernos_amd.audio import AudioChunk
+    from infernos_amd.muxer import ASMarkerNewSent, OutputMTMuxer
+    g = json.load(open(os.path.join(golden_dir, 'muxer_trace.json')))
+    data = np.load(os.path.join(golden_dir, 'muxer_data.npz'))
+    log = []
+
+    class Mk(ASMarkerNewSent):
+        def __init__(self, tag, **kw):
+            super().__init__(**kw); self.tag = tag
+
+        def on_proc(self, w, *a):
+            log.append(['marker', self.tag])
+    mux = OutputMTMuxer(8000, 800, 'cpu')
+    for i, op in enumerate(g['script']):
+        if op[0] == 'chunk':
+            c = AudioChunk(torch.from_numpy(data['in_%d' % i].copy()), 8000); c.track_id = op[1]
+            mux.chunk_in(c)
+        elif op[0] == 'marker':
+            mux.chunk_in(Mk(op[2], track_id=op[1]))
+        else:
+            r = mux.idle(None)
+            if r is None:
+                log.append(['idle', i, None])
+            else:
+                np.testing.assert_allclose(r.numpy(), data['out_%d' % i], atol=1e-7)
+                log.append(['idle', i, int(r.size(0))])
+    assert log == g['log']
