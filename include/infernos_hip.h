@@ -175,6 +175,11 @@ typedef struct ifh_conv_desc {
     int32_t out_f32;
     int64_t out_bstride;
     int32_t ldc, ostride, ooff;
+    /* optional device-resident scalar (e.g. the decoder position) so that a captured hipGraph can be
+     * replayed for every step: effective ooff += dyn_pos[0]*dyn_ooff_mul, resid += dyn_pos[0]*dyn_resid_mul */
+    const int32_t *dyn_pos;
+    int32_t dyn_ooff_mul;
+    int64_t dyn_resid_mul;
 } ifh_conv_desc;
 int ifh_conv_bf16(const ifh_conv_desc *desc, ifh_stream_t stream);
 
@@ -197,22 +202,29 @@ typedef struct ifh_attn_desc {
     int32_t nrel;
 } ifh_attn_desc;
 int ifh_attn_prefill_bf16(const ifh_attn_desc *desc, ifh_stream_t stream);
-/* one query token per (batch, head) against a KV cache of key_len[b] (or max_keys) entries */
+/* one query token per (batch, head) against a KV cache.  Number of keys: key_len[b] if given, else
+ * dyn_len[0] + dyn_add if dyn_len (device scalar; lets a captured graph be replayed per step), else
+ * max_keys (which must bound the key count in every case). */
 int ifh_attn_decode_bf16(const void *q, int64_t q_bs, const void *k, const void *v, int64_t kv_bs, int64_t kv_ts,
                          void *out, int64_t o_bs, const int32_t *key_len, int max_keys, int nbatch, int nheads,
-                         int head_dim, ifh_stream_t stream);
+                         int head_dim, const int32_t *dyn_len, int dyn_add, ifh_stream_t stream);
 
-/* out[i] = table[ids[i]] + pos_table[pos0 + i % seq_len] (pos_table may be NULL); bf16, dim % 8 == 0 */
+/* out[i] = table[ids[i]] + pos_table[pos0 + i % seq_len] (pos_table may be NULL); bf16, dim % 8 == 0.
+ * dyn_pos (device scalar, optional): pos0 += dyn_pos[0], ids += dyn_pos[0]*dyn_ids_mul */
 int ifh_embed_bf16(const int32_t *ids, const void *table, const void *pos_table, int pos0, int seq_len, int dim,
-                   int n, void *out, ifh_stream_t stream);
-/* per row of f32 logits: argmax (first on ties) and/or softmax probability of pick_token */
+                   int n, void *out, const int32_t *dyn_pos, int dyn_ids_mul, ifh_stream_t stream);
+/* per row of f32 logits: argmax (first on ties) and/or softmax probability of pick_token;
+ * dyn_pos optional: argmax_out += dyn_pos[0]*dyn_out_mul */
 int ifh_argmax_pick_f32(const float *logits, int64_t ld, int vocab, int nrows, int pick_token, int32_t *argmax_out,
-                        float *pick_prob_out, ifh_stream_t stream);
+                        float *pick_prob_out, const int32_t *dyn_pos, int dyn_out_mul, ifh_stream_t stream);
+/* value[0] += delta on the stream (advances a device-resident step counter between graph replays) */
+int ifh_add_i32(int32_t *value, int delta, ifh_stream_t stream);
 
 /* ---- TTS streaming glue, HelloSippyRTPipe.infer (HelloSippyRTPipe.py:191-240) ---- */
 /* stop rule (:227-228) on the 2 stop logits per utterance; ends_at int64[n] */
 int ifh_tts_stop_update(const float *prob_logits, int64_t *ends_at, int n, int idx, int minlen, int maxlen,
-                        float threshold, int ends_inc, ifh_stream_t stream);
+                        float threshold, int ends_inc, const int32_t *dyn_idx /* overrides idx if set */,
+                        ifh_stream_t stream);
 /* carry + 4 overlapped 12-frame chunks (:231-235): pre_frames bf16 [B][4][80] (updated), post bf16
  * [B][32][80] -> voc_in bf16 [4B][12][80] normalised by (x-mean)/scale, amd_mel bf16 [4B][12][80] =
  * channels-last form of the chunk re-viewed as [80][12] (HelloSippyRT.py:224) */

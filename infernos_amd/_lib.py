@@ -48,7 +48,7 @@ class ConvDesc(ctypes.Structure):
                 ('act', ctypes.c_int32), ('act_slope', _f), ('resid', _vp), ('resid_bstride', _i64),
                 ('resid_ld', ctypes.c_int32), ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp),
                 ('out_f32', ctypes.c_int32), ('out_bstride', _i64), ('ldc', ctypes.c_int32), ('ostride', ctypes.c_int32),
-                ('ooff', ctypes.c_int32)]
+                ('ooff', ctypes.c_int32), ('dyn_pos', _vp), ('dyn_ooff_mul', ctypes.c_int32), ('dyn_resid_mul', _i64)]
 
 
 class AttnDesc(ctypes.Structure):
@@ -65,10 +65,11 @@ SIGNATURES.update({
     'ifh_layernorm_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     'ifh_transpose_to_bf16': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     'ifh_attn_prefill_bf16': (_i, [ctypes.POINTER(AttnDesc), _vp]),
-    'ifh_attn_decode_bf16': (_i, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp]),
-    'ifh_embed_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
-    'ifh_argmax_pick_f32': (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _vp]),
-    'ifh_tts_stop_update': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp]),
+    'ifh_attn_decode_bf16': (_i, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    'ifh_embed_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    'ifh_add_i32': (_i, [_vp, _i, _vp]),
+    'ifh_argmax_pick_f32': (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    'ifh_tts_stop_update': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
     'ifh_tts_chunks_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'ifh_hifigan_post_bf16': (_i, [_vp, _vp, _f, _vp, _i, _i, _f, _vp]),
     'ifh_amend_final_bf16': (_i, [_vp, _vp, _vp, _i, _vp]),

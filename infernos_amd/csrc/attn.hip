@@ -175,60 +175,119 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const AttnParams p)
     }
 }
 
-// One query token per (batch, head); scores in LDS.  S <= smax (dynamic LDS floats).
-__global__ __launch_bounds__(64) void k_attn_decode(const uint16_t *__restrict__ q, int64_t q_bs,
-                                                    const uint16_t *__restrict__ k, const uint16_t *__restrict__ v,
-                                                    int64_t kv_bs, int64_t kv_ts, uint16_t *__restrict__ out,
-                                                    int64_t o_bs, const int32_t *__restrict__ key_len, int S)
+// One query token per (batch, head) against a KV cache.  A wave is 8 key-groups x 8 lanes; a lane owns
+// 8 of the 64 head dims (one 16-byte load per key for K and for V, 128 B coalesced per key).
+// Every key-group runs its own online softmax over keys g, g+8*NW, ...; the groups (and the NW
+// waves of the block, for long caches) are merged at the end with the usual (m, l, o) rescale.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_attn_decode(const uint16_t *__restrict__ q, int64_t q_bs,
+                                                         const uint16_t *__restrict__ k, const uint16_t *__restrict__ v,
+                                                         int64_t kv_bs, int64_t kv_ts, uint16_t *__restrict__ out,
+                                                         int64_t o_bs, const int32_t *__restrict__ key_len, int S,
+                                                         const int32_t *__restrict__ dyn_len, int dyn_add)
 {
-    extern __shared__ __attribute__((aligned(16))) float sc[];
-    const int b = blockIdx.y, h = blockIdx.x, lane = threadIdx.x;
-    const int klen = key_len ? key_len[b] : S;
-    float qv[HD];
+    __shared__ float comb[NW][8][10];
+    const int b = blockIdx.y, h = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 7, g = lane >> 3;
+    int klen = key_len ? key_len[b] : (dyn_len ? dyn_len[0] + dyn_add : S);
+    float qv[8];
     {
-        const uint16_t *qp = q + (int64_t)b * q_bs + h * HD;
+        const uint4 t = *reinterpret_cast<const uint4 *>(q + (int64_t)b * q_bs + h * HD + 8 * c);
+        const uint32_t *u = reinterpret_cast<const uint32_t *>(&t);
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint4 t = *reinterpret_cast<const uint4 *>(qp + 8 * i);
-            const uint32_t *u = reinterpret_cast<const uint32_t *>(&t);
+        for (int e = 0; e < 4; e++) {
+            qv[2 * e] = __uint_as_float(u[e] << 16);
+            qv[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+        }
+    }
+    const uint16_t *kb = k + (int64_t)b * kv_bs + h * HD + 8 * c;
+    const uint16_t *vb = v + (int64_t)b * kv_bs + h * HD + 8 * c;
+    float m = -1e30f, l = 0.0f, o[8];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                qv[8 * i + 2 * e] = __uint_as_float(u[e] << 16);
-                qv[8 * i + 2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+    for (int i = 0; i < 8; i++) o[i] = 0.0f;
+    // software-pipelined: the next key's K/V rows are in flight while the current one is consumed
+    int key = wid * 8 + g;
+    bool have = key < klen;
+    uint4 kk = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+    if (have) {
+        kk = *reinterpret_cast<const uint4 *>(kb + (int64_t)key * kv_ts);
+        vv = *reinterpret_cast<const uint4 *>(vb + (int64_t)key * kv_ts);
+    }
+    while (have) {
+        const int nkey = key + 8 * NW;
+        const bool nhave = nkey < klen;
+        uint4 nk = make_uint4(0, 0, 0, 0), nv = make_uint4(0, 0, 0, 0);
+        if (nhave) {
+            nk = *reinterpret_cast<const uint4 *>(kb + (int64_t)nkey * kv_ts);
+            nv = *reinterpret_cast<const uint4 *>(vb + (int64_t)nkey * kv_ts);
+        }
+        const uint32_t *ku = reinterpret_cast<const uint32_t *>(&kk);
+        float s = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            s = __fmaf_rn(qv[2 * e], __uint_as_float(ku[e] << 16), s);
+            s = __fmaf_rn(qv[2 * e + 1], __uint_as_float(ku[e] & 0xffff0000u), s);
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        const float mn = fmaxf(m, s);
+        const float a = __expf(m - mn), pr = __expf(s - mn);
+        l = l * a + pr;
+        const uint32_t *vu = reinterpret_cast<const uint32_t *>(&vv);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            o[2 * e] = o[2 * e] * a + pr * __uint_as_float(vu[e] << 16);
+            o[2 * e + 1] = o[2 * e + 1] * a + pr * __uint_as_float(vu[e] & 0xffff0000u);
+        }
+        m = mn;
+        kk = nk;
+        vv = nv;
+        key = nkey;
+        have = nhave;
+    }
+    // merge the 8 key-groups of the wave
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+        const float m2 = __shfl_xor(m, off, 64), l2 = __shfl_xor(l, off, 64);
+        const float mn = fmaxf(m, m2);
+        const float a = __expf(m - mn), a2 = __expf(m2 - mn);
+        l = l * a + l2 * a2;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[i] = o[i] * a + __shfl_xor(o[i], off, 64) * a2;
+        m = mn;
+    }
+    if (NW > 1) {
+        if (g == 0) {
+            comb[wid][c][0] = m;
+            comb[wid][c][1] = l;
+#pragma unroll
+            for (int i = 0; i < 8; i++) comb[wid][c][2 + i] = o[i];
+        }
+        __syncthreads();
+        if (wid == 0 && g == 0) {
+#pragma unroll
+            for (int w = 1; w < NW; w++) {
+                const float m2 = comb[w][c][0], l2 = comb[w][c][1];
+                const float mn = fmaxf(m, m2);
+                const float a = __expf(m - mn), a2 = __expf(m2 - mn);
+                l = l * a + l2 * a2;
+#pragma unroll
+                for (int i = 0; i < 8; i++) o[i] = o[i] * a + comb[w][c][2 + i] * a2;
+                m = mn;
             }
         }
     }
-    const uint16_t *kb = k + (int64_t)b * kv_bs + h * HD;
-    const uint16_t *vb = v + (int64_t)b * kv_bs + h * HD;
-    float mloc = -1e30f;
-    for (int key = lane; key < klen; key += 64) {
-        const uint16_t *kr = kb + (int64_t)key * kv_ts;
-        float acc = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint4 t = *reinterpret_cast<const uint4 *>(kr + 8 * i);
-            const uint32_t *u = reinterpret_cast<const uint32_t *>(&t);
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                acc = __fmaf_rn(qv[8 * i + 2 * e], __uint_as_float(u[e] << 16), acc);
-                acc = __fmaf_rn(qv[8 * i + 2 * e + 1], __uint_as_float(u[e] & 0xffff0000u), acc);
-            }
-        }
-        sc[key] = acc;
-        mloc = fmaxf(mloc, acc);
+    if (wid == 0 && g == 0) {
+        const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+        uint4 pk;
+        pk.x = pack2(o[0] * inv, o[1] * inv);
+        pk.y = pack2(o[2] * inv, o[3] * inv);
+        pk.z = pack2(o[4] * inv, o[5] * inv);
+        pk.w = pack2(o[6] * inv, o[7] * inv);
+        *reinterpret_cast<uint4 *>(out + (int64_t)b * o_bs + h * HD + 8 * c) = pk;
     }
-    const float m = wave_max(mloc);
-    float lsum = 0.0f;
-    for (int key = lane; key < klen; key += 64) {
-        const float pv = __expf(sc[key] - m);
-        sc[key] = pv;
-        lsum += pv;
-    }
-    const float l = wave_sum(lsum);
-    __syncthreads();
-    float acc = 0.0f;
-    for (int key = 0; key < klen; key++) acc = __fmaf_rn(sc[key], bf16_to_f32(vb[(int64_t)key * kv_ts + lane]), acc);
-    out[(int64_t)b * o_bs + h * HD + lane] = f32_to_bf16(l > 0.0f ? acc / l : 0.0f);
 }
 
 }  // namespace ifh
@@ -272,16 +331,22 @@ extern "C" int ifh_attn_prefill_bf16(const ifh_attn_desc *d, ifh_stream_t stream
 
 extern "C" int ifh_attn_decode_bf16(const void *q, int64_t q_bs, const void *k, const void *v, int64_t kv_bs,
                                     int64_t kv_ts, void *out, int64_t o_bs, const int32_t *key_len, int max_keys,
-                                    int nbatch, int nheads, int head_dim, ifh_stream_t stream)
+                                    int nbatch, int nheads, int head_dim, const int32_t *dyn_len, int dyn_add,
+                                    ifh_stream_t stream)
 {
     IFH_CHECK_ARG(nbatch >= 0);
     if (nbatch == 0) return IFH_OK;
-    IFH_CHECK_ARG(q && k && v && out && nheads > 0 && head_dim == HD && max_keys >= 1 && max_keys <= 8192);
-    IFH_CHECK_ARG(q_bs % 8 == 0 && kv_bs % 8 == 0 && kv_ts % 8 == 0 && nbatch < 65536);
+    IFH_CHECK_ARG(q && k && v && out && nheads > 0 && head_dim == HD && max_keys >= 1);
+    IFH_CHECK_ARG(q_bs % 8 == 0 && kv_bs % 8 == 0 && kv_ts % 8 == 0 && o_bs % 8 == 0 && nbatch < 65536);
     dim3 grid(nheads, nbatch);
-    hipLaunchKernelGGL(k_attn_decode, grid, dim3(64), (size_t)max_keys * sizeof(float), as_stream(stream),
-                       (const uint16_t *)q, q_bs, (const uint16_t *)k, (const uint16_t *)v, kv_bs, kv_ts, (uint16_t *)out,
-                       o_bs, key_len, max_keys);
+    if (max_keys > 256)
+        hipLaunchKernelGGL(k_attn_decode<4>, grid, dim3(256), 0, as_stream(stream), (const uint16_t *)q, q_bs,
+                           (const uint16_t *)k, (const uint16_t *)v, kv_bs, kv_ts, (uint16_t *)out, o_bs, key_len, max_keys,
+                           dyn_len, dyn_add);
+    else
+        hipLaunchKernelGGL(k_attn_decode<1>, grid, dim3(64), 0, as_stream(stream), (const uint16_t *)q, q_bs,
+                           (const uint16_t *)k, (const uint16_t *)v, kv_bs, kv_ts, (uint16_t *)out, o_bs, key_len, max_keys,
+                           dyn_len, dyn_add);
     IFH_LAUNCH_CHECK("attn_decode");
     return IFH_OK;
 }

@@ -13,9 +13,14 @@ namespace ifh {
 // out[i][:] = table[ids[i]][:] + (pos_table ? pos_table[pos0 + (i % T)][:] : 0), D % 8 == 0
 __global__ __launch_bounds__(256) void k_embed(const int32_t *__restrict__ ids, const uint16_t *__restrict__ table,
                                                const uint16_t *__restrict__ pos_table, int pos0, int T, int D,
-                                               int n, uint16_t *__restrict__ out)
+                                               int n, uint16_t *__restrict__ out, const int32_t *__restrict__ dyn,
+                                               int dyn_ids_mul)
 {
     const int vecs = D / 8;
+    if (dyn) {
+        pos0 += dyn[0];
+        ids += (int64_t)dyn[0] * dyn_ids_mul;
+    }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < (int64_t)n * vecs;
          e += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(e / vecs), c = (int)(e % vecs) * 8;
@@ -37,8 +42,10 @@ __global__ __launch_bounds__(256) void k_embed(const int32_t *__restrict__ ids, 
 
 // per row: argmax (first index on ties) and optionally softmax probability of `pick`
 __global__ __launch_bounds__(256) void k_argmax_pick(const float *__restrict__ logits, int64_t ld, int V, int pick,
-                                                     int32_t *__restrict__ arg, float *__restrict__ prob)
+                                                     int32_t *__restrict__ arg, float *__restrict__ prob,
+                                                     const int32_t *__restrict__ dyn, int dyn_out_mul)
 {
+    if (dyn && arg) arg += (int64_t)dyn[0] * dyn_out_mul;
     __shared__ float smax[4];
     __shared__ int sidx[4];
     __shared__ float ssum[4];
@@ -89,10 +96,11 @@ __global__ __launch_bounds__(256) void k_argmax_pick(const float *__restrict__ l
 
 // HelloSippyRTPipe.py:227-228: ends_at = where(ends_at<0 & minlen<=idx & (any(sigmoid>=thr) | maxlen<=idx), idx+2, ends_at)
 __global__ void k_tts_stop(const float *__restrict__ logits /* [B][2] */, int64_t *__restrict__ ends_at, int n, int idx,
-                           int minlen, int maxlen, float thr, int ends_inc)
+                           int minlen, int maxlen, float thr, int ends_inc, const int32_t *__restrict__ dyn)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n) return;
+    if (dyn) idx = dyn[0];
     const float p0 = 1.0f / (1.0f + expf(-logits[2 * b])), p1 = 1.0f / (1.0f + expf(-logits[2 * b + 1]));
     const bool hit = (ends_at[b] < 0) && (minlen <= idx) && ((p0 >= thr) || (p1 >= thr) || (maxlen <= idx));
     if (hit) ends_at[b] = idx + ends_inc;
@@ -192,12 +200,22 @@ __global__ __launch_bounds__(64) void k_l2norm_rows(const uint16_t *__restrict__
     for (int i = lane; i < D; i += 64) out[(int64_t)r * ld_out + i] = f32_to_bf16(bf16_to_f32(x[(int64_t)r * D + i]) * inv);
 }
 
+__global__ void k_add_i32(int32_t *p, int delta) { p[0] += delta; }
+
 }  // namespace ifh
 
 using namespace ifh;
 
+extern "C" int ifh_add_i32(int32_t *value, int delta, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(value);
+    hipLaunchKernelGGL(k_add_i32, dim3(1), dim3(1), 0, as_stream(stream), value, delta);
+    IFH_LAUNCH_CHECK("add_i32");
+    return IFH_OK;
+}
+
 extern "C" int ifh_embed_bf16(const int32_t *ids, const void *table, const void *pos_table, int pos0, int seq_len,
-                              int dim, int n, void *out, ifh_stream_t stream)
+                              int dim, int n, void *out, const int32_t *dyn_pos, int dyn_ids_mul, ifh_stream_t stream)
 {
     IFH_CHECK_ARG(n >= 0);
     if (n == 0) return IFH_OK;
@@ -206,32 +224,33 @@ extern "C" int ifh_embed_bf16(const int32_t *ids, const void *table, const void 
     int grid = (int)((work + 255) / 256);
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(k_embed, dim3(grid), dim3(256), 0, as_stream(stream), ids, (const uint16_t *)table,
-                       (const uint16_t *)pos_table, pos0, seq_len, dim, n, (uint16_t *)out);
+                       (const uint16_t *)pos_table, pos0, seq_len, dim, n, (uint16_t *)out, dyn_pos, dyn_ids_mul);
     IFH_LAUNCH_CHECK("embed");
     return IFH_OK;
 }
 
 extern "C" int ifh_argmax_pick_f32(const float *logits, int64_t ld, int vocab, int nrows, int pick_token,
-                                   int32_t *argmax_out, float *pick_prob_out, ifh_stream_t stream)
+                                   int32_t *argmax_out, float *pick_prob_out, const int32_t *dyn_pos, int dyn_out_mul,
+                                   ifh_stream_t stream)
 {
     IFH_CHECK_ARG(nrows >= 0);
     if (nrows == 0) return IFH_OK;
     IFH_CHECK_ARG(logits && vocab > 0 && ld >= vocab && (argmax_out || pick_prob_out));
     IFH_CHECK_ARG(!pick_prob_out || (pick_token >= 0 && pick_token < vocab));
     hipLaunchKernelGGL(k_argmax_pick, dim3(nrows), dim3(256), 0, as_stream(stream), logits, ld, vocab, pick_token,
-                       argmax_out, pick_prob_out);
+                       argmax_out, pick_prob_out, dyn_pos, dyn_out_mul);
     IFH_LAUNCH_CHECK("argmax_pick");
     return IFH_OK;
 }
 
 extern "C" int ifh_tts_stop_update(const float *prob_logits, int64_t *ends_at, int n, int idx, int minlen, int maxlen,
-                                   float threshold, int ends_inc, ifh_stream_t stream)
+                                   float threshold, int ends_inc, const int32_t *dyn_idx, ifh_stream_t stream)
 {
     IFH_CHECK_ARG(n >= 0);
     if (n == 0) return IFH_OK;
     IFH_CHECK_ARG(prob_logits && ends_at);
     hipLaunchKernelGGL(k_tts_stop, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), prob_logits, ends_at, n, idx,
-                       minlen, maxlen, threshold, ends_inc);
+                       minlen, maxlen, threshold, ends_inc, dyn_idx);
     IFH_LAUNCH_CHECK("tts_stop");
     return IFH_OK;
 }

@@ -39,6 +39,9 @@ struct IgemmParams {
     int64_t out_bstride;
     int ldc, ostride, ooff;
     int vec_ok;
+    const int32_t *dyn;       // optional device scalar (e.g. decoder position)
+    int dyn_ooff_mul;         // ooff += dyn[0] * dyn_ooff_mul
+    int64_t dyn_resid_mul;    // resid += dyn[0] * dyn_resid_mul (elements)
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_TANH = 3, ACT_LRELU = 4, ACT_SIGMOID = 5 };
@@ -66,6 +69,138 @@ __device__ __forceinline__ uint4 lrelu8(uint4 v, float slope)
         u[i] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
     }
     return v;
+}
+
+
+// epilogue for 4 consecutive output channels n..n+3 of output row m (shared by both GEMM kernels)
+__device__ __forceinline__ void igemm_store4(const IgemmParams &p, int m, int n, const float (&accv)[4], int dynv)
+{
+    const int b = m / p.T_out, t = m - b * p.T_out;
+    const int64_t orow = (int64_t)t * p.ostride + p.ooff + (int64_t)dynv * p.dyn_ooff_mul;
+    const int64_t obase = (int64_t)b * p.out_bstride + orow * p.ldc;
+    const int64_t rbase = (int64_t)b * p.resid_bstride + orow * p.resid_ld + (int64_t)dynv * p.dyn_resid_mul;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        float a = accv[r];
+        const int nn = n + r;
+        if (nn < p.N) {
+            if (p.bias) a += p.bias[nn];
+            a = apply_act(a, p.act, p.act_slope);
+            if (p.colmask) a = p.colmask[nn] ? a * 2.0f : 0.0f;
+            if (p.resid) a += bf16_to_f32(p.resid[rbase + nn]);
+            a *= p.out_scale;
+        }
+        v[r] = a;
+    }
+    if (p.vec_ok && n + 3 < p.N) {
+        if (p.out_f32) {
+            float *o = reinterpret_cast<float *>(p.out) + obase + n;
+            float4 prev = make_float4(0, 0, 0, 0);
+            if (p.accumulate) prev = *reinterpret_cast<const float4 *>(o);
+            *reinterpret_cast<float4 *>(o) = make_float4(v[0] + prev.x, v[1] + prev.y, v[2] + prev.z, v[3] + prev.w);
+        } else {
+            uint16_t *o = reinterpret_cast<uint16_t *>(p.out) + obase + n;
+            if (p.accumulate) {
+                const uint2 pv = *reinterpret_cast<const uint2 *>(o);
+                v[0] += __uint_as_float(pv.x << 16);
+                v[1] += __uint_as_float(pv.x & 0xffff0000u);
+                v[2] += __uint_as_float(pv.y << 16);
+                v[3] += __uint_as_float(pv.y & 0xffff0000u);
+            }
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2 *>(o) = pk;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            if (n + r >= p.N) break;
+            if (p.out_f32) {
+                float *o = reinterpret_cast<float *>(p.out) + obase + n + r;
+                *o = v[r] + (p.accumulate ? *o : 0.0f);
+            } else {
+                uint16_t *o = reinterpret_cast<uint16_t *>(p.out) + obase + n + r;
+                *o = f32_to_bf16(v[r] + (p.accumulate ? bf16_to_f32(*o) : 0.0f));
+            }
+        }
+    }
+}
+
+// ---- skinny GEMM for decode steps (M <= 64 rows, taps == 1): weight streaming.
+// One block = 16 output channels x all rows; its NW waves split K; every lane streams its
+// 16-byte weight/activation fragments straight from global/L2 (no LDS staging: each weight
+// byte is used once per block), partial tiles are summed through LDS.
+template <int MT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
+{
+    __shared__ __attribute__((aligned(16))) float red[NW][MT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int M = p.nbatch * p.T_out;
+    const int nk = (p.K + 31) / 32;
+    const int per = (nk + NW - 1) / NW;
+    const int kt0 = wid * per, kt1 = min(nk, kt0 + per);
+    const int nrow = n0 + fr;
+    const uint16_t *wrow = p.w + (int64_t)(nrow < p.N ? nrow : 0) * p.K + fg * 8;
+    const uint16_t *xrow[MT];
+    bool xok[MT];
+#pragma unroll
+    for (int j = 0; j < MT; j++) {
+        const int m = j * 16 + fr;
+        xok[j] = m < M;
+        const int mm = xok[j] ? m : 0;
+        const int b = mm / p.T_out, t = mm - b * p.T_out;
+        xrow[j] = p.x + (int64_t)b * p.x_bstride + (int64_t)t * p.lda + fg * 8;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int j = 0; j < MT; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool wok = nrow < p.N;
+    constexpr int U = 4;    // k-steps in flight per wave (all loads issued before the MFMAs)
+    for (int kt = kt0; kt < kt1; kt += U) {
+        uint4 wv[U], xv[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int kk = kt + u;
+            const bool kok = kk < kt1 && (kk * 32 + fg * 8) < p.K;      // K % 8 == 0
+            wv[u] = make_uint4(0, 0, 0, 0);
+            if (wok && kok) wv[u] = *reinterpret_cast<const uint4 *>(wrow + kk * 32);
+#pragma unroll
+            for (int j = 0; j < MT; j++) {
+                xv[u][j] = make_uint4(0, 0, 0, 0);
+                if (xok[j] && kok) xv[u][j] = *reinterpret_cast<const uint4 *>(xrow[j] + kk * 32);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bf16x8_t fa = __builtin_bit_cast(bf16x8_t, wv[u]);
+#pragma unroll
+            for (int j = 0; j < MT; j++)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, __builtin_bit_cast(bf16x8_t, xv[u][j]), acc[j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MT; j++) *reinterpret_cast<f32x4 *>(&red[wid][j][lane][0]) = acc[j];
+    __syncthreads();
+    const int dynv = p.dyn ? p.dyn[0] : 0;
+    for (int item = tid; item < MT * 64; item += NW * 64) {
+        const int j = item >> 6, ln = item & 63;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const float4 v = *reinterpret_cast<const float4 *>(&red[w][j][ln][0]);
+            s[0] += v.x;
+            s[1] += v.y;
+            s[2] += v.z;
+            s[3] += v.w;
+        }
+        const int m = j * 16 + (ln & 15);
+        const int n = n0 + 4 * (ln >> 4);
+        if (m < M && n < p.N) igemm_store4(p, m, n, s, dynv);
+    }
 }
 
 template <int BM, int BN, int WGM, bool PRE>
@@ -178,65 +313,17 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
     }
 
     // ---- epilogue: lane holds D[n = 4*fg + r][m = fr] of each 16x16 tile
+    const int dynv = p.dyn ? p.dyn[0] : 0;
 #pragma unroll
     for (int j = 0; j < MT; j++) {
         const int m = m0 + wm * WM + j * 16 + fr;
         if (m >= M) continue;
-        const int b = m / p.T_out, t = m - b * p.T_out;
-        const int64_t orow = (int64_t)t * p.ostride + p.ooff;
-        const int64_t obase = (int64_t)b * p.out_bstride + orow * p.ldc;
-        const int64_t rbase = (int64_t)b * p.resid_bstride + orow * p.resid_ld;
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             const int n = n0 + wn * WN + i * 16 + 4 * fg;
             if (n >= p.N) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                float a = acc[i][j][r];
-                const int nn = n + r;
-                if (nn < p.N) {
-                    if (p.bias) a += p.bias[nn];
-                    a = apply_act(a, p.act, p.act_slope);
-                    if (p.colmask) a = p.colmask[nn] ? a * 2.0f : 0.0f;
-                    if (p.resid) a += bf16_to_f32(p.resid[rbase + nn]);
-                    a *= p.out_scale;
-                }
-                v[r] = a;
-            }
-            if (p.vec_ok && n + 3 < p.N) {
-                if (p.out_f32) {
-                    float *o = reinterpret_cast<float *>(p.out) + obase + n;
-                    float4 prev = make_float4(0, 0, 0, 0);
-                    if (p.accumulate) prev = *reinterpret_cast<const float4 *>(o);
-                    *reinterpret_cast<float4 *>(o) = make_float4(v[0] + prev.x, v[1] + prev.y, v[2] + prev.z, v[3] + prev.w);
-                } else {
-                    uint16_t *o = reinterpret_cast<uint16_t *>(p.out) + obase + n;
-                    if (p.accumulate) {
-                        const uint2 pv = *reinterpret_cast<const uint2 *>(o);
-                        v[0] += __uint_as_float(pv.x << 16);
-                        v[1] += __uint_as_float(pv.x & 0xffff0000u);
-                        v[2] += __uint_as_float(pv.y << 16);
-                        v[3] += __uint_as_float(pv.y & 0xffff0000u);
-                    }
-                    uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2 *>(o) = pk;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if (n + r >= p.N) break;
-                    if (p.out_f32) {
-                        float *o = reinterpret_cast<float *>(p.out) + obase + n + r;
-                        *o = v[r] + (p.accumulate ? *o : 0.0f);
-                    } else {
-                        uint16_t *o = reinterpret_cast<uint16_t *>(p.out) + obase + n + r;
-                        *o = f32_to_bf16(v[r] + (p.accumulate ? bf16_to_f32(*o) : 0.0f));
-                    }
-                }
-            }
+            const float a4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            igemm_store4(p, m, n, a4, dynv);
         }
     }
 }
@@ -387,11 +474,23 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     p.ooff = d->ooff;
     const int esz = d->out_f32 ? 4 : 2;
     p.vec_ok = (d->ldc % 4 == 0) && (d->out_bstride % 4 == 0) && ((((uintptr_t)d->out) % (4 * esz)) == 0);
+    p.dyn = d->dyn_pos;
+    p.dyn_ooff_mul = d->dyn_ooff_mul;
+    p.dyn_resid_mul = d->dyn_resid_mul;
     const bool pre = d->pre_slope != 1.0f;
     const int64_t M = (int64_t)d->nbatch * d->t_out;
     IFH_CHECK_ARG(M < (1ll << 31));
     hipStream_t st = as_stream(stream);
-    if (d->n <= 32)
+    if (M <= 64 && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre) {
+        const dim3 grid((d->n + 15) / 16);
+        const bool deep = p.K >= 2048;
+        const int mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
+#define IFH_SKINNY(MT_, NW_) hipLaunchKernelGGL((k_gemm_skinny<MT_, NW_>), grid, dim3(NW_ * 64), 0, st, p)
+        if (mt == 1) { if (deep) IFH_SKINNY(1, 8); else IFH_SKINNY(1, 4); }
+        else if (mt == 2) { if (deep) IFH_SKINNY(2, 8); else IFH_SKINNY(2, 4); }
+        else { if (deep) IFH_SKINNY(4, 8); else IFH_SKINNY(4, 4); }
+#undef IFH_SKINNY
+    } else if (d->n <= 32)
         launch_igemm<128, 32, 4>(p, pre, st);
     else if (M <= 64)
         launch_igemm<64, 32, 2>(p, pre, st);

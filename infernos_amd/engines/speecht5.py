@@ -31,6 +31,8 @@ class SpeechT5:
     def __init__(self, sd, device, max_steps=640):
         self.device = dev = _lib.require_device(device)
         self.max_steps = max_steps
+        self.use_graphs = True
+        self._states = {}
         E = 'speecht5.encoder.'
         alpha_e = float(sd[E + 'prenet.encode_positions.alpha'])
         self.tok = sd[E + 'prenet.embed_tokens.weight'].to(BF16).contiguous().to(dev)
@@ -122,83 +124,128 @@ class SpeechT5:
 
 
 class TTSBatchState:
-    """Device-resident HelloSippyPipeStateBatched (HelloSippyRTPipe.py:81-121)."""
+    """Device-resident HelloSippyPipeStateBatched (HelloSippyRTPipe.py:81-121).  Buffers are
+    allocated once per (B, T) and reused by later batches of the same shape (`acquire`), so the
+    hipGraphs captured over them stay valid."""
 
-    def __init__(self, model: SpeechT5, input_ids, lens, speakers):
+    def __init__(self, model: 'SpeechT5', B: int, T: int):
         dev = model.device
-        self.B, self.T = input_ids.shape
-        B, T = self.B, self.T
-        self.enc_len = lens.to(dev, torch.int32).contiguous()
-        self.enc = model.encode(input_ids, lens)
+        self.model, self.B, self.T = model, B, T
         self.maxlen = int(T * 20.0 / 2)
         self.minlen = 0
-        self.idx = 0
         e = lambda *s, dt=BF16: torch.empty(s, dtype=dt, device=dev)
-        # cross-attention K|V of every decoder layer, computed once
-        self.cross = []
-        for L in model.dec_layers:
-            kv = e(B * T, 2 * D)
-            ops.linear(self.enc, L['cwkv'], L['cbkv'], kv, rows=B * T, k=D, n=2 * D)
-            self.cross.append(kv)
+        self.enc_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.cross = [e(B * T, 2 * D) for _ in model.dec_layers]
         self.smax = min(model.max_steps, self.maxlen + 32)
         self.self_kv = [torch.zeros((B, self.smax, 2 * D), dtype=BF16, device=dev) for _ in model.dec_layers]
         self.spec = torch.zeros((B, 33, 80), dtype=BF16, device=dev)       # frame 0 = carried last frame
         self.cat = torch.zeros((B, D + 512), dtype=BF16, device=dev)
-        spk = speakers.to(dev, BF16).contiguous().view(B, 512)
-        _lib.check(_lib.lib().ifh_l2norm_rows_bf16(ops._addr(spk), 512, B, ops._addr(self.cat, D), D + 512,
-                                                   _lib.stream_ptr(dev)), 'ifh_l2norm_rows_bf16')
         self.pre_frames = torch.zeros((B, 4, 80), dtype=BF16, device=dev)
         self.starts_at = torch.full((B,), 1, dtype=torch.int64, device=dev)
         self.ends_at = torch.full((B,), -1, dtype=torch.int64, device=dev)
         self.post = e(B, 32, 80)
-        self.audio = None
-        # scratch
+        self.pos_dev = torch.zeros(1, dtype=torch.int32, device=dev)       # decoder position, read by the kernels
+        self.masks = torch.zeros((16, 2, 256), dtype=torch.uint8, device=dev)
         self.h1, self.h2, self.x = e(B, 256), e(B, 256), e(B, D)
         self.q, self.att, self.t1, self.ff = e(B, D), e(B, D), e(B, D), e(B, FF)
         self.plog = e(B, 2, dt=torch.float32)
         self.pn = [e(B, 32, 256), e(B, 32, 256)]
+        self.graphs = {}
+        self.eager_calls = 0
+        self.idx = 0
+        self.audio = None
+
+    @classmethod
+    def acquire(cls, model: 'SpeechT5', input_ids, lens, speakers):
+        B, T = input_ids.shape
+        st = model._states.get((B, T))
+        if st is None:
+            st = cls(model, B, T)
+            model._states = {(B, T): st}          # keep one shape resident
+        st.reset(input_ids, lens, speakers)
+        return st
+
+    def reset(self, input_ids, lens, speakers):
+        model, dev, B, T = self.model, self.model.device, self.B, self.T
+        self.enc_len.copy_(lens.to(torch.int32))
+        self.enc = model.encode(input_ids, lens)
+        for L, kv in zip(model.dec_layers, self.cross):
+            ops.linear(self.enc, L['cwkv'], L['cbkv'], kv, rows=B * T, k=D, n=2 * D)
+        self.spec.zero_()
+        self.pre_frames.zero_()
+        self.ends_at.fill_(-1)
+        self.pos_dev.zero_()
+        self.idx = 0
+        self.audio = None
+        spk = speakers.to(dev, BF16).contiguous().view(B, 512)
+        _lib.check(_lib.lib().ifh_l2norm_rows_bf16(ops._addr(spk), 512, B, ops._addr(self.cat, D), D + 512,
+                                                   _lib.stream_ptr(dev)), 'ifh_l2norm_rows_bf16')
 
 
-def decoder_steps(model: SpeechT5, st: TTSBatchState, masks: torch.Tensor, nsteps=16, threshold=0.5):
-    """The while-loop of HelloSippyRTPipe.infer (:195-229).  masks uint8 [nsteps,2,256] on device."""
+def _decoder_step(model: 'SpeechT5', st: TTSBatchState, s: int, threshold: float):
+    """One decoder step; everything that depends on the global position reads st.pos_dev on the
+    device, so the launch sequence is identical for every step with the same in-call index s."""
     dev = model.device
     B, T = st.B, st.T
-    assert st.idx + nsteps <= st.smax, 'decoder step budget exceeded'
-    for s in range(nsteps):
-        pos = st.idx
-        # prenet on the last produced frame (frame 2s of the call buffer)
-        ops.linear(st.spec, *model.p0, st.h1, rows=B, k=80, n=256, x_off=2 * s * 80, lda=33 * 80, act=ACT_RELU,
-                   colmask=masks, colmask_off=(s * 2) * 256)
-        ops.linear(st.h1, *model.p1, st.h2, rows=B, k=256, n=256, act=ACT_RELU, colmask=masks, colmask_off=(s * 2 + 1) * 256)
-        ops.linear(st.h2, *model.pf, st.cat, rows=B, k=256, n=D, ldc=D + 512, resid=model.pe_dec, resid_off=pos * D,
-                   resid_ld=0, resid_bstride=0)
-        ops.linear(st.cat, *model.ps, st.x, rows=B, k=D + 512, n=D, act=ACT_RELU)
+    masks = st.masks
+    ops.linear(st.spec, *model.p0, st.h1, rows=B, k=80, n=256, x_off=2 * s * 80, lda=33 * 80, act=ACT_RELU,
+               colmask=masks, colmask_off=(s * 2) * 256)
+    ops.linear(st.h1, *model.p1, st.h2, rows=B, k=256, n=256, act=ACT_RELU, colmask=masks, colmask_off=(s * 2 + 1) * 256)
+    ops.linear(st.h2, *model.pf, st.cat, rows=B, k=256, n=D, ldc=D + 512, resid=model.pe_dec, resid_ld=0, resid_bstride=0,
+               dyn_pos=st.pos_dev, dyn_resid_mul=D)
+    ops.linear(st.cat, *model.ps, st.x, rows=B, k=D + 512, n=D, act=ACT_RELU)
+    x = st.x
+    for li, L in enumerate(model.dec_layers):
+        kv = st.self_kv[li]
+        ops.linear(x, L['wq'], L['bq'], st.q, rows=B, k=D, n=D)
+        ops.conv(x, L['wkv'], L['bkv'], kv, nbatch=B, t_in=1, t_out=1, cin=D, n=2 * D, out_bstride=st.smax * 2 * D,
+                 ldc=2 * D, dyn_pos=st.pos_dev, dyn_ooff_mul=1)
+        ops.attn_decode(st.q, kv, kv, st.att, nbatch=B, nheads=H, max_keys=st.smax, q_bs=D, kv_bs=st.smax * 2 * D,
+                        kv_ts=2 * D, o_bs=D, v_off=D, dyn_len=st.pos_dev, dyn_add=1)
+        ops.linear(st.att, L['wo'], L['bo'], st.t1, rows=B, k=D, n=D, resid=x)
+        ops.layernorm(st.t1, *L['ln1'], st.x, B, D)
+        ops.linear(st.x, L['cwq'], L['cbq'], st.q, rows=B, k=D, n=D)
+        ck = st.cross[li]
+        ops.attn_decode(st.q, ck, ck, st.att, nbatch=B, nheads=H, max_keys=T, q_bs=D, kv_bs=T * 2 * D, kv_ts=2 * D,
+                        o_bs=D, v_off=D, key_len=st.enc_len)
+        ops.linear(st.att, L['cwo'], L['cbo'], st.t1, rows=B, k=D, n=D, resid=st.x)
+        ops.layernorm(st.t1, *L['ln2'], st.x, B, D)
+        ops.linear(st.x, L['w1'], L['b1'], st.ff, rows=B, k=D, n=FF, act=ACT_GELU)
+        ops.linear(st.ff, L['w2'], L['b2'], st.t1, rows=B, k=FF, n=D, resid=st.x)
+        ops.layernorm(st.t1, *L['ln3'], st.x, B, D)
         x = st.x
-        for li, L in enumerate(model.dec_layers):
-            kv = st.self_kv[li]
-            ops.linear(x, L['wq'], L['bq'], st.q, rows=B, k=D, n=D)
-            ops.conv(x, L['wkv'], L['bkv'], kv, nbatch=B, t_in=1, t_out=1, cin=D, n=2 * D, out_bstride=st.smax * 2 * D,
-                     ldc=2 * D, ooff=pos)
-            ops.attn_decode(st.q, kv, kv, st.att, nbatch=B, nheads=H, max_keys=pos + 1, q_bs=D, kv_bs=st.smax * 2 * D,
-                            kv_ts=2 * D, o_bs=D, v_off=D)
-            ops.linear(st.att, L['wo'], L['bo'], st.t1, rows=B, k=D, n=D, resid=x)
-            ops.layernorm(st.t1, *L['ln1'], st.x, B, D)
-            ops.linear(st.x, L['cwq'], L['cbq'], st.q, rows=B, k=D, n=D)
-            ck = st.cross[li]
-            ops.attn_decode(st.q, ck, ck, st.att, nbatch=B, nheads=H, max_keys=T, q_bs=D, kv_bs=T * 2 * D, kv_ts=2 * D,
-                            o_bs=D, v_off=D, key_len=st.enc_len)
-            ops.linear(st.att, L['cwo'], L['cbo'], st.t1, rows=B, k=D, n=D, resid=st.x)
-            ops.layernorm(st.t1, *L['ln2'], st.x, B, D)
-            ops.linear(st.x, L['w1'], L['b1'], st.ff, rows=B, k=D, n=FF, act=ACT_GELU)
-            ops.linear(st.ff, L['w2'], L['b2'], st.t1, rows=B, k=FF, n=D, resid=st.x)
-            ops.layernorm(st.t1, *L['ln3'], st.x, B, D)
-            x = st.x
-        # two new mel frames -> frames 2s+1, 2s+2 ; stop logits
-        ops.linear(x, *model.feat, st.spec, rows=B, k=D, n=160, out_off=(2 * s + 1) * 80, ldc=33 * 80)
-        ops.linear(x, *model.prob, st.plog, rows=B, k=D, n=2)
-        _lib.check(_lib.lib().ifh_tts_stop_update(ops._addr(st.plog), ops._addr(st.ends_at), B, pos, st.minlen, st.maxlen,
-                                                  threshold, 2, _lib.stream_ptr(dev)), 'ifh_tts_stop_update')
+    # two new mel frames -> frames 2s+1, 2s+2 ; stop logits ; advance the device position
+    ops.linear(x, *model.feat, st.spec, rows=B, k=D, n=160, out_off=(2 * s + 1) * 80, ldc=33 * 80)
+    ops.linear(x, *model.prob, st.plog, rows=B, k=D, n=2)
+    _lib.check(_lib.lib().ifh_tts_stop_update(ops._addr(st.plog), ops._addr(st.ends_at), B, 0, st.minlen, st.maxlen,
+                                              threshold, 2, ops._addr(st.pos_dev), _lib.stream_ptr(dev)), 'ifh_tts_stop_update')
+    ops.add_i32(st.pos_dev, 1)
+
+
+def decoder_steps(model: 'SpeechT5', st: TTSBatchState, masks: torch.Tensor, nsteps=16, threshold=0.5, use_graphs=None):
+    """The while-loop of HelloSippyRTPipe.infer (:195-229).  masks uint8 [nsteps,2,256] on device.
+    Each of the 16 in-call step shapes is captured once into a hipGraph (launch-bound inner loop:
+    ~80 small kernels per step) and replayed for every later call on this state."""
+    assert nsteps <= 16 and st.idx + nsteps <= st.smax, 'decoder step budget exceeded'
+    use_graphs = model.use_graphs if use_graphs is None else use_graphs
+    st.masks[:nsteps].copy_(masks)
+    # the first call on a state shape runs eagerly (loads every kernel); graphs are captured from the second on
+    use_graphs = use_graphs and st.eager_calls >= 1
+    for s in range(nsteps):
+        if not use_graphs:
+            _decoder_step(model, st, s, threshold)
+        else:
+            g = st.graphs.get((s, threshold))
+            if g is None:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):          # records the launches; nothing executes until replay
+                    _decoder_step(model, st, s, threshold)
+                st.graphs[(s, threshold)] = g
+            g.replay()
         st.idx += 1
+    if not use_graphs:
+        st.eager_calls += 1
 
 
 def postnet(model: SpeechT5, st: TTSBatchState):

@@ -113,16 +113,19 @@ class Whisper:
                 cross=[e(Bn * N_CTX, 2 * d) for _ in self.dec_layers],
                 kv=[torch.zeros((Bn, self.max_tokens, 2 * d), dtype=BF16, device=dev) for _ in self.dec_layers],
                 x=e(Bn, d), hn=e(Bn, d), q=e(Bn, d), att=e(Bn, d), ff=e(Bn, self.ff),
-                logits=e(Bn, self.vocab, dt=torch.float32))}
+                logits=e(Bn, self.vocab, dt=torch.float32),
+                toks=torch.zeros((self.max_tokens + 1, Bn), dtype=torch.int32, device=dev),
+                pos=torch.zeros(1, dtype=torch.int32, device=dev), graphs={}, eager_runs=0)}
         return self._dec_bufs[Bn]
 
-    def decoder_step(self, ids: torch.Tensor, ids_off: int, ids_stride_ok: bool, pos: int, bufs, Bn: int):
-        """One token per sequence at position pos; ids int32 buffer, row-contiguous column view
-        is not needed: the caller passes a dense int32[B] tensor (ids_off selects a column block)."""
+    def decoder_step(self, bufs, Bn: int, argmax: bool):
+        """One token per sequence at the position held in bufs['pos'] (device scalar): embeds
+        toks[pos], appends K/V at pos, attends over pos+1 keys, optionally writes
+        argmax(logits) to toks[pos+1], then advances pos.  Identical launches for every position,
+        hence capturable once and replayed."""
         d, H = self.d, self.h
-        x = bufs['x']
-        _lib.check(_lib.lib().ifh_embed_bf16(ops._addr(ids, ids_off), ops._addr(self.tok), ops._addr(self.dec_pos), pos, 1,
-                                             d, Bn, ops._addr(x), _lib.stream_ptr(self.device)), 'ifh_embed_bf16')
+        x, pos, toks = bufs['x'], bufs['pos'], bufs['toks']
+        ops.embed(toks, self.tok, self.dec_pos, x, n=Bn, dim=d, pos0=0, seq_len=1, dyn_pos=pos, dyn_ids_mul=Bn)
         smax = self.max_tokens
         for li, L in enumerate(self.dec_layers):
             S, C = L['self'], L['cross']
@@ -130,9 +133,9 @@ class Whisper:
             ops.layernorm(x, *L['ln1'], bufs['hn'], Bn, d)
             ops.linear(bufs['hn'], S['wq'], S['bq'], bufs['q'], rows=Bn, k=d, n=d)
             ops.conv(bufs['hn'], S['wkv'], S['bkv'], kv, nbatch=Bn, t_in=1, t_out=1, cin=d, n=2 * d,
-                     out_bstride=smax * 2 * d, ldc=2 * d, ooff=pos)
-            ops.attn_decode(bufs['q'], kv, kv, bufs['att'], nbatch=Bn, nheads=H, max_keys=pos + 1, q_bs=d,
-                            kv_bs=smax * 2 * d, kv_ts=2 * d, o_bs=d, v_off=d)
+                     out_bstride=smax * 2 * d, ldc=2 * d, dyn_pos=pos, dyn_ooff_mul=1)
+            ops.attn_decode(bufs['q'], kv, kv, bufs['att'], nbatch=Bn, nheads=H, max_keys=smax, q_bs=d,
+                            kv_bs=smax * 2 * d, kv_ts=2 * d, o_bs=d, v_off=d, dyn_len=pos, dyn_add=1)
             ops.linear(bufs['att'], S['wo'], S['bo'], x, rows=Bn, k=d, n=d, resid=x)
             ops.layernorm(x, *L['ln2'], bufs['hn'], Bn, d)
             ops.linear(bufs['hn'], C['wq'], C['bq'], bufs['q'], rows=Bn, k=d, n=d)
@@ -145,44 +148,65 @@ class Whisper:
             ops.linear(bufs['ff'], L['w2'], L['b2'], x, rows=Bn, k=self.ff, n=d, resid=x)
         ops.layernorm(x, *self.dec_ln, bufs['hn'], Bn, d)
         ops.linear(bufs['hn'], self.tok, None, bufs['logits'], rows=Bn, k=d, n=self.vocab)
+        if argmax:
+            ops.argmax_pick(bufs['logits'], vocab=self.vocab, nrows=Bn, argmax_out=toks, out_off=Bn, dyn_pos=pos,
+                            dyn_out_mul=Bn)
+        ops.add_i32(pos, 1)
+        return bufs['logits']
+
+    def _step(self, bufs, Bn, argmax, use_graphs):
+        if not use_graphs:
+            return self.decoder_step(bufs, Bn, argmax)
+        g = bufs['graphs'].get(argmax)
+        if g is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.decoder_step(bufs, Bn, argmax)
+            bufs['graphs'][argmax] = g
+        g.replay()
         return bufs['logits']
 
     def generate(self, enc: torch.Tensor, prompts: torch.Tensor, n_new: int, no_speech_id=None, keep_logits=False,
-                 eos_id=None, check_every=16, early_exit_nsp=None):
+                 eos_id=None, check_every=16, early_exit_nsp=None, use_graphs=True):
         """Greedy decode up to n_new tokens after the prompt.
         enc bf16 [B,1500,d]; prompts int32 [B,P] -> (tokens int32 [B,n_new] on device,
         no_speech_prob f32 [B] or None, first_logits f32 [B,V] (after the whole prompt) if keep_logits).
         eos_id: stop once every row has produced it (checked every `check_every` tokens; rows are
         padded with eos).  early_exit_nsp: per-row max no-speech probabilities; if every row is
-        above its limit nothing is generated (tokens None), as InfernSTTWorker.py:91-92 does."""
+        above its limit nothing is generated (tokens None), as InfernSTTWorker.py:91-92 does.
+        The per-token launch sequence is captured into two hipGraphs (with / without argmax) after
+        the first eager run and replayed; the position lives in a device scalar."""
         dev, d = self.device, self.d
         Bn, P = prompts.shape
         n_new = min(n_new, self.max_tokens - P)
         bufs = self._dec(Bn)
+        use_graphs = use_graphs and bufs['eager_runs'] >= 1
         for li, L in enumerate(self.dec_layers):
             C = L['cross']
             ops.linear(enc, C['wkv'], C['bkv'], bufs['cross'][li], rows=Bn * N_CTX, k=d, n=2 * d)
-        # token matrix, column-major so that each step's ids are a dense int32[B] block
-        toks = torch.zeros((P + n_new, Bn), dtype=torch.int32, device=dev)
-        if eos_id is not None:
-            toks[P:] = eos_id
+        # token matrix, position-major so that each step's ids are a dense int32[B] block
+        toks = bufs['toks']
+        toks.fill_(eos_id if eos_id is not None else 0)
         toks[:P] = prompts.to(dev, torch.int32).t()
+        bufs['pos'].zero_()
         nsp = torch.empty(Bn, dtype=torch.float32, device=dev) if no_speech_id is not None else None
         first = None
         for pos in range(P + n_new - 1):
-            logits = self.decoder_step(toks, pos * Bn, True, pos, bufs, Bn)
+            gen = pos >= P - 1
+            logits = self._step(bufs, Bn, gen, use_graphs and pos > 0)
             if pos == 0 and nsp is not None:
                 ops.argmax_pick(logits, vocab=self.vocab, nrows=Bn, pick_token=no_speech_id, pick_prob_out=nsp)
                 if early_exit_nsp is not None:
                     lim = torch.tensor(early_exit_nsp, dtype=torch.float32)
                     if bool((nsp.cpu() > lim).all()):
                         return None, nsp, None
-            if pos >= P - 1:
+            if gen:
                 if pos == P - 1 and keep_logits:
                     first = logits.clone()
-                ops.argmax_pick(logits, vocab=self.vocab, nrows=Bn, argmax_out=toks, out_off=(pos + 1) * Bn)
                 done = pos - (P - 1) + 1
                 if eos_id is not None and done % check_every == 0 and done < n_new:
                     if bool((toks[P:P + done] == eos_id).any(0).all()):
                         break
-        return toks[P:].t().contiguous(), nsp, first
+        bufs['eager_runs'] += 1
+        return toks[P:P + n_new].t().contiguous(), nsp, first

@@ -22,7 +22,7 @@ def _addr(t, off=0):
 def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=1, pad=0,
          x_off=0, lda=None, x_bstride=None, act=ACT_NONE, act_slope=0.0, pre_slope=1.0, colmask=None, colmask_off=0,
          resid=None, resid_off=0, resid_ld=None, resid_bstride=None, scale=1.0, accumulate=False,
-         out_off=0, ldc=None, out_bstride=None, ostride=1, ooff=0):
+         out_off=0, ldc=None, out_bstride=None, ostride=1, ooff=0, dyn_pos=None, dyn_ooff_mul=0, dyn_resid_mul=0):
     """One implicit-GEMM launch (see ifh_conv_desc).  Strides default to dense [nbatch][t][c]."""
     d = ConvDesc()
     lda = cin if lda is None else lda
@@ -40,6 +40,7 @@ def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=
     d.out, d.out_f32 = _addr(out, out_off), int(out.dtype == torch.float32)
     d.out_bstride = (t_out * ostride * ldc if out_bstride is None else out_bstride)
     d.ldc, d.ostride, d.ooff = ldc, ostride, ooff
+    d.dyn_pos, d.dyn_ooff_mul, d.dyn_resid_mul = _addr(dyn_pos), dyn_ooff_mul, dyn_resid_mul
     _lib.check(_lib.lib().ifh_conv_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_conv_bf16')
     return out
 
@@ -76,23 +77,30 @@ def attn_prefill(q, k, v, out, *, nbatch, nheads, tq, tk, q_off=0, k_off=0, v_of
     return out
 
 
-def attn_decode(q, k, v, out, *, nbatch, nheads, max_keys, q_bs, kv_bs, kv_ts, o_bs, k_off=0, v_off=0, key_len=None):
+def attn_decode(q, k, v, out, *, nbatch, nheads, max_keys, q_bs, kv_bs, kv_ts, o_bs, k_off=0, v_off=0, key_len=None,
+                dyn_len=None, dyn_add=0):
     _lib.check(_lib.lib().ifh_attn_decode_bf16(_addr(q), q_bs, _addr(k, k_off), _addr(v, v_off), kv_bs, kv_ts, _addr(out),
-                                               o_bs, _addr(key_len), max_keys, nbatch, nheads, 64,
+                                               o_bs, _addr(key_len), max_keys, nbatch, nheads, 64, _addr(dyn_len), dyn_add,
                                                _lib.stream_ptr(out.device)), 'ifh_attn_decode_bf16')
     return out
 
 
-def embed(ids, table, pos_table, out, *, n, dim, pos0=0, seq_len=1):
-    _lib.check(_lib.lib().ifh_embed_bf16(_addr(ids), _addr(table), _addr(pos_table), pos0, seq_len, dim, n, _addr(out),
-                                         _lib.stream_ptr(out.device)), 'ifh_embed_bf16')
+def embed(ids, table, pos_table, out, *, n, dim, pos0=0, seq_len=1, ids_off=0, dyn_pos=None, dyn_ids_mul=0):
+    _lib.check(_lib.lib().ifh_embed_bf16(_addr(ids, ids_off), _addr(table), _addr(pos_table), pos0, seq_len, dim, n,
+                                         _addr(out), _addr(dyn_pos), dyn_ids_mul, _lib.stream_ptr(out.device)),
+               'ifh_embed_bf16')
     return out
 
 
-def argmax_pick(logits, *, vocab, nrows, ld=None, argmax_out=None, pick_token=0, pick_prob_out=None, out_off=0):
+def argmax_pick(logits, *, vocab, nrows, ld=None, argmax_out=None, pick_token=0, pick_prob_out=None, out_off=0,
+                dyn_pos=None, dyn_out_mul=0):
     _lib.check(_lib.lib().ifh_argmax_pick_f32(_addr(logits), vocab if ld is None else ld, vocab, nrows, pick_token,
-                                              _addr(argmax_out, out_off), _addr(pick_prob_out),
+                                              _addr(argmax_out, out_off), _addr(pick_prob_out), _addr(dyn_pos), dyn_out_mul,
                                               _lib.stream_ptr(logits.device)), 'ifh_argmax_pick_f32')
+
+
+def add_i32(value, delta):
+    _lib.check(_lib.lib().ifh_add_i32(_addr(value), delta, _lib.stream_ptr(value.device)), 'ifh_add_i32')
 
 
 # ---- weight preparation (host side, once per model load) -----------------------------------

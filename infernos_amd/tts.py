@@ -73,7 +73,7 @@ class HelloSippyPipeStateBatched:
             lens[i] = n
         spk = torch.cat([s.speaker_embeddings.reshape(1, 512).float() for s in states])
         with torch.cuda.device(pp.device):
-            self.dev = TTSBatchState(pp.model, ids, lens, spk)
+            self.dev = TTSBatchState.acquire(pp.model, ids, lens, spk)
         self.starts_at_host = [pp.post_nframes // 2] * len(states)
         self.audio = None
 

@@ -51,6 +51,10 @@ def bfr(x):
     dict(B=1, T=3, cin=768, cout=160, k=1),                             # tiny M
     dict(B=1, T=64, cin=384, cout=1003, k=1, f32=True),                 # ragged N, f32 out (logits-like)
     dict(B=1, T=130, cin=256, cout=256, k=1, act='relu', colmask=True),
+    dict(B=1, T=64, cin=3072, cout=768, k=1, resid=True),                # skinny, deep K (8 waves)
+    dict(B=1, T=20, cin=1280, cout=768, k=1, act='relu'),               # skinny, 2 row tiles
+    dict(B=1, T=33, cin=256, cout=256, k=1, act='relu', colmask=True),  # skinny with dropout mask
+    dict(B=1, T=64, cin=768, cout=2, k=1, f32=True),                    # stop logits
 ])
 def test_conv_kernel_matches_torch(dev, case):
     from infernos_amd import ops
@@ -158,11 +162,16 @@ def test_attention_prefill_matches_torch(dev):
 def test_attention_decode_matches_torch(dev):
     from infernos_amd import ops
     g = torch.Generator().manual_seed(8)
-    B, H, S, SM = 5, 12, 77, 100
+    for (B, H, S, SM, lens_l) in ((5, 12, 77, 100, [77, 1, 64, 65, 30]), (3, 6, 1500, 1500, [1500, 1499, 257])):
+        _decode_case(dev, g, B, H, S, SM, lens_l)
+
+
+def _decode_case(dev, g, B, H, S, SM, lens_l):
+    from infernos_amd import ops
     D = H * 64
     q = bfr(torch.randn(B, D, generator=g) * 0.3)
     kv = bfr(torch.randn(B, SM, 2 * D, generator=g))
-    lens = torch.tensor([77, 1, 64, 65, 30], dtype=torch.int32)
+    lens = torch.tensor(lens_l, dtype=torch.int32)
     out = torch.empty(B, D, dtype=BF, device=dev)
     ops.attn_decode(q.to(dev, BF), kv.to(dev, BF), kv.to(dev, BF), out, nbatch=B, nheads=H, max_keys=S, q_bs=D,
                     kv_bs=SM * 2 * D, kv_ts=2 * D, o_bs=D, v_off=D, key_len=lens.to(dev))
@@ -316,4 +325,9 @@ def test_whisper_matches_oracle_and_reference_fixture(dev, golden_dir):
     print('whisper: enc rel_l2 %.3e logits rel_l2 %.3e token agreement %s' % (e_enc, e_log, agree.tolist()))
     assert agree[:, 0].all() or float((o_first.topk(2).values[:, 0] - o_first.topk(2).values[:, 1]).min()) < 0.05
     assert np.array_equal(o_toks.numpy(), g['greedy'])
+    # second run replays the captured per-token hipGraphs: identical tokens and logits
+    toks2, nsp2, first2 = model.generate(enc, prompt, 8, no_speech_id=meta['no_speech_id'], keep_logits=True)
+    assert torch.equal(toks2, toks) and torch.allclose(first2, first) and torch.allclose(nsp2, nsp)
+    toks3, _, _ = model.generate(enc, prompt, 8, use_graphs=False)
+    assert torch.equal(toks3, toks)
     np.testing.assert_allclose(nsp.cpu().numpy(), meta['no_speech_prob'], rtol=0.5)
