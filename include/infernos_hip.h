@@ -180,6 +180,13 @@ typedef struct ifh_conv_desc {
     const int32_t *dyn_pos;
     int32_t dyn_ooff_mul;
     int64_t dyn_resid_mul;
+    /* optional second output region: columns n >= n_split (n_split % 16 == 0) are written to
+     * out2[b*out2_bstride + (t*ostride + ooff2 + dyn_pos[0]*dyn_ooff2_mul)*ldc2 + (n - n_split)] -- lets one
+     * launch produce q (scratch) and K|V (appended to the cache) */
+    int32_t n_split;
+    void *out2;
+    int64_t out2_bstride;
+    int32_t ldc2, ooff2, dyn_ooff2_mul;
 } ifh_conv_desc;
 int ifh_conv_bf16(const ifh_conv_desc *desc, ifh_stream_t stream);
 

@@ -48,7 +48,9 @@ class ConvDesc(ctypes.Structure):
                 ('act', ctypes.c_int32), ('act_slope', _f), ('resid', _vp), ('resid_bstride', _i64),
                 ('resid_ld', ctypes.c_int32), ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp),
                 ('out_f32', ctypes.c_int32), ('out_bstride', _i64), ('ldc', ctypes.c_int32), ('ostride', ctypes.c_int32),
-                ('ooff', ctypes.c_int32), ('dyn_pos', _vp), ('dyn_ooff_mul', ctypes.c_int32), ('dyn_resid_mul', _i64)]
+                ('ooff', ctypes.c_int32), ('dyn_pos', _vp), ('dyn_ooff_mul', ctypes.c_int32), ('dyn_resid_mul', _i64),
+                ('n_split', ctypes.c_int32), ('out2', _vp), ('out2_bstride', _i64), ('ldc2', ctypes.c_int32),
+                ('ooff2', ctypes.c_int32), ('dyn_ooff2_mul', ctypes.c_int32)]
 
 
 class AttnDesc(ctypes.Structure):

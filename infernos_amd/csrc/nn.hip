@@ -39,6 +39,10 @@ struct IgemmParams {
     int64_t out_bstride;
     int ldc, ostride, ooff;
     int vec_ok;
+    int n_split;              // columns >= n_split (if > 0) go to the second output region
+    void *out2;
+    int64_t out2_bstride;
+    int ldc2, ooff2, dyn_ooff2_mul;
     const int32_t *dyn;       // optional device scalar (e.g. decoder position)
     int dyn_ooff_mul;         // ooff += dyn[0] * dyn_ooff_mul
     int64_t dyn_resid_mul;    // resid += dyn[0] * dyn_resid_mul (elements)
@@ -76,8 +80,12 @@ __device__ __forceinline__ uint4 lrelu8(uint4 v, float slope)
 __device__ __forceinline__ void igemm_store4(const IgemmParams &p, int m, int n, const float (&accv)[4], int dynv)
 {
     const int b = m / p.T_out, t = m - b * p.T_out;
-    const int64_t orow = (int64_t)t * p.ostride + p.ooff + (int64_t)dynv * p.dyn_ooff_mul;
-    const int64_t obase = (int64_t)b * p.out_bstride + orow * p.ldc;
+    const bool second = p.n_split > 0 && n >= p.n_split;      // n_split % 16 == 0: a 4-group never straddles
+    const int64_t orow = second ? ((int64_t)t * p.ostride + p.ooff2 + (int64_t)dynv * p.dyn_ooff2_mul)
+                                : ((int64_t)t * p.ostride + p.ooff + (int64_t)dynv * p.dyn_ooff_mul);
+    const int64_t obase = second ? ((int64_t)b * p.out2_bstride + orow * p.ldc2 - p.n_split)
+                                 : ((int64_t)b * p.out_bstride + orow * p.ldc);
+    void *const outp = second ? p.out2 : p.out;
     const int64_t rbase = (int64_t)b * p.resid_bstride + orow * p.resid_ld + (int64_t)dynv * p.dyn_resid_mul;
     float v[4];
 #pragma unroll
@@ -95,12 +103,12 @@ __device__ __forceinline__ void igemm_store4(const IgemmParams &p, int m, int n,
     }
     if (p.vec_ok && n + 3 < p.N) {
         if (p.out_f32) {
-            float *o = reinterpret_cast<float *>(p.out) + obase + n;
+            float *o = reinterpret_cast<float *>(outp) + obase + n;
             float4 prev = make_float4(0, 0, 0, 0);
             if (p.accumulate) prev = *reinterpret_cast<const float4 *>(o);
             *reinterpret_cast<float4 *>(o) = make_float4(v[0] + prev.x, v[1] + prev.y, v[2] + prev.z, v[3] + prev.w);
         } else {
-            uint16_t *o = reinterpret_cast<uint16_t *>(p.out) + obase + n;
+            uint16_t *o = reinterpret_cast<uint16_t *>(outp) + obase + n;
             if (p.accumulate) {
                 const uint2 pv = *reinterpret_cast<const uint2 *>(o);
                 v[0] += __uint_as_float(pv.x << 16);
@@ -118,88 +126,71 @@ __device__ __forceinline__ void igemm_store4(const IgemmParams &p, int m, int n,
         for (int r = 0; r < 4; r++) {
             if (n + r >= p.N) break;
             if (p.out_f32) {
-                float *o = reinterpret_cast<float *>(p.out) + obase + n + r;
+                float *o = reinterpret_cast<float *>(outp) + obase + n + r;
                 *o = v[r] + (p.accumulate ? *o : 0.0f);
             } else {
-                uint16_t *o = reinterpret_cast<uint16_t *>(p.out) + obase + n + r;
+                uint16_t *o = reinterpret_cast<uint16_t *>(outp) + obase + n + r;
                 *o = f32_to_bf16(v[r] + (p.accumulate ? bf16_to_f32(*o) : 0.0f));
             }
         }
     }
 }
 
-// ---- skinny GEMM for decode steps (M <= 64 rows, taps == 1): weight streaming.
-// One block = 16 output channels x all rows; its NW waves split K; every lane streams its
-// 16-byte weight/activation fragments straight from global/L2 (no LDS staging: each weight
-// byte is used once per block), partial tiles are summed through LDS.
-template <int MT, int NW>
+// ---- skinny GEMM for decode steps (M <= 64 rows, taps == 1): latency-bound weight streaming.
+// One block = 16 output channels x 16 rows; its NW waves split K so that every lane has all of
+// its 16-byte weight/activation fragments in flight at once (one memory round trip), straight
+// from global/L2 (each weight byte is used once per block: no LDS staging); the NW partial
+// tiles are summed through LDS.  Grid (N/16, M/16): 192..768 blocks for the decoder shapes.
+template <int NW, int U>
 __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
 {
-    __shared__ __attribute__((aligned(16))) float red[NW][MT][64][4];
+    __shared__ __attribute__((aligned(16))) float red[NW][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
     const int M = p.nbatch * p.T_out;
     const int nk = (p.K + 31) / 32;
     const int per = (nk + NW - 1) / NW;
     const int kt0 = wid * per, kt1 = min(nk, kt0 + per);
     const int nrow = n0 + fr;
-    const uint16_t *wrow = p.w + (int64_t)(nrow < p.N ? nrow : 0) * p.K + fg * 8;
-    const uint16_t *xrow[MT];
-    bool xok[MT];
-#pragma unroll
-    for (int j = 0; j < MT; j++) {
-        const int m = j * 16 + fr;
-        xok[j] = m < M;
-        const int mm = xok[j] ? m : 0;
-        const int b = mm / p.T_out, t = mm - b * p.T_out;
-        xrow[j] = p.x + (int64_t)b * p.x_bstride + (int64_t)t * p.lda + fg * 8;
-    }
-    f32x4 acc[MT];
-#pragma unroll
-    for (int j = 0; j < MT; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const bool wok = nrow < p.N;
-    constexpr int U = 4;    // k-steps in flight per wave (all loads issued before the MFMAs)
+    const uint16_t *wrow = p.w + (int64_t)(wok ? nrow : 0) * p.K + fg * 8;
+    const int m = m0 + fr;
+    const bool xok = m < M;
+    const int mm = xok ? m : 0;
+    const int bb = mm / p.T_out, tt = mm - bb * p.T_out;
+    const uint16_t *xrow = p.x + (int64_t)bb * p.x_bstride + (int64_t)tt * p.lda + fg * 8;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kt = kt0; kt < kt1; kt += U) {
-        uint4 wv[U], xv[U][MT];
+        uint4 wv[U], xv[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int kk = kt + u;
             const bool kok = kk < kt1 && (kk * 32 + fg * 8) < p.K;      // K % 8 == 0
             wv[u] = make_uint4(0, 0, 0, 0);
+            xv[u] = make_uint4(0, 0, 0, 0);
             if (wok && kok) wv[u] = *reinterpret_cast<const uint4 *>(wrow + kk * 32);
-#pragma unroll
-            for (int j = 0; j < MT; j++) {
-                xv[u][j] = make_uint4(0, 0, 0, 0);
-                if (xok[j] && kok) xv[u][j] = *reinterpret_cast<const uint4 *>(xrow[j] + kk * 32);
-            }
+            if (xok && kok) xv[u] = *reinterpret_cast<const uint4 *>(xrow + kk * 32);
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            const bf16x8_t fa = __builtin_bit_cast(bf16x8_t, wv[u]);
-#pragma unroll
-            for (int j = 0; j < MT; j++)
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, __builtin_bit_cast(bf16x8_t, xv[u][j]), acc[j], 0, 0, 0);
-        }
+        for (int u = 0; u < U; u++)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[u]),
+                                                          __builtin_bit_cast(bf16x8_t, xv[u]), acc, 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < MT; j++) *reinterpret_cast<f32x4 *>(&red[wid][j][lane][0]) = acc[j];
+    *reinterpret_cast<f32x4 *>(&red[wid][lane][0]) = acc;
     __syncthreads();
-    const int dynv = p.dyn ? p.dyn[0] : 0;
-    for (int item = tid; item < MT * 64; item += NW * 64) {
-        const int j = item >> 6, ln = item & 63;
+    if (wid == 0) {
         float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < NW; w++) {
-            const float4 v = *reinterpret_cast<const float4 *>(&red[w][j][ln][0]);
+            const float4 v = *reinterpret_cast<const float4 *>(&red[w][lane][0]);
             s[0] += v.x;
             s[1] += v.y;
             s[2] += v.z;
             s[3] += v.w;
         }
-        const int m = j * 16 + (ln & 15);
-        const int n = n0 + 4 * (ln >> 4);
-        if (m < M && n < p.N) igemm_store4(p, m, n, s, dynv);
+        const int n = n0 + 4 * fg;
+        if (xok && n < p.N) igemm_store4(p, m, n, s, p.dyn ? p.dyn[0] : 0);
     }
 }
 
@@ -474,6 +465,16 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     p.ooff = d->ooff;
     const int esz = d->out_f32 ? 4 : 2;
     p.vec_ok = (d->ldc % 4 == 0) && (d->out_bstride % 4 == 0) && ((((uintptr_t)d->out) % (4 * esz)) == 0);
+    p.n_split = d->n_split;
+    p.out2 = d->out2;
+    p.out2_bstride = d->out2_bstride;
+    p.ldc2 = d->ldc2;
+    p.ooff2 = d->ooff2;
+    p.dyn_ooff2_mul = d->dyn_ooff2_mul;
+    if (d->n_split) {
+        IFH_CHECK_ARG(d->n_split % 16 == 0 && d->out2 && d->ldc2 > 0 && d->n_split < d->n);
+        p.vec_ok = p.vec_ok && (d->ldc2 % 4 == 0) && (d->out2_bstride % 4 == 0) && ((((uintptr_t)d->out2) % (4 * esz)) == 0);
+    }
     p.dyn = d->dyn_pos;
     p.dyn_ooff_mul = d->dyn_ooff_mul;
     p.dyn_resid_mul = d->dyn_resid_mul;
@@ -482,14 +483,11 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     IFH_CHECK_ARG(M < (1ll << 31));
     hipStream_t st = as_stream(stream);
     if (M <= 64 && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre) {
-        const dim3 grid((d->n + 15) / 16);
-        const bool deep = p.K >= 2048;
-        const int mt = M <= 16 ? 1 : (M <= 32 ? 2 : 4);
-#define IFH_SKINNY(MT_, NW_) hipLaunchKernelGGL((k_gemm_skinny<MT_, NW_>), grid, dim3(NW_ * 64), 0, st, p)
-        if (mt == 1) { if (deep) IFH_SKINNY(1, 8); else IFH_SKINNY(1, 4); }
-        else if (mt == 2) { if (deep) IFH_SKINNY(2, 8); else IFH_SKINNY(2, 4); }
-        else { if (deep) IFH_SKINNY(4, 8); else IFH_SKINNY(4, 4); }
-#undef IFH_SKINNY
+        const dim3 grid((d->n + 15) / 16, (unsigned)((M + 15) / 16));
+        if (p.K >= 2048)
+            hipLaunchKernelGGL((k_gemm_skinny<8, 12>), grid, dim3(512), 0, st, p);
+        else
+            hipLaunchKernelGGL((k_gemm_skinny<4, 12>), grid, dim3(256), 0, st, p);
     } else if (d->n <= 32)
         launch_igemm<128, 32, 4>(p, pre, st);
     else if (M <= 64)

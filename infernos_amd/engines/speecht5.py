@@ -70,9 +70,10 @@ class SpeechT5:
             L = Wd + 'layers.%d.' % i
             S, C = L + 'self_attn.', L + 'encoder_attn.'
             self.dec_layers.append(dict(
-                wq=ops.w_linear(sd[S + 'q_proj.weight'], dev, QS), bq=ops.w_bias(sd[S + 'q_proj.bias'], dev, QS),
-                wkv=ops.w_linear(torch.cat([sd[S + 'k_proj.weight'].float(), sd[S + 'v_proj.weight'].float()]), dev),
-                bkv=ops.w_bias(torch.cat([sd[S + 'k_proj.bias'].float(), sd[S + 'v_proj.bias'].float()]), dev),
+                wqkv=ops.w_linear(torch.cat([sd[S + 'q_proj.weight'].float() * QS, sd[S + 'k_proj.weight'].float(),
+                                             sd[S + 'v_proj.weight'].float()]), dev),
+                bqkv=ops.w_bias(torch.cat([sd[S + 'q_proj.bias'].float() * QS, sd[S + 'k_proj.bias'].float(),
+                                           sd[S + 'v_proj.bias'].float()]), dev),
                 wo=ops.w_linear(sd[S + 'out_proj.weight'], dev), bo=ops.w_bias(sd[S + 'out_proj.bias'], dev),
                 ln1=_ln(sd, L + 'self_attn_layer_norm', dev),
                 cwq=ops.w_linear(sd[C + 'q_proj.weight'], dev, QS), cbq=ops.w_bias(sd[C + 'q_proj.bias'], dev, QS),
@@ -197,9 +198,9 @@ def _decoder_step(model: 'SpeechT5', st: TTSBatchState, s: int, threshold: float
     x = st.x
     for li, L in enumerate(model.dec_layers):
         kv = st.self_kv[li]
-        ops.linear(x, L['wq'], L['bq'], st.q, rows=B, k=D, n=D)
-        ops.conv(x, L['wkv'], L['bkv'], kv, nbatch=B, t_in=1, t_out=1, cin=D, n=2 * D, out_bstride=st.smax * 2 * D,
-                 ldc=2 * D, dyn_pos=st.pos_dev, dyn_ooff_mul=1)
+        # one launch: q -> scratch, K|V -> appended to the cache at the device-held position
+        ops.conv(x, L['wqkv'], L['bqkv'], st.q, nbatch=B, t_in=1, t_out=1, cin=D, n=3 * D, ldc=D, out_bstride=D,
+                 dyn_pos=st.pos_dev, n_split=D, out2=kv, out2_bstride=st.smax * 2 * D, ldc2=2 * D, dyn_ooff2_mul=1)
         ops.attn_decode(st.q, kv, kv, st.att, nbatch=B, nheads=H, max_keys=st.smax, q_bs=D, kv_bs=st.smax * 2 * D,
                         kv_ts=2 * D, o_bs=D, v_off=D, dyn_len=st.pos_dev, dyn_add=1)
         ops.linear(st.att, L['wo'], L['bo'], st.t1, rows=B, k=D, n=D, resid=x)

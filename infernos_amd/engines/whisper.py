@@ -62,7 +62,7 @@ class Whisper:
         i = 0
         while (Dc + 'layers.%d.fc1.weight' % i) in sd:
             L = Dc + 'layers.%d.' % i
-            lay = {'self': attn(L + 'self_attn.', False), 'cross': attn(L + 'encoder_attn.', False)}
+            lay = {'self': attn(L + 'self_attn.', True), 'cross': attn(L + 'encoder_attn.', False)}
             lay.update(ln1=_ln(sd, L + 'self_attn_layer_norm', dev), ln2=_ln(sd, L + 'encoder_attn_layer_norm', dev),
                        ln3=_ln(sd, L + 'final_layer_norm', dev),
                        w1=ops.w_linear(sd[L + 'fc1.weight'], dev), b1=ops.w_bias(sd[L + 'fc1.bias'], dev),
@@ -131,9 +131,8 @@ class Whisper:
             S, C = L['self'], L['cross']
             kv = bufs['kv'][li]
             ops.layernorm(x, *L['ln1'], bufs['hn'], Bn, d)
-            ops.linear(bufs['hn'], S['wq'], S['bq'], bufs['q'], rows=Bn, k=d, n=d)
-            ops.conv(bufs['hn'], S['wkv'], S['bkv'], kv, nbatch=Bn, t_in=1, t_out=1, cin=d, n=2 * d,
-                     out_bstride=smax * 2 * d, ldc=2 * d, dyn_pos=pos, dyn_ooff_mul=1)
+            ops.conv(bufs['hn'], S['wqkv'], S['bqkv'], bufs['q'], nbatch=Bn, t_in=1, t_out=1, cin=d, n=3 * d, ldc=d,
+                     out_bstride=d, dyn_pos=pos, n_split=d, out2=kv, out2_bstride=smax * 2 * d, ldc2=2 * d, dyn_ooff2_mul=1)
             ops.attn_decode(bufs['q'], kv, kv, bufs['att'], nbatch=Bn, nheads=H, max_keys=smax, q_bs=d,
                             kv_bs=smax * 2 * d, kv_ts=2 * d, o_bs=d, v_off=d, dyn_len=pos, dyn_add=1)
             ops.linear(bufs['att'], S['wo'], S['bo'], x, rows=Bn, k=d, n=d, resid=x)

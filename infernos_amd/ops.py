@@ -22,7 +22,8 @@ def _addr(t, off=0):
 def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=1, pad=0,
          x_off=0, lda=None, x_bstride=None, act=ACT_NONE, act_slope=0.0, pre_slope=1.0, colmask=None, colmask_off=0,
          resid=None, resid_off=0, resid_ld=None, resid_bstride=None, scale=1.0, accumulate=False,
-         out_off=0, ldc=None, out_bstride=None, ostride=1, ooff=0, dyn_pos=None, dyn_ooff_mul=0, dyn_resid_mul=0):
+         out_off=0, ldc=None, out_bstride=None, ostride=1, ooff=0, dyn_pos=None, dyn_ooff_mul=0, dyn_resid_mul=0,
+         n_split=0, out2=None, out2_bstride=0, ldc2=0, ooff2=0, dyn_ooff2_mul=0):
     """One implicit-GEMM launch (see ifh_conv_desc).  Strides default to dense [nbatch][t][c]."""
     d = ConvDesc()
     lda = cin if lda is None else lda
@@ -41,6 +42,7 @@ def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=
     d.out_bstride = (t_out * ostride * ldc if out_bstride is None else out_bstride)
     d.ldc, d.ostride, d.ooff = ldc, ostride, ooff
     d.dyn_pos, d.dyn_ooff_mul, d.dyn_resid_mul = _addr(dyn_pos), dyn_ooff_mul, dyn_resid_mul
+    d.n_split, d.out2, d.out2_bstride, d.ldc2, d.ooff2, d.dyn_ooff2_mul = n_split, _addr(out2), out2_bstride, ldc2, ooff2, dyn_ooff2_mul
     _lib.check(_lib.lib().ifh_conv_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_conv_bf16')
     return out
 
