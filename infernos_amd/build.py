@@ -9,7 +9,10 @@ CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libinfernos_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-         '-ffp-contract=off']
+         '-ffp-contract=off',
+         # the accumulator-tile loops must be fully unrolled (static register indices); LLVM's default
+         # pragma-unroll budget (16K) is too small for the 16..24-tile epilogues -> tiles went to scratch
+         '-mllvm', '-pragma-unroll-threshold=1000000']
 
 
 def sources():

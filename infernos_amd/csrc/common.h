@@ -31,11 +31,15 @@ constexpr int kWave = 64;
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f)
 {
-    // round-to-nearest-even; NaN stays NaN (quiet)
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    // native conversion (v_cvt_pk_bf16_f32 on gfx950): round-to-nearest-even, NaN stays NaN
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
+}
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi)
+{
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // ---- wave / block reductions ------------------------------------------------------------

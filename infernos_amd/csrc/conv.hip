@@ -1,0 +1,181 @@
+// conv.hip -- stride-1 Conv1d with the input tile resident in LDS, for the HiFi-GAN residual
+// blocks (Cin = Cout in {32, 64, 128, 256}, kernel 3/7/11, dilation 1/3/5), which carry
+// ~97 % of the vocoder FLOPs (66.06 of 68.3 MFLOP per mel frame per level).
+//
+// Versus the generic implicit GEMM (nn.hip:k_igemm) the activation rows of a block
+// (BM + (taps-1)*dil rows x Cin) are staged ONCE -- with the fused LeakyReLU applied once per
+// element instead of once per tap -- and every tap's MFMA operand is a shifted row window of
+// that tile.  Weights: fully LDS-resident for Cin <= 64 (the K loop then runs barrier-free),
+// streamed in 64-wide K chunks through a register prefetch for Cin >= 128.
+// MFMA: v_mfma_f32_16x16x32_bf16, swapped operands (A = weight rows, B = activation rows), same
+// fused epilogue as k_igemm (bias, residual, scale, accumulate).
+#include <stdlib.h>
+
+#include "igemm.h"
+
+namespace ifh {
+
+template <int CIN, int WGM, int MT, int NT, bool RESIDENT>
+__global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
+{
+    constexpr int WGN = 4 / WGM;
+    constexpr int BM = WGM * MT * 16, BN = WGN * NT * 16;
+    constexpr int XS = CIN + 8;   // LDS row stride (elements): 16-byte pad
+    constexpr int KC = 64;        // streamed K chunk
+    constexpr int WV = RESIDENT ? 0 : (BN * KC / 8 / 256);   // prefetch vectors per thread (<= 8)
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int wm = wid % WGM, wn = wid / WGM;
+    const int b = blockIdx.y, t0 = blockIdx.x * BM;
+    const int halo = (p.taps - 1) * p.dil;
+    const int R = BM + halo;
+    const int KW = RESIDENT ? p.K : KC;
+    const int WS = KW + 8;
+    uint16_t *Xs = lds;
+    uint16_t *Ws = lds + ((R * XS + 7) & ~7);
+
+    // ---- stage the input rows once (zero outside [0, T_in)), LeakyReLU fused here
+    {
+        constexpr int VPR = CIN / 8;
+        const uint16_t *xb = p.x + (int64_t)b * p.x_bstride;
+        const bool pre = p.pre_slope != 1.0f;
+        for (int v = tid; v < R * VPR; v += 256) {
+            const int r = v / VPR, c = (v - r * VPR) * 8;
+            const int tin = t0 - p.pad + r;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (tin >= 0 && tin < p.T_in) {
+                val = *reinterpret_cast<const uint4 *>(xb + (int64_t)tin * p.lda + c);
+                if (pre) val = lrelu8(val, p.pre_slope);
+            }
+            *reinterpret_cast<uint4 *>(&Xs[r * XS + c]) = val;
+        }
+    }
+    // Prefetch registers are NAMED scalars driven by macros: as an array (or captured in a lambda)
+    // hipcc kept them in scratch memory.
+    uint4 w0, w1, w2, w3, w4, w5, w6, w7;
+    w0 = w1 = w2 = w3 = w4 = w5 = w6 = w7 = make_uint4(0, 0, 0, 0);
+#define IFH_W1(I, REG, K0)                                                                       \
+    if (I < WV) {                                                                                \
+        const int v = tid + 256 * I;                                                             \
+        REG = *reinterpret_cast<const uint4 *>(p.w + (int64_t)(v / (KC / 8)) * p.K + (K0) + (v % (KC / 8)) * 8); \
+    }
+#define IFH_W_PREFETCH(K0)                                                                       \
+    if (!RESIDENT) {                                                                             \
+        IFH_W1(0, w0, K0) IFH_W1(1, w1, K0) IFH_W1(2, w2, K0) IFH_W1(3, w3, K0)                  \
+        IFH_W1(4, w4, K0) IFH_W1(5, w5, K0) IFH_W1(6, w6, K0) IFH_W1(7, w7, K0)                  \
+    }
+#define IFH_C1(I, REG)                                                                           \
+    if (I < WV) {                                                                                \
+        const int v = tid + 256 * I;                                                             \
+        *reinterpret_cast<uint4 *>(&Ws[(v / (KC / 8)) * WS + (v % (KC / 8)) * 8]) = REG;         \
+    }
+#define IFH_W_COMMIT()                                                                           \
+    if (!RESIDENT) {                                                                             \
+        IFH_C1(0, w0) IFH_C1(1, w1) IFH_C1(2, w2) IFH_C1(3, w3)                                  \
+        IFH_C1(4, w4) IFH_C1(5, w5) IFH_C1(6, w6) IFH_C1(7, w7)                                  \
+    }
+    if (RESIDENT) {
+        const int vpr = p.K / 8;
+        for (int v = tid; v < BN * vpr; v += 256) {
+            const int n = v / vpr, kv = (v - n * vpr) * 8;
+            *reinterpret_cast<uint4 *>(&Ws[n * WS + kv]) = *reinterpret_cast<const uint4 *>(p.w + (int64_t)n * p.K + kv);
+        }
+    } else {
+        IFH_W_PREFETCH(0)
+    }
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nchunk = RESIDENT ? 1 : p.K / KC;
+    const int arow0 = (wm * MT * 16 + fr) * XS + fg * 8;
+    const int brow0 = (wn * NT * 16 + fr) * WS + fg * 8;
+    for (int ch = 0; ch < nchunk; ch++) {
+        if (!RESIDENT) {
+            if (ch > 0) __syncthreads();      // everyone is done reading the previous chunk
+            IFH_W_COMMIT()
+        }
+        __syncthreads();
+        if (!RESIDENT && ch + 1 < nchunk) IFH_W_PREFETCH((ch + 1) * KC)
+        const int ksteps = KW / 32;
+        for (int ks = 0; ks < ksteps; ks++) {
+            const int k = ch * KC + ks * 32;
+            const int tap = k / CIN, ci = k - tap * CIN;
+            const int aoff = arow0 + tap * p.dil * XS + ci;
+            bf16x8_t fa[NT], fb[MT];
+#pragma unroll
+            for (int i = 0; i < NT; i++) fa[i] = *reinterpret_cast<const bf16x8_t *>(&Ws[brow0 + i * 16 * WS + ks * 32]);
+#pragma unroll
+            for (int j = 0; j < MT; j++) fb[j] = *reinterpret_cast<const bf16x8_t *>(&Xs[aoff + j * 16 * XS]);
+#pragma unroll
+            for (int i = 0; i < NT; i++)
+#pragma unroll
+                for (int j = 0; j < MT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+#undef IFH_W_PREFETCH
+#undef IFH_W_COMMIT
+#undef IFH_W1
+#undef IFH_C1
+    const int dynv = p.dyn ? p.dyn[0] : 0;
+#pragma unroll
+    for (int j = 0; j < MT; j++) {
+        const int t = t0 + (wm * MT + j) * 16 + fr;
+        if (t >= p.T_out) continue;
+        const int m = b * p.T_out + t;
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int n = (wn * NT + i) * 16 + 4 * fg;
+            igemm_store4<true>(p, m, n, acc[i][j], dynv);
+        }
+    }
+}
+
+template <int CIN, int WGM, int MT, int NT, bool RESIDENT>
+static bool launch_direct(const IgemmParams &p, hipStream_t st)
+{
+    constexpr int WGN = 4 / WGM;
+    constexpr int BM = WGM * MT * 16, BN = WGN * NT * 16;
+    constexpr int XS = CIN + 8;
+    const int R = BM + (p.taps - 1) * p.dil;
+    const int KW = RESIDENT ? p.K : 64;
+    const size_t bytes = ((size_t)((R * XS + 7) & ~7) + (size_t)BN * (KW + 8)) * sizeof(uint16_t);
+    if (bytes > 160 * 1024) return false;
+    static size_t attr_bytes = 0;
+    if (bytes > 64 * 1024 && bytes > attr_bytes) {
+        if (hipFuncSetAttribute((const void *)k_conv_direct<CIN, WGM, MT, NT, RESIDENT>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+            return false;
+        attr_bytes = 160 * 1024;
+    }
+    dim3 grid((p.T_out + BM - 1) / BM, p.nbatch);
+    hipLaunchKernelGGL((k_conv_direct<CIN, WGM, MT, NT, RESIDENT>), grid, dim3(256), bytes, st, p);
+    return true;
+}
+
+bool try_launch_conv_direct(const IgemmParams &p, bool pre, hipStream_t st)
+{
+    (void)pre;
+    static const int mask = getenv("IFH_DIRECT_CONV_MASK") ? atoi(getenv("IFH_DIRECT_CONV_MASK")) : 15;   // tuning switch
+    if (!((p.Cin == 256 && (mask & 1)) || (p.Cin == 128 && (mask & 2)) || (p.Cin == 64 && (mask & 4)) || (p.Cin == 32 && (mask & 8))))
+        return false;
+    if (p.stride != 1 || p.taps < 2 || p.N != p.Cin || p.n_split != 0 || !p.fast_epi) return false;
+    if (p.T_out != p.T_in + 2 * p.pad - (p.taps - 1) * p.dil) return false;
+    if (p.nbatch >= 65536) return false;
+    switch (p.Cin) {
+    case 256: return p.T_out >= 32 && launch_direct<256, 1, 3, 4, false>(p, st);     // BM 48  x BN 256
+    case 128: return p.T_out >= 64 && launch_direct<128, 2, 6, 4, false>(p, st);     // BM 192 x BN 128
+    case 64: return p.T_out >= 128 && launch_direct<64, 2, 8, 2, false>(p, st);      // BM 256 x BN 64, streamed W (3 blocks/CU)
+    case 32: return p.T_out >= 128 && launch_direct<32, 4, 4, 2, true>(p, st);       // BM 256 x BN 32
+    default: return false;
+    }
+}
+
+}  // namespace ifh

@@ -1,0 +1,187 @@
+// igemm.h -- parameters and fused epilogue shared by the GEMM-shaped kernels (nn.hip, conv.hip)
+#pragma once
+#include <math.h>
+
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace ifh {
+
+struct IgemmParams {
+    const uint16_t *x;
+    int64_t x_bstride;
+    int lda;
+    int Cin, taps, stride, dil, pad;
+    int T_in, T_out, nbatch;
+    const uint16_t *w;
+    int K, N;
+    const float *bias;
+    const uint8_t *colmask;
+    float pre_slope;
+    int act;
+    float act_slope;
+    const uint16_t *resid;
+    int64_t resid_bstride;
+    int resid_ld;
+    float out_scale;
+    int accumulate;
+    void *out;
+    int out_f32;
+    int64_t out_bstride;
+    int ldc, ostride, ooff;
+    int vec_ok;
+    int res_vec_ok;           // bias/colmask/resid can be read as 16/4/8-byte vectors
+    int fast_epi;             // every 4-group of this launch can take the vector epilogue
+    int n_split;              // columns >= n_split (if > 0) go to the second output region
+    void *out2;
+    int64_t out2_bstride;
+    int ldc2, ooff2, dyn_ooff2_mul;
+    const int32_t *dyn;       // optional device scalar (e.g. decoder position)
+    int dyn_ooff_mul;         // ooff += dyn[0] * dyn_ooff_mul
+    int64_t dyn_resid_mul;    // resid += dyn[0] * dyn_resid_mul (elements)
+};
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_TANH = 3, ACT_LRELU = 4, ACT_SIGMOID = 5 };
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope)
+{
+    switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.0f);
+    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case ACT_TANH: return tanhf(v);
+    case ACT_LRELU: return v > 0.0f ? v : v * slope;
+    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+    }
+}
+
+__device__ __forceinline__ uint4 lrelu8(uint4 v, float slope)
+{
+    uint32_t *u = reinterpret_cast<uint32_t *>(&v);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
+        lo = fmaxf(lo, lo * slope);      // 0 < slope < 1
+        hi = fmaxf(hi, hi * slope);
+        u[i] = f32x2_to_bf16x2(lo, hi);
+    }
+    return v;
+}
+
+
+// ---- fused epilogue for 4 consecutive output channels n..n+3 of output row m.
+// Two forms: the vector form (16-byte bias load, 8-byte residual load, 8/16-byte store) is inlined
+// into the kernels' unrolled accumulator loops and must stay SMALL -- when it grew, hipcc stopped
+// unrolling those loops and put the accumulator tiles in scratch memory (2x slower kernels).
+// The general form (ragged N, unaligned pointers, ...) lives in separate kernel instantiations
+// (template parameter FAST = false), chosen by the host when p.fast_epi == 0.
+struct EpiRow {
+    int64_t obase, rbase;
+    void *outp;
+};
+
+__device__ __forceinline__ EpiRow epi_row(const IgemmParams &p, int m, int n, int dynv)
+{
+    const int b = m / p.T_out, t = m - b * p.T_out;
+    const bool second = p.n_split > 0 && n >= p.n_split;      // n_split % 16 == 0: a 4-group never straddles
+    const int64_t orow = second ? ((int64_t)t * p.ostride + p.ooff2 + (int64_t)dynv * p.dyn_ooff2_mul)
+                                : ((int64_t)t * p.ostride + p.ooff + (int64_t)dynv * p.dyn_ooff_mul);
+    EpiRow r;
+    r.obase = second ? ((int64_t)b * p.out2_bstride + orow * p.ldc2 - p.n_split) : ((int64_t)b * p.out_bstride + orow * p.ldc);
+    r.outp = second ? p.out2 : p.out;
+    r.rbase = (int64_t)b * p.resid_bstride + orow * p.resid_ld + (int64_t)dynv * p.dyn_resid_mul;
+    return r;
+}
+
+__device__ __forceinline__ void igemm_store4_fast(const IgemmParams &p, int m, int n, f32x4 acc, int dynv)
+{
+    const EpiRow e = epi_row(p, m, n, dynv);
+    float v0 = acc[0], v1 = acc[1], v2 = acc[2], v3 = acc[3];
+    if (p.bias) {
+        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
+        v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+    }
+    if (p.act != ACT_NONE) {
+        v0 = apply_act(v0, p.act, p.act_slope);
+        v1 = apply_act(v1, p.act, p.act_slope);
+        v2 = apply_act(v2, p.act, p.act_slope);
+        v3 = apply_act(v3, p.act, p.act_slope);
+    }
+    if (p.colmask) {
+        const uint32_t mk = *reinterpret_cast<const uint32_t *>(p.colmask + n);
+        v0 = (mk & 0xffu) ? v0 * 2.0f : 0.0f;
+        v1 = (mk & 0xff00u) ? v1 * 2.0f : 0.0f;
+        v2 = (mk & 0xff0000u) ? v2 * 2.0f : 0.0f;
+        v3 = (mk & 0xff000000u) ? v3 * 2.0f : 0.0f;
+    }
+    if (p.resid) {
+        const uint2 rv = *reinterpret_cast<const uint2 *>(p.resid + e.rbase + n);
+        v0 += __uint_as_float(rv.x << 16);
+        v1 += __uint_as_float(rv.x & 0xffff0000u);
+        v2 += __uint_as_float(rv.y << 16);
+        v3 += __uint_as_float(rv.y & 0xffff0000u);
+    }
+    v0 *= p.out_scale; v1 *= p.out_scale; v2 *= p.out_scale; v3 *= p.out_scale;
+    if (p.out_f32) {
+        float *o = reinterpret_cast<float *>(e.outp) + e.obase + n;
+        if (p.accumulate) {
+            const float4 prev = *reinterpret_cast<const float4 *>(o);
+            v0 += prev.x; v1 += prev.y; v2 += prev.z; v3 += prev.w;
+        }
+        *reinterpret_cast<float4 *>(o) = make_float4(v0, v1, v2, v3);
+    } else {
+        uint16_t *o = reinterpret_cast<uint16_t *>(e.outp) + e.obase + n;
+        if (p.accumulate) {
+            const uint2 pv = *reinterpret_cast<const uint2 *>(o);
+            v0 += __uint_as_float(pv.x << 16);
+            v1 += __uint_as_float(pv.x & 0xffff0000u);
+            v2 += __uint_as_float(pv.y << 16);
+            v3 += __uint_as_float(pv.y & 0xffff0000u);
+        }
+        uint2 pk;
+        pk.x = f32x2_to_bf16x2(v0, v1);
+        pk.y = f32x2_to_bf16x2(v2, v3);
+        *reinterpret_cast<uint2 *>(o) = pk;
+    }
+}
+
+__device__ __forceinline__ void igemm_store4_general(const IgemmParams &p, int m, int n, float a0, float a1,
+                                                               float a2, float a3, int dynv)
+{
+    const EpiRow e = epi_row(p, m, n, dynv);
+#define IFH_EPI1(V, R)                                                                                     \
+    if (n + R < p.N) {                                                                                     \
+        float v = V;                                                                                       \
+        if (p.bias) v += p.bias[n + R];                                                                    \
+        v = apply_act(v, p.act, p.act_slope);                                                              \
+        if (p.colmask) v = p.colmask[n + R] ? v * 2.0f : 0.0f;                                             \
+        if (p.resid) v += bf16_to_f32(p.resid[e.rbase + n + R]);                                           \
+        v *= p.out_scale;                                                                                  \
+        if (p.out_f32) {                                                                                   \
+            float *o = reinterpret_cast<float *>(e.outp) + e.obase + n + R;                                \
+            *o = v + (p.accumulate ? *o : 0.0f);                                                           \
+        } else {                                                                                           \
+            uint16_t *o = reinterpret_cast<uint16_t *>(e.outp) + e.obase + n + R;                          \
+            *o = f32_to_bf16(v + (p.accumulate ? bf16_to_f32(*o) : 0.0f));                                 \
+        }                                                                                                  \
+    }
+    IFH_EPI1(a0, 0) IFH_EPI1(a1, 1) IFH_EPI1(a2, 2) IFH_EPI1(a3, 3)
+#undef IFH_EPI1
+}
+
+template <bool FAST>
+__device__ __forceinline__ void igemm_store4(const IgemmParams &p, int m, int n, f32x4 acc, int dynv)
+{
+    if (FAST)
+        igemm_store4_fast(p, m, n, acc, dynv);
+    else
+        igemm_store4_general(p, m, n, acc[0], acc[1], acc[2], acc[3], dynv);
+}
+
+// conv.hip: LDS-resident-input convolution for the stride-1 residual-block shapes.
+// Returns true if it took the launch.
+bool try_launch_conv_direct(const IgemmParams &p, bool pre, hipStream_t st);
+
+}  // namespace ifh

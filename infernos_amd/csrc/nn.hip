@@ -7,134 +7,9 @@
 //   * k_transpose: [B][R][C] -> [B][C][R] with cast to bf16 (layout glue).
 // The MFMA is issued "swapped" (A = weight rows, B = activation rows) so that a lane ends
 // up holding 4 consecutive output channels of one output row -> 8/16-byte stores.
-#include <math.h>
-
-#include "common.h"
-
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "igemm.h"
 
 namespace ifh {
-
-struct IgemmParams {
-    const uint16_t *x;
-    int64_t x_bstride;
-    int lda;
-    int Cin, taps, stride, dil, pad;
-    int T_in, T_out, nbatch;
-    const uint16_t *w;
-    int K, N;
-    const float *bias;
-    const uint8_t *colmask;
-    float pre_slope;
-    int act;
-    float act_slope;
-    const uint16_t *resid;
-    int64_t resid_bstride;
-    int resid_ld;
-    float out_scale;
-    int accumulate;
-    void *out;
-    int out_f32;
-    int64_t out_bstride;
-    int ldc, ostride, ooff;
-    int vec_ok;
-    int n_split;              // columns >= n_split (if > 0) go to the second output region
-    void *out2;
-    int64_t out2_bstride;
-    int ldc2, ooff2, dyn_ooff2_mul;
-    const int32_t *dyn;       // optional device scalar (e.g. decoder position)
-    int dyn_ooff_mul;         // ooff += dyn[0] * dyn_ooff_mul
-    int64_t dyn_resid_mul;    // resid += dyn[0] * dyn_resid_mul (elements)
-};
-
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_TANH = 3, ACT_LRELU = 4, ACT_SIGMOID = 5 };
-
-__device__ __forceinline__ float apply_act(float v, int act, float slope)
-{
-    switch (act) {
-    case ACT_RELU: return fmaxf(v, 0.0f);
-    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    case ACT_TANH: return tanhf(v);
-    case ACT_LRELU: return v > 0.0f ? v : v * slope;
-    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-    default: return v;
-    }
-}
-
-__device__ __forceinline__ uint4 lrelu8(uint4 v, float slope)
-{
-    uint32_t *u = reinterpret_cast<uint32_t *>(&v);
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        float lo = __uint_as_float(u[i] << 16), hi = __uint_as_float(u[i] & 0xffff0000u);
-        lo = lo > 0.0f ? lo : lo * slope;
-        hi = hi > 0.0f ? hi : hi * slope;
-        u[i] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
-    }
-    return v;
-}
-
-
-// epilogue for 4 consecutive output channels n..n+3 of output row m (shared by both GEMM kernels)
-__device__ __forceinline__ void igemm_store4(const IgemmParams &p, int m, int n, const float (&accv)[4], int dynv)
-{
-    const int b = m / p.T_out, t = m - b * p.T_out;
-    const bool second = p.n_split > 0 && n >= p.n_split;      // n_split % 16 == 0: a 4-group never straddles
-    const int64_t orow = second ? ((int64_t)t * p.ostride + p.ooff2 + (int64_t)dynv * p.dyn_ooff2_mul)
-                                : ((int64_t)t * p.ostride + p.ooff + (int64_t)dynv * p.dyn_ooff_mul);
-    const int64_t obase = second ? ((int64_t)b * p.out2_bstride + orow * p.ldc2 - p.n_split)
-                                 : ((int64_t)b * p.out_bstride + orow * p.ldc);
-    void *const outp = second ? p.out2 : p.out;
-    const int64_t rbase = (int64_t)b * p.resid_bstride + orow * p.resid_ld + (int64_t)dynv * p.dyn_resid_mul;
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        float a = accv[r];
-        const int nn = n + r;
-        if (nn < p.N) {
-            if (p.bias) a += p.bias[nn];
-            a = apply_act(a, p.act, p.act_slope);
-            if (p.colmask) a = p.colmask[nn] ? a * 2.0f : 0.0f;
-            if (p.resid) a += bf16_to_f32(p.resid[rbase + nn]);
-            a *= p.out_scale;
-        }
-        v[r] = a;
-    }
-    if (p.vec_ok && n + 3 < p.N) {
-        if (p.out_f32) {
-            float *o = reinterpret_cast<float *>(outp) + obase + n;
-            float4 prev = make_float4(0, 0, 0, 0);
-            if (p.accumulate) prev = *reinterpret_cast<const float4 *>(o);
-            *reinterpret_cast<float4 *>(o) = make_float4(v[0] + prev.x, v[1] + prev.y, v[2] + prev.z, v[3] + prev.w);
-        } else {
-            uint16_t *o = reinterpret_cast<uint16_t *>(outp) + obase + n;
-            if (p.accumulate) {
-                const uint2 pv = *reinterpret_cast<const uint2 *>(o);
-                v[0] += __uint_as_float(pv.x << 16);
-                v[1] += __uint_as_float(pv.x & 0xffff0000u);
-                v[2] += __uint_as_float(pv.y << 16);
-                v[3] += __uint_as_float(pv.y & 0xffff0000u);
-            }
-            uint2 pk;
-            pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-            pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-            *reinterpret_cast<uint2 *>(o) = pk;
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            if (n + r >= p.N) break;
-            if (p.out_f32) {
-                float *o = reinterpret_cast<float *>(outp) + obase + n + r;
-                *o = v[r] + (p.accumulate ? *o : 0.0f);
-            } else {
-                uint16_t *o = reinterpret_cast<uint16_t *>(outp) + obase + n + r;
-                *o = f32_to_bf16(v[r] + (p.accumulate ? bf16_to_f32(*o) : 0.0f));
-            }
-        }
-    }
-}
 
 // ---- skinny GEMM for decode steps (M <= 64 rows, taps == 1): latency-bound weight streaming.
 // One block = 16 output channels x 16 rows; its NW waves split K so that every lane has all of
@@ -180,21 +55,21 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
     *reinterpret_cast<f32x4 *>(&red[wid][lane][0]) = acc;
     __syncthreads();
     if (wid == 0) {
-        float s[4] = {0.f, 0.f, 0.f, 0.f};
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < NW; w++) {
-            const float4 v = *reinterpret_cast<const float4 *>(&red[w][lane][0]);
-            s[0] += v.x;
-            s[1] += v.y;
-            s[2] += v.z;
-            s[3] += v.w;
-        }
+        for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w][lane][0]);
         const int n = n0 + 4 * fg;
-        if (xok && n < p.N) igemm_store4(p, m, n, s, p.dyn ? p.dyn[0] : 0);
+        if (xok && n < p.N) {
+            const int dynv = p.dyn ? p.dyn[0] : 0;
+            if (p.fast_epi)
+                igemm_store4<true>(p, m, n, s, dynv);
+            else
+                igemm_store4<false>(p, m, n, s, dynv);
+        }
     }
 }
 
-template <int BM, int BN, int WGM, bool PRE>
+template <int BM, int BN, int WGM, bool PRE, bool FAST>
 __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
 {
     constexpr int WGN = 4 / WGM;
@@ -231,63 +106,68 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
 #pragma unroll
         for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // NOTE: plain macros, not lambdas: arrays captured by reference in a lambda were placed in
+    // scratch memory by hipcc (272 B/lane of spills in the 128x128 tile, ~2x slower).
     uint4 ra[AV], rb[BV];
-    auto load_tiles = [&](int k0) {
-        int tap_u = 0, ci_u = 0;
-        if (uniform_tap) {
-            tap_u = k0 / p.Cin;
-            ci_u = k0 - tap_u * p.Cin;
-        }
-#pragma unroll
-        for (int i = 0; i < AV; i++) {
-            const int v = tid + 256 * i;
-            const int k = k0 + (v & 3) * 8;
-            int tap, ci;
-            if (uniform_tap) {
-                tap = tap_u;
-                ci = ci_u + (v & 3) * 8;
-            } else {
-                tap = k / p.Cin;
-                ci = k - tap * p.Cin;
-            }
-            const int tin = abase_t[i] + tap * p.dil;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (avalid[i] && k < p.K && tin >= 0 && tin < p.T_in) {
-                val = *reinterpret_cast<const uint4 *>(arow[i] + (int64_t)tin * p.lda + ci);
-                if (PRE) val = lrelu8(val, p.pre_slope);
-            }
-            ra[i] = val;
-        }
-#pragma unroll
-        for (int i = 0; i < BV; i++) {
-            const int v = tid + 256 * i;
-            const int n = n0 + (v >> 2);
-            const int k = k0 + (v & 3) * 8;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (v < BN * 4 && n < p.N && k < p.K) val = *reinterpret_cast<const uint4 *>(p.w + (int64_t)n * p.K + k);
-            rb[i] = val;
-        }
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int i = 0; i < AV; i++) {
-            const int v = tid + 256 * i;
-            *reinterpret_cast<uint4 *>(&As[(v >> 2) * LD + (v & 3) * 8]) = ra[i];
-        }
-#pragma unroll
-        for (int i = 0; i < BV; i++) {
-            const int v = tid + 256 * i;
-            if (v < BN * 4) *reinterpret_cast<uint4 *>(&Bs[(v >> 2) * LD + (v & 3) * 8]) = rb[i];
-        }
-    };
+#define IFH_LOAD_TILES(K0)                                                                               \
+    {                                                                                                    \
+        const int k0_ = (K0);                                                                            \
+        int tap_u = 0, ci_u = 0;                                                                         \
+        if (uniform_tap) {                                                                               \
+            tap_u = k0_ / p.Cin;                                                                         \
+            ci_u = k0_ - tap_u * p.Cin;                                                                  \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < AV; i++)                                                   \
+        {                                                                                                \
+            const int v = tid + 256 * i;                                                                 \
+            const int k = k0_ + (v & 3) * 8;                                                             \
+            int tap, ci;                                                                                 \
+            if (uniform_tap) {                                                                           \
+                tap = tap_u;                                                                             \
+                ci = ci_u + (v & 3) * 8;                                                                 \
+            } else {                                                                                     \
+                tap = k / p.Cin;                                                                         \
+                ci = k - tap * p.Cin;                                                                    \
+            }                                                                                            \
+            const int tin = abase_t[i] + tap * p.dil;                                                    \
+            uint4 val = make_uint4(0, 0, 0, 0);                                                          \
+            if (avalid[i] && k < p.K && tin >= 0 && tin < p.T_in)                                        \
+                val = *reinterpret_cast<const uint4 *>(arow[i] + (int64_t)tin * p.lda + ci);             \
+            ra[i] = val;                                                                                 \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < BV; i++)                                                   \
+        {                                                                                                \
+            const int v = tid + 256 * i;                                                                 \
+            const int n = n0 + (v >> 2);                                                                 \
+            const int k = k0_ + (v & 3) * 8;                                                             \
+            uint4 val = make_uint4(0, 0, 0, 0);                                                          \
+            if (v < BN * 4 && n < p.N && k < p.K) val = *reinterpret_cast<const uint4 *>(p.w + (int64_t)n * p.K + k); \
+            rb[i] = val;                                                                                 \
+        }                                                                                                \
+    }
+    // the fused input LeakyReLU is applied at LDS-store time, after the previous tile's MFMAs, so the
+    // global loads of this tile stayed in flight behind them (zeros stay zeros)
+#define IFH_STORE_TILES()                                                                                \
+    {                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < AV; i++)                                                   \
+        {                                                                                                \
+            const int v = tid + 256 * i;                                                                 \
+            *reinterpret_cast<uint4 *>(&As[(v >> 2) * LD + (v & 3) * 8]) = PRE ? lrelu8(ra[i], p.pre_slope) : ra[i]; \
+        }                                                                                                \
+        _Pragma("unroll") for (int i = 0; i < BV; i++)                                                   \
+        {                                                                                                \
+            const int v = tid + 256 * i;                                                                 \
+            if (v < BN * 4) *reinterpret_cast<uint4 *>(&Bs[(v >> 2) * LD + (v & 3) * 8]) = rb[i];        \
+        }                                                                                                \
+    }
 
     const int nk = (p.K + 31) / 32;
-    load_tiles(0);
+    IFH_LOAD_TILES(0);
     const int fr = lane & 15, fg = lane >> 4;
     for (int kt = 0; kt < nk; kt++) {
-        store_tiles();
+        IFH_STORE_TILES();
         __syncthreads();
-        if (kt + 1 < nk) load_tiles((kt + 1) * 32);
+        if (kt + 1 < nk) IFH_LOAD_TILES((kt + 1) * 32);
         bf16x8_t fa[NT], fb[MT];
 #pragma unroll
         for (int i = 0; i < NT; i++)
@@ -303,6 +183,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
         __syncthreads();
     }
 
+#undef IFH_LOAD_TILES
+#undef IFH_STORE_TILES
     // ---- epilogue: lane holds D[n = 4*fg + r][m = fr] of each 16x16 tile
     const int dynv = p.dyn ? p.dyn[0] : 0;
 #pragma unroll
@@ -313,8 +195,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
         for (int i = 0; i < NT; i++) {
             const int n = n0 + wn * WN + i * 16 + 4 * fg;
             if (n >= p.N) continue;
-            const float a4[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            igemm_store4(p, m, n, a4, dynv);
+            igemm_store4<FAST>(p, m, n, acc[i][j], dynv);
         }
     }
 }
@@ -412,10 +293,17 @@ static void launch_igemm(const IgemmParams &p, bool pre, hipStream_t st)
 {
     const int M = p.nbatch * p.T_out;
     dim3 grid((M + BM - 1) / BM, (p.N + BN - 1) / BN);
-    if (pre)
-        hipLaunchKernelGGL((k_igemm<BM, BN, WGM, true>), grid, dim3(256), 0, st, p);
-    else
-        hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false>), grid, dim3(256), 0, st, p);
+    if (p.fast_epi) {
+        if (pre)
+            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, true, true>), grid, dim3(256), 0, st, p);
+        else
+            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, true>), grid, dim3(256), 0, st, p);
+    } else {
+        if (pre)
+            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, true, false>), grid, dim3(256), 0, st, p);
+        else
+            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, false>), grid, dim3(256), 0, st, p);
+    }
 }
 
 }  // namespace ifh
@@ -465,6 +353,10 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     p.ooff = d->ooff;
     const int esz = d->out_f32 ? 4 : 2;
     p.vec_ok = (d->ldc % 4 == 0) && (d->out_bstride % 4 == 0) && ((((uintptr_t)d->out) % (4 * esz)) == 0);
+    p.res_vec_ok = (!d->bias || (((uintptr_t)d->bias) & 15) == 0) && (!d->colmask || (((uintptr_t)d->colmask) & 3) == 0) &&
+                   (!d->resid || ((((uintptr_t)d->resid) & 7) == 0 && d->resid_ld % 4 == 0 && d->resid_bstride % 4 == 0 &&
+                                  d->dyn_resid_mul % 4 == 0));
+    p.fast_epi = 0;
     p.n_split = d->n_split;
     p.out2 = d->out2;
     p.out2_bstride = d->out2_bstride;
@@ -475,6 +367,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         IFH_CHECK_ARG(d->n_split % 16 == 0 && d->out2 && d->ldc2 > 0 && d->n_split < d->n);
         p.vec_ok = p.vec_ok && (d->ldc2 % 4 == 0) && (d->out2_bstride % 4 == 0) && ((((uintptr_t)d->out2) % (4 * esz)) == 0);
     }
+    p.fast_epi = p.vec_ok && p.res_vec_ok && (d->n % 4 == 0);
     p.dyn = d->dyn_pos;
     p.dyn_ooff_mul = d->dyn_ooff_mul;
     p.dyn_resid_mul = d->dyn_resid_mul;
@@ -488,6 +381,8 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
             hipLaunchKernelGGL((k_gemm_skinny<8, 12>), grid, dim3(512), 0, st, p);
         else
             hipLaunchKernelGGL((k_gemm_skinny<4, 12>), grid, dim3(256), 0, st, p);
+    } else if (try_launch_conv_direct(p, pre, st)) {
+        // residual-block shapes: input tile resident in LDS (conv.hip)
     } else if (d->n <= 32)
         launch_igemm<128, 32, 4>(p, pre, st);
     else if (M <= 64)

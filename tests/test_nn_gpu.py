@@ -42,6 +42,9 @@ def bfr(x):
     dict(B=3, T=12, cin=80, cout=512, k=7, pad=3),                      # conv_pre (K=560, not a multiple of 32)
     dict(B=2, T=48, cin=256, cout=256, k=11, dil=5, pad=25, pre=0.1),   # resblock conv, dilated
     dict(B=2, T=200, cin=64, cout=64, k=3, dil=3, pad=3, pre=0.01, resid=True),
+    dict(B=3, T=192, cin=128, cout=128, k=7, dil=3, pad=9, pre=0.1, resid=True),      # LDS-resident-input conv, streamed W
+    dict(B=2, T=768, cin=64, cout=64, k=11, dil=5, pad=25, pre=0.1, resid=True),     # resident W, 3 row blocks
+    dict(B=2, T=300, cin=32, cout=32, k=11, dil=1, pad=5, pre=0.1),
     dict(B=5, T=3072 // 8, cin=32, cout=32, k=7, pad=3, pre=0.1, resid=True, scale=1 / 3, accumulate=True),
     dict(B=2, T=301, cin=80, cout=384, k=3, pad=1, act='gelu'),         # whisper conv1 (ragged M)
     dict(B=2, T=300, cin=384, cout=384, k=3, pad=1, stride=2, act='gelu'),
