@@ -139,12 +139,16 @@ class TTSBatchState:
         self.cross = [e(B * T, 2 * D) for _ in model.dec_layers]
         self.smax = min(model.max_steps, self.maxlen + 32)
         self.self_kv = [torch.zeros((B, self.smax, 2 * D), dtype=BF16, device=dev) for _ in model.dec_layers]
-        self.spec = torch.zeros((B, 33, 80), dtype=BF16, device=dev)       # frame 0 = carried last frame
+        # two frame buffers (call parity): frame 0 = last frame carried over from the previous call, frames
+        # 1..32 = this call.  Double-buffered so the renderer (postnet/vocoder) of call c can run on a second
+        # stream while the decoder already writes call c+1.
+        self.spec = [torch.zeros((B, 33, 80), dtype=BF16, device=dev) for _ in range(2)]
         self.cat = torch.zeros((B, D + 512), dtype=BF16, device=dev)
         self.pre_frames = torch.zeros((B, 4, 80), dtype=BF16, device=dev)
         self.starts_at = torch.full((B,), 1, dtype=torch.int64, device=dev)
         self.ends_at = torch.full((B,), -1, dtype=torch.int64, device=dev)
-        self.post = e(B, 32, 80)
+        self.post = [e(B, 32, 80), e(B, 32, 80)]
+        self.ncalls = 0
         self.pos_dev = torch.zeros(1, dtype=torch.int32, device=dev)       # decoder position, read by the kernels
         self.masks = torch.zeros((16, 2, 256), dtype=torch.uint8, device=dev)
         self.h1, self.h2, self.x = e(B, 256), e(B, 256), e(B, D)
@@ -172,7 +176,9 @@ class TTSBatchState:
         self.enc = model.encode(input_ids, lens)
         for L, kv in zip(model.dec_layers, self.cross):
             ops.linear(self.enc, L['cwkv'], L['cbkv'], kv, rows=B * T, k=D, n=2 * D)
-        self.spec.zero_()
+        self.spec[0].zero_()
+        self.spec[1].zero_()
+        self.ncalls = 0
         self.pre_frames.zero_()
         self.ends_at.fill_(-1)
         self.pos_dev.zero_()
@@ -183,13 +189,14 @@ class TTSBatchState:
                                                    _lib.stream_ptr(dev)), 'ifh_l2norm_rows_bf16')
 
 
-def _decoder_step(model: 'SpeechT5', st: TTSBatchState, s: int, threshold: float):
+def _decoder_step(model: 'SpeechT5', st: TTSBatchState, s: int, threshold: float, par: int):
     """One decoder step; everything that depends on the global position reads st.pos_dev on the
     device, so the launch sequence is identical for every step with the same in-call index s."""
     dev = model.device
     B, T = st.B, st.T
     masks = st.masks
-    ops.linear(st.spec, *model.p0, st.h1, rows=B, k=80, n=256, x_off=2 * s * 80, lda=33 * 80, act=ACT_RELU,
+    spec = st.spec[par]
+    ops.linear(spec, *model.p0, st.h1, rows=B, k=80, n=256, x_off=2 * s * 80, lda=33 * 80, act=ACT_RELU,
                colmask=masks, colmask_off=(s * 2) * 256)
     ops.linear(st.h1, *model.p1, st.h2, rows=B, k=256, n=256, act=ACT_RELU, colmask=masks, colmask_off=(s * 2 + 1) * 256)
     ops.linear(st.h2, *model.pf, st.cat, rows=B, k=256, n=D, ldc=D + 512, resid=model.pe_dec, resid_ld=0, resid_bstride=0,
@@ -216,7 +223,7 @@ def _decoder_step(model: 'SpeechT5', st: TTSBatchState, s: int, threshold: float
         ops.layernorm(st.t1, *L['ln3'], st.x, B, D)
         x = st.x
     # two new mel frames -> frames 2s+1, 2s+2 ; stop logits ; advance the device position
-    ops.linear(x, *model.feat, st.spec, rows=B, k=D, n=160, out_off=(2 * s + 1) * 80, ldc=33 * 80)
+    ops.linear(x, *model.feat, spec, rows=B, k=D, n=160, out_off=(2 * s + 1) * 80, ldc=33 * 80)
     ops.linear(x, *model.prob, st.plog, rows=B, k=D, n=2)
     _lib.check(_lib.lib().ifh_tts_stop_update(ops._addr(st.plog), ops._addr(st.ends_at), B, 0, st.minlen, st.maxlen,
                                               threshold, 2, ops._addr(st.pos_dev), _lib.stream_ptr(dev)), 'ifh_tts_stop_update')
@@ -229,38 +236,39 @@ def decoder_steps(model: 'SpeechT5', st: TTSBatchState, masks: torch.Tensor, nst
     ~80 small kernels per step) and replayed for every later call on this state."""
     assert nsteps <= 16 and st.idx + nsteps <= st.smax, 'decoder step budget exceeded'
     use_graphs = model.use_graphs if use_graphs is None else use_graphs
+    par = st.ncalls & 1
     st.masks[:nsteps].copy_(masks)
+    st.spec[par][:, 0, :].copy_(st.spec[1 - par][:, 32, :])       # carry the last produced frame
     # the first call on a state shape runs eagerly (loads every kernel); graphs are captured from the second on
-    use_graphs = use_graphs and st.eager_calls >= 1
+    use_graphs = use_graphs and st.eager_calls >= 2
     for s in range(nsteps):
         if not use_graphs:
-            _decoder_step(model, st, s, threshold)
+            _decoder_step(model, st, s, threshold, par)
         else:
-            g = st.graphs.get((s, threshold))
+            g = st.graphs.get((s, threshold, par))
             if g is None:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):          # records the launches; nothing executes until replay
-                    _decoder_step(model, st, s, threshold)
-                st.graphs[(s, threshold)] = g
+                    _decoder_step(model, st, s, threshold, par)
+                st.graphs[(s, threshold, par)] = g
             g.replay()
         st.idx += 1
     if not use_graphs:
         st.eager_calls += 1
 
 
-def postnet(model: SpeechT5, st: TTSBatchState):
-    """speech_decoder_postnet.postnet on the 32 new frames (:230) -> st.post bf16 [B,32,80]"""
+def postnet(model: SpeechT5, st: TTSBatchState, par: int):
+    """speech_decoder_postnet.postnet on the 32 new frames (:230) -> st.post[par] bf16 [B,32,80]"""
     B = st.B
-    src, lda, off, cin = st.spec, 80, 80, 80
+    spec = st.spec[par]
+    src, off, cin = spec, 80, 80
     for i, (w, shift) in enumerate(model.postnet):
         last = i == 4
-        out = st.post if last else st.pn[i % 2]
+        out = st.post[par] if last else st.pn[i % 2]
         cout = 80 if last else 256
         ops.conv(src, w, shift, out, nbatch=B, t_in=32, t_out=32, cin=cin, n=cout, taps=5, pad=2, x_off=off,
                  x_bstride=(33 * 80 if i == 0 else 32 * cin), lda=cin, act=(0 if last else ACT_TANH),
-                 resid=(st.spec if last else None), resid_off=(80 if last else 0), resid_ld=80, resid_bstride=33 * 80)
+                 resid=(spec if last else None), resid_off=(80 if last else 0), resid_ld=80, resid_bstride=33 * 80)
         src, off, cin = out, 0, cout
-    # carry the last produced frame into slot 0 for the next call
-    st.spec[:, 0, :].copy_(st.spec[:, 32, :])
-    return st.post
+    return st.post[par]

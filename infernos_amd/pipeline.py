@@ -89,6 +89,7 @@ class SpeechPipeline:
         g = torch.Generator().manual_seed(2000 + seed)
         self.speakers = torch.randn(ncalls, 512, generator=g)
         self.text_ids = torch.randint(4, 80, (ncalls, n_text), generator=g, dtype=torch.int32)
+        self._side_stream = torch.cuda.Stream(device=dev)
         self.pcm8k = torch.empty((ncalls, 160), dtype=torch.float32, device=dev)
         self.pcm16k = torch.empty((ncalls, 320), dtype=torch.float32, device=dev)
 
@@ -134,36 +135,59 @@ class SpeechPipeline:
         return toks, nsp, (lens8.float() / 8000.0)
 
     # ---- stage 3 -----------------------------------------------------------------------------
-    def synthesize(self, text_ids=None):
-        """-> (ulaw u8 [N, n_infer*A] device, valid sample count per call) with A = 8192/(16000/output_sr)"""
-        from .tts import HelloSippyPipeStateBatched
+    def synthesize(self, text_ids=None, overlap=True):
+        """-> (ulaw u8 [N, n_infer*A] device, valid sample count per call, spans) with A = 8192/(16000/output_sr).
+        Two-stream schedule: the decoder steps of call c+1 (launch/latency-bound, few CUs busy) run on the
+        main stream while postnet + HiFi-GAN + amendment + resample + mu-law of call c run on a second
+        stream (the frame buffers are double-buffered by call parity).  This is the 3-stage pipeline of the
+        reference's own harness (HelloSippyRTPipeTest.py:126-161) expressed with HIP streams/events."""
         dev, pp = self.device, self.tts
         ids = self.text_ids if text_ids is None else text_ids
         state = _make_state(pp, ids, self.speakers)
-        A = 8192 // (pp.model_sr // pp.output_sr)
-        stepsize = 512 // (pp.model_sr // pp.output_sr)
+        st = state.dev
+        rr = pp.model_sr // pp.output_sr
+        A = 8192 // rr
+        stepsize = 512 // rr
         out = torch.empty((self.n, self.n_infer * A), dtype=torch.uint8, device=dev)
         valid = torch.zeros(self.n, dtype=torch.int64)
         spans = []
+        main = torch.cuda.current_stream(dev)
+        side = self._side_stream if overlap else main
+        ren_done = [None, None]
         for c in range(self.n_infer):
-            pp.infer(state)
-            idx = state.idx
-            ends = state.ends_at.cpu().tolist()                  # the per-call sync the reference also has (.item())
-            pcm = state.audio.float().contiguous()
-            enc = out[:, c * A:(c + 1) * A]
-            tmp = torch.empty((self.n, A), dtype=torch.uint8, device=dev)
-            _lib.check(_lib.lib().ifh_g711_encode_f32_u8(_lib.ptr(pcm), _lib.ptr(tmp), pcm.numel(), _lib.stream_ptr(dev)),
-                       'ifh_g711_encode_f32_u8')
-            enc.copy_(tmp)
+            par = st.ncalls & 1
+            if ren_done[par] is not None:
+                main.wait_event(ren_done[par])          # the renderer of call c-2 has released this parity's buffers
+            pp.decode_chunk(state)
+            dec_done = torch.cuda.Event()
+            dec_done.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(dec_done)
+                bf = pp.render(st, par, use_graphs=pp.model.use_graphs)
+                pcm = bf.float()
+                if pp.resampler is not None:
+                    pcm = pp.resampler(pcm)
+                tmp = torch.empty((self.n, A), dtype=torch.uint8, device=dev)
+                _lib.check(_lib.lib().ifh_g711_encode_f32_u8(_lib.ptr(pcm), _lib.ptr(tmp), pcm.numel(), _lib.stream_ptr(dev)),
+                           'ifh_g711_encode_f32_u8')
+                out[:, c * A:(c + 1) * A].copy_(tmp)
+                ev = torch.cuda.Event()
+                ev.record(side)
+                ren_done[par] = ev
+            idx = st.idx
+            ends = st.ends_at.cpu().tolist()                     # the per-call sync the reference also has (.item())
             row = []
             for i in range(self.n):
-                s = max(0, A - (idx - 1) * stepsize)
-                e = min(A, A - ((idx - ends[i]) * stepsize if ends[i] >= 0 else 0))
-                row.append((s, max(s, e)))
-                valid[i] += max(0, e - s)
+                s_ = max(0, A - (idx - 1) * stepsize)
+                e_ = min(A, A - ((idx - ends[i]) * stepsize if ends[i] >= 0 else 0))
+                row.append((s_, max(s_, e_)))
+                valid[i] += max(0, e_ - s_)
             spans.append(row)
             if all(e >= 0 and e <= idx - 1 for e in ends):
                 break
+        for ev in ren_done:
+            if ev is not None:
+                main.wait_event(ev)
         return out, valid, spans
 
     def step(self, frames: torch.Tensor):

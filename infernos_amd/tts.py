@@ -130,23 +130,56 @@ class HelloSippyRTPipe:
         self.output_sr = output_sr
         self.mask_source = mask_source if mask_source is not None else DeviceMaskSource(dev)
 
+    def _render(self, st, par):
+        """postnet -> carry + 4 overlapped chunks -> HiFi-GAN -> AmendmentNetwork1 for the call with
+        parity `par`; writes st.render_out[par] (bf16 [B,8192]).  Pure kernel launches over buffers
+        that persist with the state, so the whole pass is captured into one hipGraph per parity."""
+        dev, B = self.device, st.B
+        post = postnet(self.model, st, par)
+        _lib.check(_lib.lib().ifh_tts_chunks_bf16(ops._addr(st.pre_frames), ops._addr(post), ops._addr(self.vocoder.mean),
+                                                  ops._addr(self.vocoder.scale), ops._addr(st.voc_in), ops._addr(st.amd_mel), B,
+                                                  _lib.stream_ptr(dev)), 'ifh_tts_chunks_bf16')
+        audio = self.vocoder(st.voc_in)
+        self.chunker(st.amd_mel, audio, st.render_out[par], B)
+
+    def render(self, st, par, use_graphs=True):
+        dev = self.device
+        if not hasattr(st, 'voc_in'):
+            st.voc_in = torch.empty((4 * st.B, 12, 80), dtype=torch.bfloat16, device=dev)
+            st.amd_mel = torch.empty((4 * st.B, 12, 80), dtype=torch.bfloat16, device=dev)
+            st.render_out = [torch.empty((st.B, 8192), dtype=torch.bfloat16, device=dev) for _ in range(2)]
+            st.render_graphs, st.render_eager = {}, 0
+        if not use_graphs or st.render_eager < 2:          # first passes eager: loads kernels, sizes the vocoder buffers
+            self._render(st, par)
+            st.render_eager += 1
+        else:
+            g = st.render_graphs.get(par)
+            if g is None:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._render(st, par)
+                st.render_graphs[par] = g
+            g.replay()
+        return st.render_out[par]
+
+    def decode_chunk(self, state: HelloSippyPipeStateBatched) -> int:
+        """The 16 decoder steps of one infer() call (HelloSippyRTPipe.py:195-229); returns the frame-buffer
+        parity the renderer must be given.  Asynchronous on the current stream."""
+        st = state.dev
+        par = st.ncalls & 1
+        masks = self.mask_source(self.chunk_size * 4 // 2).to(self.device).contiguous()
+        decoder_steps(self.model, st, masks, nsteps=self.chunk_size * 4 // 2, threshold=self.threshold)
+        st.ncalls += 1
+        return par
+
     def infer(self, state: HelloSippyPipeStateBatched) -> None:
         st = state.dev
         dev = self.device
         with self.cuda_lock, torch.cuda.device(dev):
-            masks = self.mask_source(self.chunk_size * 4 // 2).to(dev).contiguous()
-            decoder_steps(self.model, st, masks, nsteps=self.chunk_size * 4 // 2, threshold=self.threshold)
-            post = postnet(self.model, st)
-            B = st.B
-            voc_in = torch.empty((4 * B, 12, 80), dtype=torch.bfloat16, device=dev)
-            amd_mel = torch.empty((4 * B, 12, 80), dtype=torch.bfloat16, device=dev)
-            _lib.check(_lib.lib().ifh_tts_chunks_bf16(ops._addr(st.pre_frames), ops._addr(post), ops._addr(self.vocoder.mean),
-                                                      ops._addr(self.vocoder.scale), ops._addr(voc_in), ops._addr(amd_mel), B,
-                                                      _lib.stream_ptr(dev)), 'ifh_tts_chunks_bf16')
-            audio = self.vocoder(voc_in)
-            out = torch.empty((B, 8192), dtype=torch.bfloat16, device=dev)
-            self.chunker(amd_mel, audio, out, B)
-            state.stage = dict(post=post, voc_in=voc_in, vocoder=audio)
+            par = self.decode_chunk(state)
+            out = self.render(st, par, use_graphs=self.model.use_graphs)
+            state.stage = dict(post=st.post[par], voc_in=st.voc_in)
             if self.resampler is not None:
                 out = self.resampler(out.float()).to(torch.bfloat16)
             st.audio = state.audio = out

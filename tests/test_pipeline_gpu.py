@@ -17,7 +17,9 @@ def test_pipeline_cycle_small(built_lib):
     from infernos_amd.weights import synth_state_dict
     dev = _lib.require_device('cuda:0')
     N = 3
-    pipe = SpeechPipeline(N, dev, n_infer=2, n_new_tokens=6)
+    pipe = SpeechPipeline(N, dev, n_infer=4, n_new_tokens=6)
+    fixed = torch.randint(0, 2, (16, 2, 256), dtype=torch.uint8, device=dev)
+    pipe.tts.mask_source = lambda n: fixed
     x = np.stack([synth_utterance(1000 + i, 10.0) for i in range(N)])
     ulaw = odsp.g711_encode(x)
     frames = torch.from_numpy(np.ascontiguousarray(ulaw.reshape(N, 500, 160).transpose(1, 0, 2))).to(dev)
@@ -59,7 +61,11 @@ def test_pipeline_cycle_small(built_lib):
         if margin > 0.05:
             assert int(toks[i, 0]) == int(o_toks[0, 0]), (i, toks[i].tolist(), o_toks.tolist())
     ul, valid, sp = pipe.synthesize()
-    assert ul.shape == (N, 2 * 4096) and ul.dtype == torch.uint8
-    assert valid.tolist() == [2 * 4096 - 256] * N          # the first call drops its first 256 samples @8 kHz
+    assert ul.shape == (N, 4 * 4096) and ul.dtype == torch.uint8
+    assert valid.tolist() == [4 * 4096 - 256] * N          # the first call drops its first 256 samples @8 kHz
+    # second and third utterances replay the captured hipGraphs (decoder steps + render): same bytes
+    ul2, _, _ = pipe.synthesize()
+    ul3, _, _ = pipe.synthesize()
+    assert torch.equal(ul2, ul) and torch.equal(ul3, ul)
     audio = odsp.g711_decode(ul.cpu().numpy())
     assert np.isfinite(audio).all() and 1e-4 < np.abs(audio).mean() < 0.5
