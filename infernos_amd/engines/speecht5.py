@@ -249,7 +249,7 @@ def decoder_steps(model: 'SpeechT5', st: TTSBatchState, masks: torch.Tensor, nst
             if g is None:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):          # records the launches; nothing executes until replay
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):          # records the launches; nothing executes until replay
                     _decoder_step(model, st, s, threshold, par)
                 st.graphs[(s, threshold, par)] = g
             g.replay()

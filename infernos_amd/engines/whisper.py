@@ -160,7 +160,7 @@ class Whisper:
         if g is None:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 self.decoder_step(bufs, Bn, argmax)
             bufs['graphs'][argmax] = g
         g.replay()

@@ -190,6 +190,61 @@ class SpeechPipeline:
                 main.wait_event(ev)
         return out, valid, spans
 
+    def reset_calls(self):
+        """New utterance on every call slot: clear the per-call front-end state."""
+        self.calls.fifo_len.zero_()
+        self.calls.hist.zero_()
+        self.vad.st.zero_()
+        self.vad.st[:, 3] = -1
+        self.vad.blen.zero_()
+
+    def front(self, frames: torch.Tensor):
+        """ingest + STT of one utterance cycle (stages 1-2) on the current stream"""
+        self.reset_calls()
+        chunks = self.ingest(frames)
+        toks, nsp, secs = self.stt(chunks)
+        return dict(tokens=toks, no_speech_prob=nsp, stt_seconds=secs,
+                    chunks=[[(c.ipos, c.audio.numel()) for c in lst] for lst in chunks])
+
+    def run_steps(self, frames_fn, nsteps: int, pipelined: bool = True, on_cycle=None):
+        """nsteps utterance cycles.  Pipelined: a front-end thread (own HIP stream) runs ingest+STT of cycle
+        k+1 while this thread runs the TTS of cycle k -- in steady-state serving the stages always work on
+        different utterances at once; every cycle still does all of its work inside the call.
+        frames_fn(k) -> u8 [T,N,160] device tensor for cycle k (called on the front-end thread/stream);
+        on_cycle(result) runs on the calling thread after each cycle's TTS."""
+        if not pipelined or nsteps < 2:
+            out = None
+            for k in range(nsteps):
+                out = self.front(frames_fn(k))
+                out.update(zip(('ulaw', 'tts_samples', 'spans'), self.synthesize()))
+                if on_cycle is not None:
+                    on_cycle(out)
+            return out
+        from concurrent.futures import ThreadPoolExecutor
+        dev = self.device
+        if not hasattr(self, '_front_stream'):
+            self._front_stream = torch.cuda.Stream(device=dev)
+            self._pool = ThreadPoolExecutor(max_workers=1)
+
+        def job(k):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(self._front_stream):
+                r = self.front(frames_fn(k))
+                ev = torch.cuda.Event()
+                ev.record(self._front_stream)
+            return r, ev
+        fut = self._pool.submit(job, 0)
+        out = None
+        for k in range(nsteps):
+            out, ev = fut.result()
+            if k + 1 < nsteps:
+                fut = self._pool.submit(job, k + 1)
+            torch.cuda.current_stream(dev).wait_event(ev)        # T2T stub consumes the STT tokens
+            out.update(zip(('ulaw', 'tts_samples', 'spans'), self.synthesize()))
+            if on_cycle is not None:
+                on_cycle(out)                                      # e.g. egress gather of this cycle's output rows
+        return out
+
     def step(self, frames: torch.Tensor):
         chunks = self.ingest(frames)
         toks, nsp, secs = self.stt(chunks)

@@ -157,7 +157,7 @@ class HelloSippyRTPipe:
             if g is None:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode='thread_local'):
                     self._render(st, par)
                 st.render_graphs[par] = g
             g.replay()
