@@ -115,6 +115,8 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         dist.barrier()
+        # ingress (scatter, front-end thread) and egress (gather, main thread) get their own communicators
+        g_in, g_out = dist.new_group(), dist.new_group()
     from infernos_amd import _lib
     from infernos_amd.pipeline import SpeechPipeline
     from infernos_amd.shard import gather_rows, scatter_frames, shard_bounds
@@ -138,10 +140,10 @@ def main():
 
     def frames_for(k):
         # with N>1 the ingress rank scatters this cycle's frame block over RCCL (inside the timed region)
-        return scatter_frames(frames_all, n_total, TICKS, dev) if world > 1 else frames_all
+        return scatter_frames(frames_all, n_total, TICKS, dev, group=g_in) if world > 1 else frames_all
 
     def run(nsteps):
-        egress = (lambda r: gather_rows(r['ulaw'], n_total)) if world > 1 else None
+        egress = (lambda r: gather_rows(r['ulaw'], n_total, group=g_out)) if world > 1 else None
         return pipe.run_steps(frames_for, nsteps, pipelined=not args.no_pipeline, on_cycle=egress)
 
     # priming (untimed, not part of the W warm-up steps): two sequential cycles load every kernel and
@@ -165,9 +167,9 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = n_total * UTT_SECONDS / (dt / args.steps)
 
-    if args.breakdown and rank == 0:
+    if args.breakdown and rank == 0 and world == 1:
         reset_state()
-        fr = frames_all if world == 1 else scatter_frames(frames_all, n_total, TICKS, dev)
+        fr = frames_for(0)
         torch.cuda.synchronize(); a = time.perf_counter()
         ch = pipe.ingest(fr); torch.cuda.synchronize(); b = time.perf_counter()
         pipe.stt(ch); torch.cuda.synchronize(); c = time.perf_counter()

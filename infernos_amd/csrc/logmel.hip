@@ -97,22 +97,50 @@ __global__ __launch_bounds__(448) void k_logmel_dft(const float *__restrict__ au
     const float *tc = tab + 32 * w + i;
     const float *ts = tab + 224 + 32 * w + i;
     const int fb = 161 * i;  // pad_idx(f*160) for f = i (+ 161*32*q per frame tile)
-#pragma unroll 2
-    for (int step = 0; step < kTabRows / 2; step++) {
-        const int n = 2 * step + kh;
-        const float ac = tc[n * kTabCols];
-        const float as = ts[n * kTabCols];
-        const int n2 = kNfft - n;
-        const int o1 = n + (n >= 160) + (n >= 320);
-        const int o2 = n2 + (n2 >= 160) + (n2 >= 320);
+    // The table operands come from L2 (362 KB table, shared by every block).  With one block per CU
+    // nothing else hides that latency, so the loop is software-pipelined by hand: the operands of the
+    // next PF steps are in flight (registers) while the current PF steps feed the matrix pipe.
+    constexpr int PF = 8;
+    constexpr int NSTEP = kTabRows / 2;          // 101
+    float pc[PF], ps[PF];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int base = fb + 161 * 32 * q;
-            const float xa = lds[base + o1];
-            const float xb = lds[base + o2];
-            const float e = xa + xb, o = xa - xb;
-            accc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac, e, accc[q], 0, 0, 0);
-            accs[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, o, accs[q], 0, 0, 0);
+    for (int u = 0; u < PF; u++) {
+        const int n = 2 * u + kh;
+        pc[u] = tc[n * kTabCols];
+        ps[u] = ts[n * kTabCols];
+    }
+    for (int s0 = 0; s0 < NSTEP; s0 += PF) {
+        float cc[PF], cs[PF];
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            cc[u] = pc[u];
+            cs[u] = ps[u];
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++) {          // prefetch the following group (clamped: row 201 is all zeros)
+            int n = 2 * (s0 + PF + u) + kh;
+            n = n < kTabRows ? n : kTabRows - 1;
+            pc[u] = tc[n * kTabCols];
+            ps[u] = ts[n * kTabCols];
+        }
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int step = s0 + u;
+            if (step < NSTEP) {
+                const int n = 2 * step + kh;
+                const int n2 = kNfft - n;
+                const int o1 = n + (n >= 160) + (n >= 320);
+                const int o2 = n2 + (n2 >= 160) + (n2 >= 320);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int base = fb + 161 * 32 * q;
+                    const float xa = lds[base + o1];
+                    const float xb = lds[base + o2];
+                    const float e = xa + xb, o = xa - xb;
+                    accc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(cc[u], e, accc[q], 0, 0, 0);
+                    accs[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(cs[u], o, accs[q], 0, 0, 0);
+                }
+            }
         }
     }
     __syncthreads();  // everyone is done with the audio tile; overlay the power tile

@@ -210,8 +210,8 @@ class SpeechPipeline:
         """nsteps utterance cycles.  Pipelined: a front-end thread (own HIP stream) runs ingest+STT of cycle
         k+1 while this thread runs the TTS of cycle k -- in steady-state serving the stages always work on
         different utterances at once; every cycle still does all of its work inside the call.
-        frames_fn(k) -> u8 [T,N,160] device tensor for cycle k (called on the front-end thread/stream);
-        on_cycle(result) runs on the calling thread after each cycle's TTS."""
+        frames_fn(k) -> u8 [T,N,160] device tensor for cycle k and on_cycle(result) both run on the calling
+        thread (they may be collectives)."""
         if not pipelined or nsteps < 2:
             out = None
             for k in range(nsteps):
@@ -226,20 +226,32 @@ class SpeechPipeline:
             self._front_stream = torch.cuda.Stream(device=dev)
             self._pool = ThreadPoolExecutor(max_workers=1)
 
-        def job(k):
+        main = torch.cuda.current_stream(dev)
+
+        def fetch(k):
+            # frames_fn may be a collective (ingress scatter): always issued from THIS thread, in cycle order,
+            # so every rank enqueues its collectives in the same order; the front-end stream waits on the event
+            fr = frames_fn(k)
+            ev = torch.cuda.Event()
+            ev.record(main)
+            return fr, ev
+
+        def job(fr, fr_ready):
             torch.cuda.set_device(dev)
             with torch.cuda.stream(self._front_stream):
-                r = self.front(frames_fn(k))
+                self._front_stream.wait_event(fr_ready)
+                r = self.front(fr)
                 ev = torch.cuda.Event()
                 ev.record(self._front_stream)
             return r, ev
-        fut = self._pool.submit(job, 0)
+        fut = self._pool.submit(job, *fetch(0))
         out = None
         for k in range(nsteps):
+            nxt = fetch(k + 1) if k + 1 < nsteps else None
             out, ev = fut.result()
-            if k + 1 < nsteps:
-                fut = self._pool.submit(job, k + 1)
-            torch.cuda.current_stream(dev).wait_event(ev)        # T2T stub consumes the STT tokens
+            if nxt is not None:
+                fut = self._pool.submit(job, *nxt)
+            main.wait_event(ev)                                    # T2T stub consumes the STT tokens
             out.update(zip(('ulaw', 'tts_samples', 'spans'), self.synthesize()))
             if on_cycle is not None:
                 on_cycle(out)                                      # e.g. egress gather of this cycle's output rows

@@ -5,7 +5,9 @@ models replicated, no collective on the model path.
 The only exchange step is the ingress/egress of the batch: the ingress rank holds the
 mu-law frame matrix of every call and scatters each rank's rows; ranks return their encoded
 output rows by gather.  Messages are small (160 B per call per tick), so whole utterance
-blocks are moved in one collective each way rather than one per tick.
+blocks are moved in one collective each way rather than one per tick.  Ingress and egress may be issued from different host
+threads (the serving loop pipelines its stages): give each its own process group (`group=`) so that
+the per-communicator issue order is the same on every rank.
 """
 from typing import List, Optional
 
@@ -24,7 +26,7 @@ def shard_bounds(n_total: int, world: int) -> List[range]:
     return out
 
 
-def scatter_frames(frames_all: Optional[torch.Tensor], n_total: int, t: int, device, src: int = 0) -> torch.Tensor:
+def scatter_frames(frames_all: Optional[torch.Tensor], n_total: int, t: int, device, src: int = 0, group=None) -> torch.Tensor:
     """frames_all u8 [T, n_total, 160] on rank `src` (None elsewhere) -> this rank's [T, n_local, 160]."""
     rank, world = dist.get_rank(), dist.get_world_size()
     bounds = shard_bounds(n_total, world)
@@ -36,7 +38,7 @@ def scatter_frames(frames_all: Optional[torch.Tensor], n_total: int, t: int, dev
         parts = None
         if rank == src:
             parts = [frames_all[:, b.start:b.stop].contiguous() for b in bounds]
-        dist.scatter(mine, parts, src=src)
+        dist.scatter(mine, parts, src=src, group=group)
     else:                                   # ragged: point-to-point
         if rank == src:
             reqs = []
@@ -45,15 +47,15 @@ def scatter_frames(frames_all: Optional[torch.Tensor], n_total: int, t: int, dev
                 if k == src:
                     mine.copy_(part)
                 else:
-                    reqs.append(dist.isend(part, dst=k))
+                    reqs.append(dist.isend(part, dst=k, group=group))
             for r in reqs:
                 r.wait()
         else:
-            dist.recv(mine, src=src)
+            dist.recv(mine, src=src, group=group)
     return mine
 
 
-def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[torch.Tensor]:
+def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0, group=None) -> Optional[torch.Tensor]:
     """local [n_local, W] -> [n_total, W] on rank dst (None elsewhere)."""
     rank, world = dist.get_rank(), dist.get_world_size()
     if world == 1:
@@ -62,7 +64,7 @@ def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[tor
     W = local.size(1)
     if max(len(b) for b in bounds) == min(len(b) for b in bounds):
         outs = [torch.empty((len(b), W), dtype=local.dtype, device=local.device) for b in bounds] if rank == dst else None
-        dist.gather(local.contiguous(), outs, dst=dst)
+        dist.gather(local.contiguous(), outs, dst=dst, group=group)
         return torch.cat(outs) if rank == dst else None
     if rank == dst:
         full = torch.empty((n_total, W), dtype=local.dtype, device=local.device)
@@ -70,7 +72,7 @@ def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0) -> Optional[tor
             if k == dst:
                 full[b.start:b.stop] = local
             else:
-                dist.recv(full[b.start:b.stop], src=k)
+                dist.recv(full[b.start:b.stop], src=k, group=group)
         return full
-    dist.send(local.contiguous(), dst=dst)
+    dist.send(local.contiguous(), dst=dst, group=group)
     return None

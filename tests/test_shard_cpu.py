@@ -23,11 +23,12 @@ def _worker(rank, world, port, n_total, q):
     T = 5
     g = torch.Generator().manual_seed(0)
     full = torch.randint(0, 256, (T, n_total, 160), dtype=torch.uint8, generator=g)
-    mine = scatter_frames(full if rank == 0 else None, n_total, T, 'cpu')
+    g_in, g_out = dist.new_group(), dist.new_group()
+    mine = scatter_frames(full if rank == 0 else None, n_total, T, 'cpu', group=g_in)
     b = shard_bounds(n_total, world)[rank]
     ok = torch.equal(mine, full[:, b.start:b.stop])
     local = mine.sum(dim=0).to(torch.int32)                 # stand-in for the encoded output rows
-    out = gather_rows(local, n_total)
+    out = gather_rows(local, n_total, group=g_out)
     if rank == 0:
         ok = ok and torch.equal(out, full.sum(dim=0).to(torch.int32))
     q.put((rank, bool(ok)))
