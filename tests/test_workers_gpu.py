@@ -1,0 +1,123 @@
+"""GPU: the drop-in worker threads (InfernSTTWorker / InfernTTSWorker) driven through the session
+classes exactly as the reference's actors drive them."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import dsp as odsp, nn as onn  # noqa: E402
+
+
+class StubTokenizer:
+    """Whisper tokenizer stand-in (the BPE files are not available offline)."""
+    eos_token_id = 50257
+    ids = {'<|startoftranscript|>': 50258, '<|en|>': 50259, '<|transcribe|>': 50359, '<|translate|>': 50358,
+           '<|notimestamps|>': 50363, '<|nospeech|>': 50362}
+
+    def convert_tokens_to_ids(self, t):
+        return self.ids[t] if isinstance(t, str) else [self.ids[x] for x in t]
+
+    def decode(self, ids, skip_special_tokens=True):
+        return ' ' + ' '.join(str(i) for i in ids)
+
+
+class IdsProcessor:
+    def __call__(self, text, return_tensors='pt'):
+        return {'input_ids': torch.tensor([[int(t) for t in text.split()]], dtype=torch.long)}
+
+
+def test_stt_worker_through_sessions(built_lib):
+    from infernos_amd import _lib
+    from infernos_amd.audio import VadAudioChunk
+    from infernos_amd.stt import InfernSTTWorker, STTRequest, STTResult, STTSentinel, STTSession
+    from infernos_amd.synth import synth_utterance
+    from infernos_amd.weights import synth_state_dict
+    dev = _lib.require_device('cuda:0')
+    sd = synth_state_dict('whisper_tiny', 0)
+    w = InfernSTTWorker(dev, weights=sd, tokenizer=StubTokenizer(), fixed_new_tokens=6)
+    w.start()
+    try:
+        results, done = {}, threading.Event()
+        sessions = [STTSession(w, keep_context=(i == 0)) for i in range(3)]
+        x = [synth_utterance(1000 + i, 4.0) for i in range(3)]
+
+        def cb(i):
+            def f(result):
+                results[i] = result
+                if len(results) == 4:
+                    done.set()
+            return f
+        for i, s in enumerate(sessions):
+            req = STTRequest(VadAudioChunk(torch.from_numpy(x[i][8000:24000]).to(dev), 8000, 8000), cb(i), 'en')
+            req.mode = 'translate' if i == 1 else 'transcribe'
+            s.soundin(req)
+        sessions[2].soundin(STTSentinel('flush', cb(3)))          # echoed after session 2's request completes
+        assert done.wait(120)
+        for i in range(3):
+            r = results[i]
+            assert isinstance(r, STTResult) and r.duration == 2 and r.inf_time > 0
+            toks = [int(t) for t in r.text.split()]
+            assert len(toks) == 6 and not r.text.startswith(' ')
+            mel = torch.from_numpy(odsp.logmel(odsp.resample(x[i][8000:24000], 8000, 16000)))[None]
+            prompt = torch.tensor([[50258, 50259, 50358 if i == 1 else 50359, 50363]])
+            with torch.no_grad():
+                o_toks, o_first, o_l0, _ = onn.whisper_greedy(sd, mel, prompt, 6, 6)
+            top2 = o_first.topk(2).values[0]
+            if float(top2[0] - top2[1]) > 0.05:
+                assert toks[0] == int(o_toks[0, 0])
+            nsp = float(torch.softmax(o_l0, -1)[0, 50362])
+            assert abs(r.no_speech_prob - nsp) <= 0.5 * nsp + 1e-12
+        assert isinstance(results[3], STTSentinel) and results[3].signal == 'flush'
+        assert sessions[0].context == []                           # (c + t)[:-224] of a short output is empty
+        # every row above max_ns_prob -> empty text, nothing generated (InfernSTTWorker.py:91-92)
+        got = []
+        req = STTRequest(VadAudioChunk(torch.zeros(8000, device=dev), 8000, 0), lambda result: got.append(result), 'en')
+        req.max_ns_prob = -1.0
+        ev = threading.Event()
+        req.text_cb = lambda result: (got.append(result), ev.set())
+        sessions[1].soundin(req)
+        assert ev.wait(60) and got[0].text == ''
+    finally:
+        w.stop()
+
+
+def test_tts_worker_through_sessions(built_lib):
+    from infernos_amd import _lib
+    from infernos_amd.audio import AudioChunk
+    from infernos_amd.muxer import ASMarkerNewSent
+    from infernos_amd.tts import InfernTTSWorker, TTSRequest, TTSSession
+    from infernos_amd.weights import synth_state_dict
+    dev = _lib.require_device('cuda:0')
+    W = {'speecht5_tts': synth_state_dict('speecht5_tts', 0), 'hifigan': synth_state_dict('hifigan', 0),
+         'amendment': synth_state_dict('amendment', 0)}
+    g = torch.Generator().manual_seed(1)
+    voices = [torch.randn(1, 512, generator=g) for _ in range(4)]
+    w = InfernTTSWorker('en', 8000, dev, weights=W, processor=IdsProcessor(), speaker_embeddings=voices)
+    assert w.max_batch_size == 8 and w.output_sr == 8000 and w.get_voice(2) is voices[2]
+    w.start()
+    try:
+        out = {0: [], 1: []}
+        fin = threading.Event()
+
+        def so(i):
+            def f(chunk):
+                out[i].append(chunk)
+                if all(o and isinstance(o[-1], ASMarkerNewSent) for o in out.values()):
+                    fin.set()
+            return f
+        sess = [TTSSession(w, None) for _ in range(2)]
+        for i, s in enumerate(sess):
+            s.start(so(i))
+        sess[0].say(TTSRequest('44 45 46 47 48 49 50 51 52', speaker_id=1))      # stops at step 0 with these weights
+        sess[1].say(TTSRequest('5 17 33 8', speaker_id=2))
+        assert fin.wait(180)
+        for i in range(2):
+            chunks = [c for c in out[i] if isinstance(c, AudioChunk)]
+            assert chunks and all(c.samplerate == 8000 and c.audio.dim() == 1 and not c.audio.is_cuda for c in chunks)
+            assert isinstance(out[i][-1], ASMarkerNewSent)
+            assert all(torch.isfinite(c.audio.float()).all() for c in chunks)
+    finally:
+        w.stop()
