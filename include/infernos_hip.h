@@ -187,6 +187,22 @@ typedef struct ifh_conv_desc {
     void *out2;
     int64_t out2_bstride;
     int32_t ldc2, ooff2, dyn_ooff2_mul;
+    /* LayerNorm folded around a decode-step GEMM (rows <= 64, taps == 1), so that the three LayerNorm launches
+     * per transformer layer disappear from the latency-bound decode loop:
+     *   stats_out int64 [rows][2]: += (sum, sum of squares) of every stored output row in 2^16 fixed point,
+     *       by integer atomics (commutative, hence bit-reproducible); the caller zeroes it per step;
+     *       consumers receive the same array as aln_stats / rln_stats;
+     *   aln_stats/aln_c1: the A rows are LayerNorm inputs; w must hold W*diag(gamma), bias must hold
+     *       W*beta + b, aln_c1[n] = sum_k w[n][k]; then out = rstd*(acc - mean*aln_c1[n]) + bias[n];
+     *   rln_stats/rln_gamma/rln_beta: the residual rows are LayerNorm inputs, normalised on the fly.
+     * ln_dim = LayerNorm width, ln_eps its epsilon. */
+    const void *aln_stats;
+    const float *aln_c1;
+    const void *rln_stats;
+    const float *rln_gamma, *rln_beta;
+    void *stats_out;
+    int32_t ln_dim;
+    float ln_eps;
 } ifh_conv_desc;
 int ifh_conv_bf16(const ifh_conv_desc *desc, ifh_stream_t stream);
 
@@ -228,10 +244,10 @@ int ifh_argmax_pick_f32(const float *logits, int64_t ld, int vocab, int nrows, i
 int ifh_add_i32(int32_t *value, int delta, ifh_stream_t stream);
 
 /* ---- TTS streaming glue, HelloSippyRTPipe.infer (HelloSippyRTPipe.py:191-240) ---- */
-/* stop rule (:227-228) on the 2 stop logits per utterance; ends_at int64[n] */
+/* stop rule (:227-228) on the 2 stop logits per utterance (row stride logits_ld floats); ends_at int64[n] */
 int ifh_tts_stop_update(const float *prob_logits, int64_t *ends_at, int n, int idx, int minlen, int maxlen,
                         float threshold, int ends_inc, const int32_t *dyn_idx /* overrides idx if set */,
-                        ifh_stream_t stream);
+                        int logits_ld, ifh_stream_t stream);
 /* carry + 4 overlapped 12-frame chunks (:231-235): pre_frames bf16 [B][4][80] (updated), post bf16
  * [B][32][80] -> voc_in bf16 [4B][12][80] normalised by (x-mean)/scale, amd_mel bf16 [4B][12][80] =
  * channels-last form of the chunk re-viewed as [80][12] (HelloSippyRT.py:224) */

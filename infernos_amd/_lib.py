@@ -50,7 +50,9 @@ class ConvDesc(ctypes.Structure):
                 ('out_f32', ctypes.c_int32), ('out_bstride', _i64), ('ldc', ctypes.c_int32), ('ostride', ctypes.c_int32),
                 ('ooff', ctypes.c_int32), ('dyn_pos', _vp), ('dyn_ooff_mul', ctypes.c_int32), ('dyn_resid_mul', _i64),
                 ('n_split', ctypes.c_int32), ('out2', _vp), ('out2_bstride', _i64), ('ldc2', ctypes.c_int32),
-                ('ooff2', ctypes.c_int32), ('dyn_ooff2_mul', ctypes.c_int32)]
+                ('ooff2', ctypes.c_int32), ('dyn_ooff2_mul', ctypes.c_int32),
+                ('aln_stats', _vp), ('aln_c1', _vp), ('rln_stats', _vp), ('rln_gamma', _vp), ('rln_beta', _vp),
+                ('stats_out', _vp), ('ln_dim', ctypes.c_int32), ('ln_eps', _f)]
 
 
 class AttnDesc(ctypes.Structure):
@@ -71,7 +73,7 @@ SIGNATURES.update({
     'ifh_embed_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'ifh_add_i32': (_i, [_vp, _i, _vp]),
     'ifh_argmax_pick_f32': (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
-    'ifh_tts_stop_update': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp]),
+    'ifh_tts_stop_update': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     'ifh_tts_chunks_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'ifh_hifigan_post_bf16': (_i, [_vp, _vp, _f, _vp, _i, _i, _f, _vp]),
     'ifh_amend_final_bf16': (_i, [_vp, _vp, _vp, _i, _vp]),

@@ -206,46 +206,56 @@ __global__ __launch_bounds__(NW * 64) void k_attn_decode(const uint16_t *__restr
     float m = -1e30f, l = 0.0f, o[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) o[i] = 0.0f;
-    // software-pipelined: the next key's K/V rows are in flight while the current one is consumed
-    int key = wid * 8 + g;
-    bool have = key < klen;
-    uint4 kk = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-    if (have) {
-        kk = *reinterpret_cast<const uint4 *>(kb + (int64_t)key * kv_ts);
-        vv = *reinterpret_cast<const uint4 *>(vb + (int64_t)key * kv_ts);
-    }
-    while (have) {
-        const int nkey = key + 8 * NW;
-        const bool nhave = nkey < klen;
-        uint4 nk = make_uint4(0, 0, 0, 0), nv = make_uint4(0, 0, 0, 0);
-        if (nhave) {
-            nk = *reinterpret_cast<const uint4 *>(kb + (int64_t)nkey * kv_ts);
-            nv = *reinterpret_cast<const uint4 *>(vb + (int64_t)nkey * kv_ts);
-        }
-        const uint32_t *ku = reinterpret_cast<const uint32_t *>(&kk);
-        float s = 0.0f;
+    // KU keys per key-group per iteration: 2*KU independent 16-byte loads in flight per lane (the loop is
+    // pure latency: few hundred keys at most), scores reduced over the 8 dim-lanes, one online-softmax
+    // update per iteration.
+    constexpr int KU = 4;
+    for (int key0 = wid * 8 + g; key0 < klen; key0 += 8 * NW * KU) {
+        uint4 kk[KU], vv[KU];
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            s = __fmaf_rn(qv[2 * e], __uint_as_float(ku[e] << 16), s);
-            s = __fmaf_rn(qv[2 * e + 1], __uint_as_float(ku[e] & 0xffff0000u), s);
+        for (int u = 0; u < KU; u++) {
+            const int key = key0 + u * 8 * NW;
+            kk[u] = make_uint4(0, 0, 0, 0);
+            vv[u] = make_uint4(0, 0, 0, 0);
+            if (key < klen) {
+                kk[u] = *reinterpret_cast<const uint4 *>(kb + (int64_t)key * kv_ts);
+                vv[u] = *reinterpret_cast<const uint4 *>(vb + (int64_t)key * kv_ts);
+            }
         }
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        s += __shfl_xor(s, 4, 64);
-        const float mn = fmaxf(m, s);
-        const float a = __expf(m - mn), pr = __expf(s - mn);
-        l = l * a + pr;
-        const uint32_t *vu = reinterpret_cast<const uint32_t *>(&vv);
+        float sc[KU];
+        float mn = m;
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            o[2 * e] = o[2 * e] * a + pr * __uint_as_float(vu[e] << 16);
-            o[2 * e + 1] = o[2 * e + 1] * a + pr * __uint_as_float(vu[e] & 0xffff0000u);
+        for (int u = 0; u < KU; u++) {
+            const uint32_t *ku = reinterpret_cast<const uint32_t *>(&kk[u]);
+            float s = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                s = __fmaf_rn(qv[2 * e], __uint_as_float(ku[e] << 16), s);
+                s = __fmaf_rn(qv[2 * e + 1], __uint_as_float(ku[e] & 0xffff0000u), s);
+            }
+            s += __shfl_xor(s, 1, 64);
+            s += __shfl_xor(s, 2, 64);
+            s += __shfl_xor(s, 4, 64);
+            s = (key0 + u * 8 * NW < klen) ? s : -1e30f;
+            sc[u] = s;
+            mn = fmaxf(mn, s);
+        }
+        const float a = __expf(m - mn);
+        l *= a;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[i] *= a;
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const float pr = (key0 + u * 8 * NW < klen) ? __expf(sc[u] - mn) : 0.0f;
+            l += pr;
+            const uint32_t *vu = reinterpret_cast<const uint32_t *>(&vv[u]);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                o[2 * e] = __fmaf_rn(pr, __uint_as_float(vu[e] << 16), o[2 * e]);
+                o[2 * e + 1] = __fmaf_rn(pr, __uint_as_float(vu[e] & 0xffff0000u), o[2 * e + 1]);
+            }
         }
         m = mn;
-        kk = nk;
-        vv = nv;
-        key = nkey;
-        have = nhave;
     }
     // merge the 8 key-groups of the wave
 #pragma unroll

@@ -41,6 +41,14 @@ struct IgemmParams {
     const int32_t *dyn;       // optional device scalar (e.g. decoder position)
     int dyn_ooff_mul;         // ooff += dyn[0] * dyn_ooff_mul
     int64_t dyn_resid_mul;    // resid += dyn[0] * dyn_resid_mul (elements)
+    // LayerNorm folded around a skinny GEMM (decode steps; see ifh_conv_desc):
+    const void *aln_stats;    // int64 [M][2] fixed-point (2^16) (sum, sumsq) of the A rows: out = rstd*(acc - mean*aln_c1[n]) (+bias ...)
+    const float *aln_c1;      // [N] row sums of the gamma-folded weights
+    const void *rln_stats;    // int64 [M][2] stats of the residual rows: resid -> (r - mean)*rstd*rln_gamma[n] + rln_beta[n]
+    const float *rln_gamma, *rln_beta;
+    void *stats_out;          // int64 [M][2] += fixed-point (sum, sumsq) of the stored output rows (caller zeroes)
+    int ln_dim;               // LayerNorm width
+    float ln_eps;
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_TANH = 3, ACT_LRELU = 4, ACT_SIGMOID = 5 };

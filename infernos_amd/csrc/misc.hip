@@ -95,13 +95,13 @@ __global__ __launch_bounds__(256) void k_argmax_pick(const float *__restrict__ l
 }
 
 // HelloSippyRTPipe.py:227-228: ends_at = where(ends_at<0 & minlen<=idx & (any(sigmoid>=thr) | maxlen<=idx), idx+2, ends_at)
-__global__ void k_tts_stop(const float *__restrict__ logits /* [B][2] */, int64_t *__restrict__ ends_at, int n, int idx,
-                           int minlen, int maxlen, float thr, int ends_inc, const int32_t *__restrict__ dyn)
+__global__ void k_tts_stop(const float *__restrict__ logits /* [B][ld], 2 used */, int64_t *__restrict__ ends_at, int n,
+                           int idx, int minlen, int maxlen, float thr, int ends_inc, const int32_t *__restrict__ dyn, int ld)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n) return;
     if (dyn) idx = dyn[0];
-    const float p0 = 1.0f / (1.0f + expf(-logits[2 * b])), p1 = 1.0f / (1.0f + expf(-logits[2 * b + 1]));
+    const float p0 = 1.0f / (1.0f + expf(-logits[ld * b])), p1 = 1.0f / (1.0f + expf(-logits[ld * b + 1]));
     const bool hit = (ends_at[b] < 0) && (minlen <= idx) && ((p0 >= thr) || (p1 >= thr) || (maxlen <= idx));
     if (hit) ends_at[b] = idx + ends_inc;
 }
@@ -244,13 +244,13 @@ extern "C" int ifh_argmax_pick_f32(const float *logits, int64_t ld, int vocab, i
 }
 
 extern "C" int ifh_tts_stop_update(const float *prob_logits, int64_t *ends_at, int n, int idx, int minlen, int maxlen,
-                                   float threshold, int ends_inc, const int32_t *dyn_idx, ifh_stream_t stream)
+                                   float threshold, int ends_inc, const int32_t *dyn_idx, int logits_ld, ifh_stream_t stream)
 {
     IFH_CHECK_ARG(n >= 0);
     if (n == 0) return IFH_OK;
-    IFH_CHECK_ARG(prob_logits && ends_at);
+    IFH_CHECK_ARG(prob_logits && ends_at && logits_ld >= 2);
     hipLaunchKernelGGL(k_tts_stop, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), prob_logits, ends_at, n, idx,
-                       minlen, maxlen, threshold, ends_inc, dyn_idx);
+                       minlen, maxlen, threshold, ends_inc, dyn_idx, logits_ld);
     IFH_LAUNCH_CHECK("tts_stop");
     return IFH_OK;
 }

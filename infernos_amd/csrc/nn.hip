@@ -35,6 +35,15 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
     const int mm = xok ? m : 0;
     const int bb = mm / p.T_out, tt = mm - bb * p.T_out;
     const uint16_t *xrow = p.x + (int64_t)bb * p.x_bstride + (int64_t)tt * p.lda + fg * 8;
+    // LayerNorm folding (ifh_conv_desc.aln_* / rln_*): row statistics are two 64-bit fixed-point sums per row
+    // ([rows][2] int64, scale 2^16) that producers build with integer atomics -- integer addition commutes,
+    // so unlike float atomics the result is bit-reproducible.  One 16-byte load per lane, issued before the
+    // weight stream and consumed in the epilogue.
+    longlong2 st_a = make_longlong2(0, 0), st_r = make_longlong2(0, 0);
+    if (wid == 0 && xok) {
+        if (p.aln_stats) st_a = reinterpret_cast<const longlong2 *>(p.aln_stats)[m];
+        if (p.rln_stats) st_r = reinterpret_cast<const longlong2 *>(p.rln_stats)[m];
+    }
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kt = kt0; kt < kt1; kt += U) {
         uint4 wv[U], xv[U];
@@ -53,13 +62,80 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
                                                           __builtin_bit_cast(bf16x8_t, xv[u]), acc, 0, 0, 0);
     }
     *reinterpret_cast<f32x4 *>(&red[wid][lane][0]) = acc;
+    const float fx = (1.0f / 65536.0f) / (float)p.ln_dim;
+    const float a_mean = (float)st_a.x * fx, r_mean = (float)st_r.x * fx;
+    const float a_rstd = rsqrtf(fmaxf((float)st_a.y * fx - a_mean * a_mean, 0.0f) + p.ln_eps);
+    const float r_rstd = rsqrtf(fmaxf((float)st_r.y * fx - r_mean * r_mean, 0.0f) + p.ln_eps);
     __syncthreads();
     if (wid == 0) {
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w][lane][0]);
         const int n = n0 + 4 * fg;
-        if (xok && n < p.N) {
+        const bool ln_mode = p.aln_stats || p.rln_stats || p.stats_out;
+        if (ln_mode) {
+            // LayerNorm folded around the GEMM (host guarantees the vector epilogue conditions, N % 16 == 0)
+            float v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
+            const bool ok = xok && n < p.N;
+            if (ok) {
+                const EpiRow e = epi_row(p, m, n, p.dyn ? p.dyn[0] : 0);
+                if (p.aln_stats) {
+                    const float mean = a_mean, rstd = a_rstd;
+                    const float4 c1 = *reinterpret_cast<const float4 *>(p.aln_c1 + n);
+                    v0 = rstd * (v0 - mean * c1.x);
+                    v1 = rstd * (v1 - mean * c1.y);
+                    v2 = rstd * (v2 - mean * c1.z);
+                    v3 = rstd * (v3 - mean * c1.w);
+                }
+                if (p.bias) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
+                    v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
+                }
+                if (p.act != ACT_NONE) {
+                    v0 = apply_act(v0, p.act, p.act_slope);
+                    v1 = apply_act(v1, p.act, p.act_slope);
+                    v2 = apply_act(v2, p.act, p.act_slope);
+                    v3 = apply_act(v3, p.act, p.act_slope);
+                }
+                if (p.resid) {
+                    const uint2 rv = *reinterpret_cast<const uint2 *>(p.resid + e.rbase + n);
+                    float r0 = __uint_as_float(rv.x << 16), r1 = __uint_as_float(rv.x & 0xffff0000u);
+                    float r2 = __uint_as_float(rv.y << 16), r3 = __uint_as_float(rv.y & 0xffff0000u);
+                    if (p.rln_stats) {
+                        const float mean = r_mean, rstd = r_rstd;
+                        const float4 g = *reinterpret_cast<const float4 *>(p.rln_gamma + n);
+                        const float4 bt = *reinterpret_cast<const float4 *>(p.rln_beta + n);
+                        r0 = (r0 - mean) * rstd * g.x + bt.x;
+                        r1 = (r1 - mean) * rstd * g.y + bt.y;
+                        r2 = (r2 - mean) * rstd * g.z + bt.z;
+                        r3 = (r3 - mean) * rstd * g.w + bt.w;
+                    }
+                    v0 += r0; v1 += r1; v2 += r2; v3 += r3;
+                }
+                v0 *= p.out_scale; v1 *= p.out_scale; v2 *= p.out_scale; v3 *= p.out_scale;
+                if (p.out_f32) {
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(e.outp) + e.obase + n) = make_float4(v0, v1, v2, v3);
+                } else {
+                    uint2 pk;
+                    pk.x = f32x2_to_bf16x2(v0, v1);
+                    pk.y = f32x2_to_bf16x2(v2, v3);
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(e.outp) + e.obase + n) = pk;
+                    v0 = __uint_as_float(pk.x << 16); v1 = __uint_as_float(pk.x & 0xffff0000u);   // what consumers will read
+                    v2 = __uint_as_float(pk.y << 16); v3 = __uint_as_float(pk.y & 0xffff0000u);
+                }
+            }
+            if (p.stats_out) {
+                float s1 = ok ? (v0 + v1) + (v2 + v3) : 0.0f;
+                float s2 = ok ? (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3) : 0.0f;
+                s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);      // the 4 lanes fg = 0..3 share row m
+                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                if (fg == 0 && xok) {
+                    unsigned long long *so = reinterpret_cast<unsigned long long *>(p.stats_out) + 2 * m;
+                    atomicAdd(so, (unsigned long long)__double2ll_rn((double)s1 * 65536.0));
+                    atomicAdd(so + 1, (unsigned long long)__double2ll_rn((double)s2 * 65536.0));
+                }
+            }
+        } else if (xok && n < p.N) {
             const int dynv = p.dyn ? p.dyn[0] : 0;
             if (p.fast_epi)
                 igemm_store4<true>(p, m, n, s, dynv);
@@ -368,6 +444,20 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         p.vec_ok = p.vec_ok && (d->ldc2 % 4 == 0) && (d->out2_bstride % 4 == 0) && ((((uintptr_t)d->out2) % (4 * esz)) == 0);
     }
     p.fast_epi = p.vec_ok && p.res_vec_ok && (d->n % 4 == 0);
+    p.aln_stats = d->aln_stats;
+    p.aln_c1 = d->aln_c1;
+    p.rln_stats = d->rln_stats;
+    p.rln_gamma = d->rln_gamma;
+    p.rln_beta = d->rln_beta;
+    p.stats_out = d->stats_out;
+    p.ln_dim = d->ln_dim;
+    p.ln_eps = d->ln_eps;
+    if (d->aln_stats || d->rln_stats || d->stats_out) {
+        IFH_CHECK_ARG((int64_t)d->nbatch * d->t_out <= 64 && d->taps == 1 && d->stride == 1 && d->pad == 0 && d->pre_slope == 1.0f);
+        IFH_CHECK_ARG(d->n % 16 == 0 && d->ln_dim > 0 && !d->colmask && !d->accumulate && p.vec_ok && p.res_vec_ok);
+        IFH_CHECK_ARG(!d->aln_stats || d->aln_c1);
+        IFH_CHECK_ARG(!d->rln_stats || (d->rln_gamma && d->rln_beta && d->resid));
+    }
     p.dyn = d->dyn_pos;
     p.dyn_ooff_mul = d->dyn_ooff_mul;
     p.dyn_resid_mul = d->dyn_resid_mul;

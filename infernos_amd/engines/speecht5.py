@@ -10,6 +10,7 @@ Only the last time row of the prenet is computed per step: rows are independent 
 mask row, so this equals the reference's prenet-over-history followed by [:, -1:].
 """
 import math
+import os
 
 import torch
 
@@ -89,6 +90,34 @@ class SpeechT5:
         O = 'speech_decoder_postnet.'
         self.feat = (ops.w_linear(sd[O + 'feat_out.weight'], dev), ops.w_bias(sd[O + 'feat_out.bias'], dev))
         self.prob = (ops.w_linear(sd[O + 'prob_out.weight'], dev), ops.w_bias(sd[O + 'prob_out.bias'], dev))
+        # ---- LayerNorm-folded variants for the decode loop (ifh_conv_desc.aln_*/rln_*): the three LayerNorm
+        # launches per layer disappear; gamma goes into the consumer's weights, mean/rstd are applied in its
+        # epilogue from row statistics the producer's epilogue accumulated.
+        self.fold_ln = os.environ.get('IFH_FOLD_LN', '1') != '0'      # tuning switch
+        lnp = lambda name: (sd[name + '.weight'].float(), sd[name + '.bias'].float())
+        self.dec_fold = []
+        for i in range(self.n_dec_layers):
+            L = Wd + 'layers.%d.' % i
+            S, C = L + 'self_attn.', L + 'encoder_attn.'
+            f = {}
+            if i > 0:
+                g3, b3 = lnp(Wd + 'layers.%d.final_layer_norm' % (i - 1))
+                wq = torch.cat([sd[S + 'q_proj.weight'].float() * QS, sd[S + 'k_proj.weight'].float(), sd[S + 'v_proj.weight'].float()])
+                bq = torch.cat([sd[S + 'q_proj.bias'].float() * QS, sd[S + 'k_proj.bias'].float(), sd[S + 'v_proj.bias'].float()])
+                f['qkv'] = ops.w_linear_ln(wq, bq, g3, b3, dev)
+                f['ln_prev'] = (g3.contiguous().to(dev), b3.contiguous().to(dev))
+            g1, b1 = lnp(L + 'self_attn_layer_norm')
+            g2, b2 = lnp(L + 'encoder_attn_layer_norm')
+            f['cq'] = ops.w_linear_ln(sd[C + 'q_proj.weight'], sd[C + 'q_proj.bias'], g1, b1, dev, scale=QS)
+            f['ln1'] = (g1.contiguous().to(dev), b1.contiguous().to(dev))
+            f['ff1'] = ops.w_linear_ln(sd[L + 'feed_forward.intermediate_dense.weight'],
+                                       sd[L + 'feed_forward.intermediate_dense.bias'], g2, b2, dev)
+            f['ln2'] = (g2.contiguous().to(dev), b2.contiguous().to(dev))
+            self.dec_fold.append(f)
+        gl, bl = lnp(Wd + 'layers.%d.final_layer_norm' % (self.n_dec_layers - 1))
+        self.feat_fold = ops.w_linear_ln(sd[O + 'feat_out.weight'], sd[O + 'feat_out.bias'], gl, bl, dev)
+        self.prob_fold = ops.w_linear_ln(torch.cat([sd[O + 'prob_out.weight'].float(), torch.zeros(14, D)]),
+                                         torch.cat([sd[O + 'prob_out.bias'].float(), torch.zeros(14)]), gl, bl, dev)
         self.postnet = []
         for i in range(5):                  # fold eval-mode BatchNorm into the (bias-free) conv
             b = O + 'layers.%d.batch_norm.' % i
@@ -154,6 +183,9 @@ class TTSBatchState:
         self.h1, self.h2, self.x = e(B, 256), e(B, 256), e(B, D)
         self.q, self.att, self.t1, self.ff = e(B, D), e(B, D), e(B, D), e(B, FF)
         self.plog = e(B, 2, dt=torch.float32)
+        self.plog16 = e(B, 16, dt=torch.float32)            # LN-folded path: stop logits in cols 0..1 of a 16-wide tile
+        self.t2, self.t3, self.x0 = e(B, D), e(B, D), e(B, D)
+        self.stats = torch.zeros((3 * len(model.dec_layers), 64, 2), dtype=torch.int64, device=dev)
         self.pn = [e(B, 32, 256), e(B, 32, 256)]
         self.graphs = {}
         self.eager_calls = 0
@@ -226,7 +258,60 @@ def _decoder_step(model: 'SpeechT5', st: TTSBatchState, s: int, threshold: float
     ops.linear(x, *model.feat, spec, rows=B, k=D, n=160, out_off=(2 * s + 1) * 80, ldc=33 * 80)
     ops.linear(x, *model.prob, st.plog, rows=B, k=D, n=2)
     _lib.check(_lib.lib().ifh_tts_stop_update(ops._addr(st.plog), ops._addr(st.ends_at), B, 0, st.minlen, st.maxlen,
-                                              threshold, 2, ops._addr(st.pos_dev), _lib.stream_ptr(dev)), 'ifh_tts_stop_update')
+                                              threshold, 2, ops._addr(st.pos_dev), 2, _lib.stream_ptr(dev)), 'ifh_tts_stop_update')
+    ops.add_i32(st.pos_dev, 1)
+
+
+def _decoder_step_folded(model: 'SpeechT5', st: TTSBatchState, s: int, threshold: float, par: int):
+    """Same step with every LayerNorm folded around the neighbouring GEMMs (no LayerNorm launches):
+    producers accumulate row statistics in their epilogue, consumers apply mean/rstd in theirs."""
+    dev = model.device
+    B, T = st.B, st.T
+    masks, spec, stats = st.masks, st.spec[par], st.stats
+    SO = 64 * 2                                      # int64 elements per stats slot ([64 rows][2])
+    st.stats.zero_()
+    ops.linear(spec, *model.p0, st.h1, rows=B, k=80, n=256, x_off=2 * s * 80, lda=33 * 80, act=ACT_RELU,
+               colmask=masks, colmask_off=(s * 2) * 256)
+    ops.linear(st.h1, *model.p1, st.h2, rows=B, k=256, n=256, act=ACT_RELU, colmask=masks, colmask_off=(s * 2 + 1) * 256)
+    ops.linear(st.h2, *model.pf, st.cat, rows=B, k=256, n=D, ldc=D + 512, resid=model.pe_dec, resid_ld=0, resid_bstride=0,
+               dyn_pos=st.pos_dev, dyn_resid_mul=D)
+    ops.linear(st.cat, *model.ps, st.x0, rows=B, k=D + 512, n=D, act=ACT_RELU)
+    nl = len(model.dec_layers)
+    for li, (L, F) in enumerate(zip(model.dec_layers, model.dec_fold)):
+        kv = st.self_kv[li]
+        s1, s2, s3, s3p = (3 * li) * SO, (3 * li + 1) * SO, (3 * li + 2) * SO, (3 * li - 1) * SO
+        kvargs = dict(nbatch=B, t_in=1, t_out=1, cin=D, n=3 * D, ldc=D, out_bstride=D, dyn_pos=st.pos_dev, n_split=D,
+                      out2=kv, out2_bstride=st.smax * 2 * D, ldc2=2 * D, dyn_ooff2_mul=1)
+        if li == 0:
+            ops.conv(st.x0, L['wqkv'], L['bqkv'], st.q, **kvargs)
+        else:
+            w, c2, c1 = F['qkv']
+            ops.conv(st.t3, w, c2, st.q, aln=(stats, s3p, c1), ln_dim=D, **kvargs)
+        ops.attn_decode(st.q, kv, kv, st.att, nbatch=B, nheads=H, max_keys=st.smax, q_bs=D, kv_bs=st.smax * 2 * D,
+                        kv_ts=2 * D, o_bs=D, v_off=D, dyn_len=st.pos_dev, dyn_add=1)
+        if li == 0:
+            ops.linear(st.att, L['wo'], L['bo'], st.t1, rows=B, k=D, n=D, resid=st.x0, stats_out=stats, stats_off=s1, ln_dim=D)
+        else:
+            ops.linear(st.att, L['wo'], L['bo'], st.t1, rows=B, k=D, n=D, resid=st.t3, rln=(stats, s3p) + F['ln_prev'],
+                       stats_out=stats, stats_off=s1, ln_dim=D)
+        w, c2, c1 = F['cq']
+        ops.linear(st.t1, w, c2, st.q, rows=B, k=D, n=D, aln=(stats, s1, c1), ln_dim=D)
+        ck = st.cross[li]
+        ops.attn_decode(st.q, ck, ck, st.att, nbatch=B, nheads=H, max_keys=T, q_bs=D, kv_bs=T * 2 * D, kv_ts=2 * D,
+                        o_bs=D, v_off=D, key_len=st.enc_len)
+        ops.linear(st.att, L['cwo'], L['cbo'], st.t2, rows=B, k=D, n=D, resid=st.t1, rln=(stats, s1) + F['ln1'],
+                   stats_out=stats, stats_off=s2, ln_dim=D)
+        w, c2, c1 = F['ff1']
+        ops.linear(st.t2, w, c2, st.ff, rows=B, k=D, n=FF, act=ACT_GELU, aln=(stats, s2, c1), ln_dim=D)
+        ops.linear(st.ff, L['w2'], L['b2'], st.t3, rows=B, k=FF, n=D, resid=st.t2, rln=(stats, s2) + F['ln2'],
+                   stats_out=stats, stats_off=s3, ln_dim=D)
+    sl = (3 * nl - 1) * SO
+    w, c2, c1 = model.feat_fold
+    ops.linear(st.t3, w, c2, spec, rows=B, k=D, n=160, out_off=(2 * s + 1) * 80, ldc=33 * 80, aln=(stats, sl, c1), ln_dim=D)
+    w, c2, c1 = model.prob_fold
+    ops.linear(st.t3, w, c2, st.plog16, rows=B, k=D, n=16, aln=(stats, sl, c1), ln_dim=D)
+    _lib.check(_lib.lib().ifh_tts_stop_update(ops._addr(st.plog16), ops._addr(st.ends_at), B, 0, st.minlen, st.maxlen,
+                                              threshold, 2, ops._addr(st.pos_dev), 16, _lib.stream_ptr(dev)), 'ifh_tts_stop_update')
     ops.add_i32(st.pos_dev, 1)
 
 
@@ -241,17 +326,18 @@ def decoder_steps(model: 'SpeechT5', st: TTSBatchState, masks: torch.Tensor, nst
     st.spec[par][:, 0, :].copy_(st.spec[1 - par][:, 32, :])       # carry the last produced frame
     # the first call on a state shape runs eagerly (loads every kernel); graphs are captured from the second on
     use_graphs = use_graphs and st.eager_calls >= 2
+    step_fn = _decoder_step_folded if (model.fold_ln and st.B <= 64) else _decoder_step
     for s in range(nsteps):
         if not use_graphs:
-            _decoder_step(model, st, s, threshold, par)
+            step_fn(model, st, s, threshold, par)
         else:
-            g = st.graphs.get((s, threshold, par))
+            g = st.graphs.get((s, threshold, par, step_fn is _decoder_step_folded))
             if g is None:
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, capture_error_mode='thread_local'):          # records the launches; nothing executes until replay
-                    _decoder_step(model, st, s, threshold, par)
-                st.graphs[(s, threshold, par)] = g
+                    step_fn(model, st, s, threshold, par)
+                st.graphs[(s, threshold, par, step_fn is _decoder_step_folded)] = g
             g.replay()
         st.idx += 1
     if not use_graphs:

@@ -23,7 +23,9 @@ def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=
          x_off=0, lda=None, x_bstride=None, act=ACT_NONE, act_slope=0.0, pre_slope=1.0, colmask=None, colmask_off=0,
          resid=None, resid_off=0, resid_ld=None, resid_bstride=None, scale=1.0, accumulate=False,
          out_off=0, ldc=None, out_bstride=None, ostride=1, ooff=0, dyn_pos=None, dyn_ooff_mul=0, dyn_resid_mul=0,
-         n_split=0, out2=None, out2_bstride=0, ldc2=0, ooff2=0, dyn_ooff2_mul=0):
+         n_split=0, out2=None, out2_bstride=0, ldc2=0, ooff2=0, dyn_ooff2_mul=0,
+         aln=None, rln=None, stats_out=None, stats_off=0, ln_dim=0, ln_eps=1e-5):
+    # aln = (stats, stats_off, c1); rln = (stats, stats_off, gamma, beta)
     """One implicit-GEMM launch (see ifh_conv_desc).  Strides default to dense [nbatch][t][c]."""
     d = ConvDesc()
     lda = cin if lda is None else lda
@@ -43,6 +45,11 @@ def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=
     d.ldc, d.ostride, d.ooff = ldc, ostride, ooff
     d.dyn_pos, d.dyn_ooff_mul, d.dyn_resid_mul = _addr(dyn_pos), dyn_ooff_mul, dyn_resid_mul
     d.n_split, d.out2, d.out2_bstride, d.ldc2, d.ooff2, d.dyn_ooff2_mul = n_split, _addr(out2), out2_bstride, ldc2, ooff2, dyn_ooff2_mul
+    if aln is not None:
+        d.aln_stats, d.aln_c1 = _addr(aln[0], aln[1]), _addr(aln[2])
+    if rln is not None:
+        d.rln_stats, d.rln_gamma, d.rln_beta = _addr(rln[0], rln[1]), _addr(rln[2]), _addr(rln[3])
+    d.stats_out, d.ln_dim, d.ln_eps = _addr(stats_out, stats_off), ln_dim, ln_eps
     _lib.check(_lib.lib().ifh_conv_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_conv_bf16')
     return out
 
@@ -106,6 +113,19 @@ def add_i32(value, delta):
 
 
 # ---- weight preparation (host side, once per model load) -----------------------------------
+def w_linear_ln(w, b, gamma, beta, device, scale=None):
+    """Fold a preceding LayerNorm(gamma, beta) into a Linear: returns (bf16 W*diag(gamma), f32 W*beta + b,
+    f32 c1[n] = sum_k of the ROUNDED folded weights) for ifh_conv_desc.aln_*."""
+    w = w.float()
+    b = torch.zeros(w.size(0)) if b is None else b.float()
+    if scale is not None:
+        w, b = w * scale, b * scale
+    wf = (w * gamma.float()[None, :]).to(BF16)
+    c2 = w @ beta.float() + b
+    c1 = wf.float().sum(dim=1)
+    return wf.contiguous().to(device), c2.contiguous().to(device), c1.contiguous().to(device)
+
+
 def w_linear(w, device, scale=None):
     w = w.float()
     if scale is not None:
