@@ -248,6 +248,9 @@ int ifh_add_i32(int32_t *value, int delta, ifh_stream_t stream);
 int ifh_tts_stop_update(const float *prob_logits, int64_t *ends_at, int n, int idx, int minlen, int maxlen,
                         float threshold, int ends_inc, const int32_t *dyn_idx /* overrides idx if set */,
                         int logits_ld, ifh_stream_t stream);
+/* the same stop rule with idx = pos[0], followed by pos[0] += 1 (one launch; for graph-replayed decode loops) */
+int ifh_tts_stop_advance(const float *prob_logits, int64_t *ends_at, int n, int minlen, int maxlen, float threshold,
+                         int ends_inc, int32_t *pos, int logits_ld, ifh_stream_t stream);
 /* carry + 4 overlapped 12-frame chunks (:231-235): pre_frames bf16 [B][4][80] (updated), post bf16
  * [B][32][80] -> voc_in bf16 [4B][12][80] normalised by (x-mean)/scale, amd_mel bf16 [4B][12][80] =
  * channels-last form of the chunk re-viewed as [80][12] (HelloSippyRT.py:224) */

@@ -106,6 +106,21 @@ __global__ void k_tts_stop(const float *__restrict__ logits /* [B][ld], 2 used *
     if (hit) ends_at[b] = idx + ends_inc;
 }
 
+// single-block form that also advances the device-held step counter afterwards (one launch fewer per step)
+__global__ __launch_bounds__(256) void k_tts_stop_advance(const float *__restrict__ logits, int64_t *__restrict__ ends_at,
+                                                         int n, int minlen, int maxlen, float thr, int ends_inc,
+                                                         int32_t *__restrict__ pos, int ld)
+{
+    const int idx = pos[0];
+    for (int b = threadIdx.x; b < n; b += blockDim.x) {
+        const float p0 = 1.0f / (1.0f + expf(-logits[ld * b])), p1 = 1.0f / (1.0f + expf(-logits[ld * b + 1]));
+        const bool hit = (ends_at[b] < 0) && (minlen <= idx) && ((p0 >= thr) || (p1 >= thr) || (maxlen <= idx));
+        if (hit) ends_at[b] = idx + ends_inc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) pos[0] = idx + 1;
+}
+
 // HelloSippyRTPipe.py:231-235: S = cat(pre_frames[B,4,80], post[B,32,80]); pre_frames <- S[:, -4:];
 // chunk i = S[:, 8i:8i+12] stacked chunk-major.  Emits
 //   voc_in  [4B][12][80]  = (chunk - mean)/scale            (SpeechT5HifiGan normalize_before)
@@ -252,6 +267,16 @@ extern "C" int ifh_tts_stop_update(const float *prob_logits, int64_t *ends_at, i
     hipLaunchKernelGGL(k_tts_stop, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), prob_logits, ends_at, n, idx,
                        minlen, maxlen, threshold, ends_inc, dyn_idx, logits_ld);
     IFH_LAUNCH_CHECK("tts_stop");
+    return IFH_OK;
+}
+
+extern "C" int ifh_tts_stop_advance(const float *prob_logits, int64_t *ends_at, int n, int minlen, int maxlen,
+                                    float threshold, int ends_inc, int32_t *pos, int logits_ld, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(n >= 0 && prob_logits && ends_at && pos && logits_ld >= 2);
+    hipLaunchKernelGGL(k_tts_stop_advance, dim3(1), dim3(256), 0, as_stream(stream), prob_logits, ends_at, n, minlen, maxlen,
+                       threshold, ends_inc, pos, logits_ld);
+    IFH_LAUNCH_CHECK("tts_stop_advance");
     return IFH_OK;
 }
 

@@ -310,9 +310,8 @@ def _decoder_step_folded(model: 'SpeechT5', st: TTSBatchState, s: int, threshold
     ops.linear(st.t3, w, c2, spec, rows=B, k=D, n=160, out_off=(2 * s + 1) * 80, ldc=33 * 80, aln=(stats, sl, c1), ln_dim=D)
     w, c2, c1 = model.prob_fold
     ops.linear(st.t3, w, c2, st.plog16, rows=B, k=D, n=16, aln=(stats, sl, c1), ln_dim=D)
-    _lib.check(_lib.lib().ifh_tts_stop_update(ops._addr(st.plog16), ops._addr(st.ends_at), B, 0, st.minlen, st.maxlen,
-                                              threshold, 2, ops._addr(st.pos_dev), 16, _lib.stream_ptr(dev)), 'ifh_tts_stop_update')
-    ops.add_i32(st.pos_dev, 1)
+    _lib.check(_lib.lib().ifh_tts_stop_advance(ops._addr(st.plog16), ops._addr(st.ends_at), B, st.minlen, st.maxlen,
+                                               threshold, 2, ops._addr(st.pos_dev), 16, _lib.stream_ptr(dev)), 'ifh_tts_stop_advance')
 
 
 def decoder_steps(model: 'SpeechT5', st: TTSBatchState, masks: torch.Tensor, nsteps=16, threshold=0.5, use_graphs=None):
