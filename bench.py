@@ -219,6 +219,10 @@ def main():
             torch.cuda.synchronize()
             lat.append((time.perf_counter() - a) * 1e3)
         lat = np.array(lat)
+        traffic = None
+        pmc = os.path.join(ROOT, 'profiles', 'r01_vocoder_pmc.json')
+        if os.path.exists(pmc) and n_local == 64:       # PMC counters need their own rocprofv3 run: measured offline
+            traffic = json.load(open(pmc))['hbm_bytes_per_pass']
         out = {
             'metric': 'real-time-factor x concurrent calls (STT+TTS on 20 ms G.711 frames)',
             'value': round(value, 2), 'unit': 'x real-time (call-seconds/s)', 'n_gpus': world, 'steps': args.steps,
@@ -236,7 +240,8 @@ def main():
             'tts_samples_per_call': int(res['tts_samples'].float().mean()),
             'roofline': {'kernel': 'k_igemm (HiFi-GAN vocoder, %d chunks x 12 frames per launch group)' % nchunks,
                          'bound': 'mfma', 'achieved': round(ach_tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': None,
+                         'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
+                         'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r01_vocoder_pmc.json',
                          'seconds_per_vocoder_pass': t_voc},
             'roofline_logmel': {'kernel': 'k_logmel_dft+k_logmel_finish (%d x 30 s windows)' % n_local, 'bound': 'hbm',
                                 'achieved': round(ach_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
