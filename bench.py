@@ -109,11 +109,19 @@ def main():
     import __graft_entry__ as ge
     if rank == 0:
         ge.build()
+    # IFH_DRYRUN_ONE_GPU=1: every rank uses cuda:0 and the collectives run over gloo (host-staged) -- lets the
+    # N>1 code path (sharding, collective order, stage threads) be exercised on a single-GPU box
+    dry = os.environ.get('IFH_DRYRUN_ONE_GPU') == '1'
+    if dry:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        if dry:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
         dist.barrier()
         # ingress (scatter, front-end thread) and egress (gather, main thread) get their own communicators
         g_in, g_out = dist.new_group(), dist.new_group()
@@ -160,7 +168,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt], dtype=torch.float64, device='cpu' if dry else dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

@@ -15,14 +15,13 @@
 
 namespace ifh {
 
-template <int CIN, int WGM, int MT, int NT, bool RESIDENT>
+template <int CIN, int WGM, int MT, int NT, bool RESIDENT, int KC>
 __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
 {
     constexpr int WGN = 4 / WGM;
     constexpr int BM = WGM * MT * 16, BN = WGN * NT * 16;
     constexpr int XS = CIN + 8;   // LDS row stride (elements): 16-byte pad
-    constexpr int KC = 64;        // streamed K chunk
-    constexpr int WV = RESIDENT ? 0 : (BN * KC / 8 / 256);   // prefetch vectors per thread (<= 8)
+    constexpr int WV = RESIDENT ? 0 : (BN * KC / 8 / 256);   // prefetch vectors per thread (<= 16)
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -54,8 +53,8 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
     }
     // Prefetch registers are NAMED scalars driven by macros: as an array (or captured in a lambda)
     // hipcc kept them in scratch memory.
-    uint4 w0, w1, w2, w3, w4, w5, w6, w7;
-    w0 = w1 = w2 = w3 = w4 = w5 = w6 = w7 = make_uint4(0, 0, 0, 0);
+    uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15;
+    w0 = w1 = w2 = w3 = w4 = w5 = w6 = w7 = w8 = w9 = w10 = w11 = w12 = w13 = w14 = w15 = make_uint4(0, 0, 0, 0);
 #define IFH_W1(I, REG, K0)                                                                       \
     if (I < WV) {                                                                                \
         const int v = tid + 256 * I;                                                             \
@@ -65,6 +64,8 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
     if (!RESIDENT) {                                                                             \
         IFH_W1(0, w0, K0) IFH_W1(1, w1, K0) IFH_W1(2, w2, K0) IFH_W1(3, w3, K0)                  \
         IFH_W1(4, w4, K0) IFH_W1(5, w5, K0) IFH_W1(6, w6, K0) IFH_W1(7, w7, K0)                  \
+        IFH_W1(8, w8, K0) IFH_W1(9, w9, K0) IFH_W1(10, w10, K0) IFH_W1(11, w11, K0)              \
+        IFH_W1(12, w12, K0) IFH_W1(13, w13, K0) IFH_W1(14, w14, K0) IFH_W1(15, w15, K0)          \
     }
 #define IFH_C1(I, REG)                                                                           \
     if (I < WV) {                                                                                \
@@ -75,6 +76,8 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
     if (!RESIDENT) {                                                                             \
         IFH_C1(0, w0) IFH_C1(1, w1) IFH_C1(2, w2) IFH_C1(3, w3)                                  \
         IFH_C1(4, w4) IFH_C1(5, w5) IFH_C1(6, w6) IFH_C1(7, w7)                                  \
+        IFH_C1(8, w8) IFH_C1(9, w9) IFH_C1(10, w10) IFH_C1(11, w11)                              \
+        IFH_C1(12, w12) IFH_C1(13, w13) IFH_C1(14, w14) IFH_C1(15, w15)                          \
     }
     if (RESIDENT) {
         const int vpr = p.K / 8;
@@ -138,25 +141,26 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
     }
 }
 
-template <int CIN, int WGM, int MT, int NT, bool RESIDENT>
+template <int CIN, int WGM, int MT, int NT, bool RESIDENT, int KC = 64>
 static bool launch_direct(const IgemmParams &p, hipStream_t st)
 {
     constexpr int WGN = 4 / WGM;
     constexpr int BM = WGM * MT * 16, BN = WGN * NT * 16;
     constexpr int XS = CIN + 8;
     const int R = BM + (p.taps - 1) * p.dil;
-    const int KW = RESIDENT ? p.K : 64;
+    const int KW = RESIDENT ? p.K : KC;
+    if (!RESIDENT && p.K % KC != 0) return false;
     const size_t bytes = ((size_t)((R * XS + 7) & ~7) + (size_t)BN * (KW + 8)) * sizeof(uint16_t);
     if (bytes > 160 * 1024) return false;
     static size_t attr_bytes = 0;
     if (bytes > 64 * 1024 && bytes > attr_bytes) {
-        if (hipFuncSetAttribute((const void *)k_conv_direct<CIN, WGM, MT, NT, RESIDENT>,
+        if (hipFuncSetAttribute((const void *)k_conv_direct<CIN, WGM, MT, NT, RESIDENT, KC>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return false;
         attr_bytes = 160 * 1024;
     }
     dim3 grid((p.T_out + BM - 1) / BM, p.nbatch);
-    hipLaunchKernelGGL((k_conv_direct<CIN, WGM, MT, NT, RESIDENT>), grid, dim3(256), bytes, st, p);
+    hipLaunchKernelGGL((k_conv_direct<CIN, WGM, MT, NT, RESIDENT, KC>), grid, dim3(256), bytes, st, p);
     return true;
 }
 
@@ -169,9 +173,14 @@ bool try_launch_conv_direct(const IgemmParams &p, bool pre, hipStream_t st)
     if (p.stride != 1 || p.taps < 2 || p.N != p.Cin || p.n_split != 0 || !p.fast_epi) return false;
     if (p.T_out != p.T_in + 2 * p.pad - (p.taps - 1) * p.dil) return false;
     if (p.nbatch >= 65536) return false;
+    static const int kc = getenv("IFH_DIRECT_KC") ? atoi(getenv("IFH_DIRECT_KC")) : 64;      // tuning switch
     switch (p.Cin) {
-    case 256: return p.T_out >= 32 && launch_direct<256, 1, 3, 4, false>(p, st);     // BM 48  x BN 256
-    case 128: return p.T_out >= 64 && launch_direct<128, 2, 6, 4, false>(p, st);     // BM 192 x BN 128
+    case 256:                                                                        // BM 48  x BN 256
+        if (p.T_out < 32) return false;
+        return kc == 128 ? launch_direct<256, 1, 3, 4, false, 128>(p, st) : launch_direct<256, 1, 3, 4, false, 64>(p, st);
+    case 128:                                                                        // BM 192 x BN 128
+        if (p.T_out < 64) return false;
+        return kc == 128 ? launch_direct<128, 2, 6, 4, false, 128>(p, st) : launch_direct<128, 2, 6, 4, false, 64>(p, st);
     case 64: return p.T_out >= 128 && launch_direct<64, 2, 8, 2, false>(p, st);      // BM 256 x BN 64, streamed W (3 blocks/CU)
     case 32: return p.T_out >= 128 && launch_direct<32, 4, 4, 2, true>(p, st);       // BM 256 x BN 32
     default: return false;

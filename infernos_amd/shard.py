@@ -15,6 +15,11 @@ import torch
 import torch.distributed as dist
 
 
+def _stage(group):
+    """gloo has no device scatter/gather: stage through host memory (CPU tests, single-GPU dry runs)."""
+    return dist.get_backend(group) == 'gloo'
+
+
 def shard_bounds(n_total: int, world: int) -> List[range]:
     """Contiguous, balanced call ranges per rank (first n_total % world ranks get one more)."""
     q, r = divmod(n_total, world)
@@ -33,6 +38,10 @@ def scatter_frames(frames_all: Optional[torch.Tensor], n_total: int, t: int, dev
     mine = torch.empty((t, len(bounds[rank]), 160), dtype=torch.uint8, device=device)
     if world == 1:
         mine.copy_(frames_all)
+        return mine
+    if _stage(group) and torch.device(device).type != 'cpu':
+        host = scatter_frames(None if frames_all is None else frames_all.cpu(), n_total, t, 'cpu', src=src, group=group)
+        mine.copy_(host)
         return mine
     if max(len(b) for b in bounds) == min(len(b) for b in bounds):
         parts = None
@@ -60,6 +69,9 @@ def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0, group=None) -> 
     rank, world = dist.get_rank(), dist.get_world_size()
     if world == 1:
         return local
+    if _stage(group) and local.device.type != 'cpu':
+        full = gather_rows(local.cpu(), n_total, dst=dst, group=group)
+        return None if full is None else full.to(local.device)
     bounds = shard_bounds(n_total, world)
     W = local.size(1)
     if max(len(b) for b in bounds) == min(len(b) for b in bounds):
