@@ -334,3 +334,29 @@ def test_whisper_matches_oracle_and_reference_fixture(dev, golden_dir):
     toks3, _, _ = model.generate(enc, prompt, 8, use_graphs=False)
     assert torch.equal(toks3, toks)
     np.testing.assert_allclose(nsp.cpu().numpy(), meta['no_speech_prob'], rtol=0.5)
+
+
+def test_whisper_base_config3_matches_oracle(dev):
+    """BASELINE config 3 dims (Whisper-base: d=512, 6+6 layers, 8 heads, ffn 2048): encoder and the first
+    greedy tokens against the fp32 oracle on seeded weights (no reference fixture exists for base)."""
+    from infernos_amd.engines.whisper import Whisper
+    from infernos_amd.features import WhisperLogMel
+    from infernos_amd.synth import synth_utterance
+    from infernos_amd.audio import get_resampler
+    from infernos_amd.weights import synth_state_dict
+    sd = synth_state_dict('whisper_base', 1)
+    model = Whisper(sd, dev)
+    assert (model.d, model.h, model.ff, len(model.enc_layers), len(model.dec_layers)) == (512, 8, 2048, 6, 6)
+    x8 = torch.from_numpy(np.stack([synth_utterance(1100 + i, 5.0) for i in range(2)])).to(dev)
+    mel = WhisperLogMel(80, dev)(get_resampler(8000, 16000, str(dev))(x8))
+    enc = model.encode(mel)
+    prompt = torch.tensor([[50258, 50259, 50359, 50363]] * 2, dtype=torch.int32)
+    toks, nsp, first = model.generate(enc, prompt, 4, no_speech_id=50362, keep_logits=True)
+    with torch.no_grad():
+        o_toks, o_first, o_l0, o_enc = onn.whisper_greedy(sd, mel.float().cpu(), prompt.long(), 4, 8)
+    assert rel_l2(enc.float().cpu(), o_enc) < 3e-2
+    assert rel_l2(first.cpu(), o_first) < 5e-2
+    top2 = o_first.topk(2).values
+    for b in range(2):
+        if float(top2[b, 0] - top2[b, 1]) > 0.05:
+            assert int(toks[b, 0]) == int(o_toks[b, 0])
