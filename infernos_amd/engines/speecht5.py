@@ -29,7 +29,7 @@ def _ln(sd, p, dev):
 class SpeechT5:
     n_dec_layers = 6
 
-    def __init__(self, sd, device, max_steps=640):
+    def __init__(self, sd, device, max_steps=4000):
         self.device = dev = _lib.require_device(device)
         self.max_steps = max_steps
         self.use_graphs = True
@@ -158,15 +158,19 @@ class TTSBatchState:
     allocated once per (B, T) and reused by later batches of the same shape (`acquire`), so the
     hipGraphs captured over them stay valid."""
 
+    T_BUCKET = 16          # text lengths are padded (masked) up to a multiple of this so shapes -- and graphs -- recur
+    MAX_CACHED = 4
+
     def __init__(self, model: 'SpeechT5', B: int, T: int):
         dev = model.device
-        self.model, self.B, self.T = model, B, T
+        self.model, self.B, self.T = model, B, T            # T = allocated (bucketed) text length
         self.maxlen = int(T * 20.0 / 2)
         self.minlen = 0
         e = lambda *s, dt=BF16: torch.empty(s, dtype=dt, device=dev)
         self.enc_len = torch.zeros(B, dtype=torch.int32, device=dev)
         self.cross = [e(B * T, 2 * D) for _ in model.dec_layers]
-        self.smax = min(model.max_steps, self.maxlen + 32)
+        self.smax = min(model.max_steps, self.maxlen + 48)      # maxlen here is the bucket's upper bound; the loop
+        # runs at most one 16-step call past maxlen before every row has ended
         self.self_kv = [torch.zeros((B, self.smax, 2 * D), dtype=BF16, device=dev) for _ in model.dec_layers]
         # two frame buffers (call parity): frame 0 = last frame carried over from the previous call, frames
         # 1..32 = this call.  Double-buffered so the renderer (postnet/vocoder) of call c can run on a second
@@ -194,12 +198,18 @@ class TTSBatchState:
 
     @classmethod
     def acquire(cls, model: 'SpeechT5', input_ids, lens, speakers):
-        B, T = input_ids.shape
-        st = model._states.get((B, T))
+        B, T_true = input_ids.shape
+        T = -(-T_true // cls.T_BUCKET) * cls.T_BUCKET
+        if T != T_true:                           # extra right padding: token 0, masked by lens like the reference's own padding
+            input_ids = torch.nn.functional.pad(input_ids, (0, T - T_true))
+        st = model._states.pop((B, T), None)
         if st is None:
             st = cls(model, B, T)
-            model._states = {(B, T): st}          # keep one shape resident
+            while len(model._states) >= cls.MAX_CACHED:          # small LRU of state shapes (buffers + captured graphs)
+                model._states.pop(next(iter(model._states)))
+        model._states[(B, T)] = st
         st.reset(input_ids, lens, speakers)
+        st.maxlen = int(T_true * 20.0 / 2)        # HelloSippyRTPipe.py:117 uses the batch's true padded length
         return st
 
     def reset(self, input_ids, lens, speakers):
