@@ -89,6 +89,15 @@ int ifh_ingest_tick(const uint8_t *frames /* [n][160] */, const int32_t *slot, i
                     float *pcm8k, float *pcm16k, ifh_resampler_t rs8to16, ifh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
+ * Output mix + encode    replaces Core/OutputMuxer.py:75-85 (OutputMTMuxer.idle mix: zero-pad,
+ *                        sum in track order, divide by the number of tracks) + G711Codec.encode, for n calls at once.
+ * tracks f32 [n][ntracks][block_len]; present u8 [n][ntracks]; ndiv i32 [n]; out u8 [n][block_len];
+ * has_out u8 [n] (0: no track had a block, nothing to send; 1 track: unchanged; >=2: sum / ndiv).
+ * ------------------------------------------------------------------------------- */
+int ifh_mux_encode_f32_u8(const float *tracks, const uint8_t *present, const int32_t *ndiv, int ncalls, int ntracks,
+                          int block_len, uint8_t *out, uint8_t *has_out, ifh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
  * VAD                   replaces Core/VAD/SileroVADUtils.py:105-130 (hysteresis FSM) and
  *                        Core/VAD/SileroVAD.py:81-112 (chunk assembly), batched on device.
  * The speech-probability model itself (Silero v3.1 JIT, third party, weights not

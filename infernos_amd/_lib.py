@@ -27,6 +27,7 @@ SIGNATURES = {
     'ifh_resample_out_len': (_i64, [_vp, _i64]),
     'ifh_resample_run': (_i, [_vp, _vp, _i64, _vp, _i64, _i, _vp, _i64, _vp]),
     'ifh_ingest_tick': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'ifh_mux_encode_f32_u8': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'ifh_vad_energy_prob': (_i, [_vp, _vp, _i, _vp, _vp]),
     'ifh_vad_fsm_step': (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp]),
     'ifh_vad_step': (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp]),

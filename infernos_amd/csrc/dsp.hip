@@ -414,6 +414,64 @@ extern "C" int ifh_ingest_tick(const uint8_t *frames, const int32_t *slot, int n
 }
 
 // =========================================================================================
+// Output side of the per-call loop: OutputMTMuxer.idle mix (Core/OutputMuxer.py:75-85)
+// fused with G711Codec.encode (Core/Codecs/G711.py:25-32), batched over calls.
+// tracks f32 [n][K][L] (zero-padded blocks, track order = insertion order), present u8 [n][K] (1 if the
+// track produced a block), ndiv i32 [n] (= len(self.tracks)); out u8 [n][L]; has_out u8 [n].
+//   0 present -> has_out 0 (the reference sends nothing);  1 present -> that block unchanged;
+//   >= 2 -> float32 sum in track order, then one IEEE division by ndiv.
+// =========================================================================================
+namespace ifh {
+
+__global__ __launch_bounds__(256) void k_mux_encode(const float *__restrict__ tracks, const uint8_t *__restrict__ present,
+                                                    const int32_t *__restrict__ ndiv, int K, int L,
+                                                    uint8_t *__restrict__ out, uint8_t *__restrict__ has_out)
+{
+    const int c = blockIdx.x;
+    int cnt = 0, only = 0;
+    for (int k = 0; k < K; k++)
+        if (present[(int64_t)c * K + k]) {
+            cnt++;
+            only = k;
+        }
+    if (threadIdx.x == 0) has_out[c] = cnt > 0;
+    if (cnt == 0) return;
+    const float *tb = tracks + (int64_t)c * K * L;
+    const float div = (float)ndiv[c];
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        float v;
+        if (cnt == 1) {
+            v = tb[(int64_t)only * L + i];
+        } else {
+            v = 0.0f;
+            bool first = true;
+            for (int k = 0; k < K; k++)
+                if (present[(int64_t)c * K + k]) {
+                    const float x = tb[(int64_t)k * L + i];
+                    v = first ? x : v + x;
+                    first = false;
+                }
+            v = v / div;
+        }
+        out[(int64_t)c * L + i] = (uint8_t)encode_sample(v);
+    }
+}
+
+}  // namespace ifh
+
+extern "C" int ifh_mux_encode_f32_u8(const float *tracks, const uint8_t *present, const int32_t *ndiv, int ncalls,
+                                     int ntracks, int block_len, uint8_t *out, uint8_t *has_out, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(ncalls >= 0 && ntracks >= 1 && block_len >= 1);
+    if (ncalls == 0) return IFH_OK;
+    IFH_CHECK_ARG(tracks && present && ndiv && out && has_out);
+    hipLaunchKernelGGL(k_mux_encode, dim3(ncalls), dim3(256), 0, as_stream(stream), tracks, present, ndiv, ntracks,
+                       block_len, out, has_out);
+    IFH_LAUNCH_CHECK("mux_encode");
+    return IFH_OK;
+}
+
+// =========================================================================================
 // VAD: stand-in probability model, hysteresis FSM, chunk assembly
 // =========================================================================================
 namespace ifh {

@@ -43,3 +43,19 @@ class CallTable:
                 _lib.ptr(self.win_ready), _lib.ptr(self.hist), _lib.ptr(pcm8k), _lib.ptr(pcm16k), self._rs.handle,
                 _lib.stream_ptr(dev)), 'ifh_ingest_tick')
         return pcm8k, pcm16k, self.win_ready[slots.long()]
+
+
+def mux_encode(tracks: torch.Tensor, present: torch.Tensor, ndiv: torch.Tensor):
+    """Batched output mix + mu-law encode (ifh_mux_encode_f32_u8): tracks f32 [n,K,L], present u8/bool [n,K],
+    ndiv int32 [n] -> (u8 [n,L], has_out u8 [n]) on the device."""
+    dev = _lib.require_device(tracks.device if tracks.is_cuda else None)
+    tracks = tracks.to(dev, torch.float32).contiguous()
+    n, K, L = tracks.shape
+    present = present.to(dev, torch.uint8).contiguous()
+    ndiv = ndiv.to(dev, torch.int32).contiguous()
+    out = torch.empty((n, L), dtype=torch.uint8, device=dev)
+    has = torch.empty(n, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().ifh_mux_encode_f32_u8(_lib.ptr(tracks), _lib.ptr(present), _lib.ptr(ndiv), n, K, L, _lib.ptr(out),
+                                                    _lib.ptr(has), _lib.stream_ptr(dev)), 'ifh_mux_encode_f32_u8')
+    return out, has

@@ -169,3 +169,26 @@ def logmel_direct(audio, n_mel=80, nsamp=480000):
     out = np.empty((n_mel, nfr), np.float32)
     lib().orc_logmel_direct(_p(x), ctypes.c_int64(nsamp), _p(mel), n_mel, _p(out), ctypes.c_int64(nfr))
     return out
+
+
+# ---- output mix + encode (Core/OutputMuxer.py:75-85 + G711Codec.encode) ---------------------------
+def mux_encode(tracks, present, ndiv):
+    """tracks f32 [n][K][L], present bool [n][K], ndiv int [n] -> (u8 [n][L], has_out bool [n])"""
+    tracks = np.asarray(tracks, np.float32)
+    n, K, L = tracks.shape
+    out = np.zeros((n, L), np.uint8)
+    has = np.zeros(n, bool)
+    for c in range(n):
+        ks = [k for k in range(K) if present[c][k]]
+        if not ks:
+            continue
+        has[c] = True
+        if len(ks) == 1:
+            mix = tracks[c, ks[0]]
+        else:
+            acc = tracks[c, ks[0]].copy()
+            for k in ks[1:]:
+                acc = (acc + tracks[c, k]).astype(np.float32)
+            mix = (acc / np.float32(ndiv[c])).astype(np.float32)
+        out[c] = g711_encode(mix)
+    return out, has

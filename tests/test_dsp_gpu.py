@@ -292,3 +292,21 @@ def test_logmel_edge_cases(dev):
     lm128 = WhisperLogMel(128, dev)
     o128 = lm128(torch.from_numpy(xb[:1, :160000])).cpu().numpy()
     assert np.abs(o128[0] - odsp.logmel(xb[0, :160000], n_mel=128)).max() < 1e-3
+
+
+# ---- output mix + encode (8f-1) ---------------------------------------------------------------------
+def test_mux_encode_matches_oracle(dev):
+    from infernos_amd.frontend import mux_encode
+    rng = np.random.default_rng(21)
+    n, K, L = 37, 3, 800
+    tr = (rng.standard_normal((n, K, L)) * 0.4).astype(np.float32)
+    present = rng.random((n, K)) < 0.6
+    present[0] = False; present[1] = [True, False, False]; present[2] = True
+    tr[~present] = 0
+    ndiv = np.maximum(present.sum(1), 1).astype(np.int32)
+    ndiv[3] = 3                       # a track that exists but produced no block still divides
+    ref, has_ref = odsp.mux_encode(tr, present, ndiv)
+    out, has = mux_encode(torch.from_numpy(tr), torch.from_numpy(present), torch.from_numpy(ndiv))
+    assert np.array_equal(has.cpu().numpy().astype(bool), has_ref)
+    o = out.cpu().numpy()
+    assert np.array_equal(o[has_ref], ref[has_ref])

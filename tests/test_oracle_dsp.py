@@ -88,3 +88,34 @@ def test_logmel_direct_dft_agrees():
     a = dsp.logmel(x, nsamp=8000)
     b = dsp.logmel_direct(x, nsamp=8000)
     np.testing.assert_allclose(a, b, rtol=0, atol=1e-5)
+
+
+def test_mux_encode_oracle_matches_reference_mixer(golden_dir):
+    """oracle.mux_encode against the blocks the reference's OutputMTMuxer produced (2-track mix and
+    single-track pass-through) followed by the reference's encode table."""
+    import json
+    g = json.load(open(os.path.join(golden_dir, 'muxer_trace.json')))
+    data = np.load(os.path.join(golden_dir, 'muxer_data.npz'))
+    tab = np.load(os.path.join(golden_dir, 'g711_tables.npz'))['pcm_to_ulaw']
+
+    def ref_encode(x):
+        s = np.trunc(np.clip(x.astype(np.float32) * np.float32(32767.0), -32768, 32767)).astype(np.int64)
+        return tab[s + 32768]
+    # script ops 6..8: tracks 0 (1000 samples) and 1 (300) queued, then idle -> first mixed block? the log tells
+    outs = [(i, n) for kind, i, n in (e for e in g['log'] if e[0] == 'idle') if n]
+    assert outs
+    # single-track blocks: identical samples -> encode equals table lookup
+    i0 = outs[0][0]
+    blk = data['out_%d' % i0]
+    enc, has = dsp.mux_encode(blk[None, None, :], [[True]], [1])
+    assert has[0] and np.array_equal(enc[0], ref_encode(blk))
+    # synthetic two-track case reproduces torch.sum(torch.stack)/len(tracks)
+    import torch
+    rng = np.random.default_rng(3)
+    a, b = rng.standard_normal(800).astype(np.float32), rng.standard_normal(800).astype(np.float32)
+    b[500:] = 0
+    ref = (torch.sum(torch.stack([torch.from_numpy(a), torch.from_numpy(b)]), dim=0) / 2).numpy()
+    enc, has = dsp.mux_encode(np.stack([a, b])[None], [[True, True]], [2])
+    assert np.array_equal(enc[0], ref_encode(ref))
+    enc, has = dsp.mux_encode(np.stack([a, b])[None], [[False, False]], [2])
+    assert not has[0]
