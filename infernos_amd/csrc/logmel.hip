@@ -244,12 +244,37 @@ __global__ __launch_bounds__(256) void k_logmel_dft2(const float *__restrict__ a
         if (tid == 0) atomicMax(gmax + b, float_to_ordered(v0));
         return;
     }
-    // ---- stage the audio tile, 16 loads in flight per thread (one wave per SIMD: nothing else hides HBM latency)
-    for (int base = 0; base < kTile; base += 256 * 16) {
-        float v[16];
+    // ---- stage the audio tile with every load of the thread in flight at once (one wave per SIMD:
+    // nothing else hides the HBM latency).  Interior, 16-byte aligned tiles take the float4 path.
+    const bool interior = a0 >= 0 && a_last < len && ((reinterpret_cast<uintptr_t>(x + a0) & 15) == 0);
+    if (interior) {
+        constexpr int NV4 = kTile / 4;          // 5180 float4 (+1 scalar tail)
+        constexpr int NI = (NV4 + 255) / 256;   // 21
+        const float4 *x4 = reinterpret_cast<const float4 *>(x + a0);
+        float4 v[NI];
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            int a = a0 + base + tid + 256 * i;
+        for (int i = 0; i < NI; i++) {
+            const int q = tid + 256 * i;
+            v[i] = x4[q < NV4 ? q : NV4 - 1];
+        }
+        if (tid == 0) lds[pad_idx(kTile - 1)] = x[a0 + kTile - 1];
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int q = tid + 256 * i;
+            if (q < NV4) {
+                const int pi = pad_idx(4 * q);   // 4q..4q+3 never straddle a multiple of 160
+                lds[pi] = v[i].x;
+                lds[pi + 1] = v[i].y;
+                lds[pi + 2] = v[i].z;
+                lds[pi + 3] = v[i].w;
+            }
+        }
+    } else {
+        constexpr int NI = (kTile + 255) / 256;  // 81
+        float v[NI];
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            int a = a0 + tid + 256 * i;
             if (a < 0) a = -a;
             if (a >= kNsamp) a = 2 * (kNsamp - 1) - a;
             const bool ok = a >= 0 && a < len;
@@ -257,8 +282,8 @@ __global__ __launch_bounds__(256) void k_logmel_dft2(const float *__restrict__ a
             v[i] = ok ? t_ : 0.0f;
         }
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int m = base + tid + 256 * i;
+        for (int i = 0; i < NI; i++) {
+            const int m = tid + 256 * i;
             if (m < kTile) lds[pad_idx(m)] = v[i];
         }
     }
@@ -374,30 +399,51 @@ __global__ __launch_bounds__(256) void k_logmel_dft2(const float *__restrict__ a
         }
     }
     __syncthreads();
-    // ---- sparse mel projection: thread = (frame, mel parity); filter weights padded to groups of 4 in LDS
+    // ---- sparse mel projection: thread = (frame, mel parity), four filters in flight per iteration
+    // (filter weights padded to groups of 4 in LDS; group index past a filter's end reads zero weights)
     {
         const int fl = tid & (kFT - 1);
         const int f = f0 + fl;
         const float4 *w4 = reinterpret_cast<const float4 *>(mell + 384);
-        for (int m = tid >> 7; m < n_mel; m += 2) {
-            const int lo = mell[m], c4 = mell[128 + m], o4 = mell[256 + m];
-            float a = 0.0f;
-            for (int g = 0; g < c4; g++) {
-                const float4 wv = w4[o4 + g];
-                const int k = lo + 4 * g;
-                const float q0 = lds[k * kFT + fl];
-                const float q1 = lds[min(k + 1, kBins - 1) * kFT + fl];
-                const float q2 = lds[min(k + 2, kBins - 1) * kFT + fl];
-                const float q3 = lds[min(k + 3, kBins - 1) * kFT + fl];
-                a = __fmaf_rn(wv.x, q0, a);
-                a = __fmaf_rn(wv.y, q1, a);
-                a = __fmaf_rn(wv.z, q2, a);
-                a = __fmaf_rn(wv.w, q3, a);
+        const int zero_g = (mel2_words - 384) / 4 - 1;   // the last group is all-zero
+        for (int mb = tid >> 7; mb < n_mel; mb += 8) {
+            int lo[4], c4[4], o4[4];
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            int gmaxn = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int m = mb + 2 * u;
+                lo[u] = mell[m];
+                c4[u] = mell[128 + m];
+                o4[u] = mell[256 + m];
+                gmaxn = max(gmaxn, c4[u]);
             }
-            const float v = log10f(fmaxf(a, 1e-10f));
-            if (f < kFrames) {
-                rawb[(int64_t)m * kFrames + f] = v;
-                lmax = fmaxf(lmax, v);
+            for (int g = 0; g < gmaxn; g++) {
+                float4 wv[4];
+                float q[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool on = g < c4[u];
+                    wv[u] = w4[on ? o4[u] + g : zero_g];
+                    const int k = on ? lo[u] + 4 * g : 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) q[u][e] = lds[min(k + e, kBins - 1) * kFT + fl];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    a[u] = __fmaf_rn(wv[u].x, q[u][0], a[u]);
+                    a[u] = __fmaf_rn(wv[u].y, q[u][1], a[u]);
+                    a[u] = __fmaf_rn(wv[u].z, q[u][2], a[u]);
+                    a[u] = __fmaf_rn(wv[u].w, q[u][3], a[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float v = log10f(fmaxf(a[u], 1e-10f));
+                if (f < kFrames) {
+                    rawb[(int64_t)(mb + 2 * u) * kFrames + f] = v;
+                    lmax = fmaxf(lmax, v);
+                }
             }
         }
     }
@@ -516,6 +562,7 @@ extern "C" int ifh_logmel_create(int n_mel, ifh_logmel_t *out)
             mel2.push_back(bits);
         }
     }
+    for (int k = 0; k < 4; k++) mel2.push_back(0);       // trailing all-zero weight group
     h->mel2_words = (int)mel2.size();
     // ---- folded DFT table: row n, col c<224: hann[n]*cos(2pi c n/400) (c<=200), col 224+c: sin
     std::vector<float> tab((size_t)kTabRows * kTabCols, 0.0f);
