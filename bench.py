@@ -252,12 +252,12 @@ def main():
             'p99_tick_latency_ms': round(float(np.percentile(lat, 99)), 4),
             'stt_audio_seconds_per_call': round(float(res['stt_seconds'].mean()), 3),
             'tts_samples_per_call': int(res['tts_samples'].float().mean()),
-            'roofline': {'kernel': 'HiFi-GAN vocoder pass = k_conv_direct<*> + k_igemm<*> (%d chunks x 12 frames per launch group)' % nchunks,
+            'roofline': {'kernel': 'HiFi-GAN vocoder pass = k_resblock_pair<*> + k_igemm<*> (%d chunks x 12 frames per launch group)' % nchunks,
                          'bound': 'mfma', 'achieved': round(ach_tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
                          'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r01_vocoder_pmc.json',
                          'seconds_per_vocoder_pass': t_voc},
-            'roofline_logmel': {'kernel': 'k_logmel_dft+k_logmel_finish (%d x 30 s windows)' % n_local, 'bound': 'hbm',
+            'roofline_logmel': {'kernel': 'k_logmel_dft2+k_logmel_finish (%d x 30 s windows)' % n_local, 'bound': 'hbm',
                                 'achieved': round(ach_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                 'frac': round(ach_gbs / PEAK_HBM_GBS, 4), 'traffic': None, 'seconds': t_mel},
         }

@@ -215,6 +215,29 @@ typedef struct ifh_conv_desc {
 } ifh_conv_desc;
 int ifh_conv_bf16(const ifh_conv_desc *desc, ifh_stream_t stream);
 
+/* One HiFi-GAN residual pair in a single launch (transformers modeling_speecht5.py
+ * HifiGanResidualBlock.forward loop body, called from SpeechT5HifiGan.forward :3040-3047 via
+ * HelloSippyTTSRT/HelloSippyRTPipe.py:236):
+ *     out = (x + conv2(lrelu(conv1(lrelu(x); taps, dil)); taps, 1)) * out_scale  (+ out if accumulate)
+ * x, out bf16 [nbatch][t][c] channels-last with contiguous rows (batch strides in elements, % 8 == 0),
+ * c in {32,64,128,256}, w1/w2 bf16 [c][taps][c], taps odd <= 17, "same" padding.  The intermediate is
+ * rounded to bf16 exactly as two ifh_conv_bf16 launches would, so both routes give identical bits. */
+typedef struct ifh_resblock_desc {
+    const void *x;
+    int64_t x_bstride;
+    int32_t c, taps, dil, t, nbatch;
+    const void *w1;
+    const float *bias1;     /* [c] or NULL */
+    const void *w2;
+    const float *bias2;
+    float slope;            /* LeakyReLU slope ahead of both convolutions, (0, 1] */
+    float out_scale;
+    int32_t accumulate;
+    void *out;
+    int64_t out_bstride;
+} ifh_resblock_desc;
+int ifh_resblock_pair_bf16(const ifh_resblock_desc *desc, ifh_stream_t stream);
+
 /* y = LayerNorm(x (+ resid)) * gamma + beta; rows of `dim` bf16, dim <= 1024, dim % 4 == 0 */
 int ifh_layernorm_bf16(const void *x, const void *resid, const float *gamma, const float *beta, void *out,
                        int rows, int dim, float eps, ifh_stream_t stream);

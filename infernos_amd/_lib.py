@@ -56,6 +56,13 @@ class ConvDesc(ctypes.Structure):
                 ('stats_out', _vp), ('ln_dim', ctypes.c_int32), ('ln_eps', _f)]
 
 
+class ResblockDesc(ctypes.Structure):
+    """ifh_resblock_desc (include/infernos_hip.h)"""
+    _fields_ = [('x', _vp), ('x_bstride', _i64), ('c', ctypes.c_int32), ('taps', ctypes.c_int32), ('dil', ctypes.c_int32),
+                ('t', ctypes.c_int32), ('nbatch', ctypes.c_int32), ('w1', _vp), ('bias1', _vp), ('w2', _vp), ('bias2', _vp),
+                ('slope', _f), ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp), ('out_bstride', _i64)]
+
+
 class AttnDesc(ctypes.Structure):
     """ifh_attn_desc (include/infernos_hip.h)"""
     _fields_ = [('q', _vp), ('k', _vp), ('v', _vp), ('out', _vp),
@@ -67,6 +74,7 @@ class AttnDesc(ctypes.Structure):
 
 SIGNATURES.update({
     'ifh_conv_bf16': (_i, [ctypes.POINTER(ConvDesc), _vp]),
+    'ifh_resblock_pair_bf16': (_i, [ctypes.POINTER(ResblockDesc), _vp]),
     'ifh_layernorm_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     'ifh_transpose_to_bf16': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     'ifh_attn_prefill_bf16': (_i, [ctypes.POINTER(AttnDesc), _vp]),

@@ -9,6 +9,7 @@
 // streamed in 64-wide K chunks through a register prefetch for Cin >= 128.
 // MFMA: v_mfma_f32_16x16x32_bf16, swapped operands (A = weight rows, B = activation rows), same
 // fused epilogue as k_igemm (bias, residual, scale, accumulate).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "igemm.h"
@@ -24,6 +25,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
     constexpr int WV = RESIDENT ? 0 : (BN * KC / 8 / 256);   // prefetch vectors per thread (<= 16)
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
 
+    const long long tp0 = clock64();
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int wm = wid % WGM, wn = wid / WGM;
@@ -35,20 +37,49 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
     uint16_t *Xs = lds;
     uint16_t *Ws = lds + ((R * XS + 7) & ~7);
 
-    // ---- stage the input rows once (zero outside [0, T_in)), LeakyReLU fused here
+    // residual operand of the epilogue, requested first (ahead of the input tile) and consumed after the K loop
+    const int dynv = p.dyn ? p.dyn[0] : 0;
+    uint2 rpre[NT][MT];
+    float4 bpre[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+        bpre[i] = p.bias ? *reinterpret_cast<const float4 *>(p.bias + (wn * NT + i) * 16 + 4 * fg) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.resid) {
+#pragma unroll
+        for (int j = 0; j < MT; j++) {
+            const int t = min(t0 + (wm * MT + j) * 16 + fr, p.T_out - 1);
+            const EpiRow e = epi_row(p, b * p.T_out + t, 0, dynv);
+#pragma unroll
+            for (int i = 0; i < NT; i++)
+                rpre[i][j] = *reinterpret_cast<const uint2 *>(p.resid + e.rbase + (wn * NT + i) * 16 + 4 * fg);
+        }
+    }
+
+    // ---- stage the input rows once (zero outside [0, T_in)), LeakyReLU fused here.  All of a thread's
+    // loads are issued before the first LDS write (XVB covers a halo of 50 rows = 11 taps x dilation 5 in
+    // one batch): a load-use-load loop would expose one HBM round trip per vector.
     {
         constexpr int VPR = CIN / 8;
+        constexpr int XVB = ((BM + 50) * VPR + 255) / 256;
         const uint16_t *xb = p.x + (int64_t)b * p.x_bstride;
         const bool pre = p.pre_slope != 1.0f;
-        for (int v = tid; v < R * VPR; v += 256) {
-            const int r = v / VPR, c = (v - r * VPR) * 8;
-            const int tin = t0 - p.pad + r;
-            uint4 val = make_uint4(0, 0, 0, 0);
-            if (tin >= 0 && tin < p.T_in) {
-                val = *reinterpret_cast<const uint4 *>(xb + (int64_t)tin * p.lda + c);
-                if (pre) val = lrelu8(val, p.pre_slope);
+        for (int base = 0; base < R * VPR; base += 256 * XVB) {
+            uint4 xv[XVB];
+#pragma unroll
+            for (int i = 0; i < XVB; i++) {
+                const int v = base + tid + 256 * i;
+                const int r = v / VPR, c = (v - r * VPR) * 8;
+                const int tin = t0 - p.pad + r;
+                const bool ok = v < R * VPR && tin >= 0 && tin < p.T_in;
+                xv[i] = *reinterpret_cast<const uint4 *>(xb + (ok ? (int64_t)tin * p.lda + c : 0));
+                if (!ok) xv[i] = make_uint4(0, 0, 0, 0);
             }
-            *reinterpret_cast<uint4 *>(&Xs[r * XS + c]) = val;
+#pragma unroll
+            for (int i = 0; i < XVB; i++) {
+                const int v = base + tid + 256 * i;
+                const int r = v / VPR, c = (v - r * VPR) * 8;
+                if (v < R * VPR) *reinterpret_cast<uint4 *>(&Xs[r * XS + c]) = pre ? lrelu8(xv[i], p.pre_slope) : xv[i];
+            }
         }
     }
     // Prefetch registers are NAMED scalars driven by macros: as an array (or captured in a lambda)
@@ -94,8 +125,8 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
     for (int i = 0; i < NT; i++)
 #pragma unroll
         for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     const int nchunk = RESIDENT ? 1 : p.K / KC;
+    long long tp1 = 0;
     const int arow0 = (wm * MT * 16 + fr) * XS + fg * 8;
     const int brow0 = (wn * NT * 16 + fr) * WS + fg * 8;
     for (int ch = 0; ch < nchunk; ch++) {
@@ -104,6 +135,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
             IFH_W_COMMIT()
         }
         __syncthreads();
+        if (ch == 0) tp1 = clock64();
         if (!RESIDENT && ch + 1 < nchunk) IFH_W_PREFETCH((ch + 1) * KC)
         const int ksteps = KW / 32;
         for (int ks = 0; ks < ksteps; ks++) {
@@ -127,7 +159,51 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
 #undef IFH_W_COMMIT
 #undef IFH_W1
 #undef IFH_C1
-    const int dynv = p.dyn ? p.dyn[0] : 0;
+    if (p.store16) {
+        // Full-row stores: the rounded tile goes through LDS (over the dead input tile) so that every
+        // global store is 16 bytes per lane and a wave writes whole contiguous rows.  The per-lane layout of
+        // the MFMA result (4 channels x 16 different rows) stored directly costs about as much as the rest
+        // of the kernel (8-byte pieces of 16 rows per instruction).
+        constexpr int OS = BN + 8;
+        __syncthreads();
+        const long long tp2 = clock64();
+        uint16_t *Os = lds;
+#pragma unroll
+        for (int j = 0; j < MT; j++) {
+            const int tl = (wm * MT + j) * 16 + fr;
+            if (t0 + tl >= p.T_out) continue;
+            const int m = b * p.T_out + t0 + tl;
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                const int n = (wn * NT + i) * 16 + 4 * fg;
+                const uint2 pk = igemm_store4_fast<true, false, true>(p, m, n, acc[i][j], dynv, rpre[i][j], bpre[i]);
+                *reinterpret_cast<uint2 *>(&Os[tl * OS + n]) = pk;
+            }
+        }
+        __syncthreads();
+        const long long tp3 = clock64();
+        constexpr int VPR = BN / 8;
+        uint16_t *outp = reinterpret_cast<uint16_t *>(p.out);
+#pragma unroll 4
+        for (int v = tid; v < BM * VPR; v += 256) {
+            const int row = v / VPR, c = (v - row * VPR) * 8;
+            if (t0 + row < p.T_out) {
+                const EpiRow e = epi_row(p, b * p.T_out + t0 + row, 0, dynv);
+                *reinterpret_cast<uint4 *>(outp + e.obase + c) = *reinterpret_cast<const uint4 *>(&Os[row * OS + c]);
+            }
+        }
+        if (p.prof && tid == 0) {
+            const long long tp4 = clock64();
+            atomicAdd(p.prof + 0, (unsigned long long)(tp1 - tp0));
+            atomicAdd(p.prof + 1, (unsigned long long)(tp2 - tp1));
+            atomicAdd(p.prof + 2, (unsigned long long)(tp3 - tp2));
+            atomicAdd(p.prof + 3, (unsigned long long)(tp4 - tp3));
+            atomicAdd(p.prof + 4, 1ull);
+            atomicMin(p.prof + 5, (unsigned long long)tp0);
+            atomicMax(p.prof + 6, (unsigned long long)tp4);
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < MT; j++) {
         const int t = t0 + (wm * MT + j) * 16 + fr;
@@ -136,7 +212,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             const int n = (wn * NT + i) * 16 + 4 * fg;
-            igemm_store4<true>(p, m, n, acc[i][j], dynv);
+            (void)igemm_store4_fast<true, true, true>(p, m, n, acc[i][j], dynv, rpre[i][j], bpre[i]);
         }
     }
 }
@@ -164,8 +240,23 @@ static bool launch_direct(const IgemmParams &p, hipStream_t st)
     return true;
 }
 
-bool try_launch_conv_direct(const IgemmParams &p, bool pre, hipStream_t st)
+bool try_launch_conv_direct(const IgemmParams &p_, bool pre, hipStream_t st)
 {
+    IgemmParams p = p_;
+    static const bool no16 = getenv("IFH_CONV_NO_STORE16") != nullptr;      // tuning switch
+    static unsigned long long *d_prof = nullptr;
+    static const bool do_prof = getenv("IFH_CONV_PROF") != nullptr;
+    static int prof_calls = 0;
+    if (do_prof && !d_prof) (void)hipMalloc((void **)&d_prof, 64);
+    p.prof = nullptr;
+    if (do_prof) {
+        unsigned long long init[8] = {0, 0, 0, 0, 0, ~0ull, 0, 0};
+        (void)hipMemcpy(d_prof, init, 64, hipMemcpyHostToDevice);
+        p.prof = d_prof;
+    }
+    p.store16 = !no16 && !p.out_f32 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && p.ldc % 8 == 0 &&
+                p.out_bstride % 8 == 0 && ((int64_t)p.ooff * p.ldc) % 8 == 0 && ((int64_t)p.ostride * p.ldc) % 8 == 0 &&
+                (p.dyn == nullptr || ((int64_t)p.dyn_ooff_mul * p.ldc) % 8 == 0);
     (void)pre;
     static const int mask = getenv("IFH_DIRECT_CONV_MASK") ? atoi(getenv("IFH_DIRECT_CONV_MASK")) : 15;   // tuning switch
     if (!((p.Cin == 256 && (mask & 1)) || (p.Cin == 128 && (mask & 2)) || (p.Cin == 64 && (mask & 4)) || (p.Cin == 32 && (mask & 8))))
@@ -174,6 +265,16 @@ bool try_launch_conv_direct(const IgemmParams &p, bool pre, hipStream_t st)
     if (p.T_out != p.T_in + 2 * p.pad - (p.taps - 1) * p.dil) return false;
     if (p.nbatch >= 65536) return false;
     static const int kc = getenv("IFH_DIRECT_KC") ? atoi(getenv("IFH_DIRECT_KC")) : 64;      // tuning switch
+    struct ProfPrint {
+        const IgemmParams &p; hipStream_t st; bool on;
+        ~ProfPrint() {
+            if (!on || prof_calls++ > 40) return;
+            unsigned long long hp[8];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(hp, p.prof, 64, hipMemcpyDeviceToHost);
+            if (hp[4]) fprintf(stderr, "convprof C=%d taps=%d blocks=%llu stage=%llu mfma=%llu epi=%llu store=%llu span=%llu\n", p.Cin, p.taps, hp[4], hp[0] / hp[4], hp[1] / hp[4], hp[2] / hp[4], hp[3] / hp[4], hp[6] - hp[5]);
+        }
+    } pp{p, st, do_prof};
     switch (p.Cin) {
     case 256:                                                                        // BM 48  x BN 256
         if (p.T_out < 32) return false;

@@ -34,6 +34,8 @@ struct IgemmParams {
     int vec_ok;
     int res_vec_ok;           // bias/colmask/resid can be read as 16/4/8-byte vectors
     int fast_epi;             // every 4-group of this launch can take the vector epilogue
+    int store16;              // conv.hip: outputs are 16-byte addressable -> LDS-transposed full-row stores
+    unsigned long long *prof; // TEMP
     int n_split;              // columns >= n_split (if > 0) go to the second output region
     void *out2;
     int64_t out2_bstride;
@@ -103,12 +105,19 @@ __device__ __forceinline__ EpiRow epi_row(const IgemmParams &p, int m, int n, in
     return r;
 }
 
-__device__ __forceinline__ void igemm_store4_fast(const IgemmParams &p, int m, int n, f32x4 acc, int dynv)
+// HAVE_R: the residual 4-vector was loaded by the caller ahead of its K loop (rpre)
+// STORE = false: bf16 outputs only; the rounded 4-vector is returned instead of written (the caller
+// transposes it through LDS into full-row stores).
+// HAVE_B: same for the bias 4-vector (bpre; ignored when p.bias is null)
+template <bool HAVE_R = false, bool STORE = true, bool HAVE_B = false>
+__device__ __forceinline__ uint2 igemm_store4_fast(const IgemmParams &p, int m, int n, f32x4 acc, int dynv,
+                                                   uint2 rpre = make_uint2(0, 0),
+                                                   float4 bpre = make_float4(0.f, 0.f, 0.f, 0.f))
 {
     const EpiRow e = epi_row(p, m, n, dynv);
     float v0 = acc[0], v1 = acc[1], v2 = acc[2], v3 = acc[3];
     if (p.bias) {
-        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
+        const float4 bv = HAVE_B ? bpre : *reinterpret_cast<const float4 *>(p.bias + n);
         v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
     }
     if (p.act != ACT_NONE) {
@@ -125,34 +134,35 @@ __device__ __forceinline__ void igemm_store4_fast(const IgemmParams &p, int m, i
         v3 = (mk & 0xff000000u) ? v3 * 2.0f : 0.0f;
     }
     if (p.resid) {
-        const uint2 rv = *reinterpret_cast<const uint2 *>(p.resid + e.rbase + n);
+        const uint2 rv = HAVE_R ? rpre : *reinterpret_cast<const uint2 *>(p.resid + e.rbase + n);
         v0 += __uint_as_float(rv.x << 16);
         v1 += __uint_as_float(rv.x & 0xffff0000u);
         v2 += __uint_as_float(rv.y << 16);
         v3 += __uint_as_float(rv.y & 0xffff0000u);
     }
     v0 *= p.out_scale; v1 *= p.out_scale; v2 *= p.out_scale; v3 *= p.out_scale;
-    if (p.out_f32) {
+    if (STORE && p.out_f32) {
         float *o = reinterpret_cast<float *>(e.outp) + e.obase + n;
         if (p.accumulate) {
             const float4 prev = *reinterpret_cast<const float4 *>(o);
             v0 += prev.x; v1 += prev.y; v2 += prev.z; v3 += prev.w;
         }
         *reinterpret_cast<float4 *>(o) = make_float4(v0, v1, v2, v3);
-    } else {
-        uint16_t *o = reinterpret_cast<uint16_t *>(e.outp) + e.obase + n;
-        if (p.accumulate) {
-            const uint2 pv = *reinterpret_cast<const uint2 *>(o);
-            v0 += __uint_as_float(pv.x << 16);
-            v1 += __uint_as_float(pv.x & 0xffff0000u);
-            v2 += __uint_as_float(pv.y << 16);
-            v3 += __uint_as_float(pv.y & 0xffff0000u);
-        }
-        uint2 pk;
-        pk.x = f32x2_to_bf16x2(v0, v1);
-        pk.y = f32x2_to_bf16x2(v2, v3);
-        *reinterpret_cast<uint2 *>(o) = pk;
+        return make_uint2(0, 0);
     }
+    uint16_t *o = reinterpret_cast<uint16_t *>(e.outp) + e.obase + n;
+    if (p.accumulate) {
+        const uint2 pv = *reinterpret_cast<const uint2 *>(o);
+        v0 += __uint_as_float(pv.x << 16);
+        v1 += __uint_as_float(pv.x & 0xffff0000u);
+        v2 += __uint_as_float(pv.y << 16);
+        v3 += __uint_as_float(pv.y & 0xffff0000u);
+    }
+    uint2 pk;
+    pk.x = f32x2_to_bf16x2(v0, v1);
+    pk.y = f32x2_to_bf16x2(v2, v3);
+    if (STORE) *reinterpret_cast<uint2 *>(o) = pk;
+    return pk;
 }
 
 __device__ __forceinline__ void igemm_store4_general(const IgemmParams &p, int m, int n, float a0, float a1,
@@ -183,7 +193,7 @@ template <bool FAST>
 __device__ __forceinline__ void igemm_store4(const IgemmParams &p, int m, int n, f32x4 acc, int dynv)
 {
     if (FAST)
-        igemm_store4_fast(p, m, n, acc, dynv);
+        (void)igemm_store4_fast(p, m, n, acc, dynv);
     else
         igemm_store4_general(p, m, n, acc[0], acc[1], acc[2], acc[3], dynv);
 }

@@ -3,10 +3,13 @@
 Replaces `self.vocoder(spectrogram)` / `self.chunker(spectrogram, audio)` at
 HelloSippyTTSRT/HelloSippyRTPipe.py:236-237 (transformers SpeechT5HifiGan,
 modeling_speecht5.py:2954-3064; AmendmentNetwork1, HelloSippyRT.py:181-237).  Every
-convolution is one ifh_conv_bf16 launch (implicit GEMM on the matrix cores) with LeakyReLU
-fused on the operand load and bias/residual/3-way-mean fused in the epilogue; the transposed
-convolutions run as 4 two-tap phases.
+convolution is an implicit GEMM on the matrix cores with LeakyReLU fused on the operand load and
+bias/residual/3-way-mean fused in the epilogue: the residual pairs (conv k,d -> conv k,1 -> + x) are one
+ifh_resblock_pair_bf16 launch each with the intermediate held in LDS, the rest one ifh_conv_bf16 launch
+each; the transposed convolutions run as 4 two-tap phases.
 """
+import os
+
 import torch
 
 from .. import _lib, ops
@@ -33,6 +36,7 @@ class HifiGan:
         self.post_w = sd['conv_post.weight'].float()[0].t().contiguous().to(dev)     # [7][32]
         self.post_b = float(sd['conv_post.bias'].float()[0])
         self._bufs = {}
+        self.fused_pairs = os.environ.get('IFH_NO_FUSED_PAIR') is None      # tuning switch
 
     def _buffers(self, n, t0):
         key = (n, t0)
@@ -67,6 +71,13 @@ class HifiGan:
                 cur = u
                 for di, d in enumerate((1, 3, 5)):
                     w1, b1, w2, b2 = self.res[i][j][di]
+                    if self.fused_pairs:       # both convolutions in one launch, intermediate kept in LDS (same bits)
+                        last = di == 2
+                        nxt = xn if last else rbuf[di]
+                        ops.resblock_pair(cur, w1, b1, w2, b2, nxt, nbatch=n, t=t, c=c, taps=k, dil=d, slope=0.1,
+                                          scale=(1.0 / 3.0 if last else 1.0), accumulate=(last and j > 0))
+                        cur = nxt
+                        continue
                     ops.conv(cur, w1, b1, h, nbatch=n, t_in=t, t_out=t, cin=c, n=c, taps=k, dil=d, pad=(k * d - d) // 2,
                              pre_slope=0.1)
                     if di < 2:

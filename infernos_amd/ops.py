@@ -54,6 +54,19 @@ def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=
     return out
 
 
+def resblock_pair(x, w1, b1, w2, b2, out, *, nbatch, t, c, taps, dil, slope=0.1, scale=1.0, accumulate=False):
+    """out = (x + conv2(lrelu(conv1(lrelu(x); taps, dil)); taps, 1)) * scale (+ out): one launch, the
+    intermediate stays in LDS (ifh_resblock_pair_bf16).  x, out dense bf16 [nbatch][t][c]."""
+    d = _lib.ResblockDesc()
+    d.x, d.x_bstride = _addr(x), t * c
+    d.c, d.taps, d.dil, d.t, d.nbatch = c, taps, dil, t, nbatch
+    d.w1, d.bias1, d.w2, d.bias2 = _addr(w1), _addr(b1), _addr(w2), _addr(b2)
+    d.slope, d.out_scale, d.accumulate = slope, scale, int(accumulate)
+    d.out, d.out_bstride = _addr(out), t * c
+    _lib.check(_lib.lib().ifh_resblock_pair_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_resblock_pair_bf16')
+    return out
+
+
 def linear(x, w, bias, out, *, rows, k, n, **kw):
     """out[rows, n] = epi(x[rows, k] @ w[n, k]^T + bias)"""
     return conv(x, w, bias, out, nbatch=1, t_in=rows, t_out=rows, cin=k, n=n, **kw)

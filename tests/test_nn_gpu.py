@@ -114,6 +114,39 @@ def test_conv_transpose_phases_match_torch(dev):
     assert rel_l2(out.float().cpu(), ref) < 5e-3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', [
+    dict(B=3, T=48, c=256, k=3, d=1), dict(B=2, T=48, c=256, k=11, d=5), dict(B=2, T=61, c=256, k=7, d=3),
+    dict(B=3, T=192, c=128, k=3, d=3), dict(B=2, T=192, c=128, k=11, d=5), dict(B=2, T=449, c=128, k=7, d=1),
+    dict(B=3, T=768, c=64, k=3, d=1), dict(B=2, T=768, c=64, k=11, d=5), dict(B=2, T=215, c=64, k=7, d=5),
+    dict(B=2, T=3072, c=32, k=11, d=5), dict(B=3, T=500, c=32, k=3, d=3), dict(B=2, T=17, c=32, k=7, d=1),
+    dict(B=2, T=768, c=64, k=7, d=3, scale=1 / 3, accumulate=True),
+    dict(B=2, T=300, c=32, k=11, d=1, scale=1 / 3, accumulate=True),
+])
+def test_resblock_pair_is_bit_identical_to_two_convs(dev, case):
+    """ifh_resblock_pair_bf16 (intermediate kept in LDS) against the two ifh_conv_bf16 launches it replaces
+    (themselves checked against torch above): same rounding points, so the bits must agree."""
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(case['T'] * 7 + case['c'] + case['k'])
+    B, T, c, k, d = case['B'], case['T'], case['c'], case['k'], case['d']
+    scale, acc = case.get('scale', 1.0), case.get('accumulate', False)
+    x = torch.randn(B, T, c, generator=g).to(BF).to(dev)
+    w1 = ops.w_conv(torch.randn(c, c, k, generator=g) / (c * k) ** 0.5, dev)
+    w2 = ops.w_conv(torch.randn(c, c, k, generator=g) / (c * k) ** 0.5, dev)
+    b1, b2 = (torch.randn(c, generator=g) * 0.1).to(dev), (torch.randn(c, generator=g) * 0.1).to(dev)
+    prev = torch.randn(B, T, c, generator=g).to(BF).to(dev)
+    h = torch.empty(B, T, c, dtype=BF, device=dev)
+    ref = prev.clone()
+    ops.conv(x, w1, b1, h, nbatch=B, t_in=T, t_out=T, cin=c, n=c, taps=k, dil=d, pad=(k * d - d) // 2, pre_slope=0.1)
+    ops.conv(h, w2, b2, ref, nbatch=B, t_in=T, t_out=T, cin=c, n=c, taps=k, pad=(k - 1) // 2, pre_slope=0.1, resid=x,
+             scale=scale, accumulate=acc)
+    out = prev.clone()
+    ops.resblock_pair(x, w1, b1, w2, b2, out, nbatch=B, t=T, c=c, taps=k, dil=d, scale=scale, accumulate=acc)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16)), \
+        'max abs diff %g' % float((out.float() - ref.float()).abs().max())
+
+
 def test_layernorm_and_transpose(dev):
     from infernos_amd import ops
     g = torch.Generator().manual_seed(6)
