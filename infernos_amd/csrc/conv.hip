@@ -9,7 +9,6 @@
 // streamed in 64-wide K chunks through a register prefetch for Cin >= 128.
 // MFMA: v_mfma_f32_16x16x32_bf16, swapped operands (A = weight rows, B = activation rows), same
 // fused epilogue as k_igemm (bias, residual, scale, accumulate).
-#include <stdio.h>
 #include <stdlib.h>
 
 #include "igemm.h"
@@ -25,7 +24,6 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
     constexpr int WV = RESIDENT ? 0 : (BN * KC / 8 / 256);   // prefetch vectors per thread (<= 16)
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
 
-    const long long tp0 = clock64();
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int wm = wid % WGM, wn = wid / WGM;
@@ -126,7 +124,6 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
 #pragma unroll
         for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int nchunk = RESIDENT ? 1 : p.K / KC;
-    long long tp1 = 0;
     const int arow0 = (wm * MT * 16 + fr) * XS + fg * 8;
     const int brow0 = (wn * NT * 16 + fr) * WS + fg * 8;
     for (int ch = 0; ch < nchunk; ch++) {
@@ -135,7 +132,6 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
             IFH_W_COMMIT()
         }
         __syncthreads();
-        if (ch == 0) tp1 = clock64();
         if (!RESIDENT && ch + 1 < nchunk) IFH_W_PREFETCH((ch + 1) * KC)
         const int ksteps = KW / 32;
         for (int ks = 0; ks < ksteps; ks++) {
@@ -166,7 +162,6 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
         // of the kernel (8-byte pieces of 16 rows per instruction).
         constexpr int OS = BN + 8;
         __syncthreads();
-        const long long tp2 = clock64();
         uint16_t *Os = lds;
 #pragma unroll
         for (int j = 0; j < MT; j++) {
@@ -181,7 +176,6 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
             }
         }
         __syncthreads();
-        const long long tp3 = clock64();
         constexpr int VPR = BN / 8;
         uint16_t *outp = reinterpret_cast<uint16_t *>(p.out);
 #pragma unroll 4
@@ -191,16 +185,6 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
                 const EpiRow e = epi_row(p, b * p.T_out + t0 + row, 0, dynv);
                 *reinterpret_cast<uint4 *>(outp + e.obase + c) = *reinterpret_cast<const uint4 *>(&Os[row * OS + c]);
             }
-        }
-        if (p.prof && tid == 0) {
-            const long long tp4 = clock64();
-            atomicAdd(p.prof + 0, (unsigned long long)(tp1 - tp0));
-            atomicAdd(p.prof + 1, (unsigned long long)(tp2 - tp1));
-            atomicAdd(p.prof + 2, (unsigned long long)(tp3 - tp2));
-            atomicAdd(p.prof + 3, (unsigned long long)(tp4 - tp3));
-            atomicAdd(p.prof + 4, 1ull);
-            atomicMin(p.prof + 5, (unsigned long long)tp0);
-            atomicMax(p.prof + 6, (unsigned long long)tp4);
         }
         return;
     }
@@ -244,16 +228,6 @@ bool try_launch_conv_direct(const IgemmParams &p_, bool pre, hipStream_t st)
 {
     IgemmParams p = p_;
     static const bool no16 = getenv("IFH_CONV_NO_STORE16") != nullptr;      // tuning switch
-    static unsigned long long *d_prof = nullptr;
-    static const bool do_prof = getenv("IFH_CONV_PROF") != nullptr;
-    static int prof_calls = 0;
-    if (do_prof && !d_prof) (void)hipMalloc((void **)&d_prof, 64);
-    p.prof = nullptr;
-    if (do_prof) {
-        unsigned long long init[8] = {0, 0, 0, 0, 0, ~0ull, 0, 0};
-        (void)hipMemcpy(d_prof, init, 64, hipMemcpyHostToDevice);
-        p.prof = d_prof;
-    }
     p.store16 = !no16 && !p.out_f32 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && p.ldc % 8 == 0 &&
                 p.out_bstride % 8 == 0 && ((int64_t)p.ooff * p.ldc) % 8 == 0 && ((int64_t)p.ostride * p.ldc) % 8 == 0 &&
                 (p.dyn == nullptr || ((int64_t)p.dyn_ooff_mul * p.ldc) % 8 == 0);
@@ -265,16 +239,6 @@ bool try_launch_conv_direct(const IgemmParams &p_, bool pre, hipStream_t st)
     if (p.T_out != p.T_in + 2 * p.pad - (p.taps - 1) * p.dil) return false;
     if (p.nbatch >= 65536) return false;
     static const int kc = getenv("IFH_DIRECT_KC") ? atoi(getenv("IFH_DIRECT_KC")) : 64;      // tuning switch
-    struct ProfPrint {
-        const IgemmParams &p; hipStream_t st; bool on;
-        ~ProfPrint() {
-            if (!on || prof_calls++ > 40) return;
-            unsigned long long hp[8];
-            (void)hipStreamSynchronize(st);
-            (void)hipMemcpy(hp, p.prof, 64, hipMemcpyDeviceToHost);
-            if (hp[4]) fprintf(stderr, "convprof C=%d taps=%d blocks=%llu stage=%llu mfma=%llu epi=%llu store=%llu span=%llu\n", p.Cin, p.taps, hp[4], hp[0] / hp[4], hp[1] / hp[4], hp[2] / hp[4], hp[3] / hp[4], hp[6] - hp[5]);
-        }
-    } pp{p, st, do_prof};
     switch (p.Cin) {
     case 256:                                                                        // BM 48  x BN 256
         if (p.T_out < 32) return false;

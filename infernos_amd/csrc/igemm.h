@@ -35,7 +35,6 @@ struct IgemmParams {
     int res_vec_ok;           // bias/colmask/resid can be read as 16/4/8-byte vectors
     int fast_epi;             // every 4-group of this launch can take the vector epilogue
     int store16;              // conv.hip: outputs are 16-byte addressable -> LDS-transposed full-row stores
-    unsigned long long *prof; // TEMP
     int n_split;              // columns >= n_split (if > 0) go to the second output region
     void *out2;
     int64_t out2_bstride;

@@ -44,6 +44,25 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
         if (p.aln_stats) st_a = reinterpret_cast<const longlong2 *>(p.aln_stats)[m];
         if (p.rln_stats) st_r = reinterpret_cast<const longlong2 *>(p.rln_stats)[m];
     }
+    // Epilogue operands of the LN mode are requested here as well (wave 0, ahead of the weight stream): the
+    // decoder step is a chain of ~50 of these launches, each only a few microseconds long, and a second
+    // dependent round trip after the K loop is a visible fraction of it.
+    const bool ln_mode = p.aln_stats || p.rln_stats || p.stats_out;
+    float4 pc1 = make_float4(0.f, 0.f, 0.f, 0.f), pbias = pc1, pgam = pc1, pbeta = pc1;
+    uint2 presid = make_uint2(0, 0);
+    const int dynv0 = p.dyn ? p.dyn[0] : 0;
+    if (ln_mode && wid == 0 && xok && n0 + 4 * fg < p.N) {
+        const int n = n0 + 4 * fg;
+        if (p.aln_stats) pc1 = *reinterpret_cast<const float4 *>(p.aln_c1 + n);
+        if (p.bias) pbias = *reinterpret_cast<const float4 *>(p.bias + n);
+        if (p.resid) {
+            presid = *reinterpret_cast<const uint2 *>(p.resid + epi_row(p, m, n, dynv0).rbase + n);
+            if (p.rln_stats) {
+                pgam = *reinterpret_cast<const float4 *>(p.rln_gamma + n);
+                pbeta = *reinterpret_cast<const float4 *>(p.rln_beta + n);
+            }
+        }
+    }
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int kt = kt0; kt < kt1; kt += U) {
         uint4 wv[U], xv[U];
@@ -72,23 +91,22 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
 #pragma unroll
         for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w][lane][0]);
         const int n = n0 + 4 * fg;
-        const bool ln_mode = p.aln_stats || p.rln_stats || p.stats_out;
         if (ln_mode) {
             // LayerNorm folded around the GEMM (host guarantees the vector epilogue conditions, N % 16 == 0)
             float v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
             const bool ok = xok && n < p.N;
             if (ok) {
-                const EpiRow e = epi_row(p, m, n, p.dyn ? p.dyn[0] : 0);
+                const EpiRow e = epi_row(p, m, n, dynv0);
                 if (p.aln_stats) {
                     const float mean = a_mean, rstd = a_rstd;
-                    const float4 c1 = *reinterpret_cast<const float4 *>(p.aln_c1 + n);
+                    const float4 c1 = pc1;
                     v0 = rstd * (v0 - mean * c1.x);
                     v1 = rstd * (v1 - mean * c1.y);
                     v2 = rstd * (v2 - mean * c1.z);
                     v3 = rstd * (v3 - mean * c1.w);
                 }
                 if (p.bias) {
-                    const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
+                    const float4 bv = pbias;
                     v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
                 }
                 if (p.act != ACT_NONE) {
@@ -98,13 +116,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
                     v3 = apply_act(v3, p.act, p.act_slope);
                 }
                 if (p.resid) {
-                    const uint2 rv = *reinterpret_cast<const uint2 *>(p.resid + e.rbase + n);
+                    const uint2 rv = presid;
                     float r0 = __uint_as_float(rv.x << 16), r1 = __uint_as_float(rv.x & 0xffff0000u);
                     float r2 = __uint_as_float(rv.y << 16), r3 = __uint_as_float(rv.y & 0xffff0000u);
                     if (p.rln_stats) {
                         const float mean = r_mean, rstd = r_rstd;
-                        const float4 g = *reinterpret_cast<const float4 *>(p.rln_gamma + n);
-                        const float4 bt = *reinterpret_cast<const float4 *>(p.rln_beta + n);
+                        const float4 g = pgam;
+                        const float4 bt = pbeta;
                         r0 = (r0 - mean) * rstd * g.x + bt.x;
                         r1 = (r1 - mean) * rstd * g.y + bt.y;
                         r2 = (r2 - mean) * rstd * g.z + bt.z;

@@ -43,14 +43,17 @@ __device__ __forceinline__ uint2 lrelu4(uint2 v, float slope)
     return make_uint2(f32x2_to_bf16x2(a, b), f32x2_to_bf16x2(c, d));
 }
 
-template <int CIN, int WGM, int MT1, int NT, bool RESIDENT, int KC>
+template <int CIN, int WGM, int MT1, int NT, bool RESIDENT, int KC, int EPB, bool RES_LDS>
 __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
 {
     constexpr int WGN = 4 / WGM;
-    constexpr int BM1 = WGM * MT1 * 16;       // conv1 rows
-    constexpr int BM = BM1 - 16;              // conv2 rows
+    constexpr int TPE = WGM * MT1 / EPB;      // conv1 tiles per batch entry
+    constexpr int BM1E = TPE * 16;            // conv1 rows per entry
+    constexpr int BME = BM1E - 16;            // conv2 (output) rows per entry
     constexpr int BN = WGN * NT * 16;
     static_assert(BN == CIN, "a block covers every channel");
+    static_assert(EPB == 1 || WGM == 1, "several entries per block: one wave row");
+    static_assert(TPE * EPB == WGM * MT1, "tiles split evenly over the entries");
     constexpr int XS = CIN + 8;
     constexpr int WV = RESIDENT ? 0 : (BN * KC / 8 / 256);
     static_assert(WV <= 16, "prefetch registers");
@@ -59,20 +62,21 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int wm = wid % WGM, wn = wid / WGM;
-    const int b = blockIdx.y, t0 = blockIdx.x * p.rows_per_block;
+    const int b0 = blockIdx.y * EPB, t0 = blockIdx.x * p.rows_per_block;
     const int K = p.taps * CIN;
     const int halo1 = (p.taps - 1) * p.dil, h1 = halo1 / 2, h2 = (p.taps - 1) / 2;
-    const int R1 = BM1 + halo1;
+    const int R1 = BM1E + halo1;              // input rows per entry
     const int KW = RESIDENT ? K : KC;
     const int WS = KW + 8;
+    // LDS: [ input tile | later the intermediate tile | later the output tile ] [ weights ] [ raw residual rows ]
     uint16_t *Xs = lds;
-    uint16_t *Ms = Xs + ((R1 * XS + 7) & ~7);
-    uint16_t *Ws = Ms + BM1 * XS;
+    uint16_t *Ms = lds;
+    uint16_t *Ws = Xs + ((EPB * R1 * XS + 7) & ~7);
+    uint16_t *Rs = Ws + BN * WS;
     const int nvalid = min(p.rows_per_block, p.T - t0);
-    const uint16_t *xb = p.x + (int64_t)b * p.x_bstride;
-    uint16_t *ob = p.out + (int64_t)b * p.out_bstride;
 
-    // ---- epilogue operands first
+    // ---- epilogue operands first: bias vectors, rows of `out` to accumulate onto, and (when they are not
+    // kept in LDS) the residual rows
     float4 bp1[NT], bp2[NT];
     uint2 rpre[NT][MT1], apre[NT][MT1];
 #pragma unroll
@@ -83,39 +87,20 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
     }
 #pragma unroll
     for (int j = 0; j < MT1; j++) {
-        const int t = min(t0 + (wm * MT1 + j) * 16 + fr, p.T - 1);
+        const int g = wm * MT1 + j, e = g / TPE, lt = g - e * TPE;
+        const int t = min(t0 + lt * 16 + fr, p.T - 1);
+        const int be = min(b0 + e, p.nbatch - 1);
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             const int n = (wn * NT + i) * 16 + 4 * fg;
-            rpre[i][j] = *reinterpret_cast<const uint2 *>(xb + (int64_t)t * CIN + n);
-            apre[i][j] = p.accumulate ? *reinterpret_cast<const uint2 *>(ob + (int64_t)t * CIN + n) : make_uint2(0, 0);
+            rpre[i][j] = RES_LDS ? make_uint2(0, 0)
+                                 : *reinterpret_cast<const uint2 *>(p.x + (int64_t)be * p.x_bstride + (int64_t)t * CIN + n);
+            apre[i][j] = p.accumulate ? *reinterpret_cast<const uint2 *>(p.out + (int64_t)be * p.out_bstride + (int64_t)t * CIN + n)
+                                      : make_uint2(0, 0);
         }
     }
-    // ---- input tile: row q <-> time t0 - 8 - h1 + q, LeakyReLU applied once here, all loads in flight together
-    {
-        constexpr int VPR = CIN / 8;
-        constexpr int XVB = ((BM1 + 50) * VPR + 255) / 256;
-        const int tx0 = t0 - 8 - h1;
-        for (int base = 0; base < R1 * VPR; base += 256 * XVB) {
-            uint4 xv[XVB];
-#pragma unroll
-            for (int i = 0; i < XVB; i++) {
-                const int v = base + tid + 256 * i;
-                const int r = v / VPR, c = (v - r * VPR) * 8;
-                const int tin = tx0 + r;
-                const bool ok = v < R1 * VPR && tin >= 0 && tin < p.T;
-                xv[i] = *reinterpret_cast<const uint4 *>(xb + (ok ? (int64_t)tin * CIN + c : 0));
-                if (!ok) xv[i] = make_uint4(0, 0, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < XVB; i++) {
-                const int v = base + tid + 256 * i;
-                const int r = v / VPR, c = (v - r * VPR) * 8;
-                if (v < R1 * VPR) *reinterpret_cast<uint4 *>(&Xs[r * XS + c]) = lrelu8(xv[i], p.slope);
-            }
-        }
-    }
-    // ---- weight stream: chunk c < nchunk belongs to conv1, the rest to conv2 (named registers: see conv.hip)
+    // ---- weights.  Streamed: chunk c < nchunk belongs to conv1, the rest to conv2 (named registers: see
+    // conv.hip).  RESIDENT (C = 32): conv1's weights go to LDS now, conv2's wait in registers.
     const int nchunk = RESIDENT ? 1 : K / KC;
     uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15;
     w0 = w1 = w2 = w3 = w4 = w5 = w6 = w7 = w8 = w9 = w10 = w11 = w12 = w13 = w14 = w15 = make_uint4(0, 0, 0, 0);
@@ -143,11 +128,11 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
         RB_C1(0, w0) RB_C1(1, w1) RB_C1(2, w2) RB_C1(3, w3) RB_C1(4, w4) RB_C1(5, w5) RB_C1(6, w6) RB_C1(7, w7)      \
         RB_C1(8, w8) RB_C1(9, w9) RB_C1(10, w10) RB_C1(11, w11) RB_C1(12, w12) RB_C1(13, w13) RB_C1(14, w14) RB_C1(15, w15) \
     }
-    // RESIDENT (C = 32): conv1's weights go to LDS now, conv2's wait in registers and replace them later
-#define RB_R1(I, REG)                                                                            \
+    // whole-matrix transfers for RESIDENT: vector v of [BN][K/8] (at most 8 per thread: taps <= 17 at C = 32)
+#define RB_R1(I, REG, SRC)                                                                       \
     {                                                                                            \
         const int v = tid + 256 * I;                                                             \
-        if (v < BN * (K / 8)) REG = *reinterpret_cast<const uint4 *>(p.w2 + (int64_t)v * 8);     \
+        if (v < BN * (K / 8)) REG = *reinterpret_cast<const uint4 *>((SRC) + (int64_t)v * 8);    \
     }
 #define RB_RC1(I, REG)                                                                           \
     {                                                                                            \
@@ -155,25 +140,65 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
         if (v < BN * (K / 8)) *reinterpret_cast<uint4 *>(&Ws[(v / (K / 8)) * WS + (v % (K / 8)) * 8]) = REG; \
     }
     if (RESIDENT) {
-        const int vpr = K / 8;
-        for (int v = tid; v < BN * vpr; v += 256) {
-            const int n2 = v / vpr, kv = (v - n2 * vpr) * 8;
-            *reinterpret_cast<uint4 *>(&Ws[n2 * WS + kv]) = *reinterpret_cast<const uint4 *>(p.w1 + (int64_t)n2 * K + kv);
-        }
-        RB_R1(0, w0) RB_R1(1, w1) RB_R1(2, w2) RB_R1(3, w3) RB_R1(4, w4) RB_R1(5, w5) RB_R1(6, w6) RB_R1(7, w7) RB_R1(8, w8)
+        RB_R1(0, w0, p.w1) RB_R1(1, w1, p.w1) RB_R1(2, w2, p.w1) RB_R1(3, w3, p.w1)
+        RB_R1(4, w4, p.w1) RB_R1(5, w5, p.w1) RB_R1(6, w6, p.w1) RB_R1(7, w7, p.w1)
+        RB_R1(0, w8, p.w2) RB_R1(1, w9, p.w2) RB_R1(2, w10, p.w2) RB_R1(3, w11, p.w2)
+        RB_R1(4, w12, p.w2) RB_R1(5, w13, p.w2) RB_R1(6, w14, p.w2) RB_R1(7, w15, p.w2)
     } else {
         RB_W_PREFETCH(0)
+    }
+    // ---- input tile: row q of entry e <-> time t0 - 8 - h1 + q, LeakyReLU applied once here; the raw rows
+    // of the output range also go to Rs (the residual operand).  All loads in flight together.
+    {
+        constexpr int VPR = CIN / 8;
+        constexpr int XVB = (EPB * (BM1E + 50) * VPR + 255) / 256;
+        const int tx0 = t0 - 8 - h1;
+        const int nvec = EPB * R1 * VPR;
+        for (int base = 0; base < nvec; base += 256 * XVB) {
+            uint4 xv[XVB];
+#pragma unroll
+            for (int i = 0; i < XVB; i++) {
+                const int v = base + tid + 256 * i;
+                const int rr = v / VPR, c = (v - rr * VPR) * 8;
+                const int e = EPB == 1 ? 0 : rr / R1;
+                const int tin = tx0 + (rr - e * R1);
+                const bool ok = v < nvec && tin >= 0 && tin < p.T && b0 + e < p.nbatch;
+                xv[i] = *reinterpret_cast<const uint4 *>(p.x + (ok ? (int64_t)(b0 + e) * p.x_bstride + (int64_t)tin * CIN + c : 0));
+                if (!ok) xv[i] = make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < XVB; i++) {
+                const int v = base + tid + 256 * i;
+                const int rr = v / VPR, c = (v - rr * VPR) * 8;
+                if (v < nvec) {
+                    *reinterpret_cast<uint4 *>(&Xs[rr * XS + c]) = lrelu8(xv[i], p.slope);
+                    if (RES_LDS) {
+                        const int e = EPB == 1 ? 0 : rr / R1;
+                        const int q = rr - e * R1 - 8 - h1;
+                        if (q >= 0 && q < BME) *reinterpret_cast<uint4 *>(&Rs[(e * BME + q) * XS + c]) = xv[i];
+                    }
+                }
+            }
+        }
+    }
+    if (RESIDENT) {
+        RB_RC1(0, w0) RB_RC1(1, w1) RB_RC1(2, w2) RB_RC1(3, w3) RB_RC1(4, w4) RB_RC1(5, w5) RB_RC1(6, w6) RB_RC1(7, w7)
     }
 
     f32x4 acc[NT][MT1];
     const int brow0 = (wn * NT * 16 + fr) * WS + fg * 8;
-    // =========================== conv1 (dilation d) on BM1 rows -> Ms ===========================
+    // =========================== conv1 (dilation d) on BM1 rows ===========================
 #pragma unroll
     for (int i = 0; i < NT; i++)
 #pragma unroll
         for (int j = 0; j < MT1; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     {
-        const int arow0 = (wm * MT1 * 16 + fr) * XS + fg * 8;
+        int xrow[MT1];
+#pragma unroll
+        for (int j = 0; j < MT1; j++) {
+            const int g = wm * MT1 + j, e = g / TPE, lt = g - e * TPE;
+            xrow[j] = (e * R1 + lt * 16 + fr) * XS + fg * 8;
+        }
         for (int ch = 0; ch < nchunk; ch++) {
             if (!RESIDENT) {
                 if (ch > 0) __syncthreads();
@@ -181,30 +206,41 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
             }
             __syncthreads();
             if (!RESIDENT) RB_W_PREFETCH(ch + 1)          // conv2's first chunk follows conv1's last
-            const int ksteps = KW / 32;
-            for (int ks = 0; ks < ksteps; ks++) {
-                const int k = ch * KC + ks * 32;
-                const int tap = k / CIN, ci = k - tap * CIN;
-                const int aoff = arow0 + tap * p.dil * XS + ci;
-                bf16x8_t fa[NT], fb[MT1];
-#pragma unroll
-                for (int i = 0; i < NT; i++) fa[i] = *reinterpret_cast<const bf16x8_t *>(&Ws[brow0 + i * 16 * WS + ks * 32]);
-#pragma unroll
-                for (int j = 0; j < MT1; j++) fb[j] = *reinterpret_cast<const bf16x8_t *>(&Xs[aoff + j * 16 * XS]);
-#pragma unroll
-                for (int i = 0; i < NT; i++)
-#pragma unroll
-                    for (int j = 0; j < MT1; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+#define RB_KSTEP1(ks)                                                                             \
+            {\
+                const int k = ch * KC + ks * 32; \
+                const int tap = k / CIN, ci = k - tap * CIN; \
+                const int aoff = tap * p.dil * XS + ci; \
+                bf16x8_t fa[NT], fb[MT1]; \
+_Pragma("unroll") \
+                for (int i = 0; i < NT; i++) fa[i] = *reinterpret_cast<const bf16x8_t *>(&Ws[brow0 + i * 16 * WS + ks * 32]); \
+_Pragma("unroll") \
+                for (int j = 0; j < MT1; j++) fb[j] = *reinterpret_cast<const bf16x8_t *>(&Xs[xrow[j] + aoff]); \
+_Pragma("unroll") \
+                for (int i = 0; i < NT; i++) \
+_Pragma("unroll") \
+                    for (int j = 0; j < MT1; j++) \
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0); \
             }
+            // streamed weights: the k-steps of a chunk are fully unrolled so that the next step's fragment
+            // loads overlap this step's MFMAs (one wave per SIMD: nothing else hides the LDS latency)
+            if (RESIDENT) {
+#pragma unroll 2
+                for (int ks = 0; ks < KW / 32; ks++) RB_KSTEP1(ks)
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KC / 32; ks++) RB_KSTEP1(ks)
+            }
+#undef RB_KSTEP1
         }
     }
     // conv1 epilogue: + bias, round to bf16 (what the separate launch stores), LeakyReLU (what the next
-    // launch applies on load); rows outside [0, T) are conv2's zero padding
+    // launch applies on load); rows outside [0, T) are conv2's zero padding.  The tile replaces the input tile.
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < MT1; j++) {
-        const int r = (wm * MT1 + j) * 16 + fr;
-        const int tmid = t0 - 8 + r;
+        const int g = wm * MT1 + j, e = g / TPE, lt = g - e * TPE;
+        const int tmid = t0 - 8 + lt * 16 + fr;
         const bool ok = tmid >= 0 && tmid < p.T;
 #pragma unroll
         for (int i = 0; i < NT; i++) {
@@ -212,41 +248,48 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
             const f32x4 a = acc[i][j];
             uint2 pk = make_uint2(f32x2_to_bf16x2(a[0] + bp1[i].x, a[1] + bp1[i].y), f32x2_to_bf16x2(a[2] + bp1[i].z, a[3] + bp1[i].w));
             pk = lrelu4(pk, p.slope);
-            *reinterpret_cast<uint2 *>(&Ms[r * XS + n]) = ok ? pk : make_uint2(0, 0);
+            *reinterpret_cast<uint2 *>(&Ms[(g * 16 + fr) * XS + n]) = ok ? pk : make_uint2(0, 0);
             acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
     }
-    // =========================== conv2 (dilation 1) on BM rows ===========================
+    // =========================== conv2 (dilation 1) on the first TPE-1 tiles of every entry ===========================
     {
         const int arow0 = (wm * MT1 * 16 + fr + 8 - h2) * XS + fg * 8;
-        const uint16_t *Wc = Ws;
         for (int ch = 0; ch < nchunk; ch++) {
             __syncthreads();                               // previous chunk consumed (first: conv1's last chunk)
             if (!RESIDENT) {
                 RB_W_COMMIT()
             } else {
-                RB_RC1(0, w0) RB_RC1(1, w1) RB_RC1(2, w2) RB_RC1(3, w3) RB_RC1(4, w4) RB_RC1(5, w5) RB_RC1(6, w6) RB_RC1(7, w7) RB_RC1(8, w8)
+                RB_RC1(0, w8) RB_RC1(1, w9) RB_RC1(2, w10) RB_RC1(3, w11) RB_RC1(4, w12) RB_RC1(5, w13) RB_RC1(6, w14) RB_RC1(7, w15)
             }
             __syncthreads();                               // (first: also publishes Ms)
             if (!RESIDENT && ch + 1 < nchunk) RB_W_PREFETCH(nchunk + ch + 1)
-            const int ksteps = KW / 32;
-            for (int ks = 0; ks < ksteps; ks++) {
-                const int k = ch * KC + ks * 32;
-                const int tap = k / CIN, ci = k - tap * CIN;
-                const int aoff = arow0 + tap * XS + ci;
-                bf16x8_t fa[NT], fb[MT1];
-#pragma unroll
-                for (int i = 0; i < NT; i++) fa[i] = *reinterpret_cast<const bf16x8_t *>(&Wc[brow0 + i * 16 * WS + ks * 32]);
-#pragma unroll
-                for (int j = 0; j < MT1; j++)
-                    if (wm * MT1 + j < WGM * MT1 - 1) fb[j] = *reinterpret_cast<const bf16x8_t *>(&Ms[aoff + j * 16 * XS]);
-#pragma unroll
-                for (int i = 0; i < NT; i++)
-#pragma unroll
-                    for (int j = 0; j < MT1; j++)
-                        if (wm * MT1 + j < WGM * MT1 - 1)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+#define RB_KSTEP2(ks)                                                                             \
+            {\
+                const int k = ch * KC + ks * 32; \
+                const int tap = k / CIN, ci = k - tap * CIN; \
+                const int aoff = arow0 + tap * XS + ci; \
+                bf16x8_t fa[NT], fb[MT1]; \
+_Pragma("unroll") \
+                for (int i = 0; i < NT; i++) fa[i] = *reinterpret_cast<const bf16x8_t *>(&Ws[brow0 + i * 16 * WS + ks * 32]); \
+_Pragma("unroll") \
+                for (int j = 0; j < MT1; j++) \
+                    if ((wm * MT1 + j) % TPE != TPE - 1) fb[j] = *reinterpret_cast<const bf16x8_t *>(&Ms[aoff + j * 16 * XS]); \
+_Pragma("unroll") \
+                for (int i = 0; i < NT; i++) \
+_Pragma("unroll") \
+                    for (int j = 0; j < MT1; j++) \
+                        if ((wm * MT1 + j) % TPE != TPE - 1) \
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0); \
             }
+            if (RESIDENT) {
+#pragma unroll 2
+                for (int ks = 0; ks < KW / 32; ks++) RB_KSTEP2(ks)
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KC / 32; ks++) RB_KSTEP2(ks)
+            }
+#undef RB_KSTEP2
         }
     }
 #undef RB_W_PREFETCH
@@ -255,19 +298,20 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
 #undef RB_C1
 #undef RB_R1
 #undef RB_RC1
-    // conv2 epilogue (+ bias, + x, * scale, + previous out) -> LDS -> full-row 16-byte stores
+    // conv2 epilogue (+ bias, + x, * scale, + previous out) -> LDS (over the intermediate tile) -> full-row 16-byte stores
     constexpr int OS = BN + 8;
     __syncthreads();
     uint16_t *Os = lds;
 #pragma unroll
     for (int j = 0; j < MT1; j++) {
-        const int tl = (wm * MT1 + j) * 16 + fr;
-        if (wm * MT1 + j >= WGM * MT1 - 1) continue;
+        const int g = wm * MT1 + j, e = g / TPE, lt = g - e * TPE;
+        if (lt == TPE - 1) continue;
+        const int orow = e * BME + lt * 16 + fr;
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             const int n = (wn * NT + i) * 16 + 4 * fg;
             const f32x4 a = acc[i][j];
-            const uint2 rv = rpre[i][j];
+            const uint2 rv = RES_LDS ? *reinterpret_cast<const uint2 *>(&Rs[orow * XS + n]) : rpre[i][j];
             float v0 = a[0] + bp2[i].x, v1 = a[1] + bp2[i].y, v2 = a[2] + bp2[i].z, v3 = a[3] + bp2[i].w;
             v0 += __uint_as_float(rv.x << 16);
             v1 += __uint_as_float(rv.x & 0xffff0000u);
@@ -281,43 +325,46 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
                 v2 += __uint_as_float(pv.y << 16);
                 v3 += __uint_as_float(pv.y & 0xffff0000u);
             }
-            *reinterpret_cast<uint2 *>(&Os[tl * OS + n]) = make_uint2(f32x2_to_bf16x2(v0, v1), f32x2_to_bf16x2(v2, v3));
+            *reinterpret_cast<uint2 *>(&Os[orow * OS + n]) = make_uint2(f32x2_to_bf16x2(v0, v1), f32x2_to_bf16x2(v2, v3));
         }
     }
     __syncthreads();
     constexpr int VPRO = BN / 8;
 #pragma unroll 4
-    for (int v = tid; v < BM * VPRO; v += 256) {
-        const int row = v / VPRO, c = (v - row * VPRO) * 8;
-        if (row < nvalid)
-            *reinterpret_cast<uint4 *>(ob + (int64_t)(t0 + row) * CIN + c) = *reinterpret_cast<const uint4 *>(&Os[row * OS + c]);
+    for (int v = tid; v < EPB * BME * VPRO; v += 256) {
+        const int orow = v / VPRO, c = (v - orow * VPRO) * 8;
+        const int e = EPB == 1 ? 0 : orow / BME;
+        const int row = orow - e * BME;
+        if (row < nvalid && b0 + e < p.nbatch)
+            *reinterpret_cast<uint4 *>(p.out + (int64_t)(b0 + e) * p.out_bstride + (int64_t)(t0 + row) * CIN + c) =
+                *reinterpret_cast<const uint4 *>(&Os[orow * OS + c]);
     }
 }
 
-template <int CIN, int WGM, int MT1, int NT, bool RESIDENT, int KC = 64>
+template <int CIN, int WGM, int MT1, int NT, bool RESIDENT, int EPB, bool RES_LDS, int KC = 64>
 static int launch_pair(PairParams &p, hipStream_t st)
 {
     constexpr int WGN = 4 / WGM;
-    constexpr int BM1 = WGM * MT1 * 16, BM = BM1 - 16, BN = WGN * NT * 16;
+    constexpr int TPE = WGM * MT1 / EPB, BM1E = TPE * 16, BME = BM1E - 16, BN = WGN * NT * 16;
     constexpr int XS = CIN + 8;
     const int K = p.taps * CIN;
-    const int R1 = BM1 + (p.taps - 1) * p.dil;
+    const int R1 = BM1E + (p.taps - 1) * p.dil;
     const int KW = RESIDENT ? K : KC;
     if (!RESIDENT && K % KC != 0) return fail(IFH_EINVAL, "resblock_pair: taps*c must be a multiple of 64");
-    if (RESIDENT && BN * (K / 8) > 9 * 256) return fail(IFH_EINVAL, "resblock_pair: too many taps");
-    const size_t bytes = ((size_t)((R1 * XS + 7) & ~7) + (size_t)BM1 * XS + (size_t)BN * (KW + 8)) * sizeof(uint16_t);
+    if (RESIDENT && BN * (K / 8) > 8 * 256) return fail(IFH_EINVAL, "resblock_pair: too many taps");
+    const size_t bytes = ((size_t)((EPB * R1 * XS + 7) & ~7) + (size_t)BN * (KW + 8) + (RES_LDS ? (size_t)EPB * BME * XS : 0)) * sizeof(uint16_t);
     if (bytes > 160 * 1024) return fail(IFH_EINVAL, "resblock_pair: tile does not fit in LDS (taps*dil too large)");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_resblock_pair<CIN, WGM, MT1, NT, RESIDENT, KC>,
+        hipError_t e = hipFuncSetAttribute((const void *)k_resblock_pair<CIN, WGM, MT1, NT, RESIDENT, KC, EPB, RES_LDS>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return check_hip(e, "resblock_pair lds attr");
         attr_set = true;
     }
-    const int nblk = (p.T + BM - 1) / BM;
+    const int nblk = (p.T + BME - 1) / BME;
     p.rows_per_block = (p.T + nblk - 1) / nblk;
-    dim3 grid(nblk, p.nbatch);
-    hipLaunchKernelGGL((k_resblock_pair<CIN, WGM, MT1, NT, RESIDENT, KC>), grid, dim3(256), bytes, st, p);
+    dim3 grid(nblk, (p.nbatch + EPB - 1) / EPB);
+    hipLaunchKernelGGL((k_resblock_pair<CIN, WGM, MT1, NT, RESIDENT, KC, EPB, RES_LDS>), grid, dim3(256), bytes, st, p);
     return IFH_OK;
 }
 
@@ -332,7 +379,7 @@ extern "C" int ifh_resblock_pair_bf16(const ifh_resblock_desc *d, ifh_stream_t s
     IFH_CHECK_ARG(d->nbatch >= 0 && d->t >= 0);
     if (d->nbatch == 0 || d->t == 0) return IFH_OK;
     IFH_CHECK_ARG(d->c == 32 || d->c == 64 || d->c == 128 || d->c == 256);
-    IFH_CHECK_ARG(d->taps >= 1 && d->taps <= 17 && (d->taps & 1) == 1 && d->dil >= 1 && d->nbatch < 65536);
+    IFH_CHECK_ARG(d->taps >= 1 && d->taps <= 15 && (d->taps & 1) == 1 && d->dil >= 1 && d->nbatch < 65536);
     IFH_CHECK_ARG((((uintptr_t)d->x) & 15) == 0 && (((uintptr_t)d->out) & 15) == 0 && (((uintptr_t)d->w1) & 15) == 0 &&
                   (((uintptr_t)d->w2) & 15) == 0 && d->x_bstride % 8 == 0 && d->out_bstride % 8 == 0);
     IFH_CHECK_ARG((!d->bias1 || (((uintptr_t)d->bias1) & 15) == 0) && (!d->bias2 || (((uintptr_t)d->bias2) & 15) == 0));
@@ -356,11 +403,11 @@ extern "C" int ifh_resblock_pair_bf16(const ifh_resblock_desc *d, ifh_stream_t s
     p.out_bstride = d->out_bstride;
     hipStream_t st = as_stream(stream);
     int rc;
-    switch (d->c) {
-    case 256: rc = launch_pair<256, 1, 4, 4, false>(p, st); break;     // conv1 64 rows, out 48
-    case 128: rc = launch_pair<128, 2, 7, 4, false>(p, st); break;     // conv1 224 rows, out 208
-    case 64: rc = launch_pair<64, 2, 7, 2, false>(p, st); break;       // conv1 224 rows, out 208
-    default: rc = launch_pair<32, 4, 4, 2, true>(p, st); break;        // conv1 256 rows, out 240, weights resident
+    switch (d->c) {                                                                // <C, WGM, MT1, NT, resident W, entries/block, residual rows in LDS>
+    case 256: rc = launch_pair<256, 1, 4, 4, false, 1, true>(p, st); break;        // conv1 64 rows, out 48
+    case 128: rc = launch_pair<128, 2, 7, 4, false, 1, true>(p, st); break;        // conv1 224 rows, out 208
+    case 64: rc = launch_pair<64, 2, 7, 2, false, 1, true>(p, st); break;          // conv1 224 rows, out 208
+    default: rc = launch_pair<32, 4, 4, 2, true, 1, false>(p, st); break;          // conv1 256 rows, out 240
     }
     if (rc != IFH_OK) return rc;
     IFH_LAUNCH_CHECK("resblock_pair_bf16");
