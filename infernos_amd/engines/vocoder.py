@@ -24,6 +24,8 @@ class HifiGan:
         self.pre_w, self.pre_b = ops.w_conv(sd['conv_pre.weight'], dev), ops.w_bias(sd['conv_pre.bias'], dev)
         self.up = [(ops.w_convT_phases(sd['upsampler.%d.weight' % i], dev), ops.w_bias(sd['upsampler.%d.bias' % i], dev))
                    for i in range(4)]
+        self.upf = [ops.w_convT_fused(sd['upsampler.%d.weight' % i], sd['upsampler.%d.bias' % i], dev) for i in range(4)]
+        self.fused_up = os.environ.get('IFH_NO_FUSED_UP') is None        # tuning switch
         self.res = []
         for i in range(4):
             lvl = []
@@ -59,11 +61,15 @@ class HifiGan:
         ops.conv(voc_in, self.pre_w, self.pre_b, B['x0'], nbatch=n, t_in=t0, t_out=t0, cin=80, n=512, taps=7, pad=3)
         prev, t, c = B['x0'], t0, 512
         for i in range(4):
-            phases, ub = self.up[i]
             u = B['u%d' % i]
-            for r, (w, pad) in enumerate(phases):
-                ops.conv(prev, w, ub, u, nbatch=n, t_in=t, t_out=t, cin=c, n=c // 2, taps=2, pad=pad, pre_slope=0.1,
-                         ostride=4, ooff=r)
+            if self.fused_up:          # the 4 output phases as one 3-tap conv with 4*Cout channels: x read once, rows written whole
+                wf, bf = self.upf[i]
+                ops.conv(prev, wf, bf, u, nbatch=n, t_in=t, t_out=t, cin=c, n=2 * c, taps=3, pad=1, pre_slope=0.1)
+            else:
+                phases, ub = self.up[i]
+                for r, (w, pad) in enumerate(phases):
+                    ops.conv(prev, w, ub, u, nbatch=n, t_in=t, t_out=t, cin=c, n=c // 2, taps=2, pad=pad, pre_slope=0.1,
+                             ostride=4, ooff=r)
             t, c = t * 4, c // 2
             h, xn = B['h%d' % i], B['xn%d' % i]
             rbuf = (B['r0%d' % i], B['r1%d' % i])

@@ -163,6 +163,24 @@ def w_conv(w, device, scale_per_out=None):
     return w.permute(0, 2, 1).to(BF16).contiguous().to(device)
 
 
+def w_convT_fused(w, bias, device):
+    """ConvTranspose1d(k=8, stride=4, padding=2) as ONE 3-tap convolution with 4*Cout output channels:
+    output row q of [T][4*Cout] is rows 4q..4q+3 of the [4T][Cout] result.  Phase r reads inputs
+    (q-1, q) with taps (r+6, r+2) for r in {0,1} and (q, q+1) with taps (r+2, r-2) for r in {2,3}; the
+    unused third tap is zero.  Returns (bf16 [4*Cout][3][Cin], f32 bias [4*Cout]); conv pad = 1."""
+    w = w.float()
+    cin, cout, k = w.shape
+    assert k == 8
+    wf = torch.zeros(4, cout, 3, cin)
+    for r in range(4):
+        if r < 2:
+            wf[r, :, 0], wf[r, :, 1] = w[:, :, r + 6].t(), w[:, :, r + 2].t()
+        else:
+            wf[r, :, 1], wf[r, :, 2] = w[:, :, r + 2].t(), w[:, :, r - 2].t()
+    return (wf.reshape(4 * cout, 3, cin).to(BF16).contiguous().to(device),
+            bias.float().repeat(4).contiguous().to(device))
+
+
 def w_convT_phases(w, device):
     """ConvTranspose1d(k=8, stride=4, padding=2) weight [Cin, Cout, 8] -> 4 phase weights
     bf16 [Cout][2][Cin] and their left pads.  Output o = 4q + r takes input q-1 (tap k=r+6) and q

@@ -114,6 +114,21 @@ def test_conv_transpose_phases_match_torch(dev):
     assert rel_l2(out.float().cpu(), ref) < 5e-3
 
 
+def test_conv_transpose_fused_matches_torch(dev):
+    """the four output phases of ConvTranspose1d(k8, s4, p2) as one 3-tap convolution with 4*Cout channels"""
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(6)
+    for (B, T, cin, cout) in ((3, 13, 128, 64), (2, 12, 512, 256), (2, 50, 64, 32)):
+        x = bfr(torch.randn(B, T, cin, generator=g))
+        w = bfr(torch.randn(cin, cout, 8, generator=g) / (cin * 2) ** 0.5)
+        bias = torch.randn(cout, generator=g) * 0.1
+        ref = F.conv_transpose1d(bfr(F.leaky_relu(x, 0.1)).transpose(1, 2), w, bias, stride=4, padding=2).transpose(1, 2)
+        wf, bf = ops.w_convT_fused(w, bias, dev)
+        out = torch.zeros(B, 4 * T, cout, dtype=BF, device=dev)
+        ops.conv(x.to(dev, BF), wf, bf, out, nbatch=B, t_in=T, t_out=T, cin=cin, n=4 * cout, taps=3, pad=1, pre_slope=0.1)
+        assert rel_l2(out.float().cpu(), ref) < 5e-3
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', [
     dict(B=3, T=48, c=256, k=3, d=1), dict(B=2, T=48, c=256, k=11, d=5), dict(B=2, T=61, c=256, k=7, d=3),
