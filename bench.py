@@ -96,12 +96,13 @@ def cpu_baseline(ncalls=8, threads=32):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=3)
-    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--calls-per-gpu', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--latency-ticks', type=int, default=200)
     ap.add_argument('--breakdown', action='store_true', help='print per-stage wall times to stderr')
+    ap.add_argument('--tts-lanes', type=int, default=3, help='TTS engine instances whose utterance cycles may overlap')
     ap.add_argument('--no-pipeline', action='store_true', help='run the stages of consecutive cycles strictly one after another')
     args = ap.parse_args()
 
@@ -138,7 +139,7 @@ def main():
 
     n_local = args.calls_per_gpu
     n_total = n_local * world
-    pipe = SpeechPipeline(n_local, dev)
+    pipe = SpeechPipeline(n_local, dev, tts_lanes=args.tts_lanes)
     codec = G711Codec().to(dev)
 
     def enc(x):
@@ -163,6 +164,7 @@ def main():
     # priming (untimed, not part of the W warm-up steps): two sequential cycles load every kernel and
     # capture the hipGraphs of the decode loops, so the timed steps replay them
     pipe.run_steps(frames_for, 2, pipelined=False)
+    pipe.prime()
     if args.warmup:
         res = run(args.warmup)
     torch.cuda.synchronize()
@@ -181,6 +183,11 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = n_total * UTT_SECONDS / (dt / args.steps)
 
+    if args.breakdown and rank == 0 and getattr(pipe, 'stage_wall', None):
+        sw = pipe.stage_wall
+        print('pipelined job wall ms: front %.1f (n=%d)  tts %.1f (n=%d)' % (
+            1e3 * sum(sw['front']) / max(1, len(sw['front'])), len(sw['front']),
+            1e3 * sum(sw['tts']) / max(1, len(sw['tts'])), len(sw['tts'])), file=sys.stderr)
     if args.breakdown and rank == 0 and world == 1:
         reset_state()
         fr = frames_for(0)

@@ -109,8 +109,7 @@ class Amendment:
         g = lambda k: sd[k]
         self.pm_w, self.pm_b = ops.w_conv(g('conv_pre_m.weight'), dev), ops.w_bias(g('conv_pre_m.bias'), dev)
         self.pa_w, self.pa_b = ops.w_conv(g('conv_pre_a.weight'), dev), ops.w_bias(g('conv_pre_a.bias'), dev)
-        self.up = [(ops.w_convT_phases(g('upsampler.%d.weight' % i), dev), ops.w_bias(g('upsampler.%d.bias' % i), dev))
-                   for i in range(2)]
+        self.upf = [ops.w_convT_fused(g('upsampler.%d.weight' % i), g('upsampler.%d.bias' % i), dev) for i in range(2)]
         self.r1_w, self.r1_b = ops.w_conv(g('resblock.conv1.weight'), dev), ops.w_bias(g('resblock.conv1.bias'), dev)
         self.r2_w, self.r2_b = ops.w_conv(g('resblock.conv2.weight'), dev), ops.w_bias(g('resblock.conv2.bias'), dev)
         self.po_w, self.po_b = ops.w_conv(g('post_conv.weight'), dev), ops.w_bias(g('post_conv.bias'), dev)
@@ -135,11 +134,9 @@ class Amendment:
                  ldc=192, out_off=32)
         prev, t, c = B['cat'], 12, 192
         for i, co in enumerate((128, 64)):
-            phases, ub = self.up[i]
+            wf, bf = self.upf[i]
             u = B['u%d' % i]
-            for r, (w, pad) in enumerate(phases):
-                ops.conv(prev, w, ub, u, nbatch=n, t_in=t, t_out=t, cin=c, n=co, taps=2, pad=pad, pre_slope=0.01,
-                         ostride=4, ooff=r)
+            ops.conv(prev, wf, bf, u, nbatch=n, t_in=t, t_out=t, cin=c, n=4 * co, taps=3, pad=1, pre_slope=0.01)
             prev, t, c = u, t * 4, co
         ops.conv(prev, self.r1_w, self.r1_b, B['h'], nbatch=n, t_in=192, t_out=192, cin=64, n=64, taps=3, pad=1, pre_slope=0.01)
         ops.conv(B['h'], self.r2_w, self.r2_b, B['r'], nbatch=n, t_in=192, t_out=192, cin=64, n=64, taps=3, dil=3, pad=3,

@@ -25,7 +25,7 @@ class CallTable:
         self.hist = torch.zeros((capacity, 16), dtype=torch.float32, device=dev)
         self._rs = get_resampler(8000, 16000, str(dev))
 
-    def tick(self, frames: torch.Tensor, slots: torch.Tensor, pcm8k=None, pcm16k=None):
+    def tick(self, frames: torch.Tensor, slots: torch.Tensor, pcm8k=None, pcm16k=None, want_ready=True):
         """frames u8 [n,160] (device), slots int32 [n] -> (pcm8k f32 [n,160], pcm16k f32 [n,320],
         win_ready int32 [n] view by slot)."""
         dev = self.device
@@ -42,7 +42,7 @@ class CallTable:
                 _lib.ptr(frames), _lib.ptr(slots), n, _lib.ptr(self.fifo), _lib.ptr(self.fifo_len), _lib.ptr(self.win),
                 _lib.ptr(self.win_ready), _lib.ptr(self.hist), _lib.ptr(pcm8k), _lib.ptr(pcm16k), self._rs.handle,
                 _lib.stream_ptr(dev)), 'ifh_ingest_tick')
-        return pcm8k, pcm16k, self.win_ready[slots.long()]
+        return pcm8k, pcm16k, (self.win_ready[slots.long()] if want_ready else None)
 
 
 def mux_encode(tracks: torch.Tensor, present: torch.Tensor, ndiv: torch.Tensor):

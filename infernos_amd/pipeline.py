@@ -65,7 +65,7 @@ class BatchedVAD:
 
 class SpeechPipeline:
     def __init__(self, ncalls: int, device=None, whisper_family='whisper_tiny', seed=0, n_text=64, n_infer=10,
-                 n_new_tokens=32, tts_output_sr=8000, weights=None):
+                 n_new_tokens=32, tts_output_sr=8000, weights=None, tts_lanes=3):
         from .engines.whisper import Whisper
         from .features import WhisperLogMel
         from .tts import HelloSippyRTPipe
@@ -82,14 +82,19 @@ class SpeechPipeline:
             self.logmel = WhisperLogMel(self.whisper.n_mel, dev)
             tw = {k: (w.get(k) or synth_state_dict(k, seed, **({'stop_bias': -20.0} if k == 'speecht5_tts' else {})))
                   for k in ('speecht5_tts', 'hifigan', 'amendment')}
+            # TTS lanes: independent engine instances (own batch states, frame buffers, hipGraphs and streams)
+            # so that the synthesis of consecutive utterance cycles can be in flight together (run_steps)
             self.tts = HelloSippyRTPipe(dev, weights=tw, processor=_NoProcessor(), speaker_embeddings=[],
                                         output_sr=tts_output_sr)
+            self.tts_lanes = [self.tts] + [self.tts.clone_for_lane() for _ in range(max(1, tts_lanes) - 1)]
         self.slots = torch.arange(ncalls, dtype=torch.int32, device=dev)
         self.prompt = torch.tensor([[50258, 50259, 50359, 50363]] * ncalls, dtype=torch.int32)
         g = torch.Generator().manual_seed(2000 + seed)
         self.speakers = torch.randn(ncalls, 512, generator=g)
         self.text_ids = torch.randint(4, 80, (ncalls, n_text), generator=g, dtype=torch.int32)
-        self._side_stream = torch.cuda.Stream(device=dev)
+        self._side_streams = [torch.cuda.Stream(device=dev) for _ in self.tts_lanes]
+        self._lane_streams = [torch.cuda.Stream(device=dev) for _ in self.tts_lanes]
+        self._side_stream = self._side_streams[0]
         self.pcm8k = torch.empty((ncalls, 160), dtype=torch.float32, device=dev)
         self.pcm16k = torch.empty((ncalls, 320), dtype=torch.float32, device=dev)
 
@@ -100,7 +105,7 @@ class SpeechPipeline:
         chunks = [[] for _ in range(self.n)]
         nbytes = int(self.calls.fifo_len[0]) if T else 0
         for t in range(T):
-            self.calls.tick(frames[t], self.slots, self.pcm8k, self.pcm16k)
+            self.calls.tick(frames[t], self.slots, self.pcm8k, self.pcm16k, want_ready=False)
             nbytes += 160
             if nbytes >= WINDOW:                 # every stream completes its window on the same tick
                 nbytes -= WINDOW
@@ -135,13 +140,13 @@ class SpeechPipeline:
         return toks, nsp, (lens8.float() / 8000.0)
 
     # ---- stage 3 -----------------------------------------------------------------------------
-    def synthesize(self, text_ids=None, overlap=True):
+    def synthesize(self, text_ids=None, overlap=True, lane=0):
         """-> (ulaw u8 [N, n_infer*A] device, valid sample count per call, spans) with A = 8192/(16000/output_sr).
         Two-stream schedule: the decoder steps of call c+1 (launch/latency-bound, few CUs busy) run on the
         main stream while postnet + HiFi-GAN + amendment + resample + mu-law of call c run on a second
         stream (the frame buffers are double-buffered by call parity).  This is the 3-stage pipeline of the
         reference's own harness (HelloSippyRTPipeTest.py:126-161) expressed with HIP streams/events."""
-        dev, pp = self.device, self.tts
+        dev, pp = self.device, self.tts_lanes[lane]
         ids = self.text_ids if text_ids is None else text_ids
         state = _make_state(pp, ids, self.speakers)
         st = state.dev
@@ -152,7 +157,7 @@ class SpeechPipeline:
         valid = torch.zeros(self.n, dtype=torch.int64)
         spans = []
         main = torch.cuda.current_stream(dev)
-        side = self._side_stream if overlap else main
+        side = self._side_streams[lane] if overlap else main
         ren_done = [None, None]
         for c in range(self.n_infer):
             par = st.ncalls & 1
@@ -206,12 +211,21 @@ class SpeechPipeline:
         return dict(tokens=toks, no_speech_prob=nsp, stt_seconds=secs,
                     chunks=[[(c.ipos, c.audio.numel()) for c in lst] for lst in chunks])
 
+    def prime(self):
+        """Untimed preparation of every TTS lane: two eager passes (load the kernels, size the buffers) and one
+        that captures the hipGraphs of the decode steps and of the renderer."""
+        for lane in range(len(self.tts_lanes)):
+            for _ in range(3):
+                self.synthesize(lane=lane)
+        torch.cuda.synchronize(self.device)
+
     def run_steps(self, frames_fn, nsteps: int, pipelined: bool = True, on_cycle=None):
         """nsteps utterance cycles.  Pipelined: a front-end thread (own HIP stream) runs ingest+STT of cycle
-        k+1 while this thread runs the TTS of cycle k -- in steady-state serving the stages always work on
-        different utterances at once; every cycle still does all of its work inside the call.
-        frames_fn(k) -> u8 [T,N,160] device tensor for cycle k and on_cycle(result) both run on the calling
-        thread (they may be collectives)."""
+        k+1 while TTS lane k % L (own thread and streams) synthesises cycle k -- and, the decode loop being a
+        latency-bound chain of small launches that leaves most CUs idle, lane (k-1) % L may still be finishing
+        cycle k-1.  In steady-state serving the stages always work on different utterances at once; every
+        cycle still does all of its work inside the call.  frames_fn(k) -> u8 [T,N,160] device tensor for
+        cycle k and on_cycle(result) both run on the calling thread, in cycle order (they may be collectives)."""
         if not pipelined or nsteps < 2:
             out = None
             for k in range(nsteps):
@@ -222,9 +236,11 @@ class SpeechPipeline:
             return out
         from concurrent.futures import ThreadPoolExecutor
         dev = self.device
+        L = len(self.tts_lanes)
         if not hasattr(self, '_front_stream'):
             self._front_stream = torch.cuda.Stream(device=dev)
             self._pool = ThreadPoolExecutor(max_workers=1)
+            self._tts_pool = ThreadPoolExecutor(max_workers=L)
 
         main = torch.cuda.current_stream(dev)
 
@@ -236,25 +252,56 @@ class SpeechPipeline:
             ev.record(main)
             return fr, ev
 
+        import time
+        self.stage_wall = {'front': [], 'tts': []}                 # host wall seconds per job (bench --breakdown)
+
         def job(fr, fr_ready):
             torch.cuda.set_device(dev)
+            t0 = time.perf_counter()
             with torch.cuda.stream(self._front_stream):
                 self._front_stream.wait_event(fr_ready)
                 r = self.front(fr)
                 ev = torch.cuda.Event()
                 ev.record(self._front_stream)
+            self.stage_wall['front'].append(time.perf_counter() - t0)
             return r, ev
-        fut = self._pool.submit(job, *fetch(0))
+
+        def tts_job(lane, front_fut):
+            torch.cuda.set_device(dev)
+            r, stt_done = front_fut.result()
+            t0 = time.perf_counter()
+            stream = self._lane_streams[lane]
+            with torch.cuda.stream(stream):
+                stream.wait_event(stt_done)                        # T2T stub consumes the STT tokens
+                r.update(zip(('ulaw', 'tts_samples', 'spans'), self.synthesize(lane=lane)))
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            self.stage_wall['tts'].append(time.perf_counter() - t0)
+            return r, ev
+
+        fronts, ttss = {}, {}
         out = None
-        for k in range(nsteps):
-            nxt = fetch(k + 1) if k + 1 < nsteps else None
-            out, ev = fut.result()
-            if nxt is not None:
-                fut = self._pool.submit(job, *nxt)
-            main.wait_event(ev)                                    # T2T stub consumes the STT tokens
-            out.update(zip(('ulaw', 'tts_samples', 'spans'), self.synthesize()))
+        import sys
+        swi = sys.getswitchinterval()
+        sys.setswitchinterval(2e-4)        # several launch threads: hand the GIL over quickly
+
+        def retire(k):
+            r, ev = ttss.pop(k).result()
+            main.wait_event(ev)
             if on_cycle is not None:
-                on_cycle(out)                                      # e.g. egress gather of this cycle's output rows
+                on_cycle(r)                                        # e.g. egress gather of this cycle's output rows
+            return r
+        nfront = 0
+        for k in range(nsteps):
+            while nfront < min(nsteps, k + 1 + L):                 # the front end runs up to L cycles ahead of the retired one
+                fronts[nfront] = self._pool.submit(job, *fetch(nfront))
+                nfront += 1
+            ttss[k] = self._tts_pool.submit(tts_job, k % L, fronts.pop(k))
+            if k >= L - 1:
+                out = retire(k - (L - 1))
+        for k in range(max(0, nsteps - (L - 1)), nsteps):
+            out = retire(k)
+        sys.setswitchinterval(swi)
         return out
 
     def step(self, frames: torch.Tensor):

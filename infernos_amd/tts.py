@@ -130,6 +130,21 @@ class HelloSippyRTPipe:
         self.output_sr = output_sr
         self.mask_source = mask_source if mask_source is not None else DeviceMaskSource(dev)
 
+    def clone_for_lane(self) -> 'HelloSippyRTPipe':
+        """A second engine over the SAME device weights with its own batch states, frame/vocoder buffers, captured
+        graphs and dropout-mask stream: lets the synthesis of different utterance batches be in flight together
+        (SpeechPipeline.run_steps) without a second copy of the models in HBM."""
+        import copy
+        c = copy.copy(self)
+        c.model = copy.copy(self.model)
+        c.model._states = {}
+        c.vocoder = copy.copy(self.vocoder)
+        c.vocoder._bufs = {}
+        c.chunker = copy.copy(self.chunker)
+        c.chunker._bufs = {}
+        c.mask_source = DeviceMaskSource(self.device)
+        return c
+
     def _render(self, st, par):
         """postnet -> carry + 4 overlapped chunks -> HiFi-GAN -> AmendmentNetwork1 for the call with
         parity `par`; writes st.render_out[par] (bf16 [B,8192]).  Pure kernel launches over buffers

@@ -69,3 +69,34 @@ def test_pipeline_cycle_small(built_lib):
     assert torch.equal(ul2, ul) and torch.equal(ul3, ul)
     audio = odsp.g711_decode(ul.cpu().numpy())
     assert np.isfinite(audio).all() and 1e-4 < np.abs(audio).mean() < 0.5
+
+
+def test_pipelined_tts_lanes_match_sequential(built_lib):
+    """run_steps with the front-end thread and two overlapping TTS lanes returns, cycle by cycle and in order,
+    the bytes of the strictly sequential schedule."""
+    from infernos_amd import _lib
+    from infernos_amd.pipeline import SpeechPipeline
+    from infernos_amd.synth import synth_utterance
+    dev = _lib.require_device('cuda:0')
+    N = 3
+    pipe = SpeechPipeline(N, dev, n_infer=3, n_new_tokens=4, tts_lanes=2)
+    fixed = torch.randint(0, 2, (16, 2, 256), dtype=torch.uint8, device=dev)
+    for lane in pipe.tts_lanes:
+        lane.mask_source = lambda n: fixed
+    x = np.stack([synth_utterance(1000 + i, 10.0) for i in range(N)])
+    ulaw = odsp.g711_encode(x)
+    frames = [torch.from_numpy(np.ascontiguousarray(np.roll(ulaw, k, axis=0).reshape(N, 500, 160).transpose(1, 0, 2))).to(dev)
+              for k in range(2)]
+    ref = []
+    for k in range(2):
+        r = pipe.run_steps(lambda _k, k=k: frames[k], 1, pipelined=False)
+        ref.append((r['ulaw'].clone(), r['tokens'].clone()))
+    pipe.prime()
+    got = []
+    pipe.run_steps(lambda k: frames[k % 2], 6, pipelined=True,
+                   on_cycle=lambda r: got.append((r['ulaw'].clone(), r['tokens'].clone())))
+    torch.cuda.synchronize()
+    assert len(got) == 6
+    for k, (ul, tk) in enumerate(got):
+        assert torch.equal(tk, ref[k % 2][1]), k
+        assert torch.equal(ul, ref[k % 2][0]), k
