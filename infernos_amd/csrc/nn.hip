@@ -485,10 +485,13 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     hipStream_t st = as_stream(stream);
     if (M <= 64 && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre) {
         const dim3 grid((d->n + 15) / 16, (unsigned)((M + 15) / 16));
+        // waves per block = K split: 2 (12 k-steps each at K = 768) / 4 for deep K.  With several decode loops in
+        // flight (SpeechPipeline TTS lanes) fewer, longer waves beat 4/8 short ones by ~6 % end to end; alone the
+        // launch takes the same time either way.
         if (p.K >= 2048)
-            hipLaunchKernelGGL((k_gemm_skinny<8, 12>), grid, dim3(512), 0, st, p);
-        else
             hipLaunchKernelGGL((k_gemm_skinny<4, 12>), grid, dim3(256), 0, st, p);
+        else
+            hipLaunchKernelGGL((k_gemm_skinny<2, 12>), grid, dim3(128), 0, st, p);
     } else if (try_launch_conv_direct(p, pre, st)) {
         // residual-block shapes: input tile resident in LDS (conv.hip)
     } else if (d->n <= 32)
