@@ -96,8 +96,8 @@ def cpu_baseline(ncalls=8, threads=32):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=8)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=24)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--calls-per-gpu', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--latency-ticks', type=int, default=200)
