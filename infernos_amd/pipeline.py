@@ -65,13 +65,14 @@ class BatchedVAD:
 
 class SpeechPipeline:
     def __init__(self, ncalls: int, device=None, whisper_family='whisper_tiny', seed=0, n_text=64, n_infer=10,
-                 n_new_tokens=32, tts_output_sr=8000, weights=None, tts_lanes=3):
+                 n_new_tokens=32, tts_output_sr=8000, weights=None, tts_lanes=3, tts_overlap=True):
         from .engines.whisper import Whisper
         from .features import WhisperLogMel
         from .tts import HelloSippyRTPipe
         from .weights import synth_state_dict
         self.device = dev = _lib.require_device(device)
         self.n, self.n_text, self.n_infer, self.n_new = ncalls, n_text, n_infer, n_new_tokens
+        self.tts_overlap = tts_overlap      # render of chunk c on a second stream while chunk c+1 decodes (within a lane)
         with torch.cuda.device(dev):
             self.calls = CallTable(ncalls, dev)
             self.vad = BatchedVAD(ncalls, dev)
@@ -140,13 +141,14 @@ class SpeechPipeline:
         return toks, nsp, (lens8.float() / 8000.0)
 
     # ---- stage 3 -----------------------------------------------------------------------------
-    def synthesize(self, text_ids=None, overlap=True, lane=0):
+    def synthesize(self, text_ids=None, overlap=None, lane=0):
         """-> (ulaw u8 [N, n_infer*A] device, valid sample count per call, spans) with A = 8192/(16000/output_sr).
         Two-stream schedule: the decoder steps of call c+1 (launch/latency-bound, few CUs busy) run on the
         main stream while postnet + HiFi-GAN + amendment + resample + mu-law of call c run on a second
         stream (the frame buffers are double-buffered by call parity).  This is the 3-stage pipeline of the
         reference's own harness (HelloSippyRTPipeTest.py:126-161) expressed with HIP streams/events."""
         dev, pp = self.device, self.tts_lanes[lane]
+        overlap = self.tts_overlap if overlap is None else overlap
         ids = self.text_ids if text_ids is None else text_ids
         state = _make_state(pp, ids, self.speakers)
         st = state.dev
@@ -238,7 +240,7 @@ class SpeechPipeline:
         dev = self.device
         L = len(self.tts_lanes)
         if not hasattr(self, '_front_stream'):
-            self._front_stream = torch.cuda.Stream(device=dev)
+            self._front_stream = torch.cuda.Stream(device=dev)      # (a high-priority stream here made every stage slower)
             self._pool = ThreadPoolExecutor(max_workers=1)
             self._tts_pool = ThreadPoolExecutor(max_workers=L)
 
