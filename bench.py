@@ -103,6 +103,7 @@ def main():
     ap.add_argument('--latency-ticks', type=int, default=200)
     ap.add_argument('--breakdown', action='store_true', help='print per-stage wall times to stderr')
     ap.add_argument('--tts-lanes', type=int, default=3, help='TTS engine instances whose utterance cycles may overlap')
+    ap.add_argument('--tts-group', type=int, default=1, help='utterance cycles synthesised as one TTS batch')
     ap.add_argument('--no-tts-overlap', action='store_true', help='render on the lane stream instead of a second stream per lane')
     ap.add_argument('--no-pipeline', action='store_true', help='run the stages of consecutive cycles strictly one after another')
     args = ap.parse_args()
@@ -140,7 +141,7 @@ def main():
 
     n_local = args.calls_per_gpu
     n_total = n_local * world
-    pipe = SpeechPipeline(n_local, dev, tts_lanes=args.tts_lanes, tts_overlap=not args.no_tts_overlap)
+    pipe = SpeechPipeline(n_local, dev, tts_lanes=args.tts_lanes, tts_overlap=not args.no_tts_overlap, tts_group=args.tts_group)
     codec = G711Codec().to(dev)
 
     def enc(x):

@@ -196,7 +196,7 @@ typedef struct ifh_conv_desc {
     void *out2;
     int64_t out2_bstride;
     int32_t ldc2, ooff2, dyn_ooff2_mul;
-    /* LayerNorm folded around a decode-step GEMM (rows <= 64, taps == 1), so that the three LayerNorm launches
+    /* LayerNorm folded around a decode-step GEMM (rows <= 256, taps == 1), so that the three LayerNorm launches
      * per transformer layer disappear from the latency-bound decode loop:
      *   stats_out int64 [rows][2]: += (sum, sum of squares) of every stored output row in 2^16 fixed point,
      *       by integer atomics (commutative, hence bit-reproducible); the caller zeroes it per step;

@@ -11,7 +11,7 @@
 
 namespace ifh {
 
-// ---- skinny GEMM for decode steps (M <= 64 rows, taps == 1): latency-bound weight streaming.
+// ---- skinny GEMM for decode steps (M <= 256 rows, taps == 1): latency-bound weight streaming.
 // One block = 16 output channels x 16 rows; its NW waves split K so that every lane has all of
 // its 16-byte weight/activation fragments in flight at once (one memory round trip), straight
 // from global/L2 (each weight byte is used once per block: no LDS staging); the NW partial
@@ -471,7 +471,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     p.ln_dim = d->ln_dim;
     p.ln_eps = d->ln_eps;
     if (d->aln_stats || d->rln_stats || d->stats_out) {
-        IFH_CHECK_ARG((int64_t)d->nbatch * d->t_out <= 64 && d->taps == 1 && d->stride == 1 && d->pad == 0 && d->pre_slope == 1.0f);
+        IFH_CHECK_ARG((int64_t)d->nbatch * d->t_out <= 256 && d->taps == 1 && d->stride == 1 && d->pad == 0 && d->pre_slope == 1.0f);
         IFH_CHECK_ARG(d->n % 16 == 0 && d->ln_dim > 0 && !d->colmask && !d->accumulate && p.vec_ok && p.res_vec_ok);
         IFH_CHECK_ARG(!d->aln_stats || d->aln_c1);
         IFH_CHECK_ARG(!d->rln_stats || (d->rln_gamma && d->rln_beta && d->resid));
@@ -483,7 +483,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     const int64_t M = (int64_t)d->nbatch * d->t_out;
     IFH_CHECK_ARG(M < (1ll << 31));
     hipStream_t st = as_stream(stream);
-    if (M <= 64 && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre) {
+    if (M <= 256 && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre) {
         const dim3 grid((d->n + 15) / 16, (unsigned)((M + 15) / 16));
         // waves per block = K split: 2 (12 k-steps each at K = 768) / 4 for deep K.  With several decode loops in
         // flight (SpeechPipeline TTS lanes) fewer, longer waves beat 4/8 short ones by ~6 % end to end; alone the

@@ -189,7 +189,8 @@ class TTSBatchState:
         self.plog = e(B, 2, dt=torch.float32)
         self.plog16 = e(B, 16, dt=torch.float32)            # LN-folded path: stop logits in cols 0..1 of a 16-wide tile
         self.t2, self.t3, self.x0 = e(B, D), e(B, D), e(B, D)
-        self.stats = torch.zeros((3 * len(model.dec_layers), 64, 2), dtype=torch.int64, device=dev)
+        self.stat_rows = max(64, -(-B // 16) * 16)
+        self.stats = torch.zeros((3 * len(model.dec_layers), self.stat_rows, 2), dtype=torch.int64, device=dev)
         self.pn = [e(B, 32, 256), e(B, 32, 256)]
         self.graphs = {}
         self.eager_calls = 0
@@ -278,7 +279,7 @@ def _decoder_step_folded(model: 'SpeechT5', st: TTSBatchState, s: int, threshold
     dev = model.device
     B, T = st.B, st.T
     masks, spec, stats = st.masks, st.spec[par], st.stats
-    SO = 64 * 2                                      # int64 elements per stats slot ([64 rows][2])
+    SO = st.stat_rows * 2                            # int64 elements per stats slot ([rows][2])
     st.stats.zero_()
     ops.linear(spec, *model.p0, st.h1, rows=B, k=80, n=256, x_off=2 * s * 80, lda=33 * 80, act=ACT_RELU,
                colmask=masks, colmask_off=(s * 2) * 256)
@@ -335,7 +336,7 @@ def decoder_steps(model: 'SpeechT5', st: TTSBatchState, masks: torch.Tensor, nst
     st.spec[par][:, 0, :].copy_(st.spec[1 - par][:, 32, :])       # carry the last produced frame
     # the first call on a state shape runs eagerly (loads every kernel); graphs are captured from the second on
     use_graphs = use_graphs and st.eager_calls >= 2
-    step_fn = _decoder_step_folded if (model.fold_ln and st.B <= 64) else _decoder_step
+    step_fn = _decoder_step_folded if (model.fold_ln and st.B <= 256) else _decoder_step
     for s in range(nsteps):
         if not use_graphs:
             step_fn(model, st, s, threshold, par)

@@ -65,7 +65,7 @@ class BatchedVAD:
 
 class SpeechPipeline:
     def __init__(self, ncalls: int, device=None, whisper_family='whisper_tiny', seed=0, n_text=64, n_infer=10,
-                 n_new_tokens=32, tts_output_sr=8000, weights=None, tts_lanes=3, tts_overlap=True):
+                 n_new_tokens=32, tts_output_sr=8000, weights=None, tts_lanes=3, tts_overlap=True, tts_group=1):
         from .engines.whisper import Whisper
         from .features import WhisperLogMel
         from .tts import HelloSippyRTPipe
@@ -73,6 +73,7 @@ class SpeechPipeline:
         self.device = dev = _lib.require_device(device)
         self.n, self.n_text, self.n_infer, self.n_new = ncalls, n_text, n_infer, n_new_tokens
         self.tts_overlap = tts_overlap      # render of chunk c on a second stream while chunk c+1 decodes (within a lane)
+        self.tts_group = max(1, tts_group)  # utterance cycles synthesised as one TTS batch (rows = group * ncalls)
         with torch.cuda.device(dev):
             self.calls = CallTable(ncalls, dev)
             self.vad = BatchedVAD(ncalls, dev)
@@ -141,7 +142,7 @@ class SpeechPipeline:
         return toks, nsp, (lens8.float() / 8000.0)
 
     # ---- stage 3 -----------------------------------------------------------------------------
-    def synthesize(self, text_ids=None, overlap=None, lane=0):
+    def synthesize(self, text_ids=None, overlap=None, lane=0, group=1):
         """-> (ulaw u8 [N, n_infer*A] device, valid sample count per call, spans) with A = 8192/(16000/output_sr).
         Two-stream schedule: the decoder steps of call c+1 (launch/latency-bound, few CUs busy) run on the
         main stream while postnet + HiFi-GAN + amendment + resample + mu-law of call c run on a second
@@ -150,16 +151,21 @@ class SpeechPipeline:
         dev, pp = self.device, self.tts_lanes[lane]
         overlap = self.tts_overlap if overlap is None else overlap
         ids = self.text_ids if text_ids is None else text_ids
-        state = _make_state(pp, ids, self.speakers)
+        spk = self.speakers
+        if group > 1:                                  # the utterances of `group` consecutive cycles as ONE batch (rows g*n + call)
+            ids, spk = ids.repeat(group, 1), spk.repeat(group, 1)
+        nb = ids.size(0)
+        state = _make_state(pp, ids, spk)
         st = state.dev
         rr = pp.model_sr // pp.output_sr
         A = 8192 // rr
         stepsize = 512 // rr
-        out = torch.empty((self.n, self.n_infer * A), dtype=torch.uint8, device=dev)
-        valid = torch.zeros(self.n, dtype=torch.int64)
+        out = torch.empty((nb, self.n_infer * A), dtype=torch.uint8, device=dev)
+        valid = torch.zeros(nb, dtype=torch.int64)
         spans = []
         main = torch.cuda.current_stream(dev)
         side = self._side_streams[lane] if overlap else main
+        out.record_stream(side)                 # written on the render stream: the allocator must not recycle it early
         ren_done = [None, None]
         for c in range(self.n_infer):
             par = st.ncalls & 1
@@ -174,7 +180,7 @@ class SpeechPipeline:
                 pcm = bf.float()
                 if pp.resampler is not None:
                     pcm = pp.resampler(pcm)
-                tmp = torch.empty((self.n, A), dtype=torch.uint8, device=dev)
+                tmp = torch.empty((nb, A), dtype=torch.uint8, device=dev)
                 _lib.check(_lib.lib().ifh_g711_encode_f32_u8(_lib.ptr(pcm), _lib.ptr(tmp), pcm.numel(), _lib.stream_ptr(dev)),
                            'ifh_g711_encode_f32_u8')
                 out[:, c * A:(c + 1) * A].copy_(tmp)
@@ -184,7 +190,7 @@ class SpeechPipeline:
             idx = st.idx
             ends = st.ends_at.cpu().tolist()                     # the per-call sync the reference also has (.item())
             row = []
-            for i in range(self.n):
+            for i in range(nb):
                 s_ = max(0, A - (idx - 1) * stepsize)
                 e_ = min(A, A - ((idx - ends[i]) * stepsize if ends[i] >= 0 else 0))
                 row.append((s_, max(s_, e_)))
@@ -217,8 +223,9 @@ class SpeechPipeline:
         """Untimed preparation of every TTS lane: two eager passes (load the kernels, size the buffers) and one
         that captures the hipGraphs of the decode steps and of the renderer."""
         for lane in range(len(self.tts_lanes)):
-            for _ in range(3):
-                self.synthesize(lane=lane)
+            for g in sorted({self.tts_group, 1} | set(range(1, self.tts_group))):     # a trailing group may be smaller
+                for _ in range(3):
+                    self.synthesize(lane=lane, group=g)
         torch.cuda.synchronize(self.device)
 
     def run_steps(self, frames_fn, nsteps: int, pipelined: bool = True, on_cycle=None):
@@ -262,24 +269,33 @@ class SpeechPipeline:
             t0 = time.perf_counter()
             with torch.cuda.stream(self._front_stream):
                 self._front_stream.wait_event(fr_ready)
+                fr.record_stream(self._front_stream)
                 r = self.front(fr)
                 ev = torch.cuda.Event()
                 ev.record(self._front_stream)
             self.stage_wall['front'].append(time.perf_counter() - t0)
             return r, ev
 
-        def tts_job(lane, front_fut):
+        G = self.tts_group
+
+        def tts_job(lane, front_futs):
             torch.cuda.set_device(dev)
-            r, stt_done = front_fut.result()
+            rs = [f.result() for f in front_futs]                  # the G cycles of this group, in order
             t0 = time.perf_counter()
             stream = self._lane_streams[lane]
             with torch.cuda.stream(stream):
-                stream.wait_event(stt_done)                        # T2T stub consumes the STT tokens
-                r.update(zip(('ulaw', 'tts_samples', 'spans'), self.synthesize(lane=lane)))
+                for _, stt_done in rs:
+                    stream.wait_event(stt_done)                    # T2T stub consumes the STT tokens
+                g = len(rs)
+                ulaw, valid, spans = self.synthesize(lane=lane, group=g)
+                n = self.n
+                for j, (r, _) in enumerate(rs):
+                    r.update(ulaw=ulaw[j * n:(j + 1) * n], tts_samples=valid[j * n:(j + 1) * n],
+                             spans=[row[j * n:(j + 1) * n] for row in spans])
                 ev = torch.cuda.Event()
                 ev.record(stream)
             self.stage_wall['tts'].append(time.perf_counter() - t0)
-            return r, ev
+            return [r for r, _ in rs], ev
 
         fronts, ttss = {}, {}
         out = None
@@ -287,22 +303,28 @@ class SpeechPipeline:
         swi = sys.getswitchinterval()
         sys.setswitchinterval(2e-4)        # several launch threads: hand the GIL over quickly
 
-        def retire(k):
-            r, ev = ttss.pop(k).result()
+        def retire(gi):
+            rs, ev = ttss.pop(gi).result()
             main.wait_event(ev)
-            if on_cycle is not None:
-                on_cycle(r)                                        # e.g. egress gather of this cycle's output rows
-            return r
+            for r in rs:
+                for v in r.values():                               # produced on other streams, consumed on this one
+                    if torch.is_tensor(v) and v.is_cuda:
+                        v.record_stream(main)
+                if on_cycle is not None:
+                    on_cycle(r)                                    # e.g. egress gather of this cycle's output rows
+            return rs[-1]
+        ngroups = (nsteps + G - 1) // G
         nfront = 0
-        for k in range(nsteps):
-            while nfront < min(nsteps, k + 1 + L):                 # the front end runs up to L cycles ahead of the retired one
+        for gi in range(ngroups):
+            hi = min(nsteps, (gi + 1) * G)
+            while nfront < min(nsteps, hi + L * G):                # the front end runs up to L groups ahead
                 fronts[nfront] = self._pool.submit(job, *fetch(nfront))
                 nfront += 1
-            ttss[k] = self._tts_pool.submit(tts_job, k % L, fronts.pop(k))
-            if k >= L - 1:
-                out = retire(k - (L - 1))
-        for k in range(max(0, nsteps - (L - 1)), nsteps):
-            out = retire(k)
+            ttss[gi] = self._tts_pool.submit(tts_job, gi % L, [fronts.pop(k) for k in range(gi * G, hi)])
+            if gi >= L - 1:
+                out = retire(gi - (L - 1))
+        for gi in range(max(0, ngroups - (L - 1)), ngroups):
+            out = retire(gi)
         sys.setswitchinterval(swi)
         return out
 

@@ -71,15 +71,17 @@ def test_pipeline_cycle_small(built_lib):
     assert np.isfinite(audio).all() and 1e-4 < np.abs(audio).mean() < 0.5
 
 
-def test_pipelined_tts_lanes_match_sequential(built_lib):
-    """run_steps with the front-end thread and two overlapping TTS lanes returns, cycle by cycle and in order,
-    the bytes of the strictly sequential schedule."""
+@pytest.mark.parametrize('lanes,group', [(2, 1), (2, 2), (1, 3)])
+def test_pipelined_tts_lanes_match_sequential(built_lib, lanes, group):
+    """run_steps with the front-end thread, overlapping TTS lanes and grouped TTS batches (the utterances of
+    `group` consecutive cycles synthesised as one batch) returns, cycle by cycle and in order, the bytes of the
+    strictly sequential schedule."""
     from infernos_amd import _lib
     from infernos_amd.pipeline import SpeechPipeline
     from infernos_amd.synth import synth_utterance
     dev = _lib.require_device('cuda:0')
-    N = 3
-    pipe = SpeechPipeline(N, dev, n_infer=3, n_new_tokens=4, tts_lanes=2)
+    N = 5       # 5 x 64 text rows: no GEMM of the grouped batch crosses a kernel-selection threshold (M <= 256 -> skinny)
+    pipe = SpeechPipeline(N, dev, n_infer=3, n_new_tokens=4, tts_lanes=lanes, tts_group=group)
     fixed = torch.randint(0, 2, (16, 2, 256), dtype=torch.uint8, device=dev)
     for lane in pipe.tts_lanes:
         lane.mask_source = lambda n: fixed
@@ -93,10 +95,10 @@ def test_pipelined_tts_lanes_match_sequential(built_lib):
         ref.append((r['ulaw'].clone(), r['tokens'].clone()))
     pipe.prime()
     got = []
-    pipe.run_steps(lambda k: frames[k % 2], 6, pipelined=True,
+    pipe.run_steps(lambda k: frames[k % 2], 7, pipelined=True,
                    on_cycle=lambda r: got.append((r['ulaw'].clone(), r['tokens'].clone())))
     torch.cuda.synchronize()
-    assert len(got) == 6
+    assert len(got) == 7
     for k, (ul, tk) in enumerate(got):
         assert torch.equal(tk, ref[k % 2][1]), k
         assert torch.equal(ul, ref[k % 2][0]), k
