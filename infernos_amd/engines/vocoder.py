@@ -40,24 +40,33 @@ class HifiGan:
         self._bufs = {}
         self.fused_pairs = os.environ.get('IFH_NO_FUSED_PAIR') is None      # tuning switch
 
-    def _buffers(self, n, t0):
+    def _buffers(self, n, t0, cache=None):
+        """Activation buffers of one batch shape.  `cache` is a dict owned by the caller (a TTS batch state, so that
+        the buffers live exactly as long as the hipGraphs captured over them); without it one shape stays resident here."""
         key = (n, t0)
+        if cache is not None:
+            if key not in cache:
+                cache[key] = self._alloc(n, t0)
+            return cache[key]
         if key not in self._bufs:
-            dev = self.device
-            b = {'x0': torch.empty((n, t0, 512), dtype=BF16, device=dev)}
-            t, c = t0, 512
-            for i in range(4):
-                t, c = t * 4, c // 2
-                for nm in ('u', 'h', 'r0', 'r1', 'xn'):
-                    b['%s%d' % (nm, i)] = torch.empty((n, t, c), dtype=BF16, device=dev)
-            b['audio'] = torch.empty((n, t), dtype=BF16, device=dev)
-            self._bufs = {key: b}          # keep one shape resident
+            self._bufs = {key: self._alloc(n, t0)}          # keep one shape resident
         return self._bufs[key]
 
-    def __call__(self, voc_in: torch.Tensor) -> torch.Tensor:
+    def _alloc(self, n, t0):
+        dev = self.device
+        b = {'x0': torch.empty((n, t0, 512), dtype=BF16, device=dev)}
+        t, c = t0, 512
+        for i in range(4):
+            t, c = t * 4, c // 2
+            for nm in ('u', 'h', 'r0', 'r1', 'xn'):
+                b['%s%d' % (nm, i)] = torch.empty((n, t, c), dtype=BF16, device=dev)
+        b['audio'] = torch.empty((n, t), dtype=BF16, device=dev)
+        return b
+
+    def __call__(self, voc_in: torch.Tensor, cache=None) -> torch.Tensor:
         """voc_in bf16 [N, T, 80], already (x-mean)/scale normalised -> bf16 [N, 256*T]"""
         n, t0, _ = voc_in.shape
-        B = self._buffers(n, t0)
+        B = self._buffers(n, t0, cache)
         ops.conv(voc_in, self.pre_w, self.pre_b, B['x0'], nbatch=n, t_in=t0, t_out=t0, cin=80, n=512, taps=7, pad=3)
         prev, t, c = B['x0'], t0, 512
         for i in range(4):
@@ -115,19 +124,22 @@ class Amendment:
         self.po_w, self.po_b = ops.w_conv(g('post_conv.weight'), dev), ops.w_bias(g('post_conv.bias'), dev)
         self._bufs = {}
 
-    def _buffers(self, n):
-        if n not in self._bufs:
+    def _buffers(self, n, cache=None):
+        store = self._bufs if cache is None else cache
+        if n not in store:
             dev = self.device
             e = lambda *s: torch.empty(s, dtype=BF16, device=dev)
-            self._bufs = {n: dict(a_cl=e(n, 12, 256), cat=e(n, 12, 192), u0=e(n, 48, 128), u1=e(n, 192, 64),
-                                  h=e(n, 192, 64), r=e(n, 192, 64), post=e(n, 8, 256))}
-        return self._bufs[n]
+            if cache is None:
+                store.clear()                          # keep one shape resident
+            store[n] = dict(a_cl=e(n, 12, 256), cat=e(n, 12, 192), u0=e(n, 48, 128), u1=e(n, 192, 64),
+                            h=e(n, 192, 64), r=e(n, 192, 64), post=e(n, 8, 256))
+        return store[n]
 
-    def __call__(self, amd_mel: torch.Tensor, audio: torch.Tensor, out: torch.Tensor, nbatch: int):
+    def __call__(self, amd_mel: torch.Tensor, audio: torch.Tensor, out: torch.Tensor, nbatch: int, cache=None):
         """amd_mel bf16 [4B,12,80] (ifh_tts_chunks_bf16 output), audio bf16 [4B,3072] -> out bf16 [B,8192]"""
         n = audio.size(0)
         assert n == 4 * nbatch and audio.size(1) == 3072
-        B = self._buffers(n)
+        B = self._buffers(n, cache)
         ops.transpose_to_bf16(audio, B['a_cl'], n, 256, 12)                      # audio.view(N,256,12) -> [N,12,256]
         ops.conv(amd_mel, self.pm_w, self.pm_b, B['cat'], nbatch=n, t_in=12, t_out=12, cin=80, n=32, taps=3, pad=1, ldc=192)
         ops.conv(B['a_cl'], self.pa_w, self.pa_b, B['cat'], nbatch=n, t_in=12, t_out=12, cin=256, n=160, taps=3, pad=1,

@@ -154,8 +154,8 @@ class HelloSippyRTPipe:
         _lib.check(_lib.lib().ifh_tts_chunks_bf16(ops._addr(st.pre_frames), ops._addr(post), ops._addr(self.vocoder.mean),
                                                   ops._addr(self.vocoder.scale), ops._addr(st.voc_in), ops._addr(st.amd_mel), B,
                                                   _lib.stream_ptr(dev)), 'ifh_tts_chunks_bf16')
-        audio = self.vocoder(st.voc_in)
-        self.chunker(st.amd_mel, audio, st.render_out[par], B)
+        audio = self.vocoder(st.voc_in, cache=st.voc_cache)      # buffers owned by the state, like the graphs over them
+        self.chunker(st.amd_mel, audio, st.render_out[par], B, cache=st.amd_cache)
 
     def render(self, st, par, use_graphs=True):
         dev = self.device
@@ -164,6 +164,7 @@ class HelloSippyRTPipe:
             st.amd_mel = torch.empty((4 * st.B, 12, 80), dtype=torch.bfloat16, device=dev)
             st.render_out = [torch.empty((st.B, 8192), dtype=torch.bfloat16, device=dev) for _ in range(2)]
             st.render_graphs, st.render_eager = {}, 0
+            st.voc_cache, st.amd_cache = {}, {}
         if not use_graphs or st.render_eager < 2:          # first passes eager: loads kernels, sizes the vocoder buffers
             self._render(st, par)
             st.render_eager += 1
