@@ -103,6 +103,7 @@ def main():
     ap.add_argument('--latency-ticks', type=int, default=200)
     ap.add_argument('--breakdown', action='store_true', help='print per-stage wall times to stderr')
     ap.add_argument('--tts-lanes', type=int, default=3, help='TTS engine instances whose utterance cycles may overlap')
+    ap.add_argument('--front-lanes', type=int, default=1, help='ingest+STT lanes (cycles k, k+1 in flight together)')
     ap.add_argument('--tts-group', type=int, default=1, help='utterance cycles synthesised as one TTS batch')
     ap.add_argument('--no-tts-overlap', action='store_true', help='render on the lane stream instead of a second stream per lane')
     ap.add_argument('--no-pipeline', action='store_true', help='run the stages of consecutive cycles strictly one after another')
@@ -141,7 +142,7 @@ def main():
 
     n_local = args.calls_per_gpu
     n_total = n_local * world
-    pipe = SpeechPipeline(n_local, dev, tts_lanes=args.tts_lanes, tts_overlap=not args.no_tts_overlap, tts_group=args.tts_group)
+    pipe = SpeechPipeline(n_local, dev, tts_lanes=args.tts_lanes, tts_overlap=not args.no_tts_overlap, tts_group=args.tts_group, front_lanes=args.front_lanes)
     codec = G711Codec().to(dev)
 
     def enc(x):
@@ -166,7 +167,7 @@ def main():
     # priming (untimed, not part of the W warm-up steps): two sequential cycles load every kernel and
     # capture the hipGraphs of the decode loops, so the timed steps replay them
     pipe.run_steps(frames_for, 2, pipelined=False)
-    pipe.prime()
+    pipe.prime(frames_for(0))
     if args.warmup:
         res = run(args.warmup)
     torch.cuda.synchronize()

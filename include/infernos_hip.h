@@ -124,6 +124,19 @@ int ifh_vad_step(const float *win /* [ncap][768] */, const float *prob /* [n] */
                  int n, int sample_rate, double threshold, int64_t *st_i64, int32_t *buf_len, float *abuf,
                  int64_t *ev, float *emit, ifh_stream_t stream);
 
+/* Block driver for frames that are already resident: nticks consecutive 20 ms ticks of n calls, i.e. the loop of
+ * RTP/InfernRTPIngest.py:63-100 over the three entry points above (ifh_ingest_tick every tick; ifh_vad_energy_prob +
+ * ifh_vad_step whenever the lock-stepped FIFOs complete a 768-sample window), issued from one host call.  frames u8
+ * [nticks][n][160].  After every window the event table is read back (the reference's per-batch .tolist()); chunks
+ * emitted by the state machine are appended to `arena` (device f32, arena_cap floats) and logged in log4 (host int64
+ * [log_cap][4] = row in `slot`, ipos, length, arena offset).  All n slots must enter with equal FIFO fill.
+ * Uses the built-in energy probability model; a pluggable network needs the per-window calls instead. */
+int ifh_ingest_block(const uint8_t *frames, int nticks, const int32_t *slot, int n, uint8_t *fifo, int32_t *fifo_len,
+                     float *win, int32_t *win_ready, float *hist, float *pcm8k, float *pcm16k, ifh_resampler_t rs8to16,
+                     float *prob, int sample_rate, double threshold, int64_t *st_i64, int32_t *buf_len, float *abuf,
+                     int64_t *ev, float *emit, float *arena, int64_t arena_cap, int64_t *log4, int log_cap, int *nlog,
+                     int64_t *arena_used, ifh_stream_t stream);
+
 /* ---------------------------------------------------------------------------------
  * Whisper log-mel       replaces Cluster/InfernSTTWorker.py:114 (WhisperProcessor ->
  *                        WhisperFeatureExtractor, transformers feature_extraction_whisper.py:135-168)

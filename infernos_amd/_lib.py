@@ -31,6 +31,8 @@ SIGNATURES = {
     'ifh_vad_energy_prob': (_i, [_vp, _vp, _i, _vp, _vp]),
     'ifh_vad_fsm_step': (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp]),
     'ifh_vad_step': (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'ifh_ingest_block': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _i64, _vp, _i, _vp, _vp, _vp]),
     'ifh_logmel_create': (_i, [_i, ctypes.POINTER(_vp)]),
     'ifh_logmel_destroy': (_i, [_vp]),
     'ifh_logmel_filters_host': (_i, [_vp, _vp]),

@@ -682,3 +682,72 @@ extern "C" int ifh_vad_step(const float *win, const float *prob, const int32_t *
     IFH_LAUNCH_CHECK("vad_step");
     return IFH_OK;
 }
+
+// =========================================================================================
+// Block driver: T consecutive ticks of n calls from frames already resident in HBM -- the loop of
+// RTP/InfernRTPIngest.py:63-100 (per packet: VADChannel.ingest -> SileroVADWorker.process_batch) expressed
+// as the same per-tick / per-window launches as ifh_ingest_tick + ifh_vad_energy_prob + ifh_vad_step,
+// issued from this one call (no interpreter between launches).  After every window the event table is read
+// back (the reference's .tolist() sync); chunks emitted by the state machine are appended to `arena`
+// (device) and logged on the host.  All n slots must hold the same number of FIFO bytes on entry (calls
+// ticking in lock-step), as they do when every call receives one frame per tick.
+// =========================================================================================
+extern "C" int ifh_ingest_block(const uint8_t *frames, int nticks, const int32_t *slot, int n, uint8_t *fifo,
+                                int32_t *fifo_len, float *win, int32_t *win_ready, float *hist, float *pcm8k,
+                                float *pcm16k, ifh_resampler_t rs8to16, float *prob, int sample_rate, double threshold,
+                                int64_t *st_i64, int32_t *buf_len, float *abuf, int64_t *ev, float *emit, float *arena,
+                                int64_t arena_cap, int64_t *log4, int log_cap, int *nlog, int64_t *arena_used,
+                                ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(n >= 0 && nticks >= 0 && nlog && arena_used);
+    *nlog = 0;
+    *arena_used = 0;
+    if (n == 0 || nticks == 0) return IFH_OK;
+    IFH_CHECK_ARG(frames && slot && fifo && fifo_len && win && win_ready && hist && pcm8k && pcm16k && rs8to16);
+    IFH_CHECK_ARG(prob && st_i64 && buf_len && abuf && ev && emit && arena && log4 && log_cap > 0 && arena_cap > 0);
+    IFH_CHECK_ARG(rs8to16->orig == 1 && rs8to16->nw == 2 && rs8to16->ntaps == 15);
+    IFH_CHECK_ARG(sample_rate == 8000 || sample_rate == 16000);
+    hipStream_t st = as_stream(stream);
+    std::vector<int32_t> hslot(n);
+    std::vector<int64_t> hev((size_t)n * 8);
+    int32_t fill0 = 0;
+    hipError_t e = hipMemcpyAsync(hslot.data(), slot, (size_t)n * 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&fill0, fifo_len + hslot[0], 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return check_hip(e, "ingest_block setup");
+    int64_t nbytes = fill0, used = 0;
+    int nl = 0;
+    for (int t = 0; t < nticks; t++) {
+        hipLaunchKernelGGL(k_ingest_tick, dim3(n), dim3(64), 0, st, frames + (int64_t)t * n * 160, slot, fifo, fifo_len, win,
+                           win_ready, hist, pcm8k, pcm16k, rs8to16->d_taps);
+        nbytes += 160;
+        if (nbytes < IFH_VAD_WINDOW) continue;
+        nbytes -= IFH_VAD_WINDOW;
+        hipLaunchKernelGGL(k_vad_energy_prob, dim3(n), dim3(64), 0, st, win, slot, prob);
+        hipLaunchKernelGGL(k_vad_step, dim3(n), dim3(256), 0, st, win, prob, slot, sample_rate, threshold, st_i64, buf_len,
+                           abuf, ev, emit);
+        e = hipMemcpyAsync(hev.data(), ev, (size_t)n * 64, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return check_hip(e, "ingest_block window");
+        for (int i = 0; i < n; i++) {
+            const int64_t *r = &hev[(size_t)i * 8];
+            if (r[6]) return fail(IFH_EINVAL, "ingest_block: VAD buffer invariant violated (SileroVAD.py:89/95-98)");
+            if (!r[3]) continue;
+            const int64_t len = r[5];
+            if (nl >= log_cap || used + len > arena_cap) return fail(IFH_EINVAL, "ingest_block: chunk log / arena full");
+            e = hipMemcpyAsync(arena + used, emit + (int64_t)hslot[i] * IFH_EMIT_CAP, (size_t)len * 4, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return check_hip(e, "ingest_block emit copy");
+            log4[4 * nl + 0] = i;
+            log4[4 * nl + 1] = r[4];
+            log4[4 * nl + 2] = len;
+            log4[4 * nl + 3] = used;
+            used += len;
+            nl++;
+        }
+    }
+    IFH_LAUNCH_CHECK("ingest_block");
+    *nlog = nl;
+    *arena_used = used;
+    return IFH_OK;
+}

@@ -17,6 +17,8 @@ Stages of one utterance cycle (`step`):
 import ctypes
 from typing import List
 
+import os
+
 import torch
 
 from . import _lib, ops
@@ -24,6 +26,9 @@ from .audio import VadAudioChunk, get_resampler
 from .codecs import G711Codec
 from .frontend import CallTable
 from .vad import ABUF_CAP, EMIT_CAP, WINDOW
+
+
+LOG_CAP = 4096
 
 
 class BatchedVAD:
@@ -41,6 +46,8 @@ class BatchedVAD:
         self.emit = torch.empty((ncalls, EMIT_CAP), dtype=torch.float32, device=dev)
         self.ev = torch.empty((ncalls, 8), dtype=torch.int64, device=dev)
         self.prob = torch.empty(ncalls, dtype=torch.float32, device=dev)
+        self.arena = None                      # ifh_ingest_block: emitted chunk audio of one block, device f32
+        self.log = torch.zeros((LOG_CAP, 4), dtype=torch.int64)
 
     def step(self, win: torch.Tensor) -> List[VadAudioChunk]:
         """win f32 [N,768] (CallTable.win).  Returns [(call, VadAudioChunk)] emitted by this window."""
@@ -65,7 +72,8 @@ class BatchedVAD:
 
 class SpeechPipeline:
     def __init__(self, ncalls: int, device=None, whisper_family='whisper_tiny', seed=0, n_text=64, n_infer=10,
-                 n_new_tokens=32, tts_output_sr=8000, weights=None, tts_lanes=3, tts_overlap=True, tts_group=1):
+                 n_new_tokens=32, tts_output_sr=8000, weights=None, tts_lanes=3, tts_overlap=True, tts_group=1,
+                 front_lanes=1):
         from .engines.whisper import Whisper
         from .features import WhisperLogMel
         from .tts import HelloSippyRTPipe
@@ -74,6 +82,7 @@ class SpeechPipeline:
         self.n, self.n_text, self.n_infer, self.n_new = ncalls, n_text, n_infer, n_new_tokens
         self.tts_overlap = tts_overlap      # render of chunk c on a second stream while chunk c+1 decodes (within a lane)
         self.tts_group = max(1, tts_group)  # utterance cycles synthesised as one TTS batch (rows = group * ncalls)
+        self.block_ingest = os.environ.get('IFH_TICK_INGEST') is None
         with torch.cuda.device(dev):
             self.calls = CallTable(ncalls, dev)
             self.vad = BatchedVAD(ncalls, dev)
@@ -94,30 +103,56 @@ class SpeechPipeline:
         g = torch.Generator().manual_seed(2000 + seed)
         self.speakers = torch.randn(ncalls, 512, generator=g)
         self.text_ids = torch.randint(4, 80, (ncalls, n_text), generator=g, dtype=torch.int32)
-        self._side_streams = [torch.cuda.Stream(device=dev) for _ in self.tts_lanes]
         self._lane_streams = [torch.cuda.Stream(device=dev) for _ in self.tts_lanes]
+        self._side_streams = [torch.cuda.Stream(device=dev) for _ in self.tts_lanes]
         self._side_stream = self._side_streams[0]
         self.pcm8k = torch.empty((ncalls, 160), dtype=torch.float32, device=dev)
         self.pcm16k = torch.empty((ncalls, 320), dtype=torch.float32, device=dev)
+        # front-end lanes: lane 0 is this object's own call table / VAD / Whisper buffers; further lanes are private
+        # copies over the same weights, so that ingest+STT of consecutive cycles can overlap too (run_steps)
+        self.front_lanes = [_FrontLane(self, first=True)] + [_FrontLane(self) for _ in range(max(1, front_lanes) - 1)]
 
     # ---- stage 1 -----------------------------------------------------------------------------
-    def ingest(self, frames: torch.Tensor):
-        """frames u8 [T,N,160] on the device -> per-call list of VadAudioChunk"""
+    def ingest(self, frames: torch.Tensor, fl=None, block=None):
+        """frames u8 [T,N,160] on the device -> per-call list of VadAudioChunk.  With the built-in probability model the
+        T ticks are driven by one ifh_ingest_block call (same launches, no interpreter in between); block=False or a
+        pluggable VAD model takes the per-tick path."""
+        fl = self.front_lanes[0] if fl is None else fl
         T = frames.size(0)
         chunks = [[] for _ in range(self.n)]
-        nbytes = int(self.calls.fifo_len[0]) if T else 0
+        if (self.block_ingest if block is None else block) and fl.vad.model is None and T:
+            return self._ingest_block(frames.contiguous(), fl, chunks)
+        nbytes = int(fl.calls.fifo_len[0]) if T else 0
         for t in range(T):
-            self.calls.tick(frames[t], self.slots, self.pcm8k, self.pcm16k, want_ready=False)
+            fl.calls.tick(frames[t], self.slots, fl.pcm8k, fl.pcm16k, want_ready=False)
             nbytes += 160
             if nbytes >= WINDOW:                 # every stream completes its window on the same tick
                 nbytes -= WINDOW
-                for i, ch in self.vad.step(self.calls.win):
+                for i, ch in fl.vad.step(fl.calls.win):
                     chunks[i].append(ch)
         return chunks
 
+    def _ingest_block(self, frames, fl, chunks):
+        dev, v, c = self.device, fl.vad, fl.calls
+        if v.arena is None:
+            v.arena = torch.empty(self.n * EMIT_CAP, dtype=torch.float32, device=dev)
+        nlog, used = ctypes.c_int(0), ctypes.c_int64(0)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().ifh_ingest_block(
+                _lib.ptr(frames), frames.size(0), _lib.ptr(self.slots), self.n, _lib.ptr(c.fifo), _lib.ptr(c.fifo_len),
+                _lib.ptr(c.win), _lib.ptr(c.win_ready), _lib.ptr(c.hist), _lib.ptr(fl.pcm8k), _lib.ptr(fl.pcm16k),
+                c._rs.handle, _lib.ptr(v.prob), v.input_sr, float(v.threshold), _lib.ptr(v.st), _lib.ptr(v.blen),
+                _lib.ptr(v.abuf), _lib.ptr(v.ev), _lib.ptr(v.emit), _lib.ptr(v.arena), v.arena.numel(),
+                ctypes.c_void_p(v.log.data_ptr()), LOG_CAP, ctypes.byref(nlog), ctypes.byref(used), _lib.stream_ptr(dev)),
+                'ifh_ingest_block')
+        for i, ipos, ln, off in v.log[:nlog.value].tolist():
+            chunks[i].append(VadAudioChunk(v.arena[off:off + ln].clone(), v.input_sr, ipos))
+        return chunks
+
     # ---- stage 2 -----------------------------------------------------------------------------
-    def stt(self, chunks):
+    def stt(self, chunks, fl=None):
         """-> (tokens int32 [N, n_new] device, no_speech_prob f32 [N] device, audio seconds per call)"""
+        fl = self.front_lanes[0] if fl is None else fl
         dev = self.device
         merged = []
         for lst in chunks:
@@ -136,9 +171,9 @@ class SpeechPipeline:
             x8[i, :m.numel()] = m
         x16 = self.up(x8, lens=lens8)
         lens16 = (lens8 * 2).to(dev)
-        mel = self.logmel(x16, lens=lens16)
-        enc = self.whisper.encode(mel)
-        toks, nsp, _ = self.whisper.generate(enc, self.prompt, self.n_new, no_speech_id=50362)
+        mel = fl.logmel(x16, lens=lens16)
+        enc = fl.whisper.encode(mel)
+        toks, nsp, _ = fl.whisper.generate(enc, self.prompt, self.n_new, no_speech_id=50362)
         return toks, nsp, (lens8.float() / 8000.0)
 
     # ---- stage 3 -----------------------------------------------------------------------------
@@ -203,25 +238,34 @@ class SpeechPipeline:
                 main.wait_event(ev)
         return out, valid, spans
 
-    def reset_calls(self):
+    def reset_calls(self, fl=None):
         """New utterance on every call slot: clear the per-call front-end state."""
-        self.calls.fifo_len.zero_()
-        self.calls.hist.zero_()
-        self.vad.st.zero_()
-        self.vad.st[:, 3] = -1
-        self.vad.blen.zero_()
+        fl = self.front_lanes[0] if fl is None else fl
+        fl.calls.fifo_len.zero_()
+        fl.calls.hist.zero_()
+        fl.vad.st.zero_()
+        fl.vad.st[:, 3] = -1
+        fl.vad.blen.zero_()
 
-    def front(self, frames: torch.Tensor):
+    def front(self, frames: torch.Tensor, fl=None):
         """ingest + STT of one utterance cycle (stages 1-2) on the current stream"""
-        self.reset_calls()
-        chunks = self.ingest(frames)
-        toks, nsp, secs = self.stt(chunks)
+        fl = self.front_lanes[0] if fl is None else fl
+        self.reset_calls(fl)
+        chunks = self.ingest(frames, fl)
+        toks, nsp, secs = self.stt(chunks, fl)
         return dict(tokens=toks, no_speech_prob=nsp, stt_seconds=secs,
                     chunks=[[(c.ipos, c.audio.numel()) for c in lst] for lst in chunks])
 
-    def prime(self):
-        """Untimed preparation of every TTS lane: two eager passes (load the kernels, size the buffers) and one
-        that captures the hipGraphs of the decode steps and of the renderer."""
+    def prime(self, frames=None):
+        """Untimed preparation of every lane: two eager passes (load the kernels, size the buffers) and one that
+        captures the hipGraphs (TTS decode steps and renderer per lane and group size; with `frames`, the Whisper
+        token loop of every front-end lane)."""
+        if frames is not None:
+            for fl in self.front_lanes:
+                with torch.cuda.stream(fl.stream):
+                    for _ in range(3):
+                        self.front(frames, fl)
+                fl.stream.synchronize()
         for lane in range(len(self.tts_lanes)):
             for g in sorted({self.tts_group, 1} | set(range(1, self.tts_group))):     # a trailing group may be smaller
                 for _ in range(3):
@@ -246,9 +290,9 @@ class SpeechPipeline:
         from concurrent.futures import ThreadPoolExecutor
         dev = self.device
         L = len(self.tts_lanes)
-        if not hasattr(self, '_front_stream'):
-            self._front_stream = torch.cuda.Stream(device=dev)      # (a high-priority stream here made every stage slower)
-            self._pool = ThreadPoolExecutor(max_workers=1)
+        F = len(self.front_lanes)
+        if not hasattr(self, '_pool'):                              # (a high-priority front stream made every stage slower)
+            self._pool = ThreadPoolExecutor(max_workers=F)
             self._tts_pool = ThreadPoolExecutor(max_workers=L)
 
         main = torch.cuda.current_stream(dev)
@@ -264,15 +308,16 @@ class SpeechPipeline:
         import time
         self.stage_wall = {'front': [], 'tts': []}                 # host wall seconds per job (bench --breakdown)
 
-        def job(fr, fr_ready):
+        def job(k, fr, fr_ready):
             torch.cuda.set_device(dev)
             t0 = time.perf_counter()
-            with torch.cuda.stream(self._front_stream):
-                self._front_stream.wait_event(fr_ready)
-                fr.record_stream(self._front_stream)
-                r = self.front(fr)
+            fl = self.front_lanes[k % F]
+            with fl.lock, torch.cuda.stream(fl.stream):
+                fl.stream.wait_event(fr_ready)
+                fr.record_stream(fl.stream)
+                r = self.front(fr, fl)
                 ev = torch.cuda.Event()
-                ev.record(self._front_stream)
+                ev.record(fl.stream)
             self.stage_wall['front'].append(time.perf_counter() - t0)
             return r, ev
 
@@ -318,7 +363,7 @@ class SpeechPipeline:
         for gi in range(ngroups):
             hi = min(nsteps, (gi + 1) * G)
             while nfront < min(nsteps, hi + L * G):                # the front end runs up to L groups ahead
-                fronts[nfront] = self._pool.submit(job, *fetch(nfront))
+                fronts[nfront] = self._pool.submit(job, nfront, *fetch(nfront))
                 nfront += 1
             ttss[gi] = self._tts_pool.submit(tts_job, gi % L, [fronts.pop(k) for k in range(gi * G, hi)])
             if gi >= L - 1:
@@ -335,6 +380,29 @@ class SpeechPipeline:
         ulaw, valid, spans = self.synthesize()
         return dict(tokens=toks, no_speech_prob=nsp, stt_seconds=secs, ulaw=ulaw, tts_samples=valid, spans=spans,
                     chunks=[[(c.ipos, c.audio.numel()) for c in lst] for lst in chunks])
+
+
+class _FrontLane:
+    """Per-lane state of stages 1-2: call table, VAD tables, tick outputs, Whisper/log-mel working buffers, a stream."""
+
+    def __init__(self, pipe: 'SpeechPipeline', first: bool = False):
+        import copy
+        import threading
+        from .features import WhisperLogMel
+        dev = pipe.device
+        self.lock = threading.Lock()                       # one cycle at a time per lane
+        with torch.cuda.device(dev):
+            self.stream = torch.cuda.Stream(device=dev)
+            if first:
+                self.calls, self.vad, self.whisper, self.logmel = pipe.calls, pipe.vad, pipe.whisper, pipe.logmel
+                self.pcm8k, self.pcm16k = pipe.pcm8k, pipe.pcm16k
+            else:
+                self.calls, self.vad = CallTable(pipe.n, dev), BatchedVAD(pipe.n, dev)
+                self.whisper = copy.copy(pipe.whisper)     # same weight tensors, private activation / KV buffers and graphs
+                self.whisper._enc_bufs, self.whisper._dec_bufs = {}, {}
+                self.logmel = WhisperLogMel(pipe.whisper.n_mel, dev)
+                self.pcm8k = torch.empty_like(pipe.pcm8k)
+                self.pcm16k = torch.empty_like(pipe.pcm16k)
 
 
 class _NoProcessor:

@@ -71,8 +71,8 @@ def test_pipeline_cycle_small(built_lib):
     assert np.isfinite(audio).all() and 1e-4 < np.abs(audio).mean() < 0.5
 
 
-@pytest.mark.parametrize('lanes,group', [(2, 1), (2, 2), (1, 3)])
-def test_pipelined_tts_lanes_match_sequential(built_lib, lanes, group):
+@pytest.mark.parametrize('lanes,group,fronts', [(2, 1, 1), (2, 2, 1), (1, 3, 1), (3, 2, 2)])
+def test_pipelined_tts_lanes_match_sequential(built_lib, lanes, group, fronts):
     """run_steps with the front-end thread, overlapping TTS lanes and grouped TTS batches (the utterances of
     `group` consecutive cycles synthesised as one batch) returns, cycle by cycle and in order, the bytes of the
     strictly sequential schedule."""
@@ -81,7 +81,7 @@ def test_pipelined_tts_lanes_match_sequential(built_lib, lanes, group):
     from infernos_amd.synth import synth_utterance
     dev = _lib.require_device('cuda:0')
     N = 5       # 5 x 64 text rows: no GEMM of the grouped batch crosses a kernel-selection threshold (M <= 256 -> skinny)
-    pipe = SpeechPipeline(N, dev, n_infer=3, n_new_tokens=4, tts_lanes=lanes, tts_group=group)
+    pipe = SpeechPipeline(N, dev, n_infer=3, n_new_tokens=4, tts_lanes=lanes, tts_group=group, front_lanes=fronts)
     fixed = torch.randint(0, 2, (16, 2, 256), dtype=torch.uint8, device=dev)
     for lane in pipe.tts_lanes:
         lane.mask_source = lambda n: fixed
@@ -93,7 +93,7 @@ def test_pipelined_tts_lanes_match_sequential(built_lib, lanes, group):
     for k in range(2):
         r = pipe.run_steps(lambda _k, k=k: frames[k], 1, pipelined=False)
         ref.append((r['ulaw'].clone(), r['tokens'].clone()))
-    pipe.prime()
+    pipe.prime(frames[0])
     got = []
     pipe.run_steps(lambda k: frames[k % 2], 7, pipelined=True,
                    on_cycle=lambda r: got.append((r['ulaw'].clone(), r['tokens'].clone())))
@@ -102,3 +102,32 @@ def test_pipelined_tts_lanes_match_sequential(built_lib, lanes, group):
     for k, (ul, tk) in enumerate(got):
         assert torch.equal(tk, ref[k % 2][1]), k
         assert torch.equal(ul, ref[k % 2][0]), k
+
+
+def test_block_ingest_equals_per_tick_ingest(built_lib):
+    """ifh_ingest_block (the tick loop driven from one host call) emits exactly the chunks of the per-tick path."""
+    from infernos_amd import _lib
+    from infernos_amd.pipeline import SpeechPipeline
+    from infernos_amd.synth import synth_utterance
+    dev = _lib.require_device('cuda:0')
+    N = 4
+    pipe = SpeechPipeline(N, dev, n_infer=1, n_new_tokens=2, tts_lanes=1)
+    x = np.stack([synth_utterance(1000 + i, 10.0) for i in range(N)])
+    ulaw = odsp.g711_encode(x)
+    frames = torch.from_numpy(np.ascontiguousarray(ulaw.reshape(N, 500, 160).transpose(1, 0, 2))).to(dev)
+    res = []
+    for block in (False, True):
+        pipe.reset_calls()
+        a = pipe.ingest(frames[:250], block=block)            # two calls: the FIFO / VAD state carries over
+        b = pipe.ingest(frames[250:], block=block)
+        res.append([[(c.ipos, c.audio.cpu().numpy()) for c in la + lb] for la, lb in zip(a, b)])
+        st = (pipe.vad.st.cpu().numpy().copy(), pipe.vad.blen.cpu().numpy().copy(), pipe.calls.fifo_len.cpu().numpy().copy())
+        res.append(st)
+    tick, tick_st, blk, blk_st = res
+    assert sum(len(l) for l in tick) >= N
+    for lt, lb in zip(tick, blk):
+        assert [p for p, _ in lt] == [p for p, _ in lb]
+        for (_, at), (_, ab) in zip(lt, lb):
+            assert np.array_equal(at, ab)
+    for u, v in zip(tick_st, blk_st):
+        assert np.array_equal(u, v)
