@@ -15,6 +15,13 @@ in HBM when the timed region starts.  With N>1 GPUs calls are sharded (64 per GP
 scaling); rank 0 scatters the frame matrix and gathers the encoded output over RCCL inside the
 timed region.
 
+Consecutive cycles are pipelined as a serving loop would: --front-lanes ingest+STT lanes run ahead of
+--tts-lanes synthesis lanes, each of which synthesises the utterances of --tts-group consecutive cycles
+as one batch (the path is bound by the dispatch rate of small dependent kernels, DESIGN.md 5, so fewer
+and fatter launches and several independent launch chains in flight are what fill the GPU).  Every
+cycle's whole work -- and the fill and drain of this pipeline -- is inside the timed K steps; outputs
+are byte-identical to the sequential schedule (tests/test_pipeline_gpu.py).
+
     python bench.py [--gpus N] [--steps K] [--warmup W] [--calls-per-gpu 64] [--no-cpu-baseline]
 """
 import argparse
@@ -102,9 +109,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--latency-ticks', type=int, default=200)
     ap.add_argument('--breakdown', action='store_true', help='print per-stage wall times to stderr')
-    ap.add_argument('--tts-lanes', type=int, default=3, help='TTS engine instances whose utterance cycles may overlap')
-    ap.add_argument('--front-lanes', type=int, default=1, help='ingest+STT lanes (cycles k, k+1 in flight together)')
-    ap.add_argument('--tts-group', type=int, default=1, help='utterance cycles synthesised as one TTS batch')
+    ap.add_argument('--tts-lanes', type=int, default=2, help='TTS engine instances whose utterance cycles may overlap')
+    ap.add_argument('--front-lanes', type=int, default=2, help='ingest+STT lanes (cycles k, k+1 in flight together)')
+    ap.add_argument('--tts-group', type=int, default=3, help='utterance cycles synthesised as one TTS batch')
     ap.add_argument('--no-tts-overlap', action='store_true', help='render on the lane stream instead of a second stream per lane')
     ap.add_argument('--no-pipeline', action='store_true', help='run the stages of consecutive cycles strictly one after another')
     args = ap.parse_args()
@@ -257,7 +264,8 @@ def main():
                                    'mu-law' % n_local, 'calls_per_gpu': n_local, 'calls_total': n_total,
                        'utterance_seconds': UTT_SECONDS, 'weights': 'seeded random (HF shapes)',
                        'parallelism': 'calls sharded %d/GPU, models replicated; RCCL scatter/gather of frames/output' % n_local,
-                       'stage_pipelining': not args.no_pipeline},
+                       'stage_pipelining': not args.no_pipeline, 'front_lanes': args.front_lanes, 'tts_lanes': args.tts_lanes,
+                       'tts_group_cycles': args.tts_group},
             'p50_tick_latency_ms': round(float(np.percentile(lat, 50)), 4),
             'p99_tick_latency_ms': round(float(np.percentile(lat, 99)), 4),
             'stt_audio_seconds_per_call': round(float(res['stt_seconds'].mean()), 3),

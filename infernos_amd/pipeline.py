@@ -72,7 +72,7 @@ class BatchedVAD:
 
 class SpeechPipeline:
     def __init__(self, ncalls: int, device=None, whisper_family='whisper_tiny', seed=0, n_text=64, n_infer=10,
-                 n_new_tokens=32, tts_output_sr=8000, weights=None, tts_lanes=3, tts_overlap=True, tts_group=1,
+                 n_new_tokens=32, tts_output_sr=8000, weights=None, tts_lanes=2, tts_overlap=True, tts_group=1,
                  front_lanes=1):
         from .engines.whisper import Whisper
         from .features import WhisperLogMel
