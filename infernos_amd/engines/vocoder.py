@@ -86,7 +86,9 @@ class HifiGan:
                 cur = u
                 for di, d in enumerate((1, 3, 5)):
                     w1, b1, w2, b2 = self.res[i][j][di]
-                    if self.fused_pairs:       # both convolutions in one launch, intermediate kept in LDS (same bits)
+                    # both convolutions in one launch, intermediate kept in LDS (same bits) -- except at C = 256 with
+                    # >= 512 batch entries, where two launches measure 1.2-1.35x faster (tools/probe_resblock.py 768)
+                    if self.fused_pairs and not (c == 256 and n >= 512):
                         last = di == 2
                         nxt = xn if last else rbuf[di]
                         ops.resblock_pair(cur, w1, b1, w2, b2, nxt, nbatch=n, t=t, c=c, taps=k, dil=d, slope=0.1,

@@ -15,7 +15,7 @@ def timeit(fn, n=20):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e-3
-N = 256
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 for (T, C) in ((48, 256), (192, 128), (768, 64), (3072, 32)):
     x = torch.randn(N, T, C, device=dev).to(BF)
     h = torch.empty(N, T, C, dtype=BF, device=dev); out = torch.empty(N, T, C, dtype=BF, device=dev)
