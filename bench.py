@@ -217,7 +217,7 @@ def main():
                 fn()
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / n * 1e-3
-        nchunks = 4 * n_local
+        nchunks = 4 * n_local * max(1, args.tts_group)        # the vocoder launch group of the timed region: 4 chunks x (calls x grouped cycles)
         voc_in = torch.randn(nchunks, 12, 80, device=dev).to(torch.bfloat16)
         t_voc = ev_time(lambda: pipe.tts.vocoder(voc_in), n=5)
         ach_tf = nchunks * VOCODER_GFLOP_PER_CHUNK / t_voc / 1e3
@@ -253,7 +253,8 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, 'profiles', 'r01_vocoder_pmc.json')
         if os.path.exists(pmc) and n_local == 64:       # PMC counters need their own rocprofv3 run: measured offline
-            traffic = json.load(open(pmc))['hbm_bytes_per_pass']
+            pj = json.load(open(pmc))
+            traffic = pj['hbm_bytes_per_pass'] * nchunks / pj.get('chunks_per_pass', 256)
         out = {
             'metric': 'real-time-factor x concurrent calls (STT+TTS on 20 ms G.711 frames)',
             'value': round(value, 2), 'unit': 'x real-time (call-seconds/s)', 'n_gpus': world, 'steps': args.steps,
@@ -273,7 +274,7 @@ def main():
             'roofline': {'kernel': 'HiFi-GAN vocoder pass = k_resblock_pair<*> + k_igemm<*> (%d chunks x 12 frames per launch group)' % nchunks,
                          'bound': 'mfma', 'achieved': round(ach_tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-                         'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r01_vocoder_pmc.json',
+                         'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r01_vocoder_pmc.json (scaled by chunks if the pass sizes differ)',
                          'seconds_per_vocoder_pass': t_voc},
             'roofline_logmel': {'kernel': 'k_logmel_dft2+k_logmel_finish (%d x 30 s windows)' % n_local, 'bound': 'hbm',
                                 'achieved': round(ach_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
