@@ -7,6 +7,8 @@ KV-cached decoder, tied output projection, greedy argmax and the no-speech proba
 Architecture per transformers modeling_whisper.py (v5.15.0).  The decode loop runs entirely
 on the device (argmax feeds the next embedding lookup; no host sync per token).
 """
+import os
+
 import torch
 
 from .. import _lib, ops
@@ -74,6 +76,29 @@ class Whisper:
         self.dec_pos = sd[Dc + 'embed_positions.weight'].to(BF16).contiguous().to(dev)
         self._enc_bufs = {}
         self._dec_bufs = {}
+        # LayerNorm folded around the decode-step GEMMs (ifh_conv_desc.aln_* / stats_out; same scheme as the SpeechT5
+        # decoder): 13 of the 49 launches per token disappear.  The vocabulary projection is padded to a multiple of
+        # 16 rows; the padded logits are pinned to -1e30 through the folded bias so that argmax never picks them.
+        self.fold_ln = os.environ.get('IFH_FOLD_LN', '1') != '0'      # tuning switch
+        self.vpad = -(-self.vocab // 16) * 16
+        self.dec_fold = []
+        nl = len(self.dec_layers)
+        for i in range(nl):
+            L = Dc + 'layers.%d.' % i
+            g = lambda nm: (sd[L + nm + '.weight'].float(), sd[L + nm + '.bias'].float())
+            sa, ca = L + 'self_attn.', L + 'encoder_attn.'
+            wqkv = torch.cat([sd[sa + 'q_proj.weight'].float() * QS, sd[sa + 'k_proj.weight'].float(), sd[sa + 'v_proj.weight'].float()])
+            bqkv = torch.cat([sd[sa + 'q_proj.bias'].float() * QS, zero_k, sd[sa + 'v_proj.bias'].float()])
+            self.dec_fold.append(dict(
+                qkv=ops.w_linear_ln(wqkv, bqkv, *g('self_attn_layer_norm'), dev),
+                cq=ops.w_linear_ln(sd[ca + 'q_proj.weight'].float() * QS, sd[ca + 'q_proj.bias'].float() * QS,
+                                   *g('encoder_attn_layer_norm'), dev),
+                ff1=ops.w_linear_ln(sd[L + 'fc1.weight'], sd[L + 'fc1.bias'], *g('final_layer_norm'), dev)))
+        tokw = torch.zeros(self.vpad, d)
+        tokw[:self.vocab] = sd[Dc + 'embed_tokens.weight'].float()
+        w, c2, c1 = ops.w_linear_ln(tokw, None, sd[Dc + 'layer_norm.weight'].float(), sd[Dc + 'layer_norm.bias'].float(), dev)
+        c2[self.vocab:] = -1e30
+        self.logit_fold = (w, c2, c1)
 
     # ---- encoder ------------------------------------------------------------------------------
     def encode(self, mel: torch.Tensor) -> torch.Tensor:
@@ -113,9 +138,12 @@ class Whisper:
                 cross=[e(Bn * N_CTX, 2 * d) for _ in self.dec_layers],
                 kv=[torch.zeros((Bn, self.max_tokens, 2 * d), dtype=BF16, device=dev) for _ in self.dec_layers],
                 x=e(Bn, d), hn=e(Bn, d), q=e(Bn, d), att=e(Bn, d), ff=e(Bn, self.ff),
-                logits=e(Bn, self.vocab, dt=torch.float32),
+                logits_full=e(Bn, self.vpad, dt=torch.float32),
+                stats=torch.zeros((3 * len(self.dec_layers), max(64, -(-Bn // 16) * 16), 2), dtype=torch.int64, device=dev),
                 toks=torch.zeros((self.max_tokens + 1, Bn), dtype=torch.int32, device=dev),
                 pos=torch.zeros(1, dtype=torch.int32, device=dev), graphs={}, eager_runs=0)}
+            b = self._dec_bufs[Bn]
+            b['logits'] = b['logits_full'][:, :self.vocab]         # [Bn, vocab] view, row stride vpad
         return self._dec_bufs[Bn]
 
     def decoder_step(self, bufs, Bn: int, argmax: bool):
@@ -146,22 +174,72 @@ class Whisper:
             ops.linear(bufs['hn'], L['w1'], L['b1'], bufs['ff'], rows=Bn, k=d, n=self.ff, act=ACT_GELU)
             ops.linear(bufs['ff'], L['w2'], L['b2'], x, rows=Bn, k=self.ff, n=d, resid=x)
         ops.layernorm(x, *self.dec_ln, bufs['hn'], Bn, d)
-        ops.linear(bufs['hn'], self.tok, None, bufs['logits'], rows=Bn, k=d, n=self.vocab)
+        ops.linear(bufs['hn'], self.tok, None, bufs['logits_full'], rows=Bn, k=d, n=self.vocab, ldc=self.vpad)
         if argmax:
-            ops.argmax_pick(bufs['logits'], vocab=self.vocab, nrows=Bn, argmax_out=toks, out_off=Bn, dyn_pos=pos,
-                            dyn_out_mul=Bn)
+            ops.argmax_pick(bufs['logits_full'], vocab=self.vocab, nrows=Bn, ld=self.vpad, argmax_out=toks, out_off=Bn,
+                            dyn_pos=pos, dyn_out_mul=Bn)
+        ops.add_i32(pos, 1)
+        return bufs['logits']
+
+    def decoder_step_folded(self, bufs, Bn: int, argmax: bool):
+        """decoder_step with every LayerNorm but the first folded around the neighbouring GEMMs: the producers of the
+        residual stream x (out_proj, fc2; resid = x) add per-row (sum, sum of squares) in their epilogue, the consumers
+        of LayerNorm(x) (q|k|v, cross q, fc1, the vocabulary projection) apply mean/rstd in theirs."""
+        d, H = self.d, self.h
+        x, pos, toks, stats = bufs['x'], bufs['pos'], bufs['toks'], bufs['stats']
+        SO = stats.size(1) * 2
+        stats.zero_()
+        ops.embed(toks, self.tok, self.dec_pos, x, n=Bn, dim=d, pos0=0, seq_len=1, dyn_pos=pos, dyn_ids_mul=Bn)
+        smax = self.max_tokens
+        for li, (L, F) in enumerate(zip(self.dec_layers, self.dec_fold)):
+            S, C = L['self'], L['cross']
+            kv = bufs['kv'][li]
+            s1, s2, s3, s3p = (3 * li) * SO, (3 * li + 1) * SO, (3 * li + 2) * SO, (3 * li - 1) * SO
+            kvargs = dict(nbatch=Bn, t_in=1, t_out=1, cin=d, n=3 * d, ldc=d, out_bstride=d, dyn_pos=pos, n_split=d, out2=kv,
+                          out2_bstride=smax * 2 * d, ldc2=2 * d, dyn_ooff2_mul=1)
+            if li == 0:                                  # x comes from the embedding kernel: no statistics yet
+                ops.layernorm(x, *L['ln1'], bufs['hn'], Bn, d)
+                ops.conv(bufs['hn'], S['wqkv'], S['bqkv'], bufs['q'], **kvargs)
+            else:
+                w, c2, c1 = F['qkv']
+                ops.conv(x, w, c2, bufs['q'], aln=(stats, s3p, c1), ln_dim=d, **kvargs)
+            ops.attn_decode(bufs['q'], kv, kv, bufs['att'], nbatch=Bn, nheads=H, max_keys=smax, q_bs=d,
+                            kv_bs=smax * 2 * d, kv_ts=2 * d, o_bs=d, v_off=d, dyn_len=pos, dyn_add=1)
+            ops.linear(bufs['att'], S['wo'], S['bo'], x, rows=Bn, k=d, n=d, resid=x, stats_out=stats, stats_off=s1, ln_dim=d)
+            w, c2, c1 = F['cq']
+            ops.linear(x, w, c2, bufs['q'], rows=Bn, k=d, n=d, aln=(stats, s1, c1), ln_dim=d)
+            ck = bufs['cross'][li]
+            ops.attn_decode(bufs['q'], ck, ck, bufs['att'], nbatch=Bn, nheads=H, max_keys=N_CTX, q_bs=d,
+                            kv_bs=N_CTX * 2 * d, kv_ts=2 * d, o_bs=d, v_off=d)
+            ops.linear(bufs['att'], C['wo'], C['bo'], x, rows=Bn, k=d, n=d, resid=x, stats_out=stats, stats_off=s2, ln_dim=d)
+            w, c2, c1 = F['ff1']
+            ops.linear(x, w, c2, bufs['ff'], rows=Bn, k=d, n=self.ff, act=ACT_GELU, aln=(stats, s2, c1), ln_dim=d)
+            ops.linear(bufs['ff'], L['w2'], L['b2'], x, rows=Bn, k=self.ff, n=d, resid=x, stats_out=stats, stats_off=s3, ln_dim=d)
+        w, c2, c1 = self.logit_fold
+        ops.linear(x, w, c2, bufs['logits_full'], rows=Bn, k=d, n=self.vpad, aln=(stats, (3 * len(self.dec_layers) - 1) * SO, c1),
+                   ln_dim=d)
+        if argmax:
+            ops.argmax_pick(bufs['logits_full'], vocab=self.vocab, nrows=Bn, ld=self.vpad, argmax_out=toks, out_off=Bn,
+                            dyn_pos=pos, dyn_out_mul=Bn)
         ops.add_i32(pos, 1)
         return bufs['logits']
 
     def _step(self, bufs, Bn, argmax, use_graphs):
+        if self.fold_ln and Bn <= 256:
+            step = self.decoder_step_folded
+        else:
+            step = self.decoder_step
+        return self._step_with(step, bufs, Bn, argmax, use_graphs)
+
+    def _step_with(self, step_fn, bufs, Bn, argmax, use_graphs):
         if not use_graphs:
-            return self.decoder_step(bufs, Bn, argmax)
+            return step_fn(bufs, Bn, argmax)
         g = bufs['graphs'].get(argmax)
         if g is None:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                self.decoder_step(bufs, Bn, argmax)
+                step_fn(bufs, Bn, argmax)
             bufs['graphs'][argmax] = g
         g.replay()
         return bufs['logits']
@@ -195,7 +273,8 @@ class Whisper:
             gen = pos >= P - 1
             logits = self._step(bufs, Bn, gen, use_graphs and pos > 0)
             if pos == 0 and nsp is not None:
-                ops.argmax_pick(logits, vocab=self.vocab, nrows=Bn, pick_token=no_speech_id, pick_prob_out=nsp)
+                ops.argmax_pick(bufs['logits_full'], vocab=self.vocab, nrows=Bn, ld=self.vpad, pick_token=no_speech_id,
+                                pick_prob_out=nsp)
                 if early_exit_nsp is not None:
                     lim = torch.tensor(early_exit_nsp, dtype=torch.float32)
                     if bool((nsp.cpu() > lim).all()):
