@@ -131,3 +131,39 @@ def test_block_ingest_equals_per_tick_ingest(built_lib):
             assert np.array_equal(at, ab)
     for u, v in zip(tick_st, blk_st):
         assert np.array_equal(u, v)
+
+
+def test_full_size_cycle_properties(built_lib):
+    """BASELINE config 2 size (64 calls x 10 s), checked through size-independent properties: calls i and i+32 carry
+    the same audio, speaker and text, so every stage must give them identical results wherever they sit in the batch
+    (batch-position invariance); the mu-law round trip of the input is the identity on codes; STT sees the expected
+    amount of speech; the TTS output has the expected length and is finite; a second cycle reproduces the first."""
+    from infernos_amd import _lib
+    from infernos_amd.pipeline import SpeechPipeline
+    from infernos_amd.synth import synth_utterance
+    dev = _lib.require_device('cuda:0')
+    N = 64
+    pipe = SpeechPipeline(N, dev, tts_lanes=1)
+    pipe.speakers[32:] = pipe.speakers[:32]
+    pipe.text_ids[32:] = pipe.text_ids[:32]
+    fixed = torch.randint(0, 2, (16, 2, 256), dtype=torch.uint8, device=dev)
+    pipe.tts.mask_source = lambda n: fixed
+    x = np.stack([synth_utterance(1000 + (i % 32), 10.0) for i in range(N)])
+    ulaw = odsp.g711_encode(x)
+    assert np.array_equal(odsp.g711_encode(odsp.g711_decode(ulaw)), np.where(ulaw == 0x7f, 0xff, ulaw))   # 0x7F -> 0xFF only
+    frames = torch.from_numpy(np.ascontiguousarray(ulaw.reshape(N, 500, 160).transpose(1, 0, 2))).to(dev)
+    outs = []
+    for _ in range(2):
+        r = pipe.run_steps(lambda k: frames, 1, pipelined=False)
+        outs.append((r['tokens'].cpu(), r['no_speech_prob'].cpu(), r['stt_seconds'].clone(), r['ulaw'].cpu(),
+                     r['tts_samples'].clone(), r['chunks']))
+    toks, nsp, secs, ul, valid, chunks = outs[0]
+    assert torch.equal(toks[:32], toks[32:]) and torch.equal(nsp[:32], nsp[32:])
+    assert chunks[:32] == chunks[32:]
+    assert torch.equal(ul[:32], ul[32:])
+    assert bool((secs > 6.5).all()) and bool((secs < 9.5).all())
+    assert ul.shape == (N, 10 * 4096) and valid.tolist() == [10 * 4096 - 256] * N
+    audio = odsp.g711_decode(ul.numpy())
+    assert np.isfinite(audio).all() and 1e-4 < np.abs(audio).mean() < 0.5
+    for a, b in zip(outs[0][:5], outs[1][:5]):
+        assert torch.equal(a, b)
