@@ -404,9 +404,9 @@ extern "C" int ifh_resblock_pair_bf16(const ifh_resblock_desc *d, ifh_stream_t s
     hipStream_t st = as_stream(stream);
     int rc;
     switch (d->c) {                                                                // <C, WGM, MT1, NT, resident W, entries/block, residual rows in LDS>
-    case 256: rc = launch_pair<256, 1, 4, 4, false, 1, true>(p, st); break;        // conv1 64 rows, out 48
-    case 128: rc = launch_pair<128, 2, 7, 4, false, 1, true>(p, st); break;        // conv1 224 rows, out 208
-    case 64: rc = launch_pair<64, 2, 7, 2, false, 1, true>(p, st); break;          // conv1 224 rows, out 208
+    case 256: rc = launch_pair<256, 1, 4, 4, false, 1, true, 128>(p, st); break;   // conv1 64 rows, out 48; 128-wide weight chunks
+    case 128: rc = launch_pair<128, 2, 7, 4, false, 1, false, 128>(p, st); break;  // conv1 224 rows, out 208; 128-wide chunks (7-10 % over 64)
+    case 64: rc = launch_pair<64, 2, 7, 2, false, 1, true>(p, st); break;          // conv1 224 rows, out 208 (K = 64*taps: 64-wide chunks)
     default: rc = launch_pair<32, 4, 4, 2, true, 1, false>(p, st); break;          // conv1 256 rows, out 240
     }
     if (rc != IFH_OK) return rc;
