@@ -7,6 +7,8 @@
 //   * k_transpose: [B][R][C] -> [B][C][R] with cast to bf16 (layout glue).
 // The MFMA is issued "swapped" (A = weight rows, B = activation rows) so that a lane ends
 // up holding 4 consecutive output channels of one output row -> 8/16-byte stores.
+#include <stdlib.h>
+
 #include "igemm.h"
 
 namespace ifh {
@@ -16,13 +18,15 @@ namespace ifh {
 // its 16-byte weight/activation fragments in flight at once (one memory round trip), straight
 // from global/L2 (each weight byte is used once per block: no LDS staging); the NW partial
 // tiles are summed through LDS.  Grid (N/16, M/16): 192..768 blocks for the decoder shapes.
-template <int NW, int U>
+template <int NW, int U, int MT>
 __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
 {
-    __shared__ __attribute__((aligned(16))) float red[NW][64][4];
+    static_assert(MT == 1 || MT == 2, "row tiles per block");
+    static_assert(MT <= NW, "wave t stores row tile t");
+    __shared__ __attribute__((aligned(16))) float red[NW][MT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MT;
     const int M = p.nbatch * p.T_out;
     const int nk = (p.K + 31) / 32;
     const int per = (nk + NW - 1) / NW;
@@ -30,17 +34,26 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
     const int nrow = n0 + fr;
     const bool wok = nrow < p.N;
     const uint16_t *wrow = p.w + (int64_t)(wok ? nrow : 0) * p.K + fg * 8;
-    const int m = m0 + fr;
-    const bool xok = m < M;
-    const int mm = xok ? m : 0;
-    const int bb = mm / p.T_out, tt = mm - bb * p.T_out;
-    const uint16_t *xrow = p.x + (int64_t)bb * p.x_bstride + (int64_t)tt * p.lda + fg * 8;
+    // row tile 0 (and 1 when MT == 2: the weight fragment is fetched once for both); named variables, not arrays
+    const bool xok0 = m0 + fr < M, xok1 = MT > 1 && m0 + 16 + fr < M;
+    const uint16_t *xrow, *xrow1;
+    {
+        const int mm = xok0 ? m0 + fr : 0;
+        const int bb = mm / p.T_out, tt = mm - bb * p.T_out;
+        xrow = p.x + (int64_t)bb * p.x_bstride + (int64_t)tt * p.lda + fg * 8;
+        const int mm1 = xok1 ? m0 + 16 + fr : 0;
+        const int bb1 = mm1 / p.T_out, tt1 = mm1 - bb1 * p.T_out;
+        xrow1 = p.x + (int64_t)bb1 * p.x_bstride + (int64_t)tt1 * p.lda + fg * 8;
+    }
+    // the epilogue of row tile t belongs to wave t
+    const int m = m0 + 16 * (wid < MT ? wid : 0) + fr;
+    const bool xok = wid < MT && m < M;
     // LayerNorm folding (ifh_conv_desc.aln_* / rln_*): row statistics are two 64-bit fixed-point sums per row
     // ([rows][2] int64, scale 2^16) that producers build with integer atomics -- integer addition commutes,
     // so unlike float atomics the result is bit-reproducible.  One 16-byte load per lane, issued before the
     // weight stream and consumed in the epilogue.
     longlong2 st_a = make_longlong2(0, 0), st_r = make_longlong2(0, 0);
-    if (wid == 0 && xok) {
+    if (xok) {
         if (p.aln_stats) st_a = reinterpret_cast<const longlong2 *>(p.aln_stats)[m];
         if (p.rln_stats) st_r = reinterpret_cast<const longlong2 *>(p.rln_stats)[m];
     }
@@ -51,7 +64,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
     float4 pc1 = make_float4(0.f, 0.f, 0.f, 0.f), pbias = pc1, pgam = pc1, pbeta = pc1;
     uint2 presid = make_uint2(0, 0);
     const int dynv0 = p.dyn ? p.dyn[0] : 0;
-    if (ln_mode && wid == 0 && xok && n0 + 4 * fg < p.N) {
+    if (ln_mode && xok && n0 + 4 * fg < p.N) {
         const int n = n0 + 4 * fg;
         if (p.aln_stats) pc1 = *reinterpret_cast<const float4 *>(p.aln_c1 + n);
         if (p.bias) pbias = *reinterpret_cast<const float4 *>(p.bias + n);
@@ -63,9 +76,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
             }
         }
     }
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc;
     for (int kt = kt0; kt < kt1; kt += U) {
-        uint4 wv[U], xv[U];
+        uint4 wv[U], xv[U], xw[MT > 1 ? U : 1];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int kk = kt + u;
@@ -73,23 +86,30 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
             wv[u] = make_uint4(0, 0, 0, 0);
             xv[u] = make_uint4(0, 0, 0, 0);
             if (wok && kok) wv[u] = *reinterpret_cast<const uint4 *>(wrow + kk * 32);
-            if (xok && kok) xv[u] = *reinterpret_cast<const uint4 *>(xrow + kk * 32);
+            if (xok0 && kok) xv[u] = *reinterpret_cast<const uint4 *>(xrow + kk * 32);
+            if (MT > 1) {
+                xw[u] = make_uint4(0, 0, 0, 0);
+                if (xok1 && kok) xw[u] = *reinterpret_cast<const uint4 *>(xrow1 + kk * 32);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < U; u++)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wv[u]),
-                                                          __builtin_bit_cast(bf16x8_t, xv[u]), acc, 0, 0, 0);
+        for (int u = 0; u < U; u++) {
+            const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wv[u]);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, xv[u]), acc, 0, 0, 0);
+            if (MT > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, xw[u]), acc1, 0, 0, 0);
+        }
     }
-    *reinterpret_cast<f32x4 *>(&red[wid][lane][0]) = acc;
+    *reinterpret_cast<f32x4 *>(&red[wid][0][lane][0]) = acc;
+    if (MT > 1) *reinterpret_cast<f32x4 *>(&red[wid][MT - 1][lane][0]) = acc1;
     const float fx = (1.0f / 65536.0f) / (float)p.ln_dim;
     const float a_mean = (float)st_a.x * fx, r_mean = (float)st_r.x * fx;
     const float a_rstd = rsqrtf(fmaxf((float)st_a.y * fx - a_mean * a_mean, 0.0f) + p.ln_eps);
     const float r_rstd = rsqrtf(fmaxf((float)st_r.y * fx - r_mean * r_mean, 0.0f) + p.ln_eps);
     __syncthreads();
-    if (wid == 0) {
+    if (wid < MT) {
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w][lane][0]);
+        for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w][wid][lane][0]);
         const int n = n0 + 4 * fg;
         if (ln_mode) {
             // LayerNorm folded around the GEMM (host guarantees the vector epilogue conditions, N % 16 == 0)
@@ -487,11 +507,19 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         const dim3 grid((d->n + 15) / 16, (unsigned)((M + 15) / 16));
         // waves per block = K split: 2 (12 k-steps each at K = 768) / 4 for deep K.  With several decode loops in
         // flight (SpeechPipeline TTS lanes) fewer, longer waves beat 4/8 short ones by ~6 % end to end; alone the
-        // launch takes the same time either way.
-        if (p.K >= 2048)
-            hipLaunchKernelGGL((k_gemm_skinny<4, 12>), grid, dim3(256), 0, st, p);
+        // launch takes the same time either way.  Above 64 rows a block takes two row tiles per weight fragment
+        // (same K split, hence the same bits): the step time grows by the L2 re-reads of W per 16-row tile.
+        static const bool one_tile = getenv("IFH_SKINNY_MT1") != nullptr;              // tuning switch
+        if (M > 64 && !one_tile) {
+            const dim3 grid2((d->n + 15) / 16, (unsigned)((M + 31) / 32));
+            if (p.K >= 2048)
+                hipLaunchKernelGGL((k_gemm_skinny<4, 12, 2>), grid2, dim3(256), 0, st, p);
+            else
+                hipLaunchKernelGGL((k_gemm_skinny<2, 12, 2>), grid2, dim3(128), 0, st, p);
+        } else if (p.K >= 2048)
+            hipLaunchKernelGGL((k_gemm_skinny<4, 12, 1>), grid, dim3(256), 0, st, p);
         else
-            hipLaunchKernelGGL((k_gemm_skinny<2, 12>), grid, dim3(128), 0, st, p);
+            hipLaunchKernelGGL((k_gemm_skinny<2, 12, 1>), grid, dim3(128), 0, st, p);
     } else if (try_launch_conv_direct(p, pre, st)) {
         // residual-block shapes: input tile resident in LDS (conv.hip)
     } else if (d->n <= 32)

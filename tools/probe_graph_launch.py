@@ -5,10 +5,12 @@ import torch
 from infernos_amd import _lib
 from infernos_amd.pipeline import SpeechPipeline, _make_state
 dev = _lib.require_device('cuda:0')
-pipe = SpeechPipeline(64, dev, tts_lanes=1)
+G = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+pipe = SpeechPipeline(64, dev, tts_lanes=1, tts_group=G)
 pipe.prime()
 pp = pipe.tts
-state = _make_state(pp, pipe.text_ids, pipe.speakers)
+state = _make_state(pp, pipe.text_ids.repeat(G, 1), pipe.speakers.repeat(G, 1))
+print('rows', 64 * G)
 st = state.dev
 torch.cuda.synchronize()
 for rep in range(3):
