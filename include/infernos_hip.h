@@ -285,17 +285,19 @@ int ifh_embed_bf16(const int32_t *ids, const void *table, const void *pos_table,
  * dyn_pos optional: argmax_out += dyn_pos[0]*dyn_out_mul */
 int ifh_argmax_pick_f32(const float *logits, int64_t ld, int vocab, int nrows, int pick_token, int32_t *argmax_out,
                         float *pick_prob_out, const int32_t *dyn_pos, int dyn_out_mul, ifh_stream_t stream);
-/* value[0] += delta on the stream (advances a device-resident step counter between graph replays) */
-int ifh_add_i32(int32_t *value, int delta, ifh_stream_t stream);
+/* value[0] += delta on the stream (advances a device-resident step counter between graph replays); also clears
+ * zero_bytes (% 16 == 0, 16-byte aligned, may be 0) at zero_buf: the LayerNorm statistics the NEXT step accumulates into */
+int ifh_add_i32(int32_t *value, int delta, void *zero_buf, int64_t zero_bytes, ifh_stream_t stream);
 
 /* ---- TTS streaming glue, HelloSippyRTPipe.infer (HelloSippyRTPipe.py:191-240) ---- */
 /* stop rule (:227-228) on the 2 stop logits per utterance (row stride logits_ld floats); ends_at int64[n] */
 int ifh_tts_stop_update(const float *prob_logits, int64_t *ends_at, int n, int idx, int minlen, int maxlen,
                         float threshold, int ends_inc, const int32_t *dyn_idx /* overrides idx if set */,
                         int logits_ld, ifh_stream_t stream);
-/* the same stop rule with idx = pos[0], followed by pos[0] += 1 (one launch; for graph-replayed decode loops) */
+/* the same stop rule with idx = pos[0], followed by pos[0] += 1 (one launch; for graph-replayed decode loops); also
+ * clears zero_bytes at zero_buf as ifh_add_i32 does */
 int ifh_tts_stop_advance(const float *prob_logits, int64_t *ends_at, int n, int minlen, int maxlen, float threshold,
-                         int ends_inc, int32_t *pos, int logits_ld, ifh_stream_t stream);
+                         int ends_inc, int32_t *pos, int logits_ld, void *zero_buf, int64_t zero_bytes, ifh_stream_t stream);
 /* carry + 4 overlapped 12-frame chunks (:231-235): pre_frames bf16 [B][4][80] (updated), post bf16
  * [B][32][80] -> voc_in bf16 [4B][12][80] normalised by (x-mean)/scale, amd_mel bf16 [4B][12][80] =
  * channels-last form of the chunk re-viewed as [80][12] (HelloSippyRT.py:224) */

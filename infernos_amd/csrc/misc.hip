@@ -134,8 +134,9 @@ __global__ void k_tts_stop(const float *__restrict__ logits /* [B][ld], 2 used *
 // single-block form that also advances the device-held step counter afterwards (one launch fewer per step)
 __global__ __launch_bounds__(256) void k_tts_stop_advance(const float *__restrict__ logits, int64_t *__restrict__ ends_at,
                                                          int n, int minlen, int maxlen, float thr, int ends_inc,
-                                                         int32_t *__restrict__ pos, int ld)
+                                                         int32_t *__restrict__ pos, int ld, uint4 *__restrict__ zbuf, int nz16)
 {
+    for (int i = threadIdx.x; i < nz16; i += blockDim.x) zbuf[i] = make_uint4(0, 0, 0, 0);      // next step's LN statistics
     const int idx = pos[0];
     for (int b = threadIdx.x; b < n; b += blockDim.x) {
         const float p0 = 1.0f / (1.0f + expf(-logits[ld * b])), p1 = 1.0f / (1.0f + expf(-logits[ld * b + 1]));
@@ -240,16 +241,22 @@ __global__ __launch_bounds__(64) void k_l2norm_rows(const uint16_t *__restrict__
     for (int i = lane; i < D; i += 64) out[(int64_t)r * ld_out + i] = f32_to_bf16(bf16_to_f32(x[(int64_t)r * D + i]) * inv);
 }
 
-__global__ void k_add_i32(int32_t *p, int delta) { p[0] += delta; }
+__global__ __launch_bounds__(256) void k_add_i32(int32_t *p, int delta, uint4 *__restrict__ zbuf, int nz16)
+{
+    for (int i = threadIdx.x; i < nz16; i += blockDim.x) zbuf[i] = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x == 0) p[0] += delta;
+}
 
 }  // namespace ifh
 
 using namespace ifh;
 
-extern "C" int ifh_add_i32(int32_t *value, int delta, ifh_stream_t stream)
+extern "C" int ifh_add_i32(int32_t *value, int delta, void *zero_buf, int64_t zero_bytes, ifh_stream_t stream)
 {
-    IFH_CHECK_ARG(value);
-    hipLaunchKernelGGL(k_add_i32, dim3(1), dim3(1), 0, as_stream(stream), value, delta);
+    IFH_CHECK_ARG(value && zero_bytes >= 0 && zero_bytes % 16 == 0 && zero_bytes < (1ll << 30) && (zero_bytes == 0 || zero_buf));
+    IFH_CHECK_ARG((((uintptr_t)zero_buf) & 15) == 0);
+    hipLaunchKernelGGL(k_add_i32, dim3(1), dim3(zero_bytes ? 256 : 64), 0, as_stream(stream), value, delta, (uint4 *)zero_buf,
+                       (int)(zero_bytes / 16));
     IFH_LAUNCH_CHECK("add_i32");
     return IFH_OK;
 }
@@ -296,11 +303,14 @@ extern "C" int ifh_tts_stop_update(const float *prob_logits, int64_t *ends_at, i
 }
 
 extern "C" int ifh_tts_stop_advance(const float *prob_logits, int64_t *ends_at, int n, int minlen, int maxlen,
-                                    float threshold, int ends_inc, int32_t *pos, int logits_ld, ifh_stream_t stream)
+                                    float threshold, int ends_inc, int32_t *pos, int logits_ld, void *zero_buf,
+                                    int64_t zero_bytes, ifh_stream_t stream)
 {
     IFH_CHECK_ARG(n >= 0 && prob_logits && ends_at && pos && logits_ld >= 2);
+    IFH_CHECK_ARG(zero_bytes >= 0 && zero_bytes % 16 == 0 && zero_bytes < (1ll << 30) && (zero_bytes == 0 || zero_buf));
+    IFH_CHECK_ARG((((uintptr_t)zero_buf) & 15) == 0);
     hipLaunchKernelGGL(k_tts_stop_advance, dim3(1), dim3(256), 0, as_stream(stream), prob_logits, ends_at, n, minlen, maxlen,
-                       threshold, ends_inc, pos, logits_ld);
+                       threshold, ends_inc, pos, logits_ld, (uint4 *)zero_buf, (int)(zero_bytes / 16));
     IFH_LAUNCH_CHECK("tts_stop_advance");
     return IFH_OK;
 }

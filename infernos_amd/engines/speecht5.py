@@ -221,6 +221,7 @@ class TTSBatchState:
             ops.linear(self.enc, L['cwkv'], L['cbkv'], kv, rows=B * T, k=D, n=2 * D)
         self.spec[0].zero_()
         self.spec[1].zero_()
+        self.stats.zero_()                # each decoder step leaves it cleared for the next; start from a known state
         self.ncalls = 0
         self.pre_frames.zero_()
         self.ends_at.fill_(-1)
@@ -279,8 +280,8 @@ def _decoder_step_folded(model: 'SpeechT5', st: TTSBatchState, s: int, threshold
     dev = model.device
     B, T = st.B, st.T
     masks, spec, stats = st.masks, st.spec[par], st.stats
-    SO = st.stat_rows * 2                            # int64 elements per stats slot ([rows][2])
-    st.stats.zero_()
+    SO = st.stat_rows * 2                            # int64 elements per stats slot ([rows][2]); zero on entry: cleared by
+                                                     # the last launch of the previous step (ifh_tts_stop_advance)
     ops.linear(spec, *model.p0, st.h1, rows=B, k=80, n=256, x_off=2 * s * 80, lda=33 * 80, act=ACT_RELU,
                colmask=masks, colmask_off=(s * 2) * 256)
     ops.linear(st.h1, *model.p1, st.h2, rows=B, k=256, n=256, act=ACT_RELU, colmask=masks, colmask_off=(s * 2 + 1) * 256)
@@ -322,7 +323,8 @@ def _decoder_step_folded(model: 'SpeechT5', st: TTSBatchState, s: int, threshold
     w, c2, c1 = model.prob_fold
     ops.linear(st.t3, w, c2, st.plog16, rows=B, k=D, n=16, aln=(stats, sl, c1), ln_dim=D)
     _lib.check(_lib.lib().ifh_tts_stop_advance(ops._addr(st.plog16), ops._addr(st.ends_at), B, st.minlen, st.maxlen,
-                                               threshold, 2, ops._addr(st.pos_dev), 16, _lib.stream_ptr(dev)), 'ifh_tts_stop_advance')
+                                               threshold, 2, ops._addr(st.pos_dev), 16, ops._addr(st.stats),
+                                               st.stats.numel() * 8, _lib.stream_ptr(dev)), 'ifh_tts_stop_advance')
 
 
 def decoder_steps(model: 'SpeechT5', st: TTSBatchState, masks: torch.Tensor, nsteps=16, threshold=0.5, use_graphs=None):

@@ -187,8 +187,7 @@ class Whisper:
         of LayerNorm(x) (q|k|v, cross q, fc1, the vocabulary projection) apply mean/rstd in theirs."""
         d, H = self.d, self.h
         x, pos, toks, stats = bufs['x'], bufs['pos'], bufs['toks'], bufs['stats']
-        SO = stats.size(1) * 2
-        stats.zero_()
+        SO = stats.size(1) * 2                 # zero on entry: cleared by the last launch of the previous token
         ops.embed(toks, self.tok, self.dec_pos, x, n=Bn, dim=d, pos0=0, seq_len=1, dyn_pos=pos, dyn_ids_mul=Bn)
         smax = self.max_tokens
         for li, (L, F) in enumerate(zip(self.dec_layers, self.dec_fold)):
@@ -221,7 +220,7 @@ class Whisper:
         if argmax:
             ops.argmax_pick(bufs['logits_full'], vocab=self.vocab, nrows=Bn, ld=self.vpad, argmax_out=toks, out_off=Bn,
                             dyn_pos=pos, dyn_out_mul=Bn)
-        ops.add_i32(pos, 1)
+        ops.add_i32(pos, 1, zero=stats)
         return bufs['logits']
 
     def _step(self, bufs, Bn, argmax, use_graphs):
@@ -267,6 +266,7 @@ class Whisper:
         toks.fill_(eos_id if eos_id is not None else 0)
         toks[:P] = prompts.to(dev, torch.int32).t()
         bufs['pos'].zero_()
+        bufs['stats'].zero_()             # every token's last launch leaves it cleared for the next
         nsp = torch.empty(Bn, dtype=torch.float32, device=dev) if no_speech_id is not None else None
         first = None
         for pos in range(P + n_new - 1):

@@ -121,8 +121,10 @@ def argmax_pick(logits, *, vocab, nrows, ld=None, argmax_out=None, pick_token=0,
                                               _lib.stream_ptr(logits.device)), 'ifh_argmax_pick_f32')
 
 
-def add_i32(value, delta):
-    _lib.check(_lib.lib().ifh_add_i32(_addr(value), delta, _lib.stream_ptr(value.device)), 'ifh_add_i32')
+def add_i32(value, delta, zero=None):
+    """value[0] += delta; `zero` (a tensor) is cleared by the same launch"""
+    _lib.check(_lib.lib().ifh_add_i32(_addr(value), delta, _addr(zero), 0 if zero is None else zero.numel() * zero.element_size(),
+                                      _lib.stream_ptr(value.device)), 'ifh_add_i32')
 
 
 # ---- weight preparation (host side, once per model load) -----------------------------------
