@@ -709,7 +709,26 @@ extern "C" int ifh_ingest_block(const uint8_t *frames, int nticks, const int32_t
     IFH_CHECK_ARG(sample_rate == 8000 || sample_rate == 16000);
     hipStream_t st = as_stream(stream);
     std::vector<int32_t> hslot(n);
-    std::vector<int64_t> hev((size_t)n * 8);
+    // event tables come back through pinned memory and are looked at just before the NEXT window's VAD launches: the
+    // 4-5 tick launches enqueued in between keep the stream busy while the host decides (the tick kernels do not touch
+    // the emit rows, so the chunks of window w are copied out before anything can overwrite them).
+    struct Pinned {
+        int64_t *buf = nullptr;
+        size_t cap = 0;
+        hipEvent_t ev[2] = {nullptr, nullptr};
+    };
+    static thread_local Pinned pin;
+    if (pin.cap < (size_t)n * 16) {
+        if (pin.buf) (void)hipHostFree(pin.buf);
+        pin.buf = nullptr;
+        pin.cap = 0;
+        if (hipHostMalloc((void **)&pin.buf, (size_t)n * 16 * sizeof(int64_t), hipHostMallocDefault) != hipSuccess)
+            return fail(IFH_EHIP, "ingest_block: pinned event buffer");
+        pin.cap = (size_t)n * 16;
+    }
+    for (int k = 0; k < 2; k++)
+        if (!pin.ev[k] && hipEventCreateWithFlags(&pin.ev[k], hipEventDisableTiming) != hipSuccess)
+            return fail(IFH_EHIP, "ingest_block: event");
     int32_t fill0 = 0;
     hipError_t e = hipMemcpyAsync(hslot.data(), slot, (size_t)n * 4, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -717,27 +736,20 @@ extern "C" int ifh_ingest_block(const uint8_t *frames, int nticks, const int32_t
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) return check_hip(e, "ingest_block setup");
     int64_t nbytes = fill0, used = 0;
-    int nl = 0;
-    for (int t = 0; t < nticks; t++) {
-        hipLaunchKernelGGL(k_ingest_tick, dim3(n), dim3(64), 0, st, frames + (int64_t)t * n * 160, slot, fifo, fifo_len, win,
-                           win_ready, hist, pcm8k, pcm16k, rs8to16->d_taps);
-        nbytes += 160;
-        if (nbytes < IFH_VAD_WINDOW) continue;
-        nbytes -= IFH_VAD_WINDOW;
-        hipLaunchKernelGGL(k_vad_energy_prob, dim3(n), dim3(64), 0, st, win, slot, prob);
-        hipLaunchKernelGGL(k_vad_step, dim3(n), dim3(256), 0, st, win, prob, slot, sample_rate, threshold, st_i64, buf_len,
-                           abuf, ev, emit);
-        e = hipMemcpyAsync(hev.data(), ev, (size_t)n * 64, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e != hipSuccess) return check_hip(e, "ingest_block window");
+    int nl = 0, nwin = 0;
+    // consume the event table of window w (buffer w & 1): log + arena copies of its emitted chunks
+    auto consume = [&](int w) -> int {
+        hipError_t ee = hipEventSynchronize(pin.ev[w & 1]);
+        if (ee != hipSuccess) return check_hip(ee, "ingest_block window");
+        const int64_t *hev = pin.buf + (size_t)(w & 1) * n * 8;
         for (int i = 0; i < n; i++) {
-            const int64_t *r = &hev[(size_t)i * 8];
+            const int64_t *r = hev + (size_t)i * 8;
             if (r[6]) return fail(IFH_EINVAL, "ingest_block: VAD buffer invariant violated (SileroVAD.py:89/95-98)");
             if (!r[3]) continue;
             const int64_t len = r[5];
             if (nl >= log_cap || used + len > arena_cap) return fail(IFH_EINVAL, "ingest_block: chunk log / arena full");
-            e = hipMemcpyAsync(arena + used, emit + (int64_t)hslot[i] * IFH_EMIT_CAP, (size_t)len * 4, hipMemcpyDeviceToDevice, st);
-            if (e != hipSuccess) return check_hip(e, "ingest_block emit copy");
+            ee = hipMemcpyAsync(arena + used, emit + (int64_t)hslot[i] * IFH_EMIT_CAP, (size_t)len * 4, hipMemcpyDeviceToDevice, st);
+            if (ee != hipSuccess) return check_hip(ee, "ingest_block emit copy");
             log4[4 * nl + 0] = i;
             log4[4 * nl + 1] = r[4];
             log4[4 * nl + 2] = len;
@@ -745,6 +757,29 @@ extern "C" int ifh_ingest_block(const uint8_t *frames, int nticks, const int32_t
             used += len;
             nl++;
         }
+        return IFH_OK;
+    };
+    for (int t = 0; t < nticks; t++) {
+        hipLaunchKernelGGL(k_ingest_tick, dim3(n), dim3(64), 0, st, frames + (int64_t)t * n * 160, slot, fifo, fifo_len, win,
+                           win_ready, hist, pcm8k, pcm16k, rs8to16->d_taps);
+        nbytes += 160;
+        if (nbytes < IFH_VAD_WINDOW) continue;
+        nbytes -= IFH_VAD_WINDOW;
+        if (nwin > 0) {
+            const int rc = consume(nwin - 1);
+            if (rc != IFH_OK) return rc;
+        }
+        hipLaunchKernelGGL(k_vad_energy_prob, dim3(n), dim3(64), 0, st, win, slot, prob);
+        hipLaunchKernelGGL(k_vad_step, dim3(n), dim3(256), 0, st, win, prob, slot, sample_rate, threshold, st_i64, buf_len,
+                           abuf, ev, emit);
+        e = hipMemcpyAsync(pin.buf + (size_t)(nwin & 1) * n * 8, ev, (size_t)n * 64, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(pin.ev[nwin & 1], st);
+        if (e != hipSuccess) return check_hip(e, "ingest_block window");
+        nwin++;
+    }
+    if (nwin > 0) {
+        const int rc = consume(nwin - 1);
+        if (rc != IFH_OK) return rc;
     }
     IFH_LAUNCH_CHECK("ingest_block");
     *nlog = nl;
