@@ -125,8 +125,8 @@ int ifh_vad_step(const float *win /* [ncap][768] */, const float *prob /* [n] */
                  int64_t *ev, float *emit, ifh_stream_t stream);
 
 /* Block driver for frames that are already resident: nticks consecutive 20 ms ticks of n calls, i.e. the loop of
- * RTP/InfernRTPIngest.py:63-100 over the three entry points above (ifh_ingest_tick every tick; ifh_vad_energy_prob +
- * ifh_vad_step whenever the lock-stepped FIFOs complete a 768-sample window), issued from one host call.  frames u8
+ * RTP/InfernRTPIngest.py:63-100 over the three entry points above (the ticks up to the next completed 768-sample window
+ * in one launch of the ifh_ingest_tick kernel, then ifh_vad_energy_prob + ifh_vad_step), issued from one host call.  frames u8
  * [nticks][n][160].  After every window the event table is read back (the reference's per-batch .tolist()); chunks
  * emitted by the state machine are appended to `arena` (device f32, arena_cap floats) and logged in log4 (host int64
  * [log_cap][4] = row in `slot`, ipos, length, arena offset).  All n slots must enter with equal FIFO fill.

@@ -346,17 +346,22 @@ __global__ __launch_bounds__(64) void k_ingest_tick(const uint8_t *__restrict__ 
                                                     int32_t *__restrict__ fifo_len, float *__restrict__ win,
                                                     int32_t *__restrict__ win_ready, float *__restrict__ hist,
                                                     float *__restrict__ pcm8k, float *__restrict__ pcm16k,
-                                                    const float *__restrict__ taps /* [2][15] */)
+                                                    const float *__restrict__ taps /* [2][15] */, int nt,
+                                                    int64_t tick_stride)
 {
     __shared__ float xs[15 + 160];
     __shared__ float tp[32];
     __shared__ uint8_t fb[IFH_FIFO_CAP];
     const int i = blockIdx.x, t = threadIdx.x;
     const int s = slot[i];
-    const uint8_t *fr = frames + (int64_t)i * 160;
-    const int fl = fifo_len[s];
     uint8_t *ff = fifo + (int64_t)s * IFH_FIFO_CAP;
     if (t < 30) tp[t] = taps[t];
+    // nt consecutive ticks of this call (frames of tick k at frames + k*tick_stride): the per-call state goes through
+    // global memory between ticks exactly as between launches; pcm8k/pcm16k keep the last tick's samples
+    for (int tk = 0; tk < nt; tk++) {
+    if (tk) __syncthreads();
+    const uint8_t *fr = frames + (int64_t)tk * tick_stride + (int64_t)i * 160;
+    const int fl = fifo_len[s];
     if (t < 15) xs[t] = hist[(int64_t)s * 16 + t];
     // existing FIFO bytes -> LDS
     for (int k = t; k < fl; k += 64) fb[k] = ff[k];
@@ -395,6 +400,7 @@ __global__ __launch_bounds__(64) void k_ingest_tick(const uint8_t *__restrict__ 
             win_ready[s] = 0;
         }
     }
+    }
 }
 
 }  // namespace ifh
@@ -408,7 +414,7 @@ extern "C" int ifh_ingest_tick(const uint8_t *frames, const int32_t *slot, int n
     IFH_CHECK_ARG(frames && slot && fifo && fifo_len && win && win_ready && hist && pcm8k && pcm16k && rs8to16);
     IFH_CHECK_ARG(rs8to16->orig == 1 && rs8to16->nw == 2 && rs8to16->ntaps == 15);
     hipLaunchKernelGGL(k_ingest_tick, dim3(n), dim3(64), 0, as_stream(stream), frames, slot, fifo, fifo_len, win,
-                       win_ready, hist, pcm8k, pcm16k, rs8to16->d_taps);
+                       win_ready, hist, pcm8k, pcm16k, rs8to16->d_taps, 1, (int64_t)0);
     IFH_LAUNCH_CHECK("ingest_tick");
     return IFH_OK;
 }
@@ -710,7 +716,7 @@ extern "C" int ifh_ingest_block(const uint8_t *frames, int nticks, const int32_t
     hipStream_t st = as_stream(stream);
     std::vector<int32_t> hslot(n);
     // event tables come back through pinned memory and are looked at just before the NEXT window's VAD launches: the
-    // 4-5 tick launches enqueued in between keep the stream busy while the host decides (the tick kernels do not touch
+    // tick launch enqueued in between keeps the stream busy while the host decides (the tick kernel does not touch
     // the emit rows, so the chunks of window w are copied out before anything can overwrite them).
     struct Pinned {
         int64_t *buf = nullptr;
@@ -759,10 +765,14 @@ extern "C" int ifh_ingest_block(const uint8_t *frames, int nticks, const int32_t
         }
         return IFH_OK;
     };
-    for (int t = 0; t < nticks; t++) {
+    for (int t = 0; t < nticks;) {
+        // the ticks up to (and including) the one that completes the next window go in one launch
+        int k = (int)((IFH_VAD_WINDOW - nbytes + 159) / 160);
+        k = k < 1 ? 1 : (k > nticks - t ? nticks - t : k);
         hipLaunchKernelGGL(k_ingest_tick, dim3(n), dim3(64), 0, st, frames + (int64_t)t * n * 160, slot, fifo, fifo_len, win,
-                           win_ready, hist, pcm8k, pcm16k, rs8to16->d_taps);
-        nbytes += 160;
+                           win_ready, hist, pcm8k, pcm16k, rs8to16->d_taps, k, (int64_t)n * 160);
+        t += k;
+        nbytes += 160 * (int64_t)k;
         if (nbytes < IFH_VAD_WINDOW) continue;
         nbytes -= IFH_VAD_WINDOW;
         if (nwin > 0) {
