@@ -108,8 +108,10 @@ class Whisper:
         if Bn not in self._enc_bufs:
             e = lambda *s: torch.empty(s, dtype=BF16, device=dev)
             rows = Bn * N_CTX
-            self._enc_bufs = {Bn: dict(mt=e(Bn, 3000, self.n_mel), c1=e(Bn, 3000, d), x=e(rows, d), hn=e(rows, d),
-                                       qkv=e(rows, 3 * d), att=e(rows, d), ff=e(rows, FF), out=e(rows, d))}
+            while len(self._enc_bufs) >= 3:                      # a few batch shapes stay resident (grouped cycles, remainders)
+                self._enc_bufs.pop(next(iter(self._enc_bufs)))
+            self._enc_bufs[Bn] = dict(mt=e(Bn, 3000, self.n_mel), c1=e(Bn, 3000, d), x=e(rows, d), hn=e(rows, d),
+                                      qkv=e(rows, 3 * d), att=e(rows, d), ff=e(rows, FF), out=e(rows, d))
         b = self._enc_bufs[Bn]
         rows = Bn * N_CTX
         ops.transpose_to_bf16(mel.contiguous(), b['mt'], Bn, self.n_mel, 3000)
@@ -134,14 +136,16 @@ class Whisper:
         if Bn not in self._dec_bufs:
             dev, d = self.device, self.d
             e = lambda *s, dt=BF16: torch.empty(s, dtype=dt, device=dev)
-            self._dec_bufs = {Bn: dict(
+            while len(self._dec_bufs) >= 3:
+                self._dec_bufs.pop(next(iter(self._dec_bufs)))
+            self._dec_bufs[Bn] = dict(
                 cross=[e(Bn * N_CTX, 2 * d) for _ in self.dec_layers],
                 kv=[torch.zeros((Bn, self.max_tokens, 2 * d), dtype=BF16, device=dev) for _ in self.dec_layers],
                 x=e(Bn, d), hn=e(Bn, d), q=e(Bn, d), att=e(Bn, d), ff=e(Bn, self.ff),
                 logits_full=e(Bn, self.vpad, dt=torch.float32),
                 stats=torch.zeros((3 * len(self.dec_layers), max(64, -(-Bn // 16) * 16), 2), dtype=torch.int64, device=dev),
                 toks=torch.zeros((self.max_tokens + 1, Bn), dtype=torch.int32, device=dev),
-                pos=torch.zeros(1, dtype=torch.int32, device=dev), graphs={}, eager_runs=0)}
+                pos=torch.zeros(1, dtype=torch.int32, device=dev), graphs={}, eager_runs=0)
             b = self._dec_bufs[Bn]
             b['logits'] = b['logits_full'][:, :self.vocab]         # [Bn, vocab] view, row stride vpad
         return self._dec_bufs[Bn]

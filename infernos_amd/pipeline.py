@@ -166,14 +166,16 @@ class SpeechPipeline:
             merged.append(head.audio)
         lens8 = torch.tensor([m.numel() for m in merged], dtype=torch.int32)
         L8 = max(int(lens8.max()), 1)
-        x8 = torch.zeros((self.n, L8), dtype=torch.float32, device=dev)
+        nrow = len(chunks)                                   # N, or G*N when the STT of G cycles runs as one batch
+        x8 = torch.zeros((nrow, L8), dtype=torch.float32, device=dev)
         for i, m in enumerate(merged):
             x8[i, :m.numel()] = m
         x16 = self.up(x8, lens=lens8)
         lens16 = (lens8 * 2).to(dev)
         mel = fl.logmel(x16, lens=lens16)
         enc = fl.whisper.encode(mel)
-        toks, nsp, _ = fl.whisper.generate(enc, self.prompt, self.n_new, no_speech_id=50362)
+        prompt = self.prompt if nrow == self.n else self.prompt.repeat(nrow // self.n, 1)
+        toks, nsp, _ = fl.whisper.generate(enc, prompt, self.n_new, no_speech_id=50362)
         return toks, nsp, (lens8.float() / 8000.0)
 
     # ---- stage 3 -----------------------------------------------------------------------------
@@ -247,6 +249,21 @@ class SpeechPipeline:
         fl.vad.st[:, 3] = -1
         fl.vad.blen.zero_()
 
+    def front_group(self, frames_list, fl=None):
+        """ingest of each cycle in turn, then ONE STT batch over all of them (rows g*N + call): the Whisper token loop is
+        a chain of small launches whose cost hardly depends on the row count.  -> list of per-cycle result dicts"""
+        fl = self.front_lanes[0] if fl is None else fl
+        per, allc = [], []
+        for fr in frames_list:
+            self.reset_calls(fl)
+            ch = self.ingest(fr, fl)
+            per.append(ch)
+            allc.extend(ch)
+        toks, nsp, secs = self.stt(allc, fl)
+        n = self.n
+        return [dict(tokens=toks[j * n:(j + 1) * n], no_speech_prob=nsp[j * n:(j + 1) * n], stt_seconds=secs[j * n:(j + 1) * n],
+                     chunks=[[(c.ipos, c.audio.numel()) for c in lst] for lst in ch]) for j, ch in enumerate(per)]
+
     def front(self, frames: torch.Tensor, fl=None):
         """ingest + STT of one utterance cycle (stages 1-2) on the current stream"""
         fl = self.front_lanes[0] if fl is None else fl
@@ -263,8 +280,9 @@ class SpeechPipeline:
         if frames is not None:
             for fl in self.front_lanes:
                 with torch.cuda.stream(fl.stream):
-                    for _ in range(3):
-                        self.front(frames, fl)
+                    for g in sorted({self.tts_group, 1} | set(range(1, self.tts_group))):
+                        for _ in range(3):
+                            self.front_group([frames] * g, fl)
                 fl.stream.synchronize()
         for lane in range(len(self.tts_lanes)):
             for g in sorted({self.tts_group, 1} | set(range(1, self.tts_group))):     # a trailing group may be smaller
@@ -308,39 +326,38 @@ class SpeechPipeline:
         import time
         self.stage_wall = {'front': [], 'tts': []}                 # host wall seconds per job (bench --breakdown)
 
-        def job(k, fr, fr_ready):
+        def job(gi, frs):
             torch.cuda.set_device(dev)
             t0 = time.perf_counter()
-            fl = self.front_lanes[k % F]
+            fl = self.front_lanes[gi % F]
             with fl.lock, torch.cuda.stream(fl.stream):
-                fl.stream.wait_event(fr_ready)
-                fr.record_stream(fl.stream)
-                r = self.front(fr, fl)
+                for fr, fr_ready in frs:
+                    fl.stream.wait_event(fr_ready)
+                    fr.record_stream(fl.stream)
+                rs = self.front_group([fr for fr, _ in frs], fl)
                 ev = torch.cuda.Event()
                 ev.record(fl.stream)
             self.stage_wall['front'].append(time.perf_counter() - t0)
-            return r, ev
+            return rs, ev
 
         G = self.tts_group
 
-        def tts_job(lane, front_futs):
+        def tts_job(lane, front_fut):
             torch.cuda.set_device(dev)
-            rs = [f.result() for f in front_futs]                  # the G cycles of this group, in order
+            rs, stt_done = front_fut.result()                      # the G cycles of this group, in order
             t0 = time.perf_counter()
             stream = self._lane_streams[lane]
             with torch.cuda.stream(stream):
-                for _, stt_done in rs:
-                    stream.wait_event(stt_done)                    # T2T stub consumes the STT tokens
-                g = len(rs)
-                ulaw, valid, spans = self.synthesize(lane=lane, group=g)
+                stream.wait_event(stt_done)                        # T2T stub consumes the STT tokens
+                ulaw, valid, spans = self.synthesize(lane=lane, group=len(rs))
                 n = self.n
-                for j, (r, _) in enumerate(rs):
+                for j, r in enumerate(rs):
                     r.update(ulaw=ulaw[j * n:(j + 1) * n], tts_samples=valid[j * n:(j + 1) * n],
                              spans=[row[j * n:(j + 1) * n] for row in spans])
                 ev = torch.cuda.Event()
                 ev.record(stream)
             self.stage_wall['tts'].append(time.perf_counter() - t0)
-            return [r for r, _ in rs], ev
+            return rs, ev
 
         fronts, ttss = {}, {}
         out = None
@@ -359,13 +376,13 @@ class SpeechPipeline:
                     on_cycle(r)                                    # e.g. egress gather of this cycle's output rows
             return rs[-1]
         ngroups = (nsteps + G - 1) // G
-        nfront = 0
+        nfront = 0                                                 # groups whose front-end job has been submitted
         for gi in range(ngroups):
-            hi = min(nsteps, (gi + 1) * G)
-            while nfront < min(nsteps, hi + L * G):                # the front end runs up to L groups ahead
-                fronts[nfront] = self._pool.submit(job, nfront, *fetch(nfront))
+            while nfront < min(ngroups, gi + 1 + L):               # the front end runs up to L groups ahead
+                lo, hi = nfront * G, min(nsteps, (nfront + 1) * G)
+                fronts[nfront] = self._pool.submit(job, nfront, [fetch(k) for k in range(lo, hi)])
                 nfront += 1
-            ttss[gi] = self._tts_pool.submit(tts_job, gi % L, [fronts.pop(k) for k in range(gi * G, hi)])
+            ttss[gi] = self._tts_pool.submit(tts_job, gi % L, fronts.pop(gi))
             if gi >= L - 1:
                 out = retire(gi - (L - 1))
         for gi in range(max(0, ngroups - (L - 1)), ngroups):
