@@ -233,7 +233,7 @@ int ifh_conv_bf16(const ifh_conv_desc *desc, ifh_stream_t stream);
  * HelloSippyTTSRT/HelloSippyRTPipe.py:236):
  *     out = (x + conv2(lrelu(conv1(lrelu(x); taps, dil)); taps, 1)) * out_scale  (+ out if accumulate)
  * x, out bf16 [nbatch][t][c] channels-last with contiguous rows (batch strides in elements, % 8 == 0),
- * c in {32,64,128,256}, w1/w2 bf16 [c][taps][c], taps odd <= 15, "same" padding.  The intermediate is
+ * c in {32,64,128,256}, w1/w2 bf16 [c][taps][c], taps odd <= 15 (<= 11 at c = 32), "same" padding.  The intermediate is
  * rounded to bf16 exactly as two ifh_conv_bf16 launches would, so both routes give identical bits. */
 typedef struct ifh_resblock_desc {
     const void *x;

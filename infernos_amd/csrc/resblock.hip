@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
             const int n = (wn * NT + i) * 16 + 4 * fg;
             rpre[i][j] = RES_LDS ? make_uint2(0, 0)
                                  : *reinterpret_cast<const uint2 *>(p.x + (int64_t)be * p.x_bstride + (int64_t)t * CIN + n);
-            apre[i][j] = p.accumulate ? *reinterpret_cast<const uint2 *>(p.out + (int64_t)be * p.out_bstride + (int64_t)t * CIN + n)
-                                      : make_uint2(0, 0);
+            apre[i][j] = (p.accumulate && !RESIDENT)      // C = 32 reads them in its epilogue instead: 16 fewer live registers -> 3 blocks per CU
+                             ? *reinterpret_cast<const uint2 *>(p.out + (int64_t)be * p.out_bstride + (int64_t)t * CIN + n)
+                             : make_uint2(0, 0);
         }
     }
     // ---- weights.  Streamed: chunk c < nchunk belongs to conv1, the rest to conv2 (named registers: see
@@ -141,9 +142,9 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
     }
     if (RESIDENT) {
         RB_R1(0, w0, p.w1) RB_R1(1, w1, p.w1) RB_R1(2, w2, p.w1) RB_R1(3, w3, p.w1)
-        RB_R1(4, w4, p.w1) RB_R1(5, w5, p.w1) RB_R1(6, w6, p.w1) RB_R1(7, w7, p.w1)
+        RB_R1(4, w4, p.w1) RB_R1(5, w5, p.w1)
         RB_R1(0, w8, p.w2) RB_R1(1, w9, p.w2) RB_R1(2, w10, p.w2) RB_R1(3, w11, p.w2)
-        RB_R1(4, w12, p.w2) RB_R1(5, w13, p.w2) RB_R1(6, w14, p.w2) RB_R1(7, w15, p.w2)
+        RB_R1(4, w12, p.w2) RB_R1(5, w13, p.w2)                                         // <= 6 vectors: taps <= 12 at C = 32
     } else {
         RB_W_PREFETCH(0)
     }
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
         }
     }
     if (RESIDENT) {
-        RB_RC1(0, w0) RB_RC1(1, w1) RB_RC1(2, w2) RB_RC1(3, w3) RB_RC1(4, w4) RB_RC1(5, w5) RB_RC1(6, w6) RB_RC1(7, w7)
+        RB_RC1(0, w0) RB_RC1(1, w1) RB_RC1(2, w2) RB_RC1(3, w3) RB_RC1(4, w4) RB_RC1(5, w5)
     }
 
     f32x4 acc[NT][MT1];
@@ -260,7 +261,7 @@ _Pragma("unroll") \
             if (!RESIDENT) {
                 RB_W_COMMIT()
             } else {
-                RB_RC1(0, w8) RB_RC1(1, w9) RB_RC1(2, w10) RB_RC1(3, w11) RB_RC1(4, w12) RB_RC1(5, w13) RB_RC1(6, w14) RB_RC1(7, w15)
+                RB_RC1(0, w8) RB_RC1(1, w9) RB_RC1(2, w10) RB_RC1(3, w11) RB_RC1(4, w12) RB_RC1(5, w13)
             }
             __syncthreads();                               // (first: also publishes Ms)
             if (!RESIDENT && ch + 1 < nchunk) RB_W_PREFETCH(nchunk + ch + 1)
@@ -319,7 +320,9 @@ _Pragma("unroll") \
             v3 += __uint_as_float(rv.y & 0xffff0000u);
             v0 *= p.out_scale; v1 *= p.out_scale; v2 *= p.out_scale; v3 *= p.out_scale;
             if (p.accumulate) {
-                const uint2 pv = apre[i][j];
+                const uint2 pv = RESIDENT ? *reinterpret_cast<const uint2 *>(
+                                                p.out + (int64_t)min(b0 + e, p.nbatch - 1) * p.out_bstride + (int64_t)min(t0 + lt * 16 + fr, p.T - 1) * CIN + n)
+                                          : apre[i][j];
                 v0 += __uint_as_float(pv.x << 16);
                 v1 += __uint_as_float(pv.x & 0xffff0000u);
                 v2 += __uint_as_float(pv.y << 16);
@@ -351,7 +354,7 @@ static int launch_pair(PairParams &p, hipStream_t st)
     const int R1 = BM1E + (p.taps - 1) * p.dil;
     const int KW = RESIDENT ? K : KC;
     if (!RESIDENT && K % KC != 0) return fail(IFH_EINVAL, "resblock_pair: taps*c must be a multiple of 64");
-    if (RESIDENT && BN * (K / 8) > 8 * 256) return fail(IFH_EINVAL, "resblock_pair: too many taps");
+    if (RESIDENT && BN * (K / 8) > 6 * 256) return fail(IFH_EINVAL, "resblock_pair: at most 11 taps at c = 32");
     const size_t bytes = ((size_t)((EPB * R1 * XS + 7) & ~7) + (size_t)BN * (KW + 8) + (RES_LDS ? (size_t)EPB * BME * XS : 0)) * sizeof(uint16_t);
     if (bytes > 160 * 1024) return fail(IFH_EINVAL, "resblock_pair: tile does not fit in LDS (taps*dil too large)");
     static bool attr_set = false;
