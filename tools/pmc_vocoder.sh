@@ -6,3 +6,4 @@ for c in FETCH_SIZE WRITE_SIZE; do
   tail -2 $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log
 done
 ls $GRAFT_REPO_ROOT/gpurun_out/pmc_FETCH_SIZE/*/
+find $GRAFT_REPO_ROOT/gpurun_out -name '*kernel_trace.csv' -delete

@@ -6,3 +6,4 @@ f=$(find $R/gpurun_out/prof_bench -name '*kernel_stats.csv' | head -1)
 cp "$f" $R/gpurun_out/bench_kernel_stats.csv
 tail -1 $R/gpurun_out/prof_bench.log | cut -c1-300
 head -32 "$f" | cut -c1-170
+find $R/gpurun_out -name '*kernel_trace.csv' -delete   # the traces are large; only the stats travel back

@@ -6,3 +6,4 @@ for g in 1 3; do
   f=$(find $R/gpurun_out/prof_step$g -name '*kernel_stats.csv' | head -1)
   echo "== group $g"; head -9 "$f" | cut -d, -f1-4 | cut -c1-110
 done
+find $R/gpurun_out -name '*kernel_trace.csv' -delete   # the traces are large; only the stats travel back

@@ -5,3 +5,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_voc -
 f=$(find $R/gpurun_out/prof_voc -name '*kernel_stats.csv' | head -1)
 cp "$f" $R/gpurun_out/voc_kernel_stats.csv
 head -25 "$f" | cut -c1-200
+find $R/gpurun_out -name '*kernel_trace.csv' -delete   # the traces are large; only the stats travel back
