@@ -47,6 +47,7 @@ template <int CIN, int WGM, int MT1, int NT, bool RESIDENT, int KC, int EPB, boo
 __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
 {
     constexpr int WGN = 4 / WGM;
+    constexpr bool LATE_ACC = RESIDENT;       // C = 32: one exposed load in the 2-of-18 accumulating launches buys a third block per CU
     constexpr int TPE = WGM * MT1 / EPB;      // conv1 tiles per batch entry
     constexpr int BM1E = TPE * 16;            // conv1 rows per entry
     constexpr int BME = BM1E - 16;            // conv2 (output) rows per entry
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
             const int n = (wn * NT + i) * 16 + 4 * fg;
             rpre[i][j] = RES_LDS ? make_uint2(0, 0)
                                  : *reinterpret_cast<const uint2 *>(p.x + (int64_t)be * p.x_bstride + (int64_t)t * CIN + n);
-            apre[i][j] = (p.accumulate && !RESIDENT)      // C = 32 reads them in its epilogue instead: 16 fewer live registers -> 3 blocks per CU
+            apre[i][j] = (p.accumulate && !LATE_ACC)      // LATE_ACC reads them in the epilogue instead: fewer live registers
                              ? *reinterpret_cast<const uint2 *>(p.out + (int64_t)be * p.out_bstride + (int64_t)t * CIN + n)
                              : make_uint2(0, 0);
         }
@@ -320,7 +321,7 @@ _Pragma("unroll") \
             v3 += __uint_as_float(rv.y & 0xffff0000u);
             v0 *= p.out_scale; v1 *= p.out_scale; v2 *= p.out_scale; v3 *= p.out_scale;
             if (p.accumulate) {
-                const uint2 pv = RESIDENT ? *reinterpret_cast<const uint2 *>(
+                const uint2 pv = LATE_ACC ? *reinterpret_cast<const uint2 *>(
                                                 p.out + (int64_t)min(b0 + e, p.nbatch - 1) * p.out_bstride + (int64_t)min(t0 + lt * 16 + fr, p.T - 1) * CIN + n)
                                           : apre[i][j];
                 v0 += __uint_as_float(pv.x << 16);
