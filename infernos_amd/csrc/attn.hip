@@ -65,26 +65,46 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const AttnParams p)
     const int half = p.nrel >> 1;
 
     const int ntile = (klen + KT - 1) / KT;
+    // K/V tiles travel through registers one tile ahead: the loads of tile kt+1 are in flight while tile kt is being
+    // multiplied (a load -> LDS -> barrier sequence per tile left the block waiting on HBM/L2 24 times at T = 1500)
+    uint4 kk0 = make_uint4(0, 0, 0, 0), kk1 = kk0, vx0 = kk0, vx1 = kk0;
+#define AT_LOAD(KB)                                                                                                  \
+    {                                                                                                                \
+        const int kg0 = (KB) + (tid >> 3), kg1 = (KB) + ((tid + 256) >> 3);                                          \
+        const int dv = (tid & 7) * 8;                                                                                \
+        kk0 = kk1 = vx0 = vx1 = make_uint4(0, 0, 0, 0);                                                              \
+        if (kg0 < klen) {                                                                                            \
+            kk0 = *reinterpret_cast<const uint4 *>(p.k + (int64_t)b * p.k_bs + (int64_t)kg0 * p.k_ts + h * HD + dv); \
+            vx0 = *reinterpret_cast<const uint4 *>(p.v + (int64_t)b * p.v_bs + (int64_t)kg0 * p.v_ts + h * HD + dv); \
+        }                                                                                                            \
+        if (kg1 < klen) {                                                                                            \
+            kk1 = *reinterpret_cast<const uint4 *>(p.k + (int64_t)b * p.k_bs + (int64_t)kg1 * p.k_ts + h * HD + dv); \
+            vx1 = *reinterpret_cast<const uint4 *>(p.v + (int64_t)b * p.v_bs + (int64_t)kg1 * p.v_ts + h * HD + dv); \
+        }                                                                                                            \
+    }
+#define AT_COMMIT(KKV, VXV, I)                                                                                       \
+    {                                                                                                                \
+        const int vv = tid + 256 * I;                                                                                \
+        const int key = vv >> 3, dv = (vv & 7) * 8;                                                                  \
+        *reinterpret_cast<uint4 *>(&Ks[key * KLD + dv]) = KKV;                                                       \
+        Vt[(dv + 0) * KLD + key] = (uint16_t)(VXV.x & 0xffffu);                                                      \
+        Vt[(dv + 1) * KLD + key] = (uint16_t)(VXV.x >> 16);                                                          \
+        Vt[(dv + 2) * KLD + key] = (uint16_t)(VXV.y & 0xffffu);                                                      \
+        Vt[(dv + 3) * KLD + key] = (uint16_t)(VXV.y >> 16);                                                          \
+        Vt[(dv + 4) * KLD + key] = (uint16_t)(VXV.z & 0xffffu);                                                      \
+        Vt[(dv + 5) * KLD + key] = (uint16_t)(VXV.z >> 16);                                                          \
+        Vt[(dv + 6) * KLD + key] = (uint16_t)(VXV.w & 0xffffu);                                                      \
+        Vt[(dv + 7) * KLD + key] = (uint16_t)(VXV.w >> 16);                                                          \
+    }
+    if (ntile > 0) AT_LOAD(0)
     for (int kt = 0; kt < ntile; kt++) {
         const int kbase = kt * KT;
         __syncthreads();
-        // stage K [64 keys][64 d] and V^T [64 d][64 keys]; 2 x 16-byte vectors each per thread
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int vv = tid + 256 * i;
-            const int key = vv >> 3, dv = (vv & 7) * 8;
-            const int kg = kbase + key;
-            uint4 kk = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
-            if (kg < klen) {
-                kk = *reinterpret_cast<const uint4 *>(p.k + (int64_t)b * p.k_bs + (int64_t)kg * p.k_ts + h * HD + dv);
-                vx = *reinterpret_cast<const uint4 *>(p.v + (int64_t)b * p.v_bs + (int64_t)kg * p.v_ts + h * HD + dv);
-            }
-            *reinterpret_cast<uint4 *>(&Ks[key * KLD + dv]) = kk;
-            const uint16_t *ve = reinterpret_cast<const uint16_t *>(&vx);
-#pragma unroll
-            for (int e = 0; e < 8; e++) Vt[(dv + e) * KLD + key] = ve[e];
-        }
+        // stage K [64 keys][64 d] and V^T [64 d][64 keys] from the prefetched registers
+        AT_COMMIT(kk0, vx0, 0)
+        AT_COMMIT(kk1, vx1, 1)
         __syncthreads();
+        if (kt + 1 < ntile) AT_LOAD(kbase + KT)
         // S^T tiles: 4 x (16 keys x 16 queries)
         f32x4 s[4];
 #pragma unroll
