@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
     constexpr int MT = WM / 16, NT = WN / 16;
     constexpr int LD = 40;  // 32 + 8 pad (80-byte rows)
     constexpr int AV = BM * 4 / 256, BV = (BN * 4 + 255) / 256;
-    __shared__ __attribute__((aligned(16))) uint16_t As[BM * LD];
-    __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * LD];
+    __shared__ __attribute__((aligned(16))) uint16_t As2[2][BM * LD];      // double-buffered K tiles: one barrier per k-step
+    __shared__ __attribute__((aligned(16))) uint16_t Bs2[2][BN * LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid % WGM, wn = wid / WGM;
@@ -261,26 +261,35 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
     }
     // the fused input LeakyReLU is applied at LDS-store time, after the previous tile's MFMAs, so the
     // global loads of this tile stayed in flight behind them (zeros stay zeros)
-#define IFH_STORE_TILES()                                                                                \
+#define IFH_STORE_TILES(BUF)                                                                             \
     {                                                                                                    \
+        uint16_t *As_ = As2[BUF], *Bs_ = Bs2[BUF];                                                       \
         _Pragma("unroll") for (int i = 0; i < AV; i++)                                                   \
         {                                                                                                \
             const int v = tid + 256 * i;                                                                 \
-            *reinterpret_cast<uint4 *>(&As[(v >> 2) * LD + (v & 3) * 8]) = PRE ? lrelu8(ra[i], p.pre_slope) : ra[i]; \
+            *reinterpret_cast<uint4 *>(&As_[(v >> 2) * LD + (v & 3) * 8]) = PRE ? lrelu8(ra[i], p.pre_slope) : ra[i]; \
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < BV; i++)                                                   \
         {                                                                                                \
             const int v = tid + 256 * i;                                                                 \
-            if (v < BN * 4) *reinterpret_cast<uint4 *>(&Bs[(v >> 2) * LD + (v & 3) * 8]) = rb[i];        \
+            if (v < BN * 4) *reinterpret_cast<uint4 *>(&Bs_[(v >> 2) * LD + (v & 3) * 8]) = rb[i];       \
         }                                                                                                \
     }
 
     const int nk = (p.K + 31) / 32;
     IFH_LOAD_TILES(0);
     const int fr = lane & 15, fg = lane >> 4;
+    // bias 4-vectors of this lane's column groups, requested ahead of the K loop (vector epilogue only)
+    float4 bpre[NT];
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        const int n = n0 + wn * WN + i * 16 + 4 * fg;
+        bpre[i] = (FAST && p.bias && n < p.N) ? *reinterpret_cast<const float4 *>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    IFH_STORE_TILES(0);
+    __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
-        IFH_STORE_TILES();
-        __syncthreads();
+        const uint16_t *As = As2[kt & 1], *Bs = Bs2[kt & 1];
         if (kt + 1 < nk) IFH_LOAD_TILES((kt + 1) * 32);
         bf16x8_t fa[NT], fb[MT];
 #pragma unroll
@@ -294,6 +303,8 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
 #pragma unroll
             for (int j = 0; j < MT; j++)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        // the other buffer was last read one iteration ago and every wave has passed the barrier since
+        if (kt + 1 < nk) IFH_STORE_TILES((kt + 1) & 1);
         __syncthreads();
     }
 
@@ -309,7 +320,10 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
         for (int i = 0; i < NT; i++) {
             const int n = n0 + wn * WN + i * 16 + 4 * fg;
             if (n >= p.N) continue;
-            igemm_store4<FAST>(p, m, n, acc[i][j], dynv);
+            if (FAST)
+                (void)igemm_store4_fast<false, true, true>(p, m, n, acc[i][j], dynv, make_uint2(0, 0), bpre[i]);
+            else
+                igemm_store4<false>(p, m, n, acc[i][j], dynv);
         }
     }
 }
