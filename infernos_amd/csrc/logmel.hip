@@ -458,6 +458,307 @@ __global__ __launch_bounds__(256) void k_logmel_dft2(const float *__restrict__ a
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// k_logmel_fft: the power spectrum through a real FFT instead of a DFT-as-GEMM (which cannot reach the HBM roof: its
+// matrix work alone is >= 83 us per 64 windows).  Real 400-point transform via a complex 200-point one, z[n] = x[2n] +
+// i x[2n+1], 200 = 25 x 8:
+//   phase A  thread (frame f, n2 < 8): register DFT-25 (5 x 5) of z[8 n1 + n2], twiddle W200^(n2 k1) -> Y[f][k1][n2] (LDS)
+//   phase B  13 tasks per frame (k1 = 0; pairs k1 / 25-k1): the DFT-8s give Z[k1 + 25 k2]; bins k and 200-k come out
+//            together as |A +- B|^2 with A = (Z[k] + conj Z[200-k])/2, B = -(i/2) W400^k (Z[k] - conj Z[200-k])
+//   then the sparse mel projection + log10 + per-window max as before.
+// Block = 32 frames x 8 threads; LDS = 25.7 KB (audio tile, later the power tile) + 51.2 KB (Y): 2 blocks per CU.
+// Audio layout: sample m at m + 16*(m/160), so a frame's (even, odd) pairs are aligned 8-byte reads and the 8 x 4
+// (frame, n2) lanes of a half-wave hit 64 distinct banks.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFB = 32;                                 // frames per block
+constexpr int kTileF = (kFB - 1) * kHop + kNfft;        // 5360 samples
+constexpr int kAudF = kTileF + 16 * ((kTileF - 1) / kHop) + 16;   // padded audio floats (5904)
+constexpr int kPS = 201;                                // power tile row stride (odd: conflict-free over frames)
+constexpr int kReg0F = (kAudF > kFB * kPS) ? kAudF : kFB * kPS;   // audio tile / power tile overlay
+constexpr int kYF = kFB * 25 * 8 * 2;                   // Y buffer floats
+constexpr int kLdsFftBytes = (kReg0F + kYF) * 4;
+
+struct FftConst {
+    float2 w25[5][5];      // W25^(b c)
+};
+__constant__ FftConst c_fft;
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// forward 5-point DFT (in place on 5 named values)
+#define FFT5(V0, V1, V2, V3, V4)                                                                              \
+    {                                                                                                         \
+        const float c1 = 0.30901699437494745f, c2 = -0.80901699437494745f;                                    \
+        const float s1 = 0.95105651629515353f, s2 = 0.58778525229247314f;                                     \
+        const float2 t1 = cadd(V1, V4), t2 = cadd(V2, V3), t3 = csub(V1, V4), t4 = csub(V2, V3);              \
+        const float2 m1 = make_float2(V0.x + c1 * t1.x + c2 * t2.x, V0.y + c1 * t1.y + c2 * t2.y);            \
+        const float2 m2 = make_float2(V0.x + c2 * t1.x + c1 * t2.x, V0.y + c2 * t1.y + c1 * t2.y);            \
+        const float2 u1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);                          \
+        const float2 u2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);                          \
+        V0 = make_float2(V0.x + t1.x + t2.x, V0.y + t1.y + t2.y);                                             \
+        V1 = make_float2(m1.x + u1.y, m1.y - u1.x);  /* m1 - i u1 */                                          \
+        V4 = make_float2(m1.x - u1.y, m1.y + u1.x);  /* m1 + i u1 */                                          \
+        V2 = make_float2(m2.x + u2.y, m2.y - u2.x);                                                           \
+        V3 = make_float2(m2.x - u2.y, m2.y + u2.x);                                                           \
+    }
+
+// forward 8-point DFT of v[0..7] (natural order in, natural order out)
+__device__ __forceinline__ void fft8(float2 (&v)[8])
+{
+    const float h = 0.70710678118654752f;
+    // stage 1: pairs (j, j+4)
+    float2 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
+    float2 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+    float2 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
+    float2 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
+    // twiddle the odd half by W8^j: 1, (1-i)/sqrt2, -i, (-1-i)/sqrt2
+    a5 = make_float2(h * (a5.x + a5.y), h * (a5.y - a5.x));
+    a6 = make_float2(a6.y, -a6.x);
+    a7 = make_float2(h * (a7.y - a7.x), -h * (a7.x + a7.y));
+    // two 4-point DFTs: even outputs from a0..a3, odd outputs from a4..a7
+    float2 b0 = cadd(a0, a2), b2 = csub(a0, a2), b1 = cadd(a1, a3), b3 = csub(a1, a3);
+    b3 = make_float2(b3.y, -b3.x);
+    v[0] = cadd(b0, b1); v[4] = csub(b0, b1); v[2] = cadd(b2, b3); v[6] = csub(b2, b3);
+    float2 d0 = cadd(a4, a6), d2 = csub(a4, a6), d1 = cadd(a5, a7), d3 = csub(a5, a7);
+    d3 = make_float2(d3.y, -d3.x);
+    v[1] = cadd(d0, d1); v[5] = csub(d0, d1); v[3] = cadd(d2, d3); v[7] = csub(d2, d3);
+}
+
+__device__ __forceinline__ void power_pair(float2 zk, float2 zm, float2 tw, float &pk, float &pm)
+{
+    const float ax = 0.5f * (zk.x + zm.x), ay = 0.5f * (zk.y - zm.y);      // A = (Zk + conj Zm)/2
+    const float dx = zk.x - zm.x, dy = zk.y + zm.y;                          // D = Zk - conj Zm
+    const float ex = tw.x * dx - tw.y * dy, ey = tw.x * dy + tw.y * dx;      // E = tw D
+    const float bx = 0.5f * ey, by = -0.5f * ex;                             // B = -(i/2) E
+    const float px = ax + bx, py = ay + by, qx = ax - bx, qy = ay - by;
+    pk = __fmaf_rn(px, px, py * py);
+    pm = __fmaf_rn(qx, qx, qy * qy);
+}
+
+__global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ audio, int64_t stride,
+                                                    const int32_t *__restrict__ lens, const float *__restrict__ win,
+                                                    const float2 *__restrict__ tw200 /* [8][25] */,
+                                                    const float2 *__restrict__ tw400 /* [101] */,
+                                                    const int32_t *__restrict__ mel2 /* packed filters, see create */,
+                                                    int mel2_words, int n_mel, float *__restrict__ raw,
+                                                    int *__restrict__ gmax, unsigned long long *__restrict__ prof)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const long long tq0 = clock64();
+    float *aud = lds;                       // later the power tile [kFB][kPS]
+    float2 *Yb = reinterpret_cast<float2 *>(lds + kReg0F);
+    int32_t *mell = reinterpret_cast<int32_t *>(lds + kReg0F + kYF);
+    const int b = blockIdx.y;
+    const int f0 = blockIdx.x * kFB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    int len = lens ? lens[b] : kNsamp;
+    len = len > kNsamp ? kNsamp : (len < 0 ? 0 : len);
+    const float *x = audio + (int64_t)b * stride;
+    float *rawb = raw + (int64_t)b * n_mel * kFrames;
+    const int a0 = f0 * kHop - kNfft / 2;
+    float lmax = -INFINITY;
+    const int a_last = a0 + kTileF - 1;
+    const bool tail_clear = (a_last < kNsamp) || (2 * (kNsamp - 1) - a_last >= len);
+    if (len == 0 || (a0 >= len && a0 >= 0 && tail_clear)) {
+        const float v0 = log10f(fmaxf(0.0f * (float)len, 1e-10f));
+        for (int idx = tid; idx < n_mel * kFB; idx += 256) {
+            const int m = idx / kFB, f = f0 + (idx - m * kFB);
+            if (f < kFrames) rawb[(int64_t)m * kFrames + f] = v0;
+        }
+        if (tid == 0) atomicMax(gmax + b, float_to_ordered(v0));
+        return;
+    }
+    // ---- stage the audio tile (every load of the thread in flight at once)
+    const bool interior = a0 >= 0 && a_last < len && ((reinterpret_cast<uintptr_t>(x + a0) & 15) == 0);
+    if (interior) {
+        constexpr int NV4 = kTileF / 4;          // 1340
+        constexpr int NI = (NV4 + 255) / 256;    // 6
+        const float4 *x4 = reinterpret_cast<const float4 *>(x + a0);
+        float4 v[NI];
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int q = tid + 256 * i;
+            v[i] = x4[q < NV4 ? q : NV4 - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int q = tid + 256 * i;
+            if (q < NV4) *reinterpret_cast<float4 *>(&aud[4 * q + 16 * ((4 * q) / kHop)]) = v[i];
+        }
+    } else {
+        constexpr int NI = (kTileF + 255) / 256;  // 21
+        float v[NI];
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            int a = a0 + tid + 256 * i;
+            if (a < 0) a = -a;
+            if (a >= kNsamp) a = 2 * (kNsamp - 1) - a;
+            const bool ok = a >= 0 && a < len;
+            const float t_ = x[ok ? a : 0];
+            v[i] = ok ? t_ : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++) {
+            const int m = tid + 256 * i;
+            if (m < kTileF) aud[m + 16 * (m / kHop)] = v[i];
+        }
+    }
+    for (int i = tid; i < mel2_words; i += 256) mell[i] = mel2[i];
+    __syncthreads();
+    const long long tq1 = clock64();
+    const int f = tid >> 3, sub = tid & 7;
+    // ---- phase A: DFT-25 over n1 of z[8 n1 + sub], n = 8 n1 + sub, samples 2n, 2n+1 of frame f
+    {
+        float2 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15, v16, v17, v18, v19, v20, v21, v22, v23, v24;
+#define LF_LOAD(V, N1)                                                                               \
+    {                                                                                                \
+        const int n = 8 * (N1) + sub;                                                                \
+        const float2 xs = *reinterpret_cast<const float2 *>(&aud[176 * f + 2 * n + 16 * ((2 * n) / kHop)]); \
+        const float2 wv = *reinterpret_cast<const float2 *>(&win[2 * n]);                            \
+        V = make_float2(xs.x * wv.x, xs.y * wv.y);                                                   \
+    }
+        LF_LOAD(v0, 0) LF_LOAD(v1, 1) LF_LOAD(v2, 2) LF_LOAD(v3, 3) LF_LOAD(v4, 4) LF_LOAD(v5, 5) LF_LOAD(v6, 6)
+        LF_LOAD(v7, 7) LF_LOAD(v8, 8) LF_LOAD(v9, 9) LF_LOAD(v10, 10) LF_LOAD(v11, 11) LF_LOAD(v12, 12) LF_LOAD(v13, 13)
+        LF_LOAD(v14, 14) LF_LOAD(v15, 15) LF_LOAD(v16, 16) LF_LOAD(v17, 17) LF_LOAD(v18, 18) LF_LOAD(v19, 19)
+        LF_LOAD(v20, 20) LF_LOAD(v21, 21) LF_LOAD(v22, 22) LF_LOAD(v23, 23) LF_LOAD(v24, 24)
+#undef LF_LOAD
+        // n1 = 5a + b: for each b a DFT-5 over a (in place: slot 5c + b <- inner[b][c])
+        FFT5(v0, v5, v10, v15, v20) FFT5(v1, v6, v11, v16, v21) FFT5(v2, v7, v12, v17, v22)
+        FFT5(v3, v8, v13, v18, v23) FFT5(v4, v9, v14, v19, v24)
+        // twiddle inner[b][c] by W25^(b c) (b, c >= 1)
+#define LF_TW(V, B, C) V = cmul(V, c_fft.w25[B][C]);
+        LF_TW(v6, 1, 1) LF_TW(v7, 2, 1) LF_TW(v8, 3, 1) LF_TW(v9, 4, 1)
+        LF_TW(v11, 1, 2) LF_TW(v12, 2, 2) LF_TW(v13, 3, 2) LF_TW(v14, 4, 2)
+        LF_TW(v16, 1, 3) LF_TW(v17, 2, 3) LF_TW(v18, 3, 3) LF_TW(v19, 4, 3)
+        LF_TW(v21, 1, 4) LF_TW(v22, 2, 4) LF_TW(v23, 3, 4) LF_TW(v24, 4, 4)
+#undef LF_TW
+        // for each c a DFT-5 over b: slot 5c + d <- Y[k1 = c + 5 d]
+        FFT5(v0, v1, v2, v3, v4) FFT5(v5, v6, v7, v8, v9) FFT5(v10, v11, v12, v13, v14)
+        FFT5(v15, v16, v17, v18, v19) FFT5(v20, v21, v22, v23, v24)
+        const float2 *tw = tw200 + sub * 25;
+        float2 *yo = Yb + (f * 25) * 8 + sub;
+#define LF_OUT(V, C, D) yo[((C) + 5 * (D)) * 8] = cmul(V, tw[(C) + 5 * (D)]);
+        LF_OUT(v0, 0, 0) LF_OUT(v1, 0, 1) LF_OUT(v2, 0, 2) LF_OUT(v3, 0, 3) LF_OUT(v4, 0, 4)
+        LF_OUT(v5, 1, 0) LF_OUT(v6, 1, 1) LF_OUT(v7, 1, 2) LF_OUT(v8, 1, 3) LF_OUT(v9, 1, 4)
+        LF_OUT(v10, 2, 0) LF_OUT(v11, 2, 1) LF_OUT(v12, 2, 2) LF_OUT(v13, 2, 3) LF_OUT(v14, 2, 4)
+        LF_OUT(v15, 3, 0) LF_OUT(v16, 3, 1) LF_OUT(v17, 3, 2) LF_OUT(v18, 3, 3) LF_OUT(v19, 3, 4)
+        LF_OUT(v20, 4, 0) LF_OUT(v21, 4, 1) LF_OUT(v22, 4, 2) LF_OUT(v23, 4, 3) LF_OUT(v24, 4, 4)
+#undef LF_OUT
+    }
+    __syncthreads();      // Y complete; the audio tile is dead: its place becomes the power tile
+    const long long tq2 = clock64();
+    // ---- phase B: tasks sub and sub + 8 (< 13) of frame f
+    float *Pt = aud + f * kPS;
+    for (int task = sub; task < 13; task += 8) {
+        float2 za[8], zb[8];
+        const float2 *ya = Yb + (f * 25 + task) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; j++) za[j] = ya[j];
+        fft8(za);                                     // Z[task + 25 k2]
+        if (task == 0) {
+            float pk, pm;
+            power_pair(za[0], za[0], tw400[0], pk, pm);
+            Pt[0] = pk;
+            Pt[200] = pm;
+            power_pair(za[1], za[7], tw400[25], pk, pm);
+            Pt[25] = pk;
+            Pt[175] = pm;
+            power_pair(za[2], za[6], tw400[50], pk, pm);
+            Pt[50] = pk;
+            Pt[150] = pm;
+            power_pair(za[3], za[5], tw400[75], pk, pm);
+            Pt[75] = pk;
+            Pt[125] = pm;
+            power_pair(za[4], za[4], tw400[100], pk, pm);
+            Pt[100] = pk;
+        } else {
+            const int kp = 25 - task;
+            const float2 *yb = Yb + (f * 25 + kp) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j++) zb[j] = yb[j];
+            fft8(zb);                                 // Z[kp + 25 k2]
+#pragma unroll
+            for (int k2 = 0; k2 < 4; k2++) {
+                float pk, pm;
+                int k = task + 25 * k2;               // <= 87: partner 200 - k = kp + 25 (7 - k2)
+                power_pair(za[k2], zb[7 - k2], tw400[k], pk, pm);
+                Pt[k] = pk;
+                Pt[200 - k] = pm;
+                k = kp + 25 * k2;                     // <= 99: partner 200 - k = task + 25 (7 - k2)
+                power_pair(zb[k2], za[7 - k2], tw400[k], pk, pm);
+                Pt[k] = pk;
+                Pt[200 - k] = pm;
+            }
+        }
+    }
+    __syncthreads();
+    const long long tq3 = clock64();
+    // ---- sparse mel projection + log10: thread = (frame fl, mel m = mg + 8 u), four filters in flight; the packed
+    // filter table (lo | groups | first group | weights padded to groups of 4, trailing zero group) sits in LDS
+    {
+        const int fl = tid & (kFB - 1), mg = tid >> 5;
+        const float *pr = aud + fl * kPS;
+        const int fr_ = f0 + fl;
+        const float4 *w4 = reinterpret_cast<const float4 *>(mell + 384);
+        const int zero_g = (mel2_words - 384) / 4 - 1;
+        for (int mb = mg; mb < n_mel; mb += 32) {
+            int lo[4], c4[4], o4[4];
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            int gmaxn = 0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int m = mb + 8 * u;
+                const bool on = m < n_mel;
+                lo[u] = on ? mell[m] : 0;
+                c4[u] = on ? mell[128 + m] : 0;
+                o4[u] = on ? mell[256 + m] : 0;
+                gmaxn = max(gmaxn, c4[u]);
+            }
+            for (int g = 0; g < gmaxn; g++) {
+                float4 wv[4];
+                float q[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool on = g < c4[u];
+                    wv[u] = w4[on ? o4[u] + g : zero_g];
+                    const int k = on ? lo[u] + 4 * g : 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) q[u][e] = pr[min(k + e, kBins - 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    a[u] = __fmaf_rn(wv[u].x, q[u][0], a[u]);
+                    a[u] = __fmaf_rn(wv[u].y, q[u][1], a[u]);
+                    a[u] = __fmaf_rn(wv[u].z, q[u][2], a[u]);
+                    a[u] = __fmaf_rn(wv[u].w, q[u][3], a[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int m = mb + 8 * u;
+                if (m < n_mel && fr_ < kFrames) {
+                    const float v = log10f(fmaxf(a[u], 1e-10f));
+                    rawb[(int64_t)m * kFrames + fr_] = v;
+                    lmax = fmaxf(lmax, v);
+                }
+            }
+        }
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0 && lmax > -INFINITY) atomicMax(gmax + b, float_to_ordered(lmax));
+    if (prof && tid == 0) {
+        const long long tq4 = clock64();
+        atomicAdd(prof + 0, (unsigned long long)(tq1 - tq0));
+        atomicAdd(prof + 1, (unsigned long long)(tq2 - tq1));
+        atomicAdd(prof + 2, (unsigned long long)(tq3 - tq2));
+        atomicAdd(prof + 3, (unsigned long long)(tq4 - tq3));
+        atomicAdd(prof + 4, 1ull);
+    }
+}
+
 template <bool BF16>
 __global__ __launch_bounds__(256) void k_logmel_finish(const float *__restrict__ raw, void *__restrict__ out,
                                                        const int *__restrict__ gmax, int per_utt)
@@ -505,6 +806,8 @@ struct ifh_logmel {
     float *d_tab = nullptr;
     int32_t *d_mel2 = nullptr;    // packed filters for k_logmel_dft2: lo[128] | groups[128] | first group[128] | weights (x4 padded)
     int mel2_words = 0;
+    float *d_win = nullptr;       // k_logmel_fft: hann window [400], W200^(n2 k1) [8][25], W400^k [101]
+    float2 *d_tw200 = nullptr, *d_tw400 = nullptr;
     uint16_t *d_tab2 = nullptr;   // [13][3][448][16] bf16 splits of the folded DFT table (k_logmel_dft2)
     int32_t *d_lo = nullptr, *d_cnt = nullptr, *d_off = nullptr;
     float *d_w = nullptr;
@@ -608,6 +911,30 @@ extern "C" int ifh_logmel_create(int n_mel, ifh_logmel_t *out)
         e = hipMalloc(dst, bytes);
         if (e == hipSuccess) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
+    {   // FFT path tables (float, computed in double)
+        std::vector<float> winf(kNfft);
+        for (int n = 0; n < kNfft; n++) winf[n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)kNfft));
+        std::vector<float2> t200(8 * 25), t400(101);
+        for (int n2 = 0; n2 < 8; n2++)
+            for (int k1 = 0; k1 < 25; k1++) {
+                const double ang = -2.0 * M_PI * (double)((n2 * k1) % 200) / 200.0;
+                t200[n2 * 25 + k1] = make_float2((float)cos(ang), (float)sin(ang));
+            }
+        for (int k = 0; k <= 100; k++) {
+            const double ang = -2.0 * M_PI * (double)k / 400.0;
+            t400[k] = make_float2((float)cos(ang), (float)sin(ang));
+        }
+        FftConst fc;
+        for (int bb = 0; bb < 5; bb++)
+            for (int cc = 0; cc < 5; cc++) {
+                const double ang = -2.0 * M_PI * (double)((bb * cc) % 25) / 25.0;
+                fc.w25[bb][cc] = make_float2((float)cos(ang), (float)sin(ang));
+            }
+        if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_fft), &fc, sizeof(fc));
+        up((void **)&h->d_win, winf.data(), winf.size() * 4);
+        up((void **)&h->d_tw200, t200.data(), t200.size() * sizeof(float2));
+        up((void **)&h->d_tw400, t400.data(), t400.size() * sizeof(float2));
+    }
     up((void **)&h->d_tab, tab.data(), tab.size() * 4);
     up((void **)&h->d_tab2, tab2.data(), tab2.size() * 2);
     up((void **)&h->d_mel2, mel2.data(), mel2.size() * 4);
@@ -628,6 +955,9 @@ extern "C" int ifh_logmel_destroy(ifh_logmel_t h)
     if (!h) return IFH_OK;
     if (h->d_tab) (void)hipFree(h->d_tab);
     if (h->d_tab2) (void)hipFree(h->d_tab2);
+    if (h->d_win) (void)hipFree(h->d_win);
+    if (h->d_tw200) (void)hipFree(h->d_tw200);
+    if (h->d_tw400) (void)hipFree(h->d_tw400);
     if (h->d_mel2) (void)hipFree(h->d_mel2);
     if (h->d_lo) (void)hipFree(h->d_lo);
     if (h->d_cnt) (void)hipFree(h->d_cnt);
@@ -664,15 +994,32 @@ extern "C" int ifh_logmel_run(ifh_logmel_t h, const float *audio, int64_t stride
     const size_t ldsb = (size_t)kLdsFloats * sizeof(float);
     static bool attr_set = false;
     static const bool use_v1 = getenv("IFH_LOGMEL_V1") != nullptr;      // tuning switch: f32-MFMA formulation
+    static const bool use_dft = getenv("IFH_LOGMEL_DFT") != nullptr;    // tuning switch: bf16x3-MFMA DFT instead of the FFT
     if (!attr_set) {
         e = hipFuncSetAttribute((const void *)k_logmel_dft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)k_logmel_dft2, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2Bytes + 8192);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *)k_logmel_fft, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsFftBytes + 8192);
         if (e != hipSuccess) return check_hip(e, "logmel set lds attr");
         attr_set = true;
     }
     dim3 grid((kFrames + kFT - 1) / kFT, nbatch);
-    if (use_v1)
+    if (!use_v1 && !use_dft) {
+        static unsigned long long *d_proff = nullptr;
+        static const bool do_proff = getenv("IFH_LOGMEL_PROF") != nullptr;
+        if (do_proff && !d_proff) (void)hipMalloc((void **)&d_proff, 64);
+        if (do_proff) (void)hipMemsetAsync(d_proff, 0, 64, st);
+        hipLaunchKernelGGL(k_logmel_fft, dim3((kFrames + kFB - 1) / kFB, nbatch), dim3(256), (size_t)kLdsFftBytes + (size_t)h->mel2_words * 4, st, audio, stride,
+                           lens, h->d_win, h->d_tw200, h->d_tw400, h->d_mel2, h->mel2_words, h->n_mel, raw, gmax,
+                           do_proff ? d_proff : nullptr);
+        if (do_proff) {
+            unsigned long long hp[5];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(hp, d_proff, 40, hipMemcpyDeviceToHost);
+            if (hp[4]) fprintf(stderr, "logmel fft prof: blocks=%llu stage=%llu A=%llu B=%llu mel=%llu cycles/block\n", hp[4], hp[0] / hp[4], hp[1] / hp[4], hp[2] / hp[4], hp[3] / hp[4]);
+        }
+    } else if (use_v1)
         hipLaunchKernelGGL(k_logmel_dft, grid, dim3(448), ldsb, st, audio, stride, lens, h->d_tab, h->d_lo, h->d_cnt,
                            h->d_off, h->d_w, h->n_mel, raw, gmax);
     else {
