@@ -276,7 +276,7 @@ def main():
                          'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
                          'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r01_vocoder_pmc.json (scaled by chunks if the pass sizes differ)',
                          'seconds_per_vocoder_pass': t_voc},
-            'roofline_logmel': {'kernel': 'k_logmel_dft2+k_logmel_finish (%d x 30 s windows)' % n_local, 'bound': 'hbm',
+            'roofline_logmel': {'kernel': 'k_logmel_fft+k_logmel_finish (%d x 30 s windows)' % n_local, 'bound': 'hbm',
                                 'achieved': round(ach_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                 'frac': round(ach_gbs / PEAK_HBM_GBS, 4), 'traffic': None, 'seconds': t_mel},
         }

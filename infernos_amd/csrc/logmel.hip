@@ -547,47 +547,72 @@ __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ au
                                                     int *__restrict__ gmax, unsigned long long *__restrict__ prof)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const long long tq0 = clock64();
+    long long tq0 = clock64();
     float *aud = lds;                       // later the power tile [kFB][kPS]
     float2 *Yb = reinterpret_cast<float2 *>(lds + kReg0F);
-    int32_t *mell = reinterpret_cast<int32_t *>(lds + kReg0F + kYF);
+    float2 *tw4l = reinterpret_cast<float2 *>(lds + kReg0F + kYF);          // W400^k, k <= 100 (+1 pad)
+    int32_t *mell = reinterpret_cast<int32_t *>(lds + kReg0F + kYF + 204);
     const int b = blockIdx.y;
-    const int f0 = blockIdx.x * kFB;
     const int tid = threadIdx.x, lane = tid & 63;
     int len = lens ? lens[b] : kNsamp;
     len = len > kNsamp ? kNsamp : (len < 0 ? 0 : len);
     const float *x = audio + (int64_t)b * stride;
     float *rawb = raw + (int64_t)b * n_mel * kFrames;
-    const int a0 = f0 * kHop - kNfft / 2;
     float lmax = -INFINITY;
-    const int a_last = a0 + kTileF - 1;
-    const bool tail_clear = (a_last < kNsamp) || (2 * (kNsamp - 1) - a_last >= len);
-    if (len == 0 || (a0 >= len && a0 >= 0 && tail_clear)) {
+    for (int i = tid; i < mel2_words; i += 256) mell[i] = mel2[i];
+    if (tid < 101) tw4l[tid] = tw400[tid];
+    // Persistent over frame tiles (tile, tile + gridDim.x, ...): the next tile's audio is requested into registers
+    // before this tile's transforms start, so the block never sits waiting for HBM between tiles (with two blocks per
+    // CU the staging wait was half of a block's life).
+    constexpr int NV4 = kTileF / 4;          // 1340 float4 per tile
+    constexpr int NI4 = (NV4 + 255) / 256;   // 6
+    constexpr int ntiles = (kFrames + kFB - 1) / kFB;
+    static_assert(NI4 == 6, "six named prefetch registers");
+    float4 pv0, pv1, pv2, pv3, pv4, pv5;     // named: the array form was spilled to scratch
+    pv0 = pv1 = pv2 = pv3 = pv4 = pv5 = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool have_pv = false;
+#define LF_PV_LOAD(X4)                                                                                  \
+    {                                                                                                  \
+        pv0 = (X4)[tid];                                                                               \
+        pv1 = (X4)[tid + 256];                                                                         \
+        pv2 = (X4)[tid + 512];                                                                         \
+        pv3 = (X4)[tid + 768];                                                                         \
+        pv4 = (X4)[tid + 1024];                                                                        \
+        pv5 = (X4)[tid + 1280 < NV4 ? tid + 1280 : NV4 - 1];                                           \
+    }
+#define LF_PV_STORE1(I, REG)                                                                           \
+    {                                                                                                  \
+        const int q = tid + 256 * I;                                                                   \
+        if (q < NV4) *reinterpret_cast<float4 *>(&aud[4 * q + 16 * ((4 * q) / kHop)]) = REG;           \
+    }
+#define LF_TILE_GEOM(TILE)                                                                             \
+    const int f0 = (TILE) * kFB;                                                                       \
+    const int a0 = f0 * kHop - kNfft / 2;                                                              \
+    const int a_last = a0 + kTileF - 1;                                                                \
+    const bool tail_clear = (a_last < kNsamp) || (2 * (kNsamp - 1) - a_last >= len);                   \
+    const bool zero_tile = len == 0 || (a0 >= len && a0 >= 0 && tail_clear);                           \
+    const bool interior = a0 >= 0 && a_last < len && ((reinterpret_cast<uintptr_t>(x + a0) & 15) == 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    tq0 = clock64();
+    LF_TILE_GEOM(tile)
+    if (zero_tile) {
         const float v0 = log10f(fmaxf(0.0f * (float)len, 1e-10f));
         for (int idx = tid; idx < n_mel * kFB; idx += 256) {
             const int m = idx / kFB, f = f0 + (idx - m * kFB);
             if (f < kFrames) rawb[(int64_t)m * kFrames + f] = v0;
         }
-        if (tid == 0) atomicMax(gmax + b, float_to_ordered(v0));
-        return;
+        lmax = fmaxf(lmax, v0);
+        have_pv = false;
+        continue;
     }
-    // ---- stage the audio tile (every load of the thread in flight at once)
-    const bool interior = a0 >= 0 && a_last < len && ((reinterpret_cast<uintptr_t>(x + a0) & 15) == 0);
+    __syncthreads();                         // the previous tile's power tile has been consumed
+    // ---- stage the audio tile
     if (interior) {
-        constexpr int NV4 = kTileF / 4;          // 1340
-        constexpr int NI = (NV4 + 255) / 256;    // 6
-        const float4 *x4 = reinterpret_cast<const float4 *>(x + a0);
-        float4 v[NI];
-#pragma unroll
-        for (int i = 0; i < NI; i++) {
-            const int q = tid + 256 * i;
-            v[i] = x4[q < NV4 ? q : NV4 - 1];
+        if (!have_pv) {
+            const float4 *x4 = reinterpret_cast<const float4 *>(x + a0);
+            LF_PV_LOAD(x4)
         }
-#pragma unroll
-        for (int i = 0; i < NI; i++) {
-            const int q = tid + 256 * i;
-            if (q < NV4) *reinterpret_cast<float4 *>(&aud[4 * q + 16 * ((4 * q) / kHop)]) = v[i];
-        }
+        LF_PV_STORE1(0, pv0) LF_PV_STORE1(1, pv1) LF_PV_STORE1(2, pv2) LF_PV_STORE1(3, pv3) LF_PV_STORE1(4, pv4) LF_PV_STORE1(5, pv5)
     } else {
         constexpr int NI = (kTileF + 255) / 256;  // 21
         float v[NI];
@@ -606,7 +631,6 @@ __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ au
             if (m < kTileF) aud[m + 16 * (m / kHop)] = v[i];
         }
     }
-    for (int i = tid; i < mel2_words; i += 256) mell[i] = mel2[i];
     __syncthreads();
     const long long tq1 = clock64();
     const int f = tid >> 3, sub = tid & 7;
@@ -648,6 +672,20 @@ __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ au
         LF_OUT(v20, 4, 0) LF_OUT(v21, 4, 1) LF_OUT(v22, 4, 2) LF_OUT(v23, 4, 3) LF_OUT(v24, 4, 4)
 #undef LF_OUT
     }
+    have_pv = false;
+    {   // request the next tile of this block (if it is an interior one) now that phase A's own global loads (window,
+        // twiddles) have been consumed -- loads retire in order, so anything issued later would wait for these; phases B
+        // and the mel projection read LDS only and cover the round trip
+        const int nt = tile + gridDim.x;
+        if (nt < ntiles) {
+            const int nf0 = nt * kFB, na0 = nf0 * kHop - kNfft / 2, na_last = na0 + kTileF - 1;
+            if (na0 >= 0 && na_last < len && ((reinterpret_cast<uintptr_t>(x + na0) & 15) == 0)) {
+                const float4 *x4 = reinterpret_cast<const float4 *>(x + na0);
+                LF_PV_LOAD(x4)
+                have_pv = true;
+            }
+        }
+    }
     __syncthreads();      // Y complete; the audio tile is dead: its place becomes the power tile
     const long long tq2 = clock64();
     // ---- phase B: tasks sub and sub + 8 (< 13) of frame f
@@ -660,19 +698,19 @@ __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ au
         fft8(za);                                     // Z[task + 25 k2]
         if (task == 0) {
             float pk, pm;
-            power_pair(za[0], za[0], tw400[0], pk, pm);
+            power_pair(za[0], za[0], tw4l[0], pk, pm);
             Pt[0] = pk;
             Pt[200] = pm;
-            power_pair(za[1], za[7], tw400[25], pk, pm);
+            power_pair(za[1], za[7], tw4l[25], pk, pm);
             Pt[25] = pk;
             Pt[175] = pm;
-            power_pair(za[2], za[6], tw400[50], pk, pm);
+            power_pair(za[2], za[6], tw4l[50], pk, pm);
             Pt[50] = pk;
             Pt[150] = pm;
-            power_pair(za[3], za[5], tw400[75], pk, pm);
+            power_pair(za[3], za[5], tw4l[75], pk, pm);
             Pt[75] = pk;
             Pt[125] = pm;
-            power_pair(za[4], za[4], tw400[100], pk, pm);
+            power_pair(za[4], za[4], tw4l[100], pk, pm);
             Pt[100] = pk;
         } else {
             const int kp = 25 - task;
@@ -684,11 +722,11 @@ __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ au
             for (int k2 = 0; k2 < 4; k2++) {
                 float pk, pm;
                 int k = task + 25 * k2;               // <= 87: partner 200 - k = kp + 25 (7 - k2)
-                power_pair(za[k2], zb[7 - k2], tw400[k], pk, pm);
+                power_pair(za[k2], zb[7 - k2], tw4l[k], pk, pm);
                 Pt[k] = pk;
                 Pt[200 - k] = pm;
                 k = kp + 25 * k2;                     // <= 99: partner 200 - k = task + 25 (7 - k2)
-                power_pair(zb[k2], za[7 - k2], tw400[k], pk, pm);
+                power_pair(zb[k2], za[7 - k2], tw4l[k], pk, pm);
                 Pt[k] = pk;
                 Pt[200 - k] = pm;
             }
@@ -747,8 +785,6 @@ __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ au
             }
         }
     }
-    lmax = wave_max(lmax);
-    if (lane == 0 && lmax > -INFINITY) atomicMax(gmax + b, float_to_ordered(lmax));
     if (prof && tid == 0) {
         const long long tq4 = clock64();
         atomicAdd(prof + 0, (unsigned long long)(tq1 - tq0));
@@ -757,6 +793,12 @@ __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ au
         atomicAdd(prof + 3, (unsigned long long)(tq4 - tq3));
         atomicAdd(prof + 4, 1ull);
     }
+    }   // tile loop
+#undef LF_TILE_GEOM
+#undef LF_PV_LOAD
+#undef LF_PV_STORE1
+    lmax = wave_max(lmax);
+    if (lane == 0 && lmax > -INFINITY) atomicMax(gmax + b, float_to_ordered(lmax));
 }
 
 template <bool BF16>
@@ -1010,7 +1052,10 @@ extern "C" int ifh_logmel_run(ifh_logmel_t h, const float *audio, int64_t stride
         static const bool do_proff = getenv("IFH_LOGMEL_PROF") != nullptr;
         if (do_proff && !d_proff) (void)hipMalloc((void **)&d_proff, 64);
         if (do_proff) (void)hipMemsetAsync(d_proff, 0, 64, st);
-        hipLaunchKernelGGL(k_logmel_fft, dim3((kFrames + kFB - 1) / kFB, nbatch), dim3(256), (size_t)kLdsFftBytes + (size_t)h->mel2_words * 4, st, audio, stride,
+        const int ntile = (kFrames + kFB - 1) / kFB;
+        int gx = (2 * 256 + nbatch - 1) / nbatch;            // ~2 resident blocks per CU in all, each walking its share of the tiles
+        gx = gx < 1 ? 1 : (gx > ntile ? ntile : gx);
+        hipLaunchKernelGGL(k_logmel_fft, dim3(gx, nbatch), dim3(256), (size_t)kLdsFftBytes + 816 + (size_t)h->mel2_words * 4, st, audio, stride,
                            lens, h->d_win, h->d_tw200, h->d_tw400, h->d_mel2, h->mel2_words, h->n_mel, raw, gmax,
                            do_proff ? d_proff : nullptr);
         if (do_proff) {
