@@ -479,55 +479,58 @@ constexpr int kReg0F = (kAudF > kFB * kPS) ? kAudF : kFB * kPS;   // audio tile 
 constexpr int kYF = kFB * 25 * 8 * 2;                   // Y buffer floats
 constexpr int kLdsFftBytes = (kReg0F + kYF) * 4;
 
+typedef float f2v __attribute__((ext_vector_type(2)));     // native 2-vector: lets the compiler use v_pk_add/mul/fma_f32
+
 struct FftConst {
-    float2 w25[5][5];      // W25^(b c)
+    f2v w25[5][5];      // W25^(b c)
 };
 __constant__ FftConst c_fft;
 
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ f2v mk2(float a, float b) { return (f2v){a, b}; }
+__device__ __forceinline__ f2v cmul(f2v a, f2v b) { return a.x * b + a.y * mk2(-b.y, b.x); }     // packed: (ax bx - ay by, ax by + ay bx)
+__device__ __forceinline__ f2v cadd(f2v a, f2v b) { return a + b; }
+__device__ __forceinline__ f2v csub(f2v a, f2v b) { return a - b; }
 
 // forward 5-point DFT (in place on 5 named values)
 #define FFT5(V0, V1, V2, V3, V4)                                                                              \
     {                                                                                                         \
         const float c1 = 0.30901699437494745f, c2 = -0.80901699437494745f;                                    \
         const float s1 = 0.95105651629515353f, s2 = 0.58778525229247314f;                                     \
-        const float2 t1 = cadd(V1, V4), t2 = cadd(V2, V3), t3 = csub(V1, V4), t4 = csub(V2, V3);              \
-        const float2 m1 = make_float2(V0.x + c1 * t1.x + c2 * t2.x, V0.y + c1 * t1.y + c2 * t2.y);            \
-        const float2 m2 = make_float2(V0.x + c2 * t1.x + c1 * t2.x, V0.y + c2 * t1.y + c1 * t2.y);            \
-        const float2 u1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);                          \
-        const float2 u2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);                          \
-        V0 = make_float2(V0.x + t1.x + t2.x, V0.y + t1.y + t2.y);                                             \
-        V1 = make_float2(m1.x + u1.y, m1.y - u1.x);  /* m1 - i u1 */                                          \
-        V4 = make_float2(m1.x - u1.y, m1.y + u1.x);  /* m1 + i u1 */                                          \
-        V2 = make_float2(m2.x + u2.y, m2.y - u2.x);                                                           \
-        V3 = make_float2(m2.x - u2.y, m2.y + u2.x);                                                           \
+        const f2v t1 = cadd(V1, V4), t2 = cadd(V2, V3), t3 = csub(V1, V4), t4 = csub(V2, V3);              \
+        const f2v m1 = V0 + c1 * t1 + c2 * t2;                                                                \
+        const f2v m2 = V0 + c2 * t1 + c1 * t2;                                                                \
+        const f2v u1 = s1 * t3 + s2 * t4;                                                                     \
+        const f2v u2 = s2 * t3 - s1 * t4;                                                                     \
+        V0 = V0 + t1 + t2;                                                                                    \
+        V1 = mk2(m1.x + u1.y, m1.y - u1.x);  /* m1 - i u1 */                                          \
+        V4 = mk2(m1.x - u1.y, m1.y + u1.x);  /* m1 + i u1 */                                          \
+        V2 = mk2(m2.x + u2.y, m2.y - u2.x);                                                           \
+        V3 = mk2(m2.x - u2.y, m2.y + u2.x);                                                           \
     }
 
 // forward 8-point DFT of v[0..7] (natural order in, natural order out)
-__device__ __forceinline__ void fft8(float2 (&v)[8])
+__device__ __forceinline__ void fft8(f2v (&v)[8])
 {
     const float h = 0.70710678118654752f;
     // stage 1: pairs (j, j+4)
-    float2 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
-    float2 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
-    float2 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
-    float2 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
+    f2v a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
+    f2v a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+    f2v a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
+    f2v a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
     // twiddle the odd half by W8^j: 1, (1-i)/sqrt2, -i, (-1-i)/sqrt2
-    a5 = make_float2(h * (a5.x + a5.y), h * (a5.y - a5.x));
-    a6 = make_float2(a6.y, -a6.x);
-    a7 = make_float2(h * (a7.y - a7.x), -h * (a7.x + a7.y));
+    a5 = mk2(h * (a5.x + a5.y), h * (a5.y - a5.x));
+    a6 = mk2(a6.y, -a6.x);
+    a7 = mk2(h * (a7.y - a7.x), -h * (a7.x + a7.y));
     // two 4-point DFTs: even outputs from a0..a3, odd outputs from a4..a7
-    float2 b0 = cadd(a0, a2), b2 = csub(a0, a2), b1 = cadd(a1, a3), b3 = csub(a1, a3);
-    b3 = make_float2(b3.y, -b3.x);
+    f2v b0 = cadd(a0, a2), b2 = csub(a0, a2), b1 = cadd(a1, a3), b3 = csub(a1, a3);
+    b3 = mk2(b3.y, -b3.x);
     v[0] = cadd(b0, b1); v[4] = csub(b0, b1); v[2] = cadd(b2, b3); v[6] = csub(b2, b3);
-    float2 d0 = cadd(a4, a6), d2 = csub(a4, a6), d1 = cadd(a5, a7), d3 = csub(a5, a7);
-    d3 = make_float2(d3.y, -d3.x);
+    f2v d0 = cadd(a4, a6), d2 = csub(a4, a6), d1 = cadd(a5, a7), d3 = csub(a5, a7);
+    d3 = mk2(d3.y, -d3.x);
     v[1] = cadd(d0, d1); v[5] = csub(d0, d1); v[3] = cadd(d2, d3); v[7] = csub(d2, d3);
 }
 
-__device__ __forceinline__ void power_pair(float2 zk, float2 zm, float2 tw, float &pk, float &pm)
+__device__ __forceinline__ void power_pair(f2v zk, f2v zm, f2v tw, float &pk, float &pm)
 {
     const float ax = 0.5f * (zk.x + zm.x), ay = 0.5f * (zk.y - zm.y);      // A = (Zk + conj Zm)/2
     const float dx = zk.x - zm.x, dy = zk.y + zm.y;                          // D = Zk - conj Zm
@@ -540,8 +543,8 @@ __device__ __forceinline__ void power_pair(float2 zk, float2 zm, float2 tw, floa
 
 __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ audio, int64_t stride,
                                                     const int32_t *__restrict__ lens, const float *__restrict__ win,
-                                                    const float2 *__restrict__ tw200 /* [8][25] */,
-                                                    const float2 *__restrict__ tw400 /* [101] */,
+                                                    const f2v *__restrict__ tw200 /* [8][25] */,
+                                                    const f2v *__restrict__ tw400 /* [101] */,
                                                     const int32_t *__restrict__ mel2 /* packed filters, see create */,
                                                     int mel2_words, int n_mel, float *__restrict__ raw,
                                                     int *__restrict__ gmax, unsigned long long *__restrict__ prof)
@@ -549,8 +552,8 @@ __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ au
     extern __shared__ __attribute__((aligned(16))) float lds[];
     long long tq0 = clock64();
     float *aud = lds;                       // later the power tile [kFB][kPS]
-    float2 *Yb = reinterpret_cast<float2 *>(lds + kReg0F);
-    float2 *tw4l = reinterpret_cast<float2 *>(lds + kReg0F + kYF);          // W400^k, k <= 100 (+1 pad)
+    f2v *Yb = reinterpret_cast<f2v *>(lds + kReg0F);
+    f2v *tw4l = reinterpret_cast<f2v *>(lds + kReg0F + kYF);          // W400^k, k <= 100 (+1 pad)
     int32_t *mell = reinterpret_cast<int32_t *>(lds + kReg0F + kYF + 204);
     const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -636,13 +639,13 @@ __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ au
     const int f = tid >> 3, sub = tid & 7;
     // ---- phase A: DFT-25 over n1 of z[8 n1 + sub], n = 8 n1 + sub, samples 2n, 2n+1 of frame f
     {
-        float2 v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15, v16, v17, v18, v19, v20, v21, v22, v23, v24;
+        f2v v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15, v16, v17, v18, v19, v20, v21, v22, v23, v24;
 #define LF_LOAD(V, N1)                                                                               \
     {                                                                                                \
         const int n = 8 * (N1) + sub;                                                                \
-        const float2 xs = *reinterpret_cast<const float2 *>(&aud[176 * f + 2 * n + 16 * ((2 * n) / kHop)]); \
-        const float2 wv = *reinterpret_cast<const float2 *>(&win[2 * n]);                            \
-        V = make_float2(xs.x * wv.x, xs.y * wv.y);                                                   \
+        const f2v xs = *reinterpret_cast<const f2v *>(&aud[176 * f + 2 * n + 16 * ((2 * n) / kHop)]); \
+        const f2v wv = *reinterpret_cast<const f2v *>(&win[2 * n]);                            \
+        V = mk2(xs.x * wv.x, xs.y * wv.y);                                                   \
     }
         LF_LOAD(v0, 0) LF_LOAD(v1, 1) LF_LOAD(v2, 2) LF_LOAD(v3, 3) LF_LOAD(v4, 4) LF_LOAD(v5, 5) LF_LOAD(v6, 6)
         LF_LOAD(v7, 7) LF_LOAD(v8, 8) LF_LOAD(v9, 9) LF_LOAD(v10, 10) LF_LOAD(v11, 11) LF_LOAD(v12, 12) LF_LOAD(v13, 13)
@@ -662,8 +665,8 @@ __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ au
         // for each c a DFT-5 over b: slot 5c + d <- Y[k1 = c + 5 d]
         FFT5(v0, v1, v2, v3, v4) FFT5(v5, v6, v7, v8, v9) FFT5(v10, v11, v12, v13, v14)
         FFT5(v15, v16, v17, v18, v19) FFT5(v20, v21, v22, v23, v24)
-        const float2 *tw = tw200 + sub * 25;
-        float2 *yo = Yb + (f * 25) * 8 + sub;
+        const f2v *tw = tw200 + sub * 25;
+        f2v *yo = Yb + (f * 25) * 8 + sub;
 #define LF_OUT(V, C, D) yo[((C) + 5 * (D)) * 8] = cmul(V, tw[(C) + 5 * (D)]);
         LF_OUT(v0, 0, 0) LF_OUT(v1, 0, 1) LF_OUT(v2, 0, 2) LF_OUT(v3, 0, 3) LF_OUT(v4, 0, 4)
         LF_OUT(v5, 1, 0) LF_OUT(v6, 1, 1) LF_OUT(v7, 1, 2) LF_OUT(v8, 1, 3) LF_OUT(v9, 1, 4)
@@ -691,8 +694,8 @@ __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ au
     // ---- phase B: tasks sub and sub + 8 (< 13) of frame f
     float *Pt = aud + f * kPS;
     for (int task = sub; task < 13; task += 8) {
-        float2 za[8], zb[8];
-        const float2 *ya = Yb + (f * 25 + task) * 8;
+        f2v za[8], zb[8];
+        const f2v *ya = Yb + (f * 25 + task) * 8;
 #pragma unroll
         for (int j = 0; j < 8; j++) za[j] = ya[j];
         fft8(za);                                     // Z[task + 25 k2]
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ au
             Pt[100] = pk;
         } else {
             const int kp = 25 - task;
-            const float2 *yb = Yb + (f * 25 + kp) * 8;
+            const f2v *yb = Yb + (f * 25 + kp) * 8;
 #pragma unroll
             for (int j = 0; j < 8; j++) zb[j] = yb[j];
             fft8(zb);                                 // Z[kp + 25 k2]
@@ -849,7 +852,7 @@ struct ifh_logmel {
     int32_t *d_mel2 = nullptr;    // packed filters for k_logmel_dft2: lo[128] | groups[128] | first group[128] | weights (x4 padded)
     int mel2_words = 0;
     float *d_win = nullptr;       // k_logmel_fft: hann window [400], W200^(n2 k1) [8][25], W400^k [101]
-    float2 *d_tw200 = nullptr, *d_tw400 = nullptr;
+    f2v *d_tw200 = nullptr, *d_tw400 = nullptr;
     uint16_t *d_tab2 = nullptr;   // [13][3][448][16] bf16 splits of the folded DFT table (k_logmel_dft2)
     int32_t *d_lo = nullptr, *d_cnt = nullptr, *d_off = nullptr;
     float *d_w = nullptr;
@@ -956,26 +959,26 @@ extern "C" int ifh_logmel_create(int n_mel, ifh_logmel_t *out)
     {   // FFT path tables (float, computed in double)
         std::vector<float> winf(kNfft);
         for (int n = 0; n < kNfft; n++) winf[n] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * (double)n / (double)kNfft));
-        std::vector<float2> t200(8 * 25), t400(101);
+        std::vector<f2v> t200(8 * 25), t400(101);
         for (int n2 = 0; n2 < 8; n2++)
             for (int k1 = 0; k1 < 25; k1++) {
                 const double ang = -2.0 * M_PI * (double)((n2 * k1) % 200) / 200.0;
-                t200[n2 * 25 + k1] = make_float2((float)cos(ang), (float)sin(ang));
+                t200[n2 * 25 + k1] = (f2v){(float)cos(ang), (float)sin(ang)};
             }
         for (int k = 0; k <= 100; k++) {
             const double ang = -2.0 * M_PI * (double)k / 400.0;
-            t400[k] = make_float2((float)cos(ang), (float)sin(ang));
+            t400[k] = (f2v){(float)cos(ang), (float)sin(ang)};
         }
         FftConst fc;
         for (int bb = 0; bb < 5; bb++)
             for (int cc = 0; cc < 5; cc++) {
                 const double ang = -2.0 * M_PI * (double)((bb * cc) % 25) / 25.0;
-                fc.w25[bb][cc] = make_float2((float)cos(ang), (float)sin(ang));
+                fc.w25[bb][cc] = (f2v){(float)cos(ang), (float)sin(ang)};
             }
         if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_fft), &fc, sizeof(fc));
         up((void **)&h->d_win, winf.data(), winf.size() * 4);
-        up((void **)&h->d_tw200, t200.data(), t200.size() * sizeof(float2));
-        up((void **)&h->d_tw400, t400.data(), t400.size() * sizeof(float2));
+        up((void **)&h->d_tw200, t200.data(), t200.size() * sizeof(f2v));
+        up((void **)&h->d_tw400, t400.data(), t400.size() * sizeof(f2v));
     }
     up((void **)&h->d_tab, tab.data(), tab.size() * 4);
     up((void **)&h->d_tab2, tab2.data(), tab2.size() * 2);
