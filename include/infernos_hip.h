@@ -32,6 +32,7 @@ extern "C" {
 #define IFH_EINVAL (-1)   /* bad argument */
 #define IFH_EHIP (-2)     /* HIP runtime error (text in ifh_last_error) */
 #define IFH_ENOMEM (-3)
+#define IFH_ERTPPARSE (-4) /* malformed RTP datagram (the reference's RTPParseError); nothing was changed */
 
 typedef void *ifh_stream_t;
 
@@ -87,6 +88,68 @@ int ifh_resample_run(ifh_resampler_t h, const float *in, int64_t in_stride, cons
 int ifh_ingest_tick(const uint8_t *frames /* [n][160] */, const int32_t *slot, int n,
                     uint8_t *fifo, int32_t *fifo_len, float *win, int32_t *win_ready, float *hist,
                     float *pcm8k, float *pcm16k, ifh_resampler_t rs8to16, ifh_stream_t stream);
+
+/* ---------------------------------------------------------------------------------
+ * RTP ingress stage     (host only, no stream) replaces the per-packet Python of
+ *                        RTP/InfernRTPIngest.py:63-100: `RtpJBuf(jb_size=8).udp_in(data)` (third-party
+ *                        rtpsynth, absent: restated from its call site, PARITY UNPINNED),
+ *                        the ERS -> `codec.silence(ts_diff)` fill (:84-86) and the hand-over of payload
+ *                        bytes to the per-call VAD FIFO (:96), for a table of calls.
+ * ifh_rtp_parse          RFC 3550 fixed header (+CSRC list, header extension, padding).  Malformed ->
+ *                        IFH_ERTPPARSE (RTPParseError at :76-79).
+ * ifh_rtpjb_create       n_streams calls; depth = packets a call may hold while waiting for a gap to fill
+ *                        (RTPInStream.jb_size = 8, :32); frame_bytes = bytes per tick frame (160);
+ *                        ts_per_byte = RTP timestamp units per payload byte (1 for G.711 at 8 kHz);
+ *                        fill_byte = the codec's silence byte (0xFF, G711.py:61-62); fifo_cap = bytes of
+ *                        released payload a call may hold before ifh_rtpjb_pop_tick takes them.
+ * ifh_rtpjb_push         one datagram of one call.  Released frames, in order, are appended to the call's
+ *                        byte FIFO and (when recs != NULL) reported: an in-order packet passes straight
+ *                        through followed by every held packet that now continues the sequence; a late or
+ *                        duplicate packet is dropped; an early one is held, and once more than `depth` are
+ *                        held the gap in front is given up: ONE IFH_RTP_FRAME_ERS record {lseq_start,
+ *                        lseq_end, ts_diff = timestamp of the next packet - timestamp expected} and
+ *                        ts_diff / ts_per_byte fill bytes, then the held run.  Consecutive records of a
+ *                        call always satisfy lseq_start == previous lseq_end + 1 (the assert at :91).
+ *                        payload (optional) receives the released RTP payloads back to back.
+ * ifh_rtpjb_push_batch   n datagrams (buf + off[n+1], stream[n]); returns how many were refused, codes in status[n].
+ * ifh_rtpjb_pop_tick     for every call holding >= frame_bytes: one frame into frames[k][frame_bytes] and its
+ *                        index into slots[k] -- the host-side inputs of ifh_ingest_tick / ifh_ingest_block.
+ * ifh_rtpjb_reset_stream a new jitter buffer for the call (WIStreamUpdate, :66-70); drop_fifo also empties
+ *                        its released bytes.
+ * ------------------------------------------------------------------------------- */
+#define IFH_RTP_MAX_PAYLOAD 1472
+#define IFH_RTP_FRAME_RTP 0
+#define IFH_RTP_FRAME_ERS 1
+typedef struct ifh_rtp_hdr {
+    int32_t version, padding, extension, cc, marker, pt;
+    uint32_t seq, ts, ssrc;
+    int32_t payload_off, payload_len;
+} ifh_rtp_hdr;
+typedef struct ifh_rtp_rec {
+    int32_t stream, type;            /* IFH_RTP_FRAME_* */
+    int64_t lseq_start, lseq_end;    /* RTP: both the packet's extended sequence number */
+    uint32_t ts, ts_diff;            /* ERS: ts = timestamp of the packet after the gap */
+    int64_t payload_off;             /* offset into the payload buffer passed to ifh_rtpjb_push, -1 if none */
+    int32_t payload_len;             /* ERS: number of fill bytes appended */
+    ifh_rtp_hdr hdr;                 /* RTP only */
+} ifh_rtp_rec;
+enum {
+    IFH_RTP_STAT_RECEIVED = 0, IFH_RTP_STAT_RELEASED, IFH_RTP_STAT_LATE, IFH_RTP_STAT_DUPLICATE, IFH_RTP_STAT_REORDERED,
+    IFH_RTP_STAT_ERS_EVENTS, IFH_RTP_STAT_ERS_PACKETS, IFH_RTP_STAT_ERS_BYTES, IFH_RTP_STAT_PARSE_ERRORS,
+    IFH_RTP_STAT_OVERFLOW_BYTES, IFH_RTP_STAT_FIFO_BYTES, IFH_RTP_STAT_HELD, IFH_RTP_STAT_LAST_LSEQ, IFH_RTP_NSTATS
+};
+typedef void *ifh_rtpjb_t;
+int ifh_rtp_parse(const uint8_t *pkt, int len, ifh_rtp_hdr *out);
+int ifh_rtpjb_create(int n_streams, int depth, int frame_bytes, int ts_per_byte, int fill_byte, int fifo_cap,
+                     ifh_rtpjb_t *out);
+int ifh_rtpjb_destroy(ifh_rtpjb_t h);
+int ifh_rtpjb_reset_stream(ifh_rtpjb_t h, int stream, int drop_fifo);
+int ifh_rtpjb_push(ifh_rtpjb_t h, int stream, const uint8_t *pkt, int len, ifh_rtp_rec *recs, int rec_cap,
+                   uint8_t *payload, int64_t payload_cap, int *nrec);
+int ifh_rtpjb_push_batch(ifh_rtpjb_t h, const uint8_t *buf, const int32_t *off, const int32_t *stream, int n,
+                         int32_t *status);
+int ifh_rtpjb_pop_tick(ifh_rtpjb_t h, uint8_t *frames, int32_t *slots, int cap, int *n_out);
+int ifh_rtpjb_stats(ifh_rtpjb_t h, int stream, int64_t *stats /* [IFH_RTP_NSTATS] */);
 
 /* ---------------------------------------------------------------------------------
  * Output mix + encode    replaces Core/OutputMuxer.py:75-85 (OutputMTMuxer.idle mix: zero-pad,

@@ -28,6 +28,14 @@ SIGNATURES = {
     'ifh_resample_run': (_i, [_vp, _vp, _i64, _vp, _i64, _i, _vp, _i64, _vp]),
     'ifh_ingest_tick': (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ifh_mux_encode_f32_u8': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    'ifh_rtp_parse': (_i, [_vp, _i, _vp]),
+    'ifh_rtpjb_create': (_i, [_i, _i, _i, _i, _i, _i, ctypes.POINTER(_vp)]),
+    'ifh_rtpjb_destroy': (_i, [_vp]),
+    'ifh_rtpjb_reset_stream': (_i, [_vp, _i, _i]),
+    'ifh_rtpjb_push': (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i64, c_i32p]),
+    'ifh_rtpjb_push_batch': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
+    'ifh_rtpjb_pop_tick': (_i, [_vp, _vp, _vp, _i, c_i32p]),
+    'ifh_rtpjb_stats': (_i, [_vp, _i, _vp]),
     'ifh_vad_energy_prob': (_i, [_vp, _vp, _i, _vp, _vp]),
     'ifh_vad_fsm_step': (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp]),
     'ifh_vad_step': (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -63,6 +71,26 @@ class ResblockDesc(ctypes.Structure):
     _fields_ = [('x', _vp), ('x_bstride', _i64), ('c', ctypes.c_int32), ('taps', ctypes.c_int32), ('dil', ctypes.c_int32),
                 ('t', ctypes.c_int32), ('nbatch', ctypes.c_int32), ('w1', _vp), ('bias1', _vp), ('w2', _vp), ('bias2', _vp),
                 ('slope', _f), ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp), ('out_bstride', _i64)]
+
+
+class RtpHdr(ctypes.Structure):
+    """ifh_rtp_hdr (include/infernos_hip.h)"""
+    _fields_ = [(n, ctypes.c_int32) for n in ('version', 'padding', 'extension', 'cc', 'marker', 'pt')] + \
+               [(n, ctypes.c_uint32) for n in ('seq', 'ts', 'ssrc')] + \
+               [('payload_off', ctypes.c_int32), ('payload_len', ctypes.c_int32)]
+
+
+class RtpRec(ctypes.Structure):
+    """ifh_rtp_rec (include/infernos_hip.h)"""
+    _fields_ = [('stream', ctypes.c_int32), ('type', ctypes.c_int32), ('lseq_start', _i64), ('lseq_end', _i64),
+                ('ts', ctypes.c_uint32), ('ts_diff', ctypes.c_uint32), ('payload_off', _i64),
+                ('payload_len', ctypes.c_int32), ('hdr', RtpHdr)]
+
+
+RTP_STATS = ('received', 'released', 'late', 'duplicate', 'reordered', 'ers_events', 'ers_packets', 'ers_bytes',
+             'parse_errors', 'overflow_bytes', 'fifo_bytes', 'held', 'last_lseq')
+IFH_ERTPPARSE = -4
+IFH_RTP_MAX_PAYLOAD = 1472
 
 
 class AttnDesc(ctypes.Structure):

@@ -140,6 +140,52 @@ def test_ingest_tick_stream(dev):
     assert ct.fifo_len[slots.long()].cpu().tolist() == [(nticks * 160) % 768] * ncalls
 
 
+def test_rtp_table_feeds_tick_kernel(dev):
+    """8f-2 -> a7: shuffled / lossy RTP arrivals through RTPIngestTable.pop_tick + CallTable.tick give the decoded
+    stream of the in-order payloads with 0xFF (decodes to 0.0) where a packet was given up on."""
+    from infernos_amd.frontend import CallTable
+    from infernos_amd.rtp import RTPIngestTable
+    from oracle import rtp as ortp
+    rng = np.random.default_rng(21)
+    ncalls, npk = 9, 40
+    payload = rng.integers(0, 256, (ncalls, npk, 160), dtype=np.uint8)
+    tab = RTPIngestTable(ncalls, depth=4)
+    ct = CallTable(16, dev)
+    lost = {(c, int(k)) for c in range(ncalls) for k in rng.choice(np.arange(2, npk - 8), 2, replace=False)}
+    out = [[] for _ in range(ncalls)]
+    for t in range(npk + 2):
+        dg, sid = [], []
+        for c in range(ncalls):
+            ks = [t] if t < npk else []
+            if t % 5 == 1 and t + 1 < npk:
+                ks = [t + 1]                   # swap neighbours: t+1 arrives first ...
+            elif t % 5 == 2:
+                ks = [t - 1, t]                # ... then t and the tick's own packet
+            for k in ks:
+                if k < npk and (c, k) not in lost:
+                    dg.append(ortp.build_packet(500 * c + k, 160 * k, payload[c, k].tobytes())); sid.append(c)
+        if dg:
+            assert not tab.push_batch(dg, sid).any()
+        while True:
+            frames, slots = tab.pop_tick()
+            if slots.numel() == 0:
+                break
+            p8, _, _ = ct.tick(frames.to(dev, non_blocking=True), slots.to(dev, non_blocking=True), want_ready=False)
+            p8 = p8.cpu().numpy()
+            for j, c in enumerate(slots.tolist()):
+                out[c].append(p8[j])
+    for c in range(ncalls):
+        want = payload[c].copy()
+        for (cc, k) in lost:
+            if cc == c:
+                want[k] = 0xff
+        got = np.concatenate(out[c])
+        assert got.size == npk * 160
+        assert np.array_equal(got, odsp.g711_decode(want.reshape(-1)))
+        st = tab.stats(c)
+        assert st['ers_packets'] == 2 and st['ers_bytes'] == 320 and st['held'] == 0
+
+
 # ---- VAD ----------------------------------------------------------------------------------------
 class ScriptedModel:
     def __init__(self, dev):
