@@ -109,9 +109,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--latency-ticks', type=int, default=200)
     ap.add_argument('--breakdown', action='store_true', help='print per-stage wall times to stderr')
-    ap.add_argument('--tts-lanes', type=int, default=3, help='TTS engine instances whose utterance cycles may overlap')
+    ap.add_argument('--tts-lanes', type=int, default=4, help='TTS engine instances whose utterance cycles may overlap')
     ap.add_argument('--front-lanes', type=int, default=2, help='ingest+STT lanes (cycles k, k+1 in flight together)')
-    ap.add_argument('--tts-group', type=int, default=3, help='utterance cycles synthesised as one TTS batch')
+    ap.add_argument('--tts-group', type=int, default=4, help='utterance cycles synthesised as one TTS batch')
     ap.add_argument('--no-tts-overlap', action='store_true', help='render on the lane stream instead of a second stream per lane')
     ap.add_argument('--no-pipeline', action='store_true', help='run the stages of consecutive cycles strictly one after another')
     args = ap.parse_args()

@@ -15,25 +15,31 @@
 
 namespace ifh {
 
-template <int CIN, int WGM, int MT, int NT, bool RESIDENT, int KC>
-__global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
+// EPB > 1: one block covers EPB consecutive batch rows (vocoder chunks), one 4-wave group each, sharing the streamed
+// weight chunks in LDS -- at Cin 256 a 48-row block re-reads all of W from L2 and the launch is bound by the L2 -> CU
+// rate (measured 6.4 us per tap at 768 chunks = 100 MB of W per tap = 15.7 TB/s); two chunks per block halve that.
+template <int CIN, int WGM, int MT, int NT, bool RESIDENT, int KC, int EPB>
+__global__ __launch_bounds__(256 * EPB) void k_conv_direct(const IgemmParams p)
 {
+    constexpr int NTHR = 256 * EPB;
     constexpr int WGN = 4 / WGM;
     constexpr int BM = WGM * MT * 16, BN = WGN * NT * 16;
     constexpr int XS = CIN + 8;   // LDS row stride (elements): 16-byte pad
-    constexpr int WV = RESIDENT ? 0 : (BN * KC / 8 / 256);   // prefetch vectors per thread (<= 16)
+    constexpr int WV = RESIDENT ? 0 : (BN * KC / 8 / NTHR);   // prefetch vectors per thread (<= 16)
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wid = (tid >> 6) & 3, grp = tid >> 8, gt = tid & 255;
     const int fr = lane & 15, fg = lane >> 4;
     const int wm = wid % WGM, wn = wid / WGM;
-    const int b = blockIdx.y, t0 = blockIdx.x * BM;
+    const bool live = (int)blockIdx.y * EPB + grp < p.nbatch;       // a group past the last batch row computes on a copy
+    const int b = live ? blockIdx.y * EPB + grp : p.nbatch - 1, t0 = blockIdx.x * BM;
     const int halo = (p.taps - 1) * p.dil;
     const int R = BM + halo;
     const int KW = RESIDENT ? p.K : KC;
     const int WS = KW + 8;
-    uint16_t *Xs = lds;
-    uint16_t *Ws = lds + ((R * XS + 7) & ~7);
+    const int XT = (R * XS + 7) & ~7;
+    uint16_t *Xs = lds + grp * XT;
+    uint16_t *Ws = lds + EPB * XT;
 
     // residual operand of the epilogue, requested first (ahead of the input tile) and consumed after the K loop
     const int dynv = p.dyn ? p.dyn[0] : 0;
@@ -65,7 +71,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
             uint4 xv[XVB];
 #pragma unroll
             for (int i = 0; i < XVB; i++) {
-                const int v = base + tid + 256 * i;
+                const int v = base + gt + 256 * i;
                 const int r = v / VPR, c = (v - r * VPR) * 8;
                 const int tin = t0 - p.pad + r;
                 const bool ok = v < R * VPR && tin >= 0 && tin < p.T_in;
@@ -74,7 +80,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
             }
 #pragma unroll
             for (int i = 0; i < XVB; i++) {
-                const int v = base + tid + 256 * i;
+                const int v = base + gt + 256 * i;
                 const int r = v / VPR, c = (v - r * VPR) * 8;
                 if (v < R * VPR) *reinterpret_cast<uint4 *>(&Xs[r * XS + c]) = pre ? lrelu8(xv[i], p.pre_slope) : xv[i];
             }
@@ -86,7 +92,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
     w0 = w1 = w2 = w3 = w4 = w5 = w6 = w7 = w8 = w9 = w10 = w11 = w12 = w13 = w14 = w15 = make_uint4(0, 0, 0, 0);
 #define IFH_W1(I, REG, K0)                                                                       \
     if (I < WV) {                                                                                \
-        const int v = tid + 256 * I;                                                             \
+        const int v = tid + NTHR * I;                                                            \
         REG = *reinterpret_cast<const uint4 *>(p.w + (int64_t)(v / (KC / 8)) * p.K + (K0) + (v % (KC / 8)) * 8); \
     }
 #define IFH_W_PREFETCH(K0)                                                                       \
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
     }
 #define IFH_C1(I, REG)                                                                           \
     if (I < WV) {                                                                                \
-        const int v = tid + 256 * I;                                                             \
+        const int v = tid + NTHR * I;                                                            \
         *reinterpret_cast<uint4 *>(&Ws[(v / (KC / 8)) * WS + (v % (KC / 8)) * 8]) = REG;         \
     }
 #define IFH_W_COMMIT()                                                                           \
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
     }
     if (RESIDENT) {
         const int vpr = p.K / 8;
-        for (int v = tid; v < BN * vpr; v += 256) {
+        for (int v = tid; v < BN * vpr; v += NTHR) {
             const int n = v / vpr, kv = (v - n * vpr) * 8;
             *reinterpret_cast<uint4 *>(&Ws[n * WS + kv]) = *reinterpret_cast<const uint4 *>(p.w + (int64_t)n * p.K + kv);
         }
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
         // of the kernel (8-byte pieces of 16 rows per instruction).
         constexpr int OS = BN + 8;
         __syncthreads();
-        uint16_t *Os = lds;
+        uint16_t *Os = Xs;
 #pragma unroll
         for (int j = 0; j < MT; j++) {
             const int tl = (wm * MT + j) * 16 + fr;
@@ -179,9 +185,9 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
         constexpr int VPR = BN / 8;
         uint16_t *outp = reinterpret_cast<uint16_t *>(p.out);
 #pragma unroll 4
-        for (int v = tid; v < BM * VPR; v += 256) {
+        for (int v = gt; v < BM * VPR; v += 256) {
             const int row = v / VPR, c = (v - row * VPR) * 8;
-            if (t0 + row < p.T_out) {
+            if (live && t0 + row < p.T_out) {
                 const EpiRow e = epi_row(p, b * p.T_out + t0 + row, 0, dynv);
                 *reinterpret_cast<uint4 *>(outp + e.obase + c) = *reinterpret_cast<const uint4 *>(&Os[row * OS + c]);
             }
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
 #pragma unroll
     for (int j = 0; j < MT; j++) {
         const int t = t0 + (wm * MT + j) * 16 + fr;
-        if (t >= p.T_out) continue;
+        if (t >= p.T_out || !live) continue;
         const int m = b * p.T_out + t;
 #pragma unroll
         for (int i = 0; i < NT; i++) {
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(256) void k_conv_direct(const IgemmParams p)
     }
 }
 
-template <int CIN, int WGM, int MT, int NT, bool RESIDENT, int KC = 64>
+template <int CIN, int WGM, int MT, int NT, bool RESIDENT, int KC = 64, int EPB = 1>
 static bool launch_direct(const IgemmParams &p, hipStream_t st)
 {
     constexpr int WGN = 4 / WGM;
@@ -210,17 +216,18 @@ static bool launch_direct(const IgemmParams &p, hipStream_t st)
     const int R = BM + (p.taps - 1) * p.dil;
     const int KW = RESIDENT ? p.K : KC;
     if (!RESIDENT && p.K % KC != 0) return false;
-    const size_t bytes = ((size_t)((R * XS + 7) & ~7) + (size_t)BN * (KW + 8)) * sizeof(uint16_t);
+    static_assert(EPB == 1 || BM * (BN + 8) <= BM * XS, "the store16 staging of a group lies inside its own input tile");
+    const size_t bytes = ((size_t)EPB * ((R * XS + 7) & ~7) + (size_t)BN * (KW + 8)) * sizeof(uint16_t);
     if (bytes > 160 * 1024) return false;
     static size_t attr_bytes = 0;
     if (bytes > 64 * 1024 && bytes > attr_bytes) {
-        if (hipFuncSetAttribute((const void *)k_conv_direct<CIN, WGM, MT, NT, RESIDENT, KC>,
+        if (hipFuncSetAttribute((const void *)k_conv_direct<CIN, WGM, MT, NT, RESIDENT, KC, EPB>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return false;
         attr_bytes = 160 * 1024;
     }
-    dim3 grid((p.T_out + BM - 1) / BM, p.nbatch);
-    hipLaunchKernelGGL((k_conv_direct<CIN, WGM, MT, NT, RESIDENT, KC>), grid, dim3(256), bytes, st, p);
+    dim3 grid((p.T_out + BM - 1) / BM, (p.nbatch + EPB - 1) / EPB);
+    hipLaunchKernelGGL((k_conv_direct<CIN, WGM, MT, NT, RESIDENT, KC, EPB>), grid, dim3(256 * EPB), bytes, st, p);
     return true;
 }
 
@@ -238,10 +245,20 @@ bool try_launch_conv_direct(const IgemmParams &p_, bool pre, hipStream_t st)
     if (p.stride != 1 || p.taps < 2 || p.N != p.Cin || p.n_split != 0 || !p.fast_epi) return false;
     if (p.T_out != p.T_in + 2 * p.pad - (p.taps - 1) * p.dil) return false;
     if (p.nbatch >= 65536) return false;
+    static const int epb = getenv("IFH_CONV_EPB") ? atoi(getenv("IFH_CONV_EPB")) : 2;       // tuning switch
     static const int kc = getenv("IFH_DIRECT_KC") ? atoi(getenv("IFH_DIRECT_KC")) : 64;      // tuning switch
     switch (p.Cin) {
     case 256:                                                                        // BM 48  x BN 256
         if (p.T_out < 32) return false;
+        // Two chunks per block (shared W chunks: half the L2 -> CU weight traffic, the bound of this shape) when the
+        // block count still fills the 256 CUs evenly, or when one 48-row block alone already takes more than half a
+        // CU's LDS (11 taps x dilation 5).  Measured per 9-conv set: 1024 chunks 778 -> 655 us; 768 chunks
+        // (384 blocks = 1.5 per CU) no gain except the 11x5 conv, 119 -> 94 us.
+        if (epb == 2 && p.T_out <= 48 && p.nbatch >= 512) {
+            const int half = (p.nbatch + 1) / 2;
+            const bool lds_bound = (48 + (p.taps - 1) * p.dil) * (256 + 8) * 2 + 256 * (64 + 8) * 2 > 80 * 1024;
+            if ((half % 256 == 0 || half >= 1024 || lds_bound) && launch_direct<256, 1, 3, 4, false, 64, 2>(p, st)) return true;
+        }
         return kc == 128 ? launch_direct<256, 1, 3, 4, false, 128>(p, st) : launch_direct<256, 1, 3, 4, false, 64>(p, st);
     case 128:                                                                        // BM 192 x BN 128
         if (p.T_out < 64) return false;

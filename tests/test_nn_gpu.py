@@ -41,6 +41,7 @@ def bfr(x):
 @pytest.mark.parametrize('case', [
     dict(B=3, T=12, cin=80, cout=512, k=7, pad=3),                      # conv_pre (K=560, not a multiple of 32)
     dict(B=2, T=48, cin=256, cout=256, k=11, dil=5, pad=25, pre=0.1),   # resblock conv, dilated
+    dict(B=513, T=48, cin=256, cout=256, k=7, dil=3, pad=9, pre=0.1, resid=True),     # two chunks per block, odd count
     dict(B=2, T=200, cin=64, cout=64, k=3, dil=3, pad=3, pre=0.01, resid=True),
     dict(B=3, T=192, cin=128, cout=128, k=7, dil=3, pad=9, pre=0.1, resid=True),      # LDS-resident-input conv, streamed W
     dict(B=2, T=768, cin=64, cout=64, k=11, dil=5, pad=25, pre=0.1, resid=True),     # resident W, 3 row blocks

@@ -1,5 +1,5 @@
 """Runs P HiFi-GAN vocoder passes (N chunks x 12 frames, as in bench.py's roofline leg: N = 4 x calls x grouped
-cycles = 768 by default) -- used under rocprofv3 --pmc to collect FETCH_SIZE / WRITE_SIZE per pass:
+cycles = 1024 by default) -- used under rocprofv3 --pmc to collect FETCH_SIZE / WRITE_SIZE per pass:
 python3 tools/probe_vocoder.py [passes] [chunks]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,7 +10,7 @@ from infernos_amd.weights import synth_state_dict
 dev = _lib.require_device('cuda:0')
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 voc = HifiGan(synth_state_dict('hifigan', 0), dev)
-N = int(sys.argv[2]) if len(sys.argv) > 2 else 768
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 x = torch.randn(N, 12, 80, device=dev).to(torch.bfloat16)
 for _ in range(P):
     voc(x)
