@@ -43,10 +43,12 @@ __device__ __forceinline__ uint2 lrelu4(uint2 v, float slope)
     return make_uint2(f32x2_to_bf16x2(a, b), f32x2_to_bf16x2(c, d));
 }
 
-template <int CIN, int WGM, int MT1, int NT, bool RESIDENT, int KC, int EPB, bool RES_LDS>
-__global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
+template <int CIN, int WGM, int MT1, int NT, bool RESIDENT, int KC, int EPB, bool RES_LDS, int NWV>
+__global__ __launch_bounds__(64 * NWV) void k_resblock_pair(const PairParams p)
 {
-    constexpr int WGN = 4 / WGM;
+    constexpr int NTHR = 64 * NWV;            // 8 waves: two per SIMD inside the one block a CU holds at C = 128
+    constexpr int WGN = NWV / WGM;
+    static_assert(!RESIDENT || NWV == 4, "the resident-weight transfers assume 256 threads");
     constexpr bool LATE_ACC = RESIDENT;       // C = 32: one exposed load in the 2-of-18 accumulating launches buys a third block per CU
     constexpr int TPE = WGM * MT1 / EPB;      // conv1 tiles per batch entry
     constexpr int BM1E = TPE * 16;            // conv1 rows per entry
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
     static_assert(EPB == 1 || WGM == 1, "several entries per block: one wave row");
     static_assert(TPE * EPB == WGM * MT1, "tiles split evenly over the entries");
     constexpr int XS = CIN + 8;
-    constexpr int WV = RESIDENT ? 0 : (BN * KC / 8 / 256);
+    constexpr int WV = RESIDENT ? 0 : (BN * KC / 8 / NTHR);
     static_assert(WV <= 16, "prefetch registers");
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
 
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
     w0 = w1 = w2 = w3 = w4 = w5 = w6 = w7 = w8 = w9 = w10 = w11 = w12 = w13 = w14 = w15 = make_uint4(0, 0, 0, 0);
 #define RB_W1(I, REG, SRC, K0)                                                                   \
     if (I < WV) {                                                                                \
-        const int v = tid + 256 * I;                                                             \
+        const int v = tid + NTHR * I;                                                            \
         REG = *reinterpret_cast<const uint4 *>((SRC) + (int64_t)(v / (KC / 8)) * K + (K0) + (v % (KC / 8)) * 8); \
     }
 #define RB_W_PREFETCH(CH)                                                                        \
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
     }
 #define RB_C1(I, REG)                                                                            \
     if (I < WV) {                                                                                \
-        const int v = tid + 256 * I;                                                             \
+        const int v = tid + NTHR * I;                                                            \
         *reinterpret_cast<uint4 *>(&Ws[(v / (KC / 8)) * WS + (v % (KC / 8)) * 8]) = REG;         \
     }
 #define RB_W_COMMIT()                                                                            \
@@ -153,14 +155,14 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
     // of the output range also go to Rs (the residual operand).  All loads in flight together.
     {
         constexpr int VPR = CIN / 8;
-        constexpr int XVB = (EPB * (BM1E + 50) * VPR + 255) / 256;
+        constexpr int XVB = (EPB * (BM1E + 50) * VPR + NTHR - 1) / NTHR;
         const int tx0 = t0 - 8 - h1;
         const int nvec = EPB * R1 * VPR;
-        for (int base = 0; base < nvec; base += 256 * XVB) {
+        for (int base = 0; base < nvec; base += NTHR * XVB) {
             uint4 xv[XVB];
 #pragma unroll
             for (int i = 0; i < XVB; i++) {
-                const int v = base + tid + 256 * i;
+                const int v = base + tid + NTHR * i;
                 const int rr = v / VPR, c = (v - rr * VPR) * 8;
                 const int e = EPB == 1 ? 0 : rr / R1;
                 const int tin = tx0 + (rr - e * R1);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void k_resblock_pair(const PairParams p)
             }
 #pragma unroll
             for (int i = 0; i < XVB; i++) {
-                const int v = base + tid + 256 * i;
+                const int v = base + tid + NTHR * i;
                 const int rr = v / VPR, c = (v - rr * VPR) * 8;
                 if (v < nvec) {
                     *reinterpret_cast<uint4 *>(&Xs[rr * XS + c]) = lrelu8(xv[i], p.slope);
@@ -335,7 +337,7 @@ _Pragma("unroll") \
     __syncthreads();
     constexpr int VPRO = BN / 8;
 #pragma unroll 4
-    for (int v = tid; v < EPB * BME * VPRO; v += 256) {
+    for (int v = tid; v < EPB * BME * VPRO; v += NTHR) {
         const int orow = v / VPRO, c = (v - orow * VPRO) * 8;
         const int e = EPB == 1 ? 0 : orow / BME;
         const int row = orow - e * BME;
@@ -345,10 +347,10 @@ _Pragma("unroll") \
     }
 }
 
-template <int CIN, int WGM, int MT1, int NT, bool RESIDENT, int EPB, bool RES_LDS, int KC = 64>
+template <int CIN, int WGM, int MT1, int NT, bool RESIDENT, int EPB, bool RES_LDS, int KC = 64, int NWV = 4>
 static int launch_pair(PairParams &p, hipStream_t st)
 {
-    constexpr int WGN = 4 / WGM;
+    constexpr int WGN = NWV / WGM;
     constexpr int TPE = WGM * MT1 / EPB, BM1E = TPE * 16, BME = BM1E - 16, BN = WGN * NT * 16;
     constexpr int XS = CIN + 8;
     const int K = p.taps * CIN;
@@ -360,7 +362,7 @@ static int launch_pair(PairParams &p, hipStream_t st)
     if (bytes > 160 * 1024) return fail(IFH_EINVAL, "resblock_pair: tile does not fit in LDS (taps*dil too large)");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_resblock_pair<CIN, WGM, MT1, NT, RESIDENT, KC, EPB, RES_LDS>,
+        hipError_t e = hipFuncSetAttribute((const void *)k_resblock_pair<CIN, WGM, MT1, NT, RESIDENT, KC, EPB, RES_LDS, NWV>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return check_hip(e, "resblock_pair lds attr");
         attr_set = true;
@@ -368,7 +370,7 @@ static int launch_pair(PairParams &p, hipStream_t st)
     const int nblk = (p.T + BME - 1) / BME;
     p.rows_per_block = (p.T + nblk - 1) / nblk;
     dim3 grid(nblk, (p.nbatch + EPB - 1) / EPB);
-    hipLaunchKernelGGL((k_resblock_pair<CIN, WGM, MT1, NT, RESIDENT, KC, EPB, RES_LDS>), grid, dim3(256), bytes, st, p);
+    hipLaunchKernelGGL((k_resblock_pair<CIN, WGM, MT1, NT, RESIDENT, KC, EPB, RES_LDS, NWV>), grid, dim3(64 * NWV), bytes, st, p);
     return IFH_OK;
 }
 
@@ -406,10 +408,16 @@ extern "C" int ifh_resblock_pair_bf16(const ifh_resblock_desc *d, ifh_stream_t s
     p.out = (uint16_t *)d->out;
     p.out_bstride = d->out_bstride;
     hipStream_t st = as_stream(stream);
+    static const int nwv8 = getenv("IFH_PAIR_NWV8") ? atoi(getenv("IFH_PAIR_NWV8")) : 1;      // tuning switch: 8-wave blocks at C = 128
     int rc;
     switch (d->c) {                                                                // <C, WGM, MT1, NT, resident W, entries/block, residual rows in LDS>
     case 256: rc = launch_pair<256, 1, 4, 4, false, 1, true, 128>(p, st); break;   // conv1 64 rows, out 48; 128-wide weight chunks
-    case 128: rc = launch_pair<128, 2, 7, 4, false, 1, false, 128>(p, st); break;  // conv1 224 rows, out 208; 128-wide chunks (7-10 % over 64)
+    case 128:                                                                      // conv1 224 rows, out 208; 128-wide chunks (7-10 % over 64)
+        // the tile takes 109 KB of LDS (one block per CU): 8 waves give every SIMD a second wave to cover the two
+        // barriers per weight chunk -- 10-13 % over 4 waves at 1024 chunks (88 -> 77, 141 -> 127, 195 -> 177 us for
+        // 3 / 7 / 11 taps).  At C = 64 (2 blocks per CU already) the same split costs 35 % (NT = 1 doubles the LDS reads per MFMA).
+        rc = nwv8 ? launch_pair<128, 2, 7, 2, false, 1, false, 128, 8>(p, st) : launch_pair<128, 2, 7, 4, false, 1, false, 128>(p, st);
+        break;
     case 64: rc = launch_pair<64, 2, 7, 2, false, 1, true>(p, st); break;          // conv1 224 rows, out 208 (K = 64*taps: 64-wide chunks)
     default: rc = launch_pair<32, 4, 4, 2, true, 1, false>(p, st); break;          // conv1 256 rows, out 240
     }

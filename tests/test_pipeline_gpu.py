@@ -133,6 +133,40 @@ def test_block_ingest_equals_per_tick_ingest(built_lib):
         assert np.array_equal(u, v)
 
 
+def test_config4_front_end_256_calls_per_gpu(built_lib):
+    """BASELINE config 4 per-GPU size (256 calls): the batched front end against the oracle call by call -- decoded
+    PCM and the VAD chunk list of every call equal what the oracle's per-call path gives for that call's own stream
+    (calls j and j+128 carry the same audio and must agree bit for bit wherever they sit in the 256-row table)."""
+    from infernos_amd import _lib
+    from infernos_amd.pipeline import SpeechPipeline
+    from infernos_amd.synth import synth_utterance
+    dev = _lib.require_device('cuda:0')
+    N = 256
+    pipe = SpeechPipeline(N, dev, n_infer=1, n_new_tokens=2, tts_lanes=1)
+    base = np.stack([synth_utterance(1000 + i, 4.0) for i in range(8)])
+    x = base[np.arange(N) % 8]
+    x[128:] = x[:128]
+    ulaw = odsp.g711_encode(x)
+    nt = ulaw.shape[1] // 160
+    frames = torch.from_numpy(np.ascontiguousarray(ulaw.reshape(N, nt, 160).transpose(1, 0, 2))).to(dev)
+    pipe.reset_calls()
+    chunks = pipe.ingest(frames, block=True)
+    got = [[(c.ipos, c.audio.cpu().numpy()) for c in lst] for lst in chunks]
+    assert sum(len(g) for g in got) >= N // 2
+    for j in range(N):
+        k = j % 8
+        assert [p for p, _ in got[j]] == [p for p, _ in got[k]]
+        for (_, a), (_, b) in zip(got[j], got[k]):
+            assert np.array_equal(a, b)
+    # the first 8 calls against the oracle's decode of their own stream: every emitted chunk is a slice of it, except
+    # its 240-sample start pad, which the reference takes from the stale head of its idle buffer (SileroVAD.py:90,101-102)
+    for k in range(8):
+        pcm = odsp.g711_decode(ulaw[k])
+        for ipos, a in got[k]:
+            assert np.array_equal(a[240:], pcm[ipos + 240:ipos + a.size])
+    assert pipe.calls.fifo_len.cpu().tolist() == [(nt * 160) % 768] * N
+
+
 def test_full_size_cycle_properties(built_lib):
     """BASELINE config 2 size (64 calls x 10 s), checked through size-independent properties: calls i and i+32 carry
     the same audio, speaker and text, so every stage must give them identical results wherever they sit in the batch
