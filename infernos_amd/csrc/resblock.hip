@@ -43,13 +43,14 @@ __device__ __forceinline__ uint2 lrelu4(uint2 v, float slope)
     return make_uint2(f32x2_to_bf16x2(a, b), f32x2_to_bf16x2(c, d));
 }
 
-template <int CIN, int WGM, int MT1, int NT, bool RESIDENT, int KC, int EPB, bool RES_LDS, int NWV>
-__global__ __launch_bounds__(64 * NWV) void k_resblock_pair(const PairParams p)
+template <int CIN, int WGM, int MT1, int NT, bool RESIDENT, int KC, int EPB, bool RES_LDS, int NWV, int MINW>
+__global__ __launch_bounds__(64 * NWV, MINW) void k_resblock_pair(const PairParams p)
 {
     constexpr int NTHR = 64 * NWV;            // 8 waves: two per SIMD inside the one block a CU holds at C = 128
     constexpr int WGN = NWV / WGM;
     static_assert(!RESIDENT || NWV == 4, "the resident-weight transfers assume 256 threads");
-    constexpr bool LATE_ACC = RESIDENT;       // C = 32: one exposed load in the 2-of-18 accumulating launches buys a third block per CU
+    constexpr bool LATE_ACC = RESIDENT || (CIN == 64 && !RES_LDS) || NWV > 8;       // C = 32: one exposed load in the 2-of-18 accumulating launches buys a third block per CU
+    constexpr bool LATE_RES = !RES_LDS && (CIN == 64 || NWV > 8);      // residual rows read (L2-hot) in the epilogue: 28 fewer live registers
     constexpr int TPE = WGM * MT1 / EPB;      // conv1 tiles per batch entry
     constexpr int BM1E = TPE * 16;            // conv1 rows per entry
     constexpr int BME = BM1E - 16;            // conv2 (output) rows per entry
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(64 * NWV) void k_resblock_pair(const PairParams p)
     static_assert(EPB == 1 || WGM == 1, "several entries per block: one wave row");
     static_assert(TPE * EPB == WGM * MT1, "tiles split evenly over the entries");
     constexpr int XS = CIN + 8;
-    constexpr int WV = RESIDENT ? 0 : (BN * KC / 8 / NTHR);
+    constexpr int WV = RESIDENT ? 0 : (BN * KC / 8 + NTHR - 1) / NTHR;
     static_assert(WV <= 16, "prefetch registers");
     extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
 
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(64 * NWV) void k_resblock_pair(const PairParams p)
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             const int n = (wn * NT + i) * 16 + 4 * fg;
-            rpre[i][j] = RES_LDS ? make_uint2(0, 0)
+            rpre[i][j] = (RES_LDS || LATE_RES) ? make_uint2(0, 0)
                                  : *reinterpret_cast<const uint2 *>(p.x + (int64_t)be * p.x_bstride + (int64_t)t * CIN + n);
             apre[i][j] = (p.accumulate && !LATE_ACC)      // LATE_ACC reads them in the epilogue instead: fewer live registers
                              ? *reinterpret_cast<const uint2 *>(p.out + (int64_t)be * p.out_bstride + (int64_t)t * CIN + n)
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(64 * NWV) void k_resblock_pair(const PairParams p)
     uint4 w0, w1, w2, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15;
     w0 = w1 = w2 = w3 = w4 = w5 = w6 = w7 = w8 = w9 = w10 = w11 = w12 = w13 = w14 = w15 = make_uint4(0, 0, 0, 0);
 #define RB_W1(I, REG, SRC, K0)                                                                   \
-    if (I < WV) {                                                                                \
+    if (I < WV && ((I + 1) * NTHR <= BN * KC / 8 || tid + NTHR * I < BN * KC / 8)) {             \
         const int v = tid + NTHR * I;                                                            \
         REG = *reinterpret_cast<const uint4 *>((SRC) + (int64_t)(v / (KC / 8)) * K + (K0) + (v % (KC / 8)) * 8); \
     }
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(64 * NWV) void k_resblock_pair(const PairParams p)
         RB_W1(12, w12, src_, k0_) RB_W1(13, w13, src_, k0_) RB_W1(14, w14, src_, k0_) RB_W1(15, w15, src_, k0_) \
     }
 #define RB_C1(I, REG)                                                                            \
-    if (I < WV) {                                                                                \
+    if (I < WV && ((I + 1) * NTHR <= BN * KC / 8 || tid + NTHR * I < BN * KC / 8)) {             \
         const int v = tid + NTHR * I;                                                            \
         *reinterpret_cast<uint4 *>(&Ws[(v / (KC / 8)) * WS + (v % (KC / 8)) * 8]) = REG;         \
     }
@@ -315,7 +316,10 @@ _Pragma("unroll") \
         for (int i = 0; i < NT; i++) {
             const int n = (wn * NT + i) * 16 + 4 * fg;
             const f32x4 a = acc[i][j];
-            const uint2 rv = RES_LDS ? *reinterpret_cast<const uint2 *>(&Rs[orow * XS + n]) : rpre[i][j];
+            const uint2 rv = RES_LDS ? *reinterpret_cast<const uint2 *>(&Rs[orow * XS + n])
+                             : LATE_RES ? *reinterpret_cast<const uint2 *>(p.x + (int64_t)min(b0 + e, p.nbatch - 1) * p.x_bstride +
+                                                                           (int64_t)min(t0 + lt * 16 + fr, p.T - 1) * CIN + n)
+                                        : rpre[i][j];
             float v0 = a[0] + bp2[i].x, v1 = a[1] + bp2[i].y, v2 = a[2] + bp2[i].z, v3 = a[3] + bp2[i].w;
             v0 += __uint_as_float(rv.x << 16);
             v1 += __uint_as_float(rv.x & 0xffff0000u);
@@ -347,7 +351,7 @@ _Pragma("unroll") \
     }
 }
 
-template <int CIN, int WGM, int MT1, int NT, bool RESIDENT, int EPB, bool RES_LDS, int KC = 64, int NWV = 4>
+template <int CIN, int WGM, int MT1, int NT, bool RESIDENT, int EPB, bool RES_LDS, int KC = 64, int NWV = 4, int MINW = 1>
 static int launch_pair(PairParams &p, hipStream_t st)
 {
     constexpr int WGN = NWV / WGM;
@@ -362,7 +366,7 @@ static int launch_pair(PairParams &p, hipStream_t st)
     if (bytes > 160 * 1024) return fail(IFH_EINVAL, "resblock_pair: tile does not fit in LDS (taps*dil too large)");
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_resblock_pair<CIN, WGM, MT1, NT, RESIDENT, KC, EPB, RES_LDS, NWV>,
+        hipError_t e = hipFuncSetAttribute((const void *)k_resblock_pair<CIN, WGM, MT1, NT, RESIDENT, KC, EPB, RES_LDS, NWV, MINW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return check_hip(e, "resblock_pair lds attr");
         attr_set = true;
@@ -370,7 +374,7 @@ static int launch_pair(PairParams &p, hipStream_t st)
     const int nblk = (p.T + BME - 1) / BME;
     p.rows_per_block = (p.T + nblk - 1) / nblk;
     dim3 grid(nblk, (p.nbatch + EPB - 1) / EPB);
-    hipLaunchKernelGGL((k_resblock_pair<CIN, WGM, MT1, NT, RESIDENT, KC, EPB, RES_LDS, NWV>), grid, dim3(64 * NWV), bytes, st, p);
+    hipLaunchKernelGGL((k_resblock_pair<CIN, WGM, MT1, NT, RESIDENT, KC, EPB, RES_LDS, NWV, MINW>), grid, dim3(64 * NWV), bytes, st, p);
     return IFH_OK;
 }
 
@@ -409,6 +413,8 @@ extern "C" int ifh_resblock_pair_bf16(const ifh_resblock_desc *d, ifh_stream_t s
     p.out_bstride = d->out_bstride;
     hipStream_t st = as_stream(stream);
     static const int nwv8 = getenv("IFH_PAIR_NWV8") ? atoi(getenv("IFH_PAIR_NWV8")) : 1;      // tuning switch: 8-wave blocks at C = 128
+    static const int c64v = getenv("IFH_PAIR_C64V") ? atoi(getenv("IFH_PAIR_C64V")) : 1;      // tuning switch
+    static const int c32v = getenv("IFH_PAIR_C32V") ? atoi(getenv("IFH_PAIR_C32V")) : 1;      // tuning switch
     int rc;
     switch (d->c) {                                                                // <C, WGM, MT1, NT, resident W, entries/block, residual rows in LDS>
     case 256: rc = launch_pair<256, 1, 4, 4, false, 1, true, 128>(p, st); break;   // conv1 64 rows, out 48; 128-wide weight chunks
@@ -416,10 +422,19 @@ extern "C" int ifh_resblock_pair_bf16(const ifh_resblock_desc *d, ifh_stream_t s
         // the tile takes 109 KB of LDS (one block per CU): 8 waves give every SIMD a second wave to cover the two
         // barriers per weight chunk -- 10-13 % over 4 waves at 1024 chunks (88 -> 77, 141 -> 127, 195 -> 177 us for
         // 3 / 7 / 11 taps).  At C = 64 (2 blocks per CU already) the same split costs 35 % (NT = 1 doubles the LDS reads per MFMA).
+        // (14 waves -- 7 row groups x 2 -- measured 3-4 % slower than 8)
         rc = nwv8 ? launch_pair<128, 2, 7, 2, false, 1, false, 128, 8>(p, st) : launch_pair<128, 2, 7, 4, false, 1, false, 128>(p, st);
         break;
-    case 64: rc = launch_pair<64, 2, 7, 2, false, 1, true>(p, st); break;          // conv1 224 rows, out 208 (K = 64*taps: 64-wide chunks)
-    default: rc = launch_pair<32, 4, 4, 2, true, 1, false>(p, st); break;          // conv1 256 rows, out 240
+    case 64:                                                                       // conv1 224 rows, out 208 (K = 64*taps: 64-wide chunks)
+        // residual rows re-read from L2 in the epilogue instead of kept in LDS (49 KB per block) and the kernel compiled
+        // for 168 registers: 3 blocks per CU instead of 2 -- 15-19 % per launch (97 -> 82, 152 -> 127, 210 -> 171 us)
+        rc = c64v ? launch_pair<64, 2, 7, 2, false, 1, false, 64, 4, 3>(p, st) : launch_pair<64, 2, 7, 2, false, 1, true>(p, st);
+        break;
+    default:                                                                       // conv1 256 rows, out 240
+        // compiled for 128 registers (126 used, no spills; 160 without the bound): 4 blocks per CU where LDS allows
+        // (3 / 7 taps), 7-13 % per launch (139 -> 128, 189 -> 166, 238 -> 210 us at 1024 chunks).  A 96-register build spills.
+        rc = c32v ? launch_pair<32, 4, 4, 2, true, 1, false, 64, 4, 4>(p, st) : launch_pair<32, 4, 4, 2, true, 1, false>(p, st);
+        break;
     }
     if (rc != IFH_OK) return rc;
     IFH_LAUNCH_CHECK("resblock_pair_bf16");
