@@ -53,10 +53,10 @@ def make_frames(ncalls, first_call, codec_encode):
     return np.ascontiguousarray(ulaw.reshape(ncalls, TICKS, 160).transpose(1, 0, 2))
 
 
-def cpu_baseline(ncalls=8, threads=32):
+def cpu_baseline(ncalls=16, threads=32):
     """The oracle (CPU restatement, kind "port") timed on this host, bounded: one 10 s cycle for `ncalls`
-    calls batched the way the reference batches them (its TTS cap is 8): full ingest + STT measured, TTS
-    timed for 2 of the 10 infer() calls and scaled.  Threads capped (a 1-call fp32 graph on 128 threads
+    calls batched (the reference's own TTS cap is 8): ingest + STT + all 10 TTS infer() calls measured, nothing
+    scaled (about 10 s of CPU work).  Threads capped (a 1-call fp32 graph on 128 threads
     is slower than on 32)."""
     from oracle import dsp as odsp, nn as onn
     from infernos_amd.synth import synth_utterance
@@ -86,18 +86,18 @@ def cpu_baseline(ncalls=8, threads=32):
             t_enc = time.perf_counter() - t1
             masks = (torch.rand(16, 2, 256, generator=g) < 0.5).to(torch.uint8)
             t2 = time.perf_counter()
-            nmeas = 2
+            nmeas = 10
             for _ in range(nmeas):
                 a = onn.tts_infer(sd_t, sd_v, sd_a, st, masks)
                 odsp.g711_encode(odsp.resample(a.numpy(), 16000, 8000))
             t_inf = (time.perf_counter() - t2) / nmeas
     finally:
         torch.set_num_threads(prev)
-    total = t_stt + t_enc + 10 * t_inf
+    total = t_stt + t_enc + nmeas * t_inf
     return {'value': ncalls * UTT_SECONDS / total, 'unit': 'x real-time (call-seconds/s)', 'cores': nthreads, 'kind': 'port',
             'sample': '%d calls, one 10 s cycle on the fp32 oracle (oracle/): ingest + log-mel + Whisper-tiny 32 tokens '
-                      'measured (%.2f s), SpeechT5 encoder (%.2f s), 2 of 10 TTS infer() calls measured (%.2f s each) and '
-                      'scaled to 10; torch threads=%d of os.cpu_count()=%s' % (ncalls, t_stt, t_enc, t_inf, nthreads, os.cpu_count())}
+                      '(%.2f s), SpeechT5 encoder (%.2f s), 10 TTS infer() calls + resample + mu-law encode (%.2f s each), all '
+                      'measured; torch threads=%d of os.cpu_count()=%s' % (ncalls, t_stt, t_enc, t_inf, nthreads, os.cpu_count())}
 
 
 def main():
