@@ -26,6 +26,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
     __shared__ __attribute__((aligned(16))) float red[NW][MT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
+    // (an XCD-contiguous remap of the column tiles -- 1/8 of W per L2 -- was measured: no change at 64 or 256 rows)
     const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MT;
     const int M = p.nbatch * p.T_out;
     const int nk = (p.K + 31) / 32;
@@ -526,8 +527,15 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         static const bool one_tile = getenv("IFH_SKINNY_MT1") != nullptr;              // tuning switch
         if (M > 64 && !one_tile) {
             const dim3 grid2((d->n + 15) / 16, (unsigned)((M + 31) / 32));
+            // Grids beyond what the chip holds at once (qkv, ff1 at 192-256 rows: 1152-1536 blocks against 4 x 256
+            // co-resident at 200 registers) take the half-depth load batch: 128 registers, twice the blocks per CU --
+            // ff1 20.2 -> 15.4 us, qkv 14.6 -> 13.1 us at 256 rows, same bits (the k order of a wave is unchanged).
+            // Measured without effect on the deep-K GEMM (ff2, 19 us at 256 rows): 8 waves, one row tile, shallower batches.
+            static const bool u6 = getenv("IFH_SKINNY_U6") ? atoi(getenv("IFH_SKINNY_U6")) != 0 : true;      // tuning switch
             if (p.K >= 2048)
                 hipLaunchKernelGGL((k_gemm_skinny<4, 12, 2>), grid2, dim3(256), 0, st, p);
+            else if (u6 && (int64_t)grid2.x * grid2.y > 1024)
+                hipLaunchKernelGGL((k_gemm_skinny<2, 6, 2>), grid2, dim3(128), 0, st, p);
             else
                 hipLaunchKernelGGL((k_gemm_skinny<2, 12, 2>), grid2, dim3(128), 0, st, p);
         } else if (p.K >= 2048)

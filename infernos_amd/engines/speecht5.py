@@ -19,6 +19,8 @@ from ..ops import ACT_GELU, ACT_RELU, ACT_TANH, BF16
 from ..weights import scaled_positional_table
 
 D, H, FF = 768, 12, 3072
+ROW_PAD = 8             # elements added to the row stride of decode-step activations (see TTSBatchState)
+KVP = 2 * D             # K|V row stride of the caches (padding it like the activations was measured: 0.69 -> 0.72-0.76 ms per step)
 QS = 64 ** -0.5
 
 
@@ -168,10 +170,10 @@ class TTSBatchState:
         self.minlen = 0
         e = lambda *s, dt=BF16: torch.empty(s, dtype=dt, device=dev)
         self.enc_len = torch.zeros(B, dtype=torch.int32, device=dev)
-        self.cross = [e(B * T, 2 * D) for _ in model.dec_layers]
+        self.cross = [e(B * T, KVP) for _ in model.dec_layers]
         self.smax = min(model.max_steps, self.maxlen + 48)      # maxlen here is the bucket's upper bound; the loop
         # runs at most one 16-step call past maxlen before every row has ended
-        self.self_kv = [torch.zeros((B, self.smax, 2 * D), dtype=BF16, device=dev) for _ in model.dec_layers]
+        self.self_kv = [torch.zeros((B, self.smax, KVP), dtype=BF16, device=dev) for _ in model.dec_layers]
         # two frame buffers (call parity): frame 0 = last frame carried over from the previous call, frames
         # 1..32 = this call.  Double-buffered so the renderer (postnet/vocoder) of call c can run on a second
         # stream while the decoder already writes call c+1.
@@ -184,11 +186,16 @@ class TTSBatchState:
         self.ncalls = 0
         self.pos_dev = torch.zeros(1, dtype=torch.int32, device=dev)       # decoder position, read by the kernels
         self.masks = torch.zeros((16, 2, 256), dtype=torch.uint8, device=dev)
+        # Row stride of the step's activation buffers: D + 8 elements, i.e. 16 bytes past a multiple of 128.  The skinny
+        # GEMM reads 16 rows x 64 bytes per wave-instruction; with rows a whole number of 128-byte lines apart those
+        # pieces collide in the vector L1 (measured at 256 rows: qkv 13.2 -> 9.7 us, ff1 15.5 -> 11.6, ff2 18.9 -> 14.5; the whole
+        # step 0.78 -> 0.66 ms).  Padding the weight rows the same way changes nothing (tools/probe_skinny.py).
+        self.DP, self.FP = D + ROW_PAD, FF + ROW_PAD
         self.h1, self.h2, self.x = e(B, 256), e(B, 256), e(B, D)
-        self.q, self.att, self.t1, self.ff = e(B, D), e(B, D), e(B, D), e(B, FF)
+        self.q, self.att, self.t1, self.ff = e(B, self.DP), e(B, self.DP), e(B, self.DP), e(B, self.FP)
         self.plog = e(B, 2, dt=torch.float32)
         self.plog16 = e(B, 16, dt=torch.float32)            # LN-folded path: stop logits in cols 0..1 of a 16-wide tile
-        self.t2, self.t3, self.x0 = e(B, D), e(B, D), e(B, D)
+        self.t2, self.t3, self.x0 = e(B, self.DP), e(B, self.DP), e(B, self.DP)
         self.stat_rows = max(64, -(-B // 16) * 16)
         self.stats = torch.zeros((3 * len(model.dec_layers), self.stat_rows, 2), dtype=torch.int64, device=dev)
         self.pn = [e(B, 32, 256), e(B, 32, 256)]
@@ -218,7 +225,7 @@ class TTSBatchState:
         self.enc_len.copy_(lens.to(torch.int32))
         self.enc = model.encode(input_ids, lens)
         for L, kv in zip(model.dec_layers, self.cross):
-            ops.linear(self.enc, L['cwkv'], L['cbkv'], kv, rows=B * T, k=D, n=2 * D)
+            ops.linear(self.enc, L['cwkv'], L['cbkv'], kv, rows=B * T, k=D, n=2 * D, ldc=KVP)
         self.spec[0].zero_()
         self.spec[1].zero_()
         self.stats.zero_()                # each decoder step leaves it cleared for the next; start from a known state
@@ -235,7 +242,8 @@ class TTSBatchState:
 
 def _decoder_step(model: 'SpeechT5', st: TTSBatchState, s: int, threshold: float, par: int):
     """One decoder step; everything that depends on the global position reads st.pos_dev on the
-    device, so the launch sequence is identical for every step with the same in-call index s."""
+    device, so the launch sequence is identical for every step with the same in-call index s.
+    (The scratch buffers are used as dense [B, D] / [B, FF] storage here; the folded step pads their rows.)"""
     dev = model.device
     B, T = st.B, st.T
     masks = st.masks
@@ -251,14 +259,14 @@ def _decoder_step(model: 'SpeechT5', st: TTSBatchState, s: int, threshold: float
         kv = st.self_kv[li]
         # one launch: q -> scratch, K|V -> appended to the cache at the device-held position
         ops.conv(x, L['wqkv'], L['bqkv'], st.q, nbatch=B, t_in=1, t_out=1, cin=D, n=3 * D, ldc=D, out_bstride=D,
-                 dyn_pos=st.pos_dev, n_split=D, out2=kv, out2_bstride=st.smax * 2 * D, ldc2=2 * D, dyn_ooff2_mul=1)
-        ops.attn_decode(st.q, kv, kv, st.att, nbatch=B, nheads=H, max_keys=st.smax, q_bs=D, kv_bs=st.smax * 2 * D,
-                        kv_ts=2 * D, o_bs=D, v_off=D, dyn_len=st.pos_dev, dyn_add=1)
+                 dyn_pos=st.pos_dev, n_split=D, out2=kv, out2_bstride=st.smax * KVP, ldc2=KVP, dyn_ooff2_mul=1)
+        ops.attn_decode(st.q, kv, kv, st.att, nbatch=B, nheads=H, max_keys=st.smax, q_bs=D, kv_bs=st.smax * KVP,
+                        kv_ts=KVP, o_bs=D, v_off=D, dyn_len=st.pos_dev, dyn_add=1)
         ops.linear(st.att, L['wo'], L['bo'], st.t1, rows=B, k=D, n=D, resid=x)
         ops.layernorm(st.t1, *L['ln1'], st.x, B, D)
         ops.linear(st.x, L['cwq'], L['cbq'], st.q, rows=B, k=D, n=D)
         ck = st.cross[li]
-        ops.attn_decode(st.q, ck, ck, st.att, nbatch=B, nheads=H, max_keys=T, q_bs=D, kv_bs=T * 2 * D, kv_ts=2 * D,
+        ops.attn_decode(st.q, ck, ck, st.att, nbatch=B, nheads=H, max_keys=T, q_bs=D, kv_bs=T * KVP, kv_ts=KVP,
                         o_bs=D, v_off=D, key_len=st.enc_len)
         ops.linear(st.att, L['cwo'], L['cbo'], st.t1, rows=B, k=D, n=D, resid=st.x)
         ops.layernorm(st.t1, *L['ln2'], st.x, B, D)
@@ -280,6 +288,7 @@ def _decoder_step_folded(model: 'SpeechT5', st: TTSBatchState, s: int, threshold
     dev = model.device
     B, T = st.B, st.T
     masks, spec, stats = st.masks, st.spec[par], st.stats
+    DP, FP = st.DP, st.FP
     SO = st.stat_rows * 2                            # int64 elements per stats slot ([rows][2]); zero on entry: cleared by
                                                      # the last launch of the previous step (ifh_tts_stop_advance)
     ops.linear(spec, *model.p0, st.h1, rows=B, k=80, n=256, x_off=2 * s * 80, lda=33 * 80, act=ACT_RELU,
@@ -287,41 +296,42 @@ def _decoder_step_folded(model: 'SpeechT5', st: TTSBatchState, s: int, threshold
     ops.linear(st.h1, *model.p1, st.h2, rows=B, k=256, n=256, act=ACT_RELU, colmask=masks, colmask_off=(s * 2 + 1) * 256)
     ops.linear(st.h2, *model.pf, st.cat, rows=B, k=256, n=D, ldc=D + 512, resid=model.pe_dec, resid_ld=0, resid_bstride=0,
                dyn_pos=st.pos_dev, dyn_resid_mul=D)
-    ops.linear(st.cat, *model.ps, st.x0, rows=B, k=D + 512, n=D, act=ACT_RELU)
+    ops.linear(st.cat, *model.ps, st.x0, rows=B, k=D + 512, n=D, act=ACT_RELU, ldc=DP)
     nl = len(model.dec_layers)
+    ld = dict(lda=DP, ldc=DP, resid_ld=DP)
     for li, (L, F) in enumerate(zip(model.dec_layers, model.dec_fold)):
         kv = st.self_kv[li]
         s1, s2, s3, s3p = (3 * li) * SO, (3 * li + 1) * SO, (3 * li + 2) * SO, (3 * li - 1) * SO
-        kvargs = dict(nbatch=B, t_in=1, t_out=1, cin=D, n=3 * D, ldc=D, out_bstride=D, dyn_pos=st.pos_dev, n_split=D,
-                      out2=kv, out2_bstride=st.smax * 2 * D, ldc2=2 * D, dyn_ooff2_mul=1)
+        kvargs = dict(nbatch=B, t_in=1, t_out=1, cin=D, n=3 * D, lda=DP, ldc=DP, out_bstride=DP, dyn_pos=st.pos_dev, n_split=D,
+                      out2=kv, out2_bstride=st.smax * KVP, ldc2=KVP, dyn_ooff2_mul=1)
         if li == 0:
             ops.conv(st.x0, L['wqkv'], L['bqkv'], st.q, **kvargs)
         else:
             w, c2, c1 = F['qkv']
             ops.conv(st.t3, w, c2, st.q, aln=(stats, s3p, c1), ln_dim=D, **kvargs)
-        ops.attn_decode(st.q, kv, kv, st.att, nbatch=B, nheads=H, max_keys=st.smax, q_bs=D, kv_bs=st.smax * 2 * D,
-                        kv_ts=2 * D, o_bs=D, v_off=D, dyn_len=st.pos_dev, dyn_add=1)
+        ops.attn_decode(st.q, kv, kv, st.att, nbatch=B, nheads=H, max_keys=st.smax, q_bs=DP, kv_bs=st.smax * KVP,
+                        kv_ts=KVP, o_bs=DP, v_off=D, dyn_len=st.pos_dev, dyn_add=1)
         if li == 0:
-            ops.linear(st.att, L['wo'], L['bo'], st.t1, rows=B, k=D, n=D, resid=st.x0, stats_out=stats, stats_off=s1, ln_dim=D)
+            ops.linear(st.att, L['wo'], L['bo'], st.t1, rows=B, k=D, n=D, resid=st.x0, stats_out=stats, stats_off=s1, ln_dim=D, **ld)
         else:
             ops.linear(st.att, L['wo'], L['bo'], st.t1, rows=B, k=D, n=D, resid=st.t3, rln=(stats, s3p) + F['ln_prev'],
-                       stats_out=stats, stats_off=s1, ln_dim=D)
+                       stats_out=stats, stats_off=s1, ln_dim=D, **ld)
         w, c2, c1 = F['cq']
-        ops.linear(st.t1, w, c2, st.q, rows=B, k=D, n=D, aln=(stats, s1, c1), ln_dim=D)
+        ops.linear(st.t1, w, c2, st.q, rows=B, k=D, n=D, aln=(stats, s1, c1), ln_dim=D, lda=DP, ldc=DP)
         ck = st.cross[li]
-        ops.attn_decode(st.q, ck, ck, st.att, nbatch=B, nheads=H, max_keys=T, q_bs=D, kv_bs=T * 2 * D, kv_ts=2 * D,
-                        o_bs=D, v_off=D, key_len=st.enc_len)
+        ops.attn_decode(st.q, ck, ck, st.att, nbatch=B, nheads=H, max_keys=T, q_bs=DP, kv_bs=T * KVP, kv_ts=KVP,
+                        o_bs=DP, v_off=D, key_len=st.enc_len)
         ops.linear(st.att, L['cwo'], L['cbo'], st.t2, rows=B, k=D, n=D, resid=st.t1, rln=(stats, s1) + F['ln1'],
-                   stats_out=stats, stats_off=s2, ln_dim=D)
+                   stats_out=stats, stats_off=s2, ln_dim=D, **ld)
         w, c2, c1 = F['ff1']
-        ops.linear(st.t2, w, c2, st.ff, rows=B, k=D, n=FF, act=ACT_GELU, aln=(stats, s2, c1), ln_dim=D)
+        ops.linear(st.t2, w, c2, st.ff, rows=B, k=D, n=FF, act=ACT_GELU, aln=(stats, s2, c1), ln_dim=D, lda=DP, ldc=FP)
         ops.linear(st.ff, L['w2'], L['b2'], st.t3, rows=B, k=FF, n=D, resid=st.t2, rln=(stats, s2) + F['ln2'],
-                   stats_out=stats, stats_off=s3, ln_dim=D)
+                   stats_out=stats, stats_off=s3, ln_dim=D, lda=FP, ldc=DP, resid_ld=DP)
     sl = (3 * nl - 1) * SO
     w, c2, c1 = model.feat_fold
-    ops.linear(st.t3, w, c2, spec, rows=B, k=D, n=160, out_off=(2 * s + 1) * 80, ldc=33 * 80, aln=(stats, sl, c1), ln_dim=D)
+    ops.linear(st.t3, w, c2, spec, rows=B, k=D, n=160, out_off=(2 * s + 1) * 80, ldc=33 * 80, aln=(stats, sl, c1), ln_dim=D, lda=DP)
     w, c2, c1 = model.prob_fold
-    ops.linear(st.t3, w, c2, st.plog16, rows=B, k=D, n=16, aln=(stats, sl, c1), ln_dim=D)
+    ops.linear(st.t3, w, c2, st.plog16, rows=B, k=D, n=16, aln=(stats, sl, c1), ln_dim=D, lda=DP)
     _lib.check(_lib.lib().ifh_tts_stop_advance(ops._addr(st.plog16), ops._addr(st.ends_at), B, st.minlen, st.maxlen,
                                                threshold, 2, ops._addr(st.pos_dev), 16, ops._addr(st.stats),
                                                st.stats.numel() * 8, _lib.stream_ptr(dev)), 'ifh_tts_stop_advance')
