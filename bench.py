@@ -255,6 +255,11 @@ def main():
         if os.path.exists(pmc) and n_local == 64:       # PMC counters need their own rocprofv3 run: measured offline
             pj = json.load(open(pmc))
             traffic = pj['hbm_bytes_per_pass'] * nchunks / pj.get('chunks_per_pass', 256)
+        traffic_lm = None
+        pmc_lm = os.path.join(ROOT, 'profiles', 'r01_logmel_pmc.json')
+        if os.path.exists(pmc_lm):
+            pj = json.load(open(pmc_lm))
+            traffic_lm = pj['hbm_bytes_per_pass'] * n_local / pj.get('chunks_per_pass', 64)
         out = {
             'metric': 'real-time-factor x concurrent calls (STT+TTS on 20 ms G.711 frames)',
             'value': round(value, 2), 'unit': 'x real-time (call-seconds/s)', 'n_gpus': world, 'steps': args.steps,
@@ -278,7 +283,9 @@ def main():
                          'seconds_per_vocoder_pass': t_voc},
             'roofline_logmel': {'kernel': 'k_logmel_fft+k_logmel_finish (%d x 30 s windows)' % n_local, 'bound': 'hbm',
                                 'achieved': round(ach_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                'frac': round(ach_gbs / PEAK_HBM_GBS, 4), 'traffic': None, 'seconds': t_mel},
+                                'frac': round(ach_gbs / PEAK_HBM_GBS, 4), 'traffic': traffic_lm,
+                                'traffic_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r01_logmel_pmc.json',
+                                'seconds': t_mel},
         }
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

@@ -27,11 +27,13 @@ def main():
     if sys.argv[1] == 'pmc':
         dF, dW, passes, out = sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
         chunks = int(sys.argv[6]) if len(sys.argv) > 6 else 768
+        what = sys.argv[7] if len(sys.argv) > 7 else 'vocoder'
         nF, sF, bF = pmc_sum(dF, 'FETCH_SIZE', passes)
         nW, sW, bW = pmc_sum(dW, 'WRITE_SIZE', passes)
         res = {
-            'command': 'rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 tools/probe_vocoder.py %d  (tools/pmc_vocoder.sh; last of %d passes)' % (passes, passes),
-            'workload': 'one HiFi-GAN vocoder pass, %d chunks x 12 frames (bench.py roofline leg)' % chunks,
+            'command': 'rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 tools/probe_%s.py %d  (tools/pmc_%s.sh; last of %d passes)' % (what, passes, 'vocoder' if what == 'vocoder' else 'logmel_hbm', passes),
+            'workload': ('one HiFi-GAN vocoder pass, %d chunks x 12 frames (bench.py roofline leg)' % chunks) if what == 'vocoder'
+                        else ('one log-mel launch, %d windows of 30 s -> [80,3000] f32 (bench.py roofline_logmel leg)' % chunks),
             'chunks_per_pass': chunks,
             'correction': 'gfx950: FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; both in KB',
             'fetch_bytes_corrected': sF * 1024 * 2, 'write_bytes': sW * 1024,
