@@ -163,3 +163,56 @@ def test_compat_names(R):
     from RTP.InfernRTPIngest import InfernRTPIngest, RTPInStream          # noqa: F401
     from RTP.AudioInput import AudioInput                                 # noqa: F401
     assert RtpJBuf is R.RtpJBuf and RTPInStream.jb_size == 8
+
+
+def test_rtp_in_stream_feeds_vad_channel_in_order(R):
+    """RTPInStream._proc_in_tread (InfernRTPIngest.py:63-100): shuffled / lossy datagrams reach VADChannel.ingest as the
+    in-order payload bytes with codec.silence(ts_diff) where a gap was given up; WIStreamUpdate starts a new buffer;
+    a malformed datagram is ignored."""
+    class Codec:
+        def to(self, dev): return self
+        def decode(self, *a, **k): raise AssertionError('not reached: the fake channel swallows the bytes')
+        def silence(self, n): return b'\xff' * n
+
+    class Params:
+        codec = Codec
+
+    class Ring:
+        device, debug = 'cpu', False
+        def __init__(self):
+            from queue import Queue
+            self.pkt_queue = Queue()
+        def dprint(self, *a): pass
+
+    ring = Ring()
+    st = R.RTPInStream(ring, Params(), get_direct_soundout=lambda u: None)
+    st.jbuf = R.RtpJBuf(2)                        # small buffer so that a loss is given up on quickly
+    fed = []
+
+    class Chan:
+        def ingest(self, svad, data, codec):
+            fed.append(bytes(data))
+    st.vchan = Chan()
+    pk = lambda s: O.build_packet(1000 + s, 160 * s, bytes([s]) * 160)
+    for s in (0, 2, 1, 3, 5, 6, 7, 8):            # 4 is lost
+        st.rtp_received(pk(s), ('10.0.0.1', 5004), 0.0)
+    st.rtp_received(b'\x80\x00', ('10.0.0.1', 5004), 0.0)
+    while not ring.pkt_queue.empty():
+        wi = ring.pkt_queue.get()
+        wi.stream._proc_in_tread(wi, svad=None)
+    assert b''.join(fed) == b''.join(bytes([s]) * 160 for s in (0, 1, 2, 3)) + b'\xff' * 160 + \
+        b''.join(bytes([s]) * 160 for s in (5, 6, 7, 8))
+    assert st.last_output_lseq == 1008 and st.npkts == 8
+    st.stream_update()
+    wi = ring.pkt_queue.get()
+    st._proc_in_tread(wi, None)
+    assert st.last_output_lseq is None
+    st._proc_in_tread(R.WIPkt(st, O.build_packet(7, 0, b'\x11' * 160), None, 0.0), None)
+    assert fed[-1] == b'\x11' * 160 and st.last_output_lseq == 7
+    ain = R.AudioInput(audio_in=lambda chunk: fed.append(('audio', chunk)))
+    st.stream_connect(ain)
+    st._proc_in_tread(ring.pkt_queue.get(), None)
+    class C: pass
+    c = C()
+    st.audio_chunk_out(c, True)
+    assert fed[-1] == ('audio', c) and c.active is True
