@@ -18,16 +18,19 @@ namespace ifh {
 // its 16-byte weight/activation fragments in flight at once (one memory round trip), straight
 // from global/L2 (each weight byte is used once per block: no LDS staging); the NW partial
 // tiles are summed through LDS.  Grid (N/16, M/16): 192..768 blocks for the decoder shapes.
-template <int NW, int U, int MT>
+// NT = 2: two column tiles per block (32 x 32 outputs): each activation fragment meets two weight fragments and vice
+// versa, a third fewer L2 -> CU bytes per output than the 32 x 16 block.
+template <int NW, int U, int MT, int NT = 1>
 __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
 {
     static_assert(MT == 1 || MT == 2, "row tiles per block");
-    static_assert(MT <= NW, "wave t stores row tile t");
-    __shared__ __attribute__((aligned(16))) float red[NW][MT][64][4];
+    static_assert(NT == 1 || (NT == 2 && MT == 2), "column tiles per block");
+    static_assert(MT * NT <= NW, "wave t stores output tile t (row tile t % MT, column tile t / MT)");
+    __shared__ __attribute__((aligned(16))) float red[NW][MT * NT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     // (an XCD-contiguous remap of the column tiles -- 1/8 of W per L2 -- was measured: no change at 64 or 256 rows)
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16 * MT;
+    const int n0 = blockIdx.x * 16 * NT, m0 = blockIdx.y * 16 * MT;
     const int M = p.nbatch * p.T_out;
     const int nk = (p.K + 31) / 32;
     const int per = (nk + NW - 1) / NW;
@@ -35,6 +38,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
     const int nrow = n0 + fr;
     const bool wok = nrow < p.N;
     const uint16_t *wrow = p.w + (int64_t)(wok ? nrow : 0) * p.K + fg * 8;
+    const bool wok1 = NT > 1 && nrow + 16 < p.N;
+    const uint16_t *wrow1 = p.w + (int64_t)(wok1 ? nrow + 16 : 0) * p.K + fg * 8;
     // row tile 0 (and 1 when MT == 2: the weight fragment is fetched once for both); named variables, not arrays
     const bool xok0 = m0 + fr < M, xok1 = MT > 1 && m0 + 16 + fr < M;
     const uint16_t *xrow, *xrow1;
@@ -46,9 +51,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
         const int bb1 = mm1 / p.T_out, tt1 = mm1 - bb1 * p.T_out;
         xrow1 = p.x + (int64_t)bb1 * p.x_bstride + (int64_t)tt1 * p.lda + fg * 8;
     }
-    // the epilogue of row tile t belongs to wave t
-    const int m = m0 + 16 * (wid < MT ? wid : 0) + fr;
-    const bool xok = wid < MT && m < M;
+    // the epilogue of output tile t (row tile t % MT, column tile t / MT) belongs to wave t
+    const bool owner = wid < MT * NT;
+    const int m = m0 + 16 * (owner ? wid % MT : 0) + fr;
+    const int nb = n0 + 16 * (owner ? wid / MT : 0);          // first column of this wave's tile
+    const bool xok = owner && m < M;
     // LayerNorm folding (ifh_conv_desc.aln_* / rln_*): row statistics are two 64-bit fixed-point sums per row
     // ([rows][2] int64, scale 2^16) that producers build with integer atomics -- integer addition commutes,
     // so unlike float atomics the result is bit-reproducible.  One 16-byte load per lane, issued before the
@@ -65,8 +72,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
     float4 pc1 = make_float4(0.f, 0.f, 0.f, 0.f), pbias = pc1, pgam = pc1, pbeta = pc1;
     uint2 presid = make_uint2(0, 0);
     const int dynv0 = p.dyn ? p.dyn[0] : 0;
-    if (ln_mode && xok && n0 + 4 * fg < p.N) {
-        const int n = n0 + 4 * fg;
+    if (ln_mode && xok && nb + 4 * fg < p.N) {
+        const int n = nb + 4 * fg;
         if (p.aln_stats) pc1 = *reinterpret_cast<const float4 *>(p.aln_c1 + n);
         if (p.bias) pbias = *reinterpret_cast<const float4 *>(p.bias + n);
         if (p.resid) {
@@ -77,9 +84,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
             }
         }
     }
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc, acc2 = acc, acc3 = acc;
     for (int kt = kt0; kt < kt1; kt += U) {
-        uint4 wv[U], xv[U], xw[MT > 1 ? U : 1];
+        uint4 wv[U], xv[U], xw[MT > 1 ? U : 1], wv1[NT > 1 ? U : 1];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int kk = kt + u;
@@ -92,26 +99,39 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
                 xw[u] = make_uint4(0, 0, 0, 0);
                 if (xok1 && kok) xw[u] = *reinterpret_cast<const uint4 *>(xrow1 + kk * 32);
             }
+            if (NT > 1) {
+                wv1[u] = make_uint4(0, 0, 0, 0);
+                if (wok1 && kok) wv1[u] = *reinterpret_cast<const uint4 *>(wrow1 + kk * 32);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wv[u]);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, xv[u]), acc, 0, 0, 0);
             if (MT > 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, xw[u]), acc1, 0, 0, 0);
+            if (NT > 1) {
+                const bf16x8_t wf1 = __builtin_bit_cast(bf16x8_t, wv1[u]);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, __builtin_bit_cast(bf16x8_t, xv[u]), acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf1, __builtin_bit_cast(bf16x8_t, xw[u]), acc3, 0, 0, 0);
+            }
         }
     }
     *reinterpret_cast<f32x4 *>(&red[wid][0][lane][0]) = acc;
     if (MT > 1) *reinterpret_cast<f32x4 *>(&red[wid][MT - 1][lane][0]) = acc1;
+    if (NT > 1) {
+        *reinterpret_cast<f32x4 *>(&red[wid][MT * (NT - 1)][lane][0]) = acc2;
+        *reinterpret_cast<f32x4 *>(&red[wid][MT * NT - 1][lane][0]) = acc3;
+    }
     const float fx = (1.0f / 65536.0f) / (float)p.ln_dim;
     const float a_mean = (float)st_a.x * fx, r_mean = (float)st_r.x * fx;
     const float a_rstd = rsqrtf(fmaxf((float)st_a.y * fx - a_mean * a_mean, 0.0f) + p.ln_eps);
     const float r_rstd = rsqrtf(fmaxf((float)st_r.y * fx - r_mean * r_mean, 0.0f) + p.ln_eps);
     __syncthreads();
-    if (wid < MT) {
+    if (owner) {
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w][wid][lane][0]);
-        const int n = n0 + 4 * fg;
+        const int n = nb + 4 * fg;
         if (ln_mode) {
             // LayerNorm folded around the GEMM (host guarantees the vector epilogue conditions, N % 16 == 0)
             float v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
@@ -532,9 +552,15 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
             // ff1 20.2 -> 15.4 us, qkv 14.6 -> 13.1 us at 256 rows, same bits (the k order of a wave is unchanged).
             // Measured without effect on the deep-K GEMM (ff2, 19 us at 256 rows): 8 waves, one row tile, shallower batches.
             static const bool u6 = getenv("IFH_SKINNY_U6") ? atoi(getenv("IFH_SKINNY_U6")) != 0 : true;      // tuning switch
-            if (p.K >= 2048)
-                hipLaunchKernelGGL((k_gemm_skinny<4, 12, 2>), grid2, dim3(256), 0, st, p);
-            else if (u6 && (int64_t)grid2.x * grid2.y > 1024)
+            static const int nt2 = getenv("IFH_SKINNY_NT2") ? atoi(getenv("IFH_SKINNY_NT2")) : 3;            // tuning switch: bit 0 deep K, bit 1 big grids
+            const bool big = (int64_t)grid2.x * grid2.y > 1024;
+            const dim3 grid3((d->n + 31) / 32, (unsigned)((M + 31) / 32));
+            if (p.K >= 2048) {
+                if (nt2 & 1) hipLaunchKernelGGL((k_gemm_skinny<4, 6, 2, 2>), grid3, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((k_gemm_skinny<4, 12, 2>), grid2, dim3(256), 0, st, p);
+            } else if (big && (nt2 & 2))
+                hipLaunchKernelGGL((k_gemm_skinny<4, 6, 2, 2>), grid3, dim3(256), 0, st, p);
+            else if (u6 && big)
                 hipLaunchKernelGGL((k_gemm_skinny<2, 6, 2>), grid2, dim3(128), 0, st, p);
             else
                 hipLaunchKernelGGL((k_gemm_skinny<2, 12, 2>), grid2, dim3(128), 0, st, p);
