@@ -151,6 +151,24 @@ int ifh_rtpjb_push_batch(ifh_rtpjb_t h, const uint8_t *buf, const int32_t *off, 
 int ifh_rtpjb_pop_tick(ifh_rtpjb_t h, uint8_t *frames, int32_t *slots, int cap, int *n_out);
 int ifh_rtpjb_stats(ifh_rtpjb_t h, int stream, int64_t *stats /* [IFH_RTP_NSTATS] */);
 
+/* RTP egress: header synthesis for the [n][plen] payload matrix ifh_mux_encode_f32_u8 produces -- the reference's
+ * `rsynth = RtpSynth(codec.crate, out_ft)` / `rsynth.next_pkt(out_psize, out_pt, pload=packet)` / `rsynth.skip(1)`
+ * (RTP/RTPOutputWorker.py:88,104,136; third-party rtpsynth, PARITY UNPINNED: RFC 3550 header, sequence +1 and timestamp
+ * +ts_step per packet, timestamp +ts_step per skipped frame, marker bit on the first packet and on the first one after a skip).
+ * ifh_rtpsynth_create   ts_step = clock rate x ptime / 1000 (160); SSRC, first sequence number and timestamp of every call
+ *                       are derived from seed (ifh_rtpsynth_set overrides them).
+ * ifh_rtpsynth_next_batch  n calls (slots[i], or i when slots is NULL): has[i] == 0 -> the call sends nothing this tick and,
+ *                       once it has started, its clock skips one frame; otherwise out[i] = 12-byte header + payload[i]
+ *                       and out_len[i] = 12 + plen.  out is [n][12 + plen]. */
+typedef void *ifh_rtpsynth_t;
+int ifh_rtpsynth_create(int n_streams, int ts_step, uint64_t seed, ifh_rtpsynth_t *out);
+int ifh_rtpsynth_destroy(ifh_rtpsynth_t h);
+int ifh_rtpsynth_set(ifh_rtpsynth_t h, int stream, uint32_t ssrc, uint32_t seq, uint32_t ts, int marker);
+int ifh_rtpsynth_get(ifh_rtpsynth_t h, int stream, uint32_t *ssrc, uint32_t *seq, uint32_t *ts, int64_t *sent, int64_t *skipped);
+int ifh_rtpsynth_skip(ifh_rtpsynth_t h, int stream, int nframes);
+int ifh_rtpsynth_next_batch(ifh_rtpsynth_t h, const uint8_t *payload, const uint8_t *has, const int32_t *slots, int n,
+                            int plen, int pt, uint8_t *out, int32_t *out_len);
+
 /* ---------------------------------------------------------------------------------
  * Output mix + encode    replaces Core/OutputMuxer.py:75-85 (OutputMTMuxer.idle mix: zero-pad,
  *                        sum in track order, divide by the number of tracks) + G711Codec.encode, for n calls at once.

@@ -36,6 +36,12 @@ SIGNATURES = {
     'ifh_rtpjb_push_batch': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     'ifh_rtpjb_pop_tick': (_i, [_vp, _vp, _vp, _i, c_i32p]),
     'ifh_rtpjb_stats': (_i, [_vp, _i, _vp]),
+    'ifh_rtpsynth_create': (_i, [_i, _i, ctypes.c_uint64, ctypes.POINTER(_vp)]),
+    'ifh_rtpsynth_destroy': (_i, [_vp]),
+    'ifh_rtpsynth_set': (_i, [_vp, _i, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _i]),
+    'ifh_rtpsynth_get': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    'ifh_rtpsynth_skip': (_i, [_vp, _i, _i]),
+    'ifh_rtpsynth_next_batch': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'ifh_vad_energy_prob': (_i, [_vp, _vp, _i, _vp, _vp]),
     'ifh_vad_fsm_step': (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp]),
     'ifh_vad_step': (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -26,6 +26,7 @@ MAP = {
     'safetorch.InfernTorcher': ('infernos_amd.torcher', ['InfernTorcher', 'InfernTorcherDeadlock', 'rc_filter']),
     'config.InfernGlobals': ('infernos_amd.torcher', ['InfernGlobals']),
     'rtpsynth.RtpJBuf': ('infernos_amd.rtp', ['RtpJBuf', 'RTPFrameType', 'RTPParseError']),
+    'rtpsynth.RtpSynth': ('infernos_amd.rtp', ['RtpSynth']),
     'RTP.AudioInput': ('infernos_amd.rtp', ['AudioInput']),
     'RTP.InfernRTPIngest': ('infernos_amd.rtp', ['InfernRTPIngest', 'RTPInStream', 'WIPkt', 'WIStreamUpdate', 'WIStreamConnect']),
 }
