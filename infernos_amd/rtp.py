@@ -266,6 +266,18 @@ class AudioInput:
         self.audio_in = audio_in
 
 
+class RTPParams:
+    """RTP/RTPParams.py:5-13 (the codec class is G.711 here; G.722 is out of scope)."""
+    default_ptime: int = 20
+
+    def __init__(self, rtp_target, out_ptime=None, codec=None):
+        assert isinstance(rtp_target, tuple) and len(rtp_target) == 2
+        from .codecs import G711Codec
+        self.rtp_target = rtp_target
+        self.out_ptime = out_ptime if out_ptime is not None else self.default_ptime
+        self.codec = codec if codec is not None else G711Codec
+
+
 class WIPkt:
     def __init__(self, stream: 'RTPInStream', data, address, rtime):
         self.stream, self.data, self.address, self.rtime = stream, data, address, rtime

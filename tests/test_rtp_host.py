@@ -162,6 +162,10 @@ def test_compat_names(R):
     from rtpsynth.RtpJBuf import RtpJBuf, RTPFrameType, RTPParseError     # noqa: F401  (InfernRTPIngest.py:6)
     from RTP.InfernRTPIngest import InfernRTPIngest, RTPInStream          # noqa: F401
     from RTP.AudioInput import AudioInput                                 # noqa: F401
+    from RTP.RTPParams import RTPParams
+    from rtpsynth.RtpSynth import RtpSynth                                # noqa: F401  (RTPOutputWorker.py:7)
+    prm = RTPParams(('127.0.0.1', 5004), None)
+    assert prm.out_ptime == 20 and prm.codec.ptype == 0 and prm.codec().rtpmap() == 'rtpmap:0 PCMU/8000'
     assert RtpJBuf is R.RtpJBuf and RTPInStream.jb_size == 8
 
 
