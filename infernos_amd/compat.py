@@ -27,9 +27,6 @@ MAP = {
     'config.InfernGlobals': ('infernos_amd.torcher', ['InfernGlobals']),
     'rtpsynth.RtpJBuf': ('infernos_amd.rtp', ['RtpJBuf', 'RTPFrameType', 'RTPParseError']),
     'rtpsynth.RtpSynth': ('infernos_amd.rtp', ['RtpSynth']),
-    'RTP.AudioInput': ('infernos_amd.rtp', ['AudioInput']),
-    'RTP.RTPParams': ('infernos_amd.rtp', ['RTPParams']),
-    'RTP.InfernRTPIngest': ('infernos_amd.rtp', ['InfernRTPIngest', 'RTPInStream', 'WIPkt', 'WIStreamUpdate', 'WIStreamConnect']),
 }
 
 

@@ -1,10 +1,11 @@
 """RTP ingress in front of the tick kernel.
 
-Host mirror of RTP/InfernRTPIngest.py:15-160 (`WIPkt`, `WIStreamUpdate`, `WIStreamConnect`, `RTPInStream`,
-`InfernRTPIngest`), RTP/AudioInput.py:3-8 and of the three names the reference imports from the third-party
-`rtpsynth.RtpJBuf` module (`RtpJBuf`, `RTPFrameType`, `RTPParseError`, InfernRTPIngest.py:6), all over the
-C-ABI entry points `ifh_rtp_parse` / `ifh_rtpjb_*` (csrc/rtp.hip).  rtpsynth is not in the reference tree nor in
-the image, so its behaviour is restated from the call site (PARITY UNPINNED).
+The three names the reference imports from the third-party `rtpsynth.RtpJBuf` module (`RtpJBuf`, `RTPFrameType`,
+`RTPParseError`, InfernRTPIngest.py:6) over the C-ABI entry points `ifh_rtp_parse` / `ifh_rtpjb_*` (csrc/rtp.hip).
+rtpsynth is not in the reference tree nor in the image, so its behaviour is restated from the call site (PARITY
+UNPINNED).  The reference's own RTP/InfernRTPIngest.py (per-packet thread, `RTPInStream`) is NOT
+mirrored here: it runs unchanged on top of these names once `compat.install()` has aliased `rtpsynth.RtpJBuf`,
+`Core.VAD.SileroVAD` and `Core.Codecs.G711`.
 
 `RtpSynth` / `RTPEgressTable` are the egress counterpart (`rtpsynth.RtpSynth`, RTP/RTPOutputWorker.py:88,104,136) over
 `ifh_rtpsynth_*`.  `RTPIngestTable` is the batched form the MI355X path uses: datagrams of all calls are pushed into one table and
@@ -12,15 +13,11 @@ the image, so its behaviour is restated from the call site (PARITY UNPINNED, DES
 that have a whole 20 ms frame, instead of one Python `VADChannel.ingest` call per packet per call.
 """
 import ctypes
-from queue import Queue
-from threading import Lock
-from typing import Optional, Union
-from uuid import UUID
+from typing import Optional
 
 import numpy as np
 
 from . import _lib
-from .workers import InfernWrkThread, RTPWrkTRun
 
 
 class RTPParseError(Exception):
@@ -251,162 +248,3 @@ class RTPEgressTable(_SynthTable):
         _lib.check(_lib.lib().ifh_rtpsynth_next_batch(self._h, vp(pl), vp(hs), vp(sl), n, plen, self.pt, vp(out), vp(ln)),
                    'ifh_rtpsynth_next_batch')
         return [out[i, :ln[i]].tobytes() for i in range(n)]
-
-
-# ------------------------------------------------------------------------------------------------
-# The reference's own per-call objects (drop-in for RTP/InfernRTPIngest.py), over RtpJBuf above
-# ------------------------------------------------------------------------------------------------
-class AudioInput:
-    """RTP/AudioInput.py:3-8"""
-    vad_chunk_in: Optional[callable]
-    audio_in: Optional[callable]
-
-    def __init__(self, audio_in: Optional[callable] = None, vad_chunk_in: Optional[callable] = None):
-        self.vad_chunk_in = vad_chunk_in
-        self.audio_in = audio_in
-
-
-class RTPParams:
-    """RTP/RTPParams.py:5-13 (the codec class is G.711 here; G.722 is out of scope)."""
-    default_ptime: int = 20
-
-    def __init__(self, rtp_target, out_ptime=None, codec=None):
-        assert isinstance(rtp_target, tuple) and len(rtp_target) == 2
-        from .codecs import G711Codec
-        self.rtp_target = rtp_target
-        self.out_ptime = out_ptime if out_ptime is not None else self.default_ptime
-        self.codec = codec if codec is not None else G711Codec
-
-
-class WIPkt:
-    def __init__(self, stream: 'RTPInStream', data, address, rtime):
-        self.stream, self.data, self.address, self.rtime = stream, data, address, rtime
-
-
-class WIStreamUpdate:
-    def __init__(self, stream: 'RTPInStream'):
-        self.stream = stream
-
-
-class WIStreamConnect:
-    def __init__(self, stream: 'RTPInStream', ain: AudioInput):
-        self.stream, self.ain = stream, ain
-
-
-class RTPInStream:
-    """InfernRTPIngest.py:31-110: one call's jitter buffer -> codec bytes -> VADChannel."""
-    jb_size: int = 8
-    input_sr: int = 8000
-    last_output_lseq: Optional[int] = None
-    output_sr: int = 16000
-    npkts: int = 0
-
-    def __init__(self, ring: 'InfernRTPIngest', rtp_params, get_direct_soundout: callable):
-        from .vad import VADChannel
-        self.jbuf = RtpJBuf(self.jb_size)
-        self.codec = rtp_params.codec().to(ring.device)
-        self.ring = ring
-        self.get_direct_soundout = get_direct_soundout
-        self.ain = AudioInput()
-        self.ain_lock = Lock()
-        self.vchan = VADChannel(self.audio_chunk_out, self.vad_chunk_out, self.codec.decode, ring.device)
-
-    def rtp_received(self, data, address, rtime):
-        self.ring.pkt_queue.put(WIPkt(self, data, address, rtime))
-
-    def stream_update(self):
-        self.ring.pkt_queue.put(WIStreamUpdate(self))
-
-    def stream_connect(self, ain: AudioInput):
-        if isinstance(ain.vad_chunk_in, UUID):
-            ain.vad_chunk_in = self.get_direct_soundout(ain.vad_chunk_in)
-        if isinstance(ain.audio_in, UUID):
-            ain.audio_in = self.get_direct_soundout(ain.audio_in)
-        self.ring.pkt_queue.put(WIStreamConnect(self, ain))
-
-    def _proc_in_tread(self, wi: Union[WIPkt, WIStreamUpdate, WIStreamConnect], svad):
-        if isinstance(wi, WIStreamUpdate):
-            self.jbuf = RtpJBuf(self.jb_size)
-            self.last_output_lseq = None
-            return
-        if isinstance(wi, WIStreamConnect):
-            with self.ain_lock:
-                self.ain = wi.ain
-            return
-        try:
-            res = self.jbuf.udp_in(wi.data)
-        except RTPParseError as e:
-            self.ring.dprint(f'InfernRTPIngest.run: RTPParseError: {e}')
-            return
-        self.npkts += 1
-        for pkt in res:
-            if pkt.content.type == RTPFrameType.ERS:
-                self.last_output_lseq = pkt.content.lseq_end
-                rtp_data = self.codec.silence(pkt.content.ts_diff)
-            else:
-                lseq = pkt.content.frame.rtp.lseq
-                assert self.last_output_lseq is None or lseq == self.last_output_lseq + 1
-                self.last_output_lseq = lseq
-                rtp_data = pkt.rtp_data
-            self.vchan.ingest(svad, rtp_data, self.codec)
-
-    def audio_chunk_out(self, chunk, active: bool):
-        chunk.active = active
-        with self.ain_lock:
-            if self.ain.audio_in is None:
-                return
-            self.ain.audio_in(chunk=chunk)
-
-    def vad_chunk_out(self, chunk):
-        with self.ain_lock:
-            if self.ain.vad_chunk_in is None:
-                return
-            self.ain.vad_chunk_in(chunk=chunk)
-
-
-class InfernRTPIngest(InfernWrkThread):
-    """InfernRTPIngest.py:112-160: the thread that owns the VAD worker and drains the packet queue."""
-    debug = False
-
-    def __init__(self, device: str, vad_factory=None):
-        super().__init__()
-        self.pkt_queue = Queue()
-        self.device = device
-        self._vad_factory = vad_factory
-
-    def start(self):
-        self._start_queue = Queue()
-        super().start()
-        r = self._start_queue.get()
-        if isinstance(r, Exception):
-            super().join()
-            raise r
-        del self._start_queue
-
-    def dprint(self, *args):
-        if self.debug:
-            print(*args)
-
-    def run(self):
-        super().thread_started()
-        try:
-            if self._vad_factory is not None:
-                svad = self._vad_factory(self.device)
-            else:
-                from .vad import SileroVADWorker
-                svad = SileroVADWorker(self.device)
-            svad.start()
-        except Exception as e:
-            self._start_queue.put(e)
-            return
-        self._start_queue.put(0)
-        while self.get_state() == RTPWrkTRun:
-            wi = self.pkt_queue.get()
-            if wi is None:
-                break
-            wi.stream._proc_in_tread(wi, svad)
-        svad.stop()
-
-    def stop(self):
-        self.pkt_queue.put(None)
-        super().stop()

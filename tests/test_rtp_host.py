@@ -1,6 +1,8 @@
 """CPU: the RTP ingress stage (ifh_rtp_parse / ifh_rtpjb_*, host-only C++ in the C-ABI library)
 against oracle/rtp.py on scripted and random arrival orders, and the call-site contract of
 RTP/InfernRTPIngest.py:76-96.  PARITY UNPINNED vs the third-party rtpsynth the reference uses (see oracle/rtp.py)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -160,66 +162,87 @@ def test_compat_names(R):
     import infernos_amd.compat as compat
     compat.install()
     from rtpsynth.RtpJBuf import RtpJBuf, RTPFrameType, RTPParseError     # noqa: F401  (InfernRTPIngest.py:6)
-    from RTP.InfernRTPIngest import InfernRTPIngest, RTPInStream          # noqa: F401
-    from RTP.AudioInput import AudioInput                                 # noqa: F401
-    from RTP.RTPParams import RTPParams
     from rtpsynth.RtpSynth import RtpSynth                                # noqa: F401  (RTPOutputWorker.py:7)
-    prm = RTPParams(('127.0.0.1', 5004), None)
-    assert prm.out_ptime == 20 and prm.codec.ptype == 0 and prm.codec().rtpmap() == 'rtpmap:0 PCMU/8000'
-    assert RtpJBuf is R.RtpJBuf and RTPInStream.jb_size == 8
+    assert RtpJBuf is R.RtpJBuf
+    # the per-packet thread of RTP/InfernRTPIngest.py is the reference's own file, not mirrored here
+    assert 'RTP.InfernRTPIngest' not in compat.MAP and not hasattr(R, 'RTPInStream')
 
 
-def test_rtp_in_stream_feeds_vad_channel_in_order(R):
-    """RTPInStream._proc_in_tread (InfernRTPIngest.py:63-100): shuffled / lossy datagrams reach VADChannel.ingest as the
-    in-order payload bytes with codec.silence(ts_diff) where a gap was given up; WIStreamUpdate starts a new buffer;
-    a malformed datagram is ignored."""
-    class Codec:
-        def to(self, dev): return self
-        def decode(self, *a, **k): raise AssertionError('not reached: the fake channel swallows the bytes')
-        def silence(self, n): return b'\xff' * n
+REF = '/root/reference'
 
-    class Params:
-        codec = Codec
 
-    class Ring:
-        device, debug = 'cpu', False
-        def __init__(self):
-            from queue import Queue
-            self.pkt_queue = Queue()
-        def dprint(self, *a): pass
+@pytest.mark.skipif(not os.path.isdir(REF), reason='needs the reference tree (build container only)')
+def test_reference_rtp_ingest_runs_unchanged_on_the_aliased_names(R):
+    """INTEGRATION.md's claim: the reference's own RTP/InfernRTPIngest.py (loaded from where it lies, nothing copied)
+    works once compat.install() has aliased rtpsynth.RtpJBuf / Core.VAD.SileroVAD / Core.Codecs.G711 / Core.AudioChunk /
+    Core.InfernWrkThread.  Shuffled / lossy datagrams reach VADChannel.ingest as the in-order payload bytes with
+    codec.silence(ts_diff) where a gap was given up (InfernRTPIngest.py:63-100)."""
+    import importlib.util
+    import sys
+    import types
+    import infernos_amd.compat as compat
+    compat.install()
+    saved = {k: sys.modules.get(k) for k in ('Core.Codecs.G722', 'RTP', 'RTP.AudioInput', 'RTP.RTPParams', 'RTP.InfernRTPIngest')}
+    try:
+        g722 = types.ModuleType('Core.Codecs.G722')          # third-party G722 is absent (DESIGN.md 7): name only
+        g722.G722Codec = type('G722Codec', (), {})
+        sys.modules['Core.Codecs.G722'] = g722
+        pkg = types.ModuleType('RTP')
+        pkg.__path__ = [os.path.join(REF, 'RTP')]
+        sys.modules['RTP'] = pkg
+        sys.dont_write_bytecode = True
 
-    ring = Ring()
-    st = R.RTPInStream(ring, Params(), get_direct_soundout=lambda u: None)
-    st.jbuf = R.RtpJBuf(2)                        # small buffer so that a loss is given up on quickly
-    fed = []
+        def load(name):
+            spec = importlib.util.spec_from_file_location('RTP.' + name, os.path.join(REF, 'RTP', name + '.py'))
+            m = importlib.util.module_from_spec(spec)
+            sys.modules['RTP.' + name] = m
+            spec.loader.exec_module(m)
+            return m
+        load('AudioInput')
+        load('RTPParams')
+        ing = load('InfernRTPIngest')
+        assert ing.RtpJBuf is R.RtpJBuf
 
-    class Chan:
-        def ingest(self, svad, data, codec):
-            fed.append(bytes(data))
-    st.vchan = Chan()
-    pk = lambda s: O.build_packet(1000 + s, 160 * s, bytes([s]) * 160)
-    for s in (0, 2, 1, 3, 5, 6, 7, 8):            # 4 is lost
-        st.rtp_received(pk(s), ('10.0.0.1', 5004), 0.0)
-    st.rtp_received(b'\x80\x00', ('10.0.0.1', 5004), 0.0)
-    while not ring.pkt_queue.empty():
-        wi = ring.pkt_queue.get()
-        wi.stream._proc_in_tread(wi, svad=None)
-    assert b''.join(fed) == b''.join(bytes([s]) * 160 for s in (0, 1, 2, 3)) + b'\xff' * 160 + \
-        b''.join(bytes([s]) * 160 for s in (5, 6, 7, 8))
-    assert st.last_output_lseq == 1008 and st.npkts == 8
-    st.stream_update()
-    wi = ring.pkt_queue.get()
-    st._proc_in_tread(wi, None)
-    assert st.last_output_lseq is None
-    st._proc_in_tread(R.WIPkt(st, O.build_packet(7, 0, b'\x11' * 160), None, 0.0), None)
-    assert fed[-1] == b'\x11' * 160 and st.last_output_lseq == 7
-    ain = R.AudioInput(audio_in=lambda chunk: fed.append(('audio', chunk)))
-    st.stream_connect(ain)
-    st._proc_in_tread(ring.pkt_queue.get(), None)
-    class C: pass
-    c = C()
-    st.audio_chunk_out(c, True)
-    assert fed[-1] == ('audio', c) and c.active is True
+        class Codec:
+            def to(self, dev): return self
+            def decode(self, *a, **k): raise AssertionError('not reached: the fake channel swallows the bytes')
+            def silence(self, n): return b'\xff' * n
+
+        class Params:
+            codec = Codec
+
+        class Ring:
+            device, debug = 'cpu', False
+            def __init__(self):
+                from queue import Queue
+                self.pkt_queue = Queue()
+            def dprint(self, *a): pass
+
+        ring = Ring()
+        st = ing.RTPInStream(ring, Params(), get_direct_soundout=lambda u: None)
+        st.jbuf = R.RtpJBuf(2)                        # small buffer so that a loss is given up on quickly
+        fed = []
+
+        class Chan:
+            def ingest(self, svad, data, codec):
+                fed.append(bytes(data))
+        st.vchan = Chan()
+        pk = lambda s: O.build_packet(1000 + s, 160 * s, bytes([s]) * 160)
+        for s in (0, 2, 1, 3, 5, 6, 7, 8):            # 4 is lost
+            st.rtp_received(pk(s), ('10.0.0.1', 5004), 0.0)
+        st.rtp_received(b'\x80\x00', ('10.0.0.1', 5004), 0.0)
+        while not ring.pkt_queue.empty():
+            wi = ring.pkt_queue.get()
+            wi.stream._proc_in_tread(wi, svad=None)
+        assert b''.join(fed) == b''.join(bytes([s]) * 160 for s in (0, 1, 2, 3)) + b'\xff' * 160 + \
+            b''.join(bytes([s]) * 160 for s in (5, 6, 7, 8))
+        assert st.last_output_lseq == 1008 and st.npkts == 8
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
 
 
 def test_rtp_synth_headers_and_round_trip(R):
