@@ -112,6 +112,8 @@ int ifh_ingest_tick(const uint8_t *frames /* [n][160] */, const int32_t *slot, i
  *                        call always satisfy lseq_start == previous lseq_end + 1 (the assert at :91).
  *                        payload (optional) receives the released RTP payloads back to back.
  * ifh_rtpjb_push_batch   n datagrams (buf + off[n+1], stream[n]); returns how many were refused, codes in status[n].
+ *                        Threading: a table has no lock -- push*, pop_tick, reset_stream and stats of ONE table must
+ *                        come from one thread (or be serialised by the caller); different tables are independent.
  * ifh_rtpjb_pop_tick     for every call holding >= frame_bytes: one frame into frames[k][frame_bytes] and its
  *                        index into slots[k] -- the host-side inputs of ifh_ingest_tick / ifh_ingest_block.
  * ifh_rtpjb_reset_stream a new jitter buffer for the call (WIStreamUpdate, :66-70); drop_fifo also empties
@@ -371,14 +373,17 @@ int ifh_argmax_pick_f32(const float *logits, int64_t ld, int vocab, int nrows, i
 int ifh_add_i32(int32_t *value, int delta, void *zero_buf, int64_t zero_bytes, ifh_stream_t stream);
 
 /* ---- TTS streaming glue, HelloSippyRTPipe.infer (HelloSippyRTPipe.py:191-240) ---- */
-/* stop rule (:227-228) on the 2 stop logits per utterance (row stride logits_ld floats); ends_at int64[n] */
+/* stop rule (:227-228) on the 2 stop logits per utterance (row stride logits_ld floats); ends_at int64[n].
+ * dyn_minmax (optional, device int32[2] = {minlen, maxlen}) overrides the by-value lengths: a launch captured in a
+ * hipGraph then follows the lengths of whichever batch currently occupies the state (HelloSippyRTPipe.py:117-118) */
 int ifh_tts_stop_update(const float *prob_logits, int64_t *ends_at, int n, int idx, int minlen, int maxlen,
                         float threshold, int ends_inc, const int32_t *dyn_idx /* overrides idx if set */,
-                        int logits_ld, ifh_stream_t stream);
+                        int logits_ld, const int32_t *dyn_minmax, ifh_stream_t stream);
 /* the same stop rule with idx = pos[0], followed by pos[0] += 1 (one launch; for graph-replayed decode loops); also
  * clears zero_bytes at zero_buf as ifh_add_i32 does */
 int ifh_tts_stop_advance(const float *prob_logits, int64_t *ends_at, int n, int minlen, int maxlen, float threshold,
-                         int ends_inc, int32_t *pos, int logits_ld, void *zero_buf, int64_t zero_bytes, ifh_stream_t stream);
+                         int ends_inc, int32_t *pos, int logits_ld, void *zero_buf, int64_t zero_bytes,
+                         const int32_t *dyn_minmax, ifh_stream_t stream);
 /* carry + 4 overlapped 12-frame chunks (:231-235): pre_frames bf16 [B][4][80] (updated), post bf16
  * [B][32][80] -> voc_in bf16 [4B][12][80] normalised by (x-mean)/scale, amd_mel bf16 [4B][12][80] =
  * channels-last form of the chunk re-viewed as [80][12] (HelloSippyRT.py:224) */

@@ -278,6 +278,13 @@ extern "C" int ifh_resample_create(int orig_sr, int new_sr, ifh_resampler_t *out
         delete r;
         return fail(IFH_EINVAL, "ifh_resample_create: unsupported ratio (reduced new must divide 2048, both <= 64)");
     }
+    {   // the tile of k_resample: ((2048 / new) * orig + ntaps) input samples + new * ntaps taps, f32, in LDS
+        const size_t lds = ((size_t)(kRsTile / r->nw) * r->orig + r->ntaps + (size_t)r->nw * r->ntaps) * sizeof(float);
+        if (lds > 64 * 1024) {
+            delete r;
+            return fail(IFH_EINVAL, "ifh_resample_create: ratio needs more than 64 KB of LDS per tile (orig/new too large, e.g. 8:1)");
+        }
+    }
     const size_t bytes = r->taps.size() * sizeof(float);
     hipError_t e = hipMalloc((void **)&r->d_taps, bytes);
     if (e != hipSuccess) {

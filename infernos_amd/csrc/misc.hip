@@ -121,11 +121,13 @@ __global__ __launch_bounds__(256) void k_argmax_pick(const float *__restrict__ l
 
 // HelloSippyRTPipe.py:227-228: ends_at = where(ends_at<0 & minlen<=idx & (any(sigmoid>=thr) | maxlen<=idx), idx+2, ends_at)
 __global__ void k_tts_stop(const float *__restrict__ logits /* [B][ld], 2 used */, int64_t *__restrict__ ends_at, int n,
-                           int idx, int minlen, int maxlen, float thr, int ends_inc, const int32_t *__restrict__ dyn, int ld)
+                           int idx, int minlen, int maxlen, float thr, int ends_inc, const int32_t *__restrict__ dyn, int ld,
+                           const int32_t *__restrict__ dyn_minmax)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n) return;
     if (dyn) idx = dyn[0];
+    if (dyn_minmax) { minlen = dyn_minmax[0]; maxlen = dyn_minmax[1]; }
     const float p0 = 1.0f / (1.0f + expf(-logits[ld * b])), p1 = 1.0f / (1.0f + expf(-logits[ld * b + 1]));
     const bool hit = (ends_at[b] < 0) && (minlen <= idx) && ((p0 >= thr) || (p1 >= thr) || (maxlen <= idx));
     if (hit) ends_at[b] = idx + ends_inc;
@@ -134,10 +136,12 @@ __global__ void k_tts_stop(const float *__restrict__ logits /* [B][ld], 2 used *
 // single-block form that also advances the device-held step counter afterwards (one launch fewer per step)
 __global__ __launch_bounds__(256) void k_tts_stop_advance(const float *__restrict__ logits, int64_t *__restrict__ ends_at,
                                                          int n, int minlen, int maxlen, float thr, int ends_inc,
-                                                         int32_t *__restrict__ pos, int ld, uint4 *__restrict__ zbuf, int nz16)
+                                                         int32_t *__restrict__ pos, int ld, uint4 *__restrict__ zbuf, int nz16,
+                                                         const int32_t *__restrict__ dyn_minmax)
 {
     for (int i = threadIdx.x; i < nz16; i += blockDim.x) zbuf[i] = make_uint4(0, 0, 0, 0);      // next step's LN statistics
     const int idx = pos[0];
+    if (dyn_minmax) { minlen = dyn_minmax[0]; maxlen = dyn_minmax[1]; }
     for (int b = threadIdx.x; b < n; b += blockDim.x) {
         const float p0 = 1.0f / (1.0f + expf(-logits[ld * b])), p1 = 1.0f / (1.0f + expf(-logits[ld * b + 1]));
         const bool hit = (ends_at[b] < 0) && (minlen <= idx) && ((p0 >= thr) || (p1 >= thr) || (maxlen <= idx));
@@ -291,26 +295,27 @@ extern "C" int ifh_argmax_pick_f32(const float *logits, int64_t ld, int vocab, i
 }
 
 extern "C" int ifh_tts_stop_update(const float *prob_logits, int64_t *ends_at, int n, int idx, int minlen, int maxlen,
-                                   float threshold, int ends_inc, const int32_t *dyn_idx, int logits_ld, ifh_stream_t stream)
+                                   float threshold, int ends_inc, const int32_t *dyn_idx, int logits_ld,
+                                   const int32_t *dyn_minmax, ifh_stream_t stream)
 {
     IFH_CHECK_ARG(n >= 0);
     if (n == 0) return IFH_OK;
     IFH_CHECK_ARG(prob_logits && ends_at && logits_ld >= 2);
     hipLaunchKernelGGL(k_tts_stop, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), prob_logits, ends_at, n, idx,
-                       minlen, maxlen, threshold, ends_inc, dyn_idx, logits_ld);
+                       minlen, maxlen, threshold, ends_inc, dyn_idx, logits_ld, dyn_minmax);
     IFH_LAUNCH_CHECK("tts_stop");
     return IFH_OK;
 }
 
 extern "C" int ifh_tts_stop_advance(const float *prob_logits, int64_t *ends_at, int n, int minlen, int maxlen,
                                     float threshold, int ends_inc, int32_t *pos, int logits_ld, void *zero_buf,
-                                    int64_t zero_bytes, ifh_stream_t stream)
+                                    int64_t zero_bytes, const int32_t *dyn_minmax, ifh_stream_t stream)
 {
     IFH_CHECK_ARG(n >= 0 && prob_logits && ends_at && pos && logits_ld >= 2);
     IFH_CHECK_ARG(zero_bytes >= 0 && zero_bytes % 16 == 0 && zero_bytes < (1ll << 30) && (zero_bytes == 0 || zero_buf));
     IFH_CHECK_ARG((((uintptr_t)zero_buf) & 15) == 0);
     hipLaunchKernelGGL(k_tts_stop_advance, dim3(1), dim3(256), 0, as_stream(stream), prob_logits, ends_at, n, minlen, maxlen,
-                       threshold, ends_inc, pos, logits_ld, (uint4 *)zero_buf, (int)(zero_bytes / 16));
+                       threshold, ends_inc, pos, logits_ld, (uint4 *)zero_buf, (int)(zero_bytes / 16), dyn_minmax);
     IFH_LAUNCH_CHECK("tts_stop_advance");
     return IFH_OK;
 }

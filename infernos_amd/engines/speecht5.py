@@ -185,6 +185,9 @@ class TTSBatchState:
         self.post = [e(B, 32, 80), e(B, 32, 80)]
         self.ncalls = 0
         self.pos_dev = torch.zeros(1, dtype=torch.int32, device=dev)       # decoder position, read by the kernels
+        # {minlen, maxlen} of the batch that currently occupies this state, read by the stop kernels: the captured
+        # step graphs are shared by every batch of the (B, bucketed T) slot, whose true lengths differ
+        self.lens_dev = torch.tensor([self.minlen, self.maxlen], dtype=torch.int32, device=dev)
         self.masks = torch.zeros((16, 2, 256), dtype=torch.uint8, device=dev)
         # Row stride of the step's activation buffers: D + 8 elements, i.e. 16 bytes past a multiple of 128.  The skinny
         # GEMM reads 16 rows x 64 bytes per wave-instruction; with rows a whole number of 128-byte lines apart those
@@ -217,8 +220,12 @@ class TTSBatchState:
                 model._states.pop(next(iter(model._states)))
         model._states[(B, T)] = st
         st.reset(input_ids, lens, speakers)
-        st.maxlen = int(T_true * 20.0 / 2)        # HelloSippyRTPipe.py:117 uses the batch's true padded length
+        st.set_lengths(0, int(T_true * 20.0 / 2))  # HelloSippyRTPipe.py:117-118 use the batch's true padded length
         return st
+
+    def set_lengths(self, minlen: int, maxlen: int):
+        self.minlen, self.maxlen = minlen, maxlen
+        self.lens_dev.copy_(torch.tensor([minlen, maxlen], dtype=torch.int32), non_blocking=False)
 
     def reset(self, input_ids, lens, speakers):
         model, dev, B, T = self.model, self.model.device, self.B, self.T
@@ -278,7 +285,8 @@ def _decoder_step(model: 'SpeechT5', st: TTSBatchState, s: int, threshold: float
     ops.linear(x, *model.feat, spec, rows=B, k=D, n=160, out_off=(2 * s + 1) * 80, ldc=33 * 80)
     ops.linear(x, *model.prob, st.plog, rows=B, k=D, n=2)
     _lib.check(_lib.lib().ifh_tts_stop_update(ops._addr(st.plog), ops._addr(st.ends_at), B, 0, st.minlen, st.maxlen,
-                                              threshold, 2, ops._addr(st.pos_dev), 2, _lib.stream_ptr(dev)), 'ifh_tts_stop_update')
+                                              threshold, 2, ops._addr(st.pos_dev), 2, ops._addr(st.lens_dev), _lib.stream_ptr(dev)),
+               'ifh_tts_stop_update')
     ops.add_i32(st.pos_dev, 1)
 
 
@@ -334,7 +342,7 @@ def _decoder_step_folded(model: 'SpeechT5', st: TTSBatchState, s: int, threshold
     ops.linear(st.t3, w, c2, st.plog16, rows=B, k=D, n=16, aln=(stats, sl, c1), ln_dim=D, lda=DP)
     _lib.check(_lib.lib().ifh_tts_stop_advance(ops._addr(st.plog16), ops._addr(st.ends_at), B, st.minlen, st.maxlen,
                                                threshold, 2, ops._addr(st.pos_dev), 16, ops._addr(st.stats),
-                                               st.stats.numel() * 8, _lib.stream_ptr(dev)), 'ifh_tts_stop_advance')
+                                               st.stats.numel() * 8, ops._addr(st.lens_dev), _lib.stream_ptr(dev)), 'ifh_tts_stop_advance')
 
 
 def decoder_steps(model: 'SpeechT5', st: TTSBatchState, masks: torch.Tensor, nsteps=16, threshold=0.5, use_graphs=None):

@@ -46,6 +46,10 @@ class BatchedVAD:
         self.emit = torch.empty((ncalls, EMIT_CAP), dtype=torch.float32, device=dev)
         self.ev = torch.empty((ncalls, 8), dtype=torch.int64, device=dev)
         self.prob = torch.empty(ncalls, dtype=torch.float32, device=dev)
+        # recurrent state of a stateful probability model (SileroVADUtils.py:11,99,131): every step covers all N
+        # calls in slot order, so the [2,N,64] tables are handed to the model as they are
+        self.mh = torch.zeros((2, ncalls, 64), dtype=torch.float32, device=dev)
+        self.mc = torch.zeros((2, ncalls, 64), dtype=torch.float32, device=dev)
         self.arena = None                      # ifh_ingest_block: emitted chunk audio of one block, device f32
         self.log = torch.zeros((LOG_CAP, 4), dtype=torch.int64)
 
@@ -57,7 +61,12 @@ class BatchedVAD:
                                              _lib.stream_ptr(dev)), 'ifh_vad_energy_prob')
             prob = self.prob
         else:
+            from .vad import _inject_state, _stateful
+            if _stateful(self.model):
+                _inject_state(self.model, self.mh, self.mc, self.input_sr, self.n)
             prob = self.model(win, self.input_sr).to(dev, torch.float32).contiguous()
+            if _stateful(self.model):
+                self.mh, self.mc = self.model._c._h, self.model._c._c
         _lib.check(L.ifh_vad_step(_lib.ptr(win), _lib.ptr(prob), _lib.ptr(self.slot), self.n, self.input_sr,
                                   float(self.threshold), _lib.ptr(self.st), _lib.ptr(self.blen), _lib.ptr(self.abuf),
                                   _lib.ptr(self.ev), _lib.ptr(self.emit), _lib.stream_ptr(dev)), 'ifh_vad_step')
@@ -248,6 +257,8 @@ class SpeechPipeline:
         fl.vad.st.zero_()
         fl.vad.st[:, 3] = -1
         fl.vad.blen.zero_()
+        fl.vad.mh = torch.zeros_like(fl.vad.mh)
+        fl.vad.mc = torch.zeros_like(fl.vad.mc)
 
     def front_group(self, frames_list, fl=None):
         """ingest of each cycle in turn, then ONE STT batch over all of them (rows g*N + call): the Whisper token loop is

@@ -139,12 +139,19 @@ class RtpJBuf:
 class RTPIngestTable(_Table):
     """All calls of one ingest thread: push datagrams as they arrive, pop one frame matrix per 20 ms tick."""
 
+    RING = 4
+
     def __init__(self, n_streams, depth=8, frame_bytes=160, fifo_cap=8192, pin=None):
         super().__init__(n_streams, depth, frame_bytes, 1, 0xff, fifo_cap)
         import torch
         pin = torch.cuda.is_available() if pin is None else pin
-        self.frames = torch.empty((n_streams, frame_bytes), dtype=torch.uint8, pin_memory=pin)
-        self.slots = torch.empty(n_streams, dtype=torch.int32, pin_memory=pin)
+        # a small ring of pinned (frames, slots) pairs: the views pop_tick() hands out stay untouched for RING - 1
+        # further ticks, so an asynchronous H2D copy of tick t is not overwritten while the host already pops t+1
+        # (catching up after a stall).  push_batch / pop_tick must be called from ONE thread (the table has no lock).
+        self._ring = [(torch.empty((n_streams, frame_bytes), dtype=torch.uint8, pin_memory=pin),
+                       torch.empty(n_streams, dtype=torch.int32, pin_memory=pin)) for _ in range(self.RING)]
+        self._tick = 0
+        self.frames, self.slots = self._ring[0]
         self._n = ctypes.c_int32()
 
     def push_batch(self, datagrams, streams):
@@ -164,7 +171,10 @@ class RTPIngestTable(_Table):
 
     def pop_tick(self):
         """-> (frames u8 [n,frame_bytes], slots int32 [n]) host views (pinned when a GPU is present) of the calls
-        that hold a whole frame; feed `.to(device, non_blocking=True)` of both to CallTable.tick."""
+        that hold a whole frame; feed `.to(device, non_blocking=True)` of both to CallTable.tick.  The views belong to
+        a ring of RING buffers: they are valid until RING - 1 further pop_tick() calls have been made."""
+        self.frames, self.slots = self._ring[self._tick % self.RING]
+        self._tick += 1
         _lib.check(_lib.lib().ifh_rtpjb_pop_tick(self._h, ctypes.c_void_p(self.frames.data_ptr()),
                                                  ctypes.c_void_p(self.slots.data_ptr()), self.n_streams,
                                                  ctypes.byref(self._n)), 'ifh_rtpjb_pop_tick')

@@ -5,6 +5,7 @@ Interface of safetorch/InfernTorcher.py:20-66 and the InfernGlobals singleton th
 the lock only serialises host-side state mutation of one engine between the worker thread
 (infer) and dispatch; it is kept because callers use `with InfernGlobals().torcher:`.
 """
+import math
 from threading import Lock
 from time import monotonic
 
@@ -14,50 +15,63 @@ class InfernTorcherDeadlock(Exception):
 
 
 class rc_filter:
-    def __init__(self, fcoef, initval=0.0):
-        self.fcoef, self.val = fcoef, initval
+    """First-order low-pass `y += alpha * (x - y)`, alpha = 1 / (1 + 2*pi*x0) (safetorch/InfernTorcher.py:8-18:
+    constructor `(x=10, init_y=0.0)`, applied by calling the object, state in `last_y`)."""
 
-    def apply(self, x):
-        self.val = self.fcoef * x + (1.0 - self.fcoef) * self.val
-        return self.val
+    def __init__(self, x=10, init_y=0.0):
+        self.alpha = 1.0 / (1.0 + 2.0 * math.pi * x)
+        self.last_y = init_y
+
+    def __call__(self, x):
+        self.last_y += self.alpha * (x - self.last_y)
+        return self.last_y
 
 
 class InfernTorcher:
-    timeout = 10.0
-    report_every = 100
+    """lock(timeout=10) / unlock(), acquire() / release(), context manager returning the torcher
+    (safetorch/InfernTorcher.py:34-66).  Every 100th unlock reports busy / (busy + free) like the reference does
+    (`quiet = True` silences it)."""
+    quiet = False
 
     def __init__(self):
-        self._lock = Lock()
-        self._last = monotonic()
-        self._busy = rc_filter(0.1)
-        self._idle = rc_filter(0.1)
-        self.nlocks = 0
-        self.verbose = False
+        self._torch_lock = Lock()
+        self._t_lock = self._t_unlock = monotonic()
+        self._free_time, self._busy_time = rc_filter(), rc_filter()
+        self._nlocks = 0
 
-    def acquire(self):
-        if not self._lock.acquire(timeout=self.timeout):
-            raise InfernTorcherDeadlock('device lock not released for %.0f s' % self.timeout)
-        now = monotonic()
-        self._idle.apply(now - self._last)
-        self._last = now
+    def lock(self, timeout: int = 10):
+        if not self._torch_lock.acquire(timeout=timeout):
+            raise InfernTorcherDeadlock(f'Could not acquire lock within {timeout} seconds')
+        self._t_lock = monotonic()
+        self._free_time(self._t_lock - self._t_unlock)
 
-    def release(self):
-        now = monotonic()
-        self._busy.apply(now - self._last)
-        self._last = now
-        self.nlocks += 1
-        if self.verbose and self.nlocks % self.report_every == 0:
-            print('Torch load: %.3f' % self.load())
-        self._lock.release()
+    def unlock(self):
+        self._t_unlock = monotonic()
+        self._busy_time(self._t_unlock - self._t_lock)
+        self._nlocks += 1
+        report = not self.quiet and self._nlocks % 100 == 0
+        load = self.load()
+        self._torch_lock.release()
+        if report:
+            print(f'Torch load: {load}')
 
     def load(self):
-        tot = self._busy.val + self._idle.val
-        return self._busy.val / tot if tot > 0 else 0.0
+        bt, ft = self._busy_time.last_y, self._free_time.last_y
+        return bt / (bt + ft) if bt + ft > 0 else 0.0
 
-    __enter__ = lambda self: self.acquire()
+    acquire = lock
+    release = unlock
 
-    def __exit__(self, *a):
-        self.release()
+    @property
+    def nlocks(self):
+        return self._nlocks
+
+    def __enter__(self):
+        self.lock()
+        return self
+
+    def __exit__(self, exc_type, exc_value, traceback):
+        self.unlock()
 
 
 class InfernGlobals:
@@ -76,6 +90,11 @@ class InfernGlobals:
     def get_resampler(from_sr: int, to_sr: int, device='cuda'):
         from .audio import get_resampler
         return get_resampler(from_sr, to_sr, str(device))
+
+    @staticmethod
+    def get_translator(from_lang: str, to_lang: str, **kwa):
+        """config/InfernGlobals.py:28-31.  The T2T translator (argostranslate) is outside the hot path."""
+        raise NotImplementedError('T2T translation is not part of the MI355X hot path; keep Core.T2T.Translator')
 
     @staticmethod
     def stdtss():

@@ -9,9 +9,13 @@ attributes the reference exposes.
 
 The speech-probability network of the reference (Silero v3.1 TorchScript from torch.hub)
 is third-party and not obtainable offline.  It is a plug-in here: `model(x[B,W], sr) ->
-prob[B]` (device tensors).  The default, EnergyVADModel, is a documented stand-in
-(ifh_vad_energy_prob), not a Silero equivalent.
+prob[B]` (device tensors).  A model that carries recurrent state the way the Silero TorchScript
+object does (`model._c._h`, `model._c._c`: [2,B,64] each) gets the per-channel state injected
+before and saved after every call, exactly as SileroVADUtils.py:21-26,99,131 do -- the state of
+all attached channels lives in one device table indexed by slot.  The default,
+EnergyVADModel, is a documented stateless stand-in (ifh_vad_energy_prob), not a Silero equivalent.
 """
+import weakref
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -54,6 +58,16 @@ class VADBatchFromList(VADBatchState):
     def __init__(self, states: List[VADChannelState]):
         self.batch_size = len(states)
         self.channels = states
+
+
+def _stateful(model) -> bool:
+    """True when `model` exposes the Silero JIT object's recurrent-state attributes (SileroVADUtils.py:99,131)."""
+    return hasattr(model, '_c')
+
+
+def _inject_state(model, h: torch.Tensor, c: torch.Tensor, sr: int, n: int):
+    mc = model._c
+    mc._h, mc._c, mc._last_sr, mc._last_batch_size = h, c, sr, n
 
 
 class EnergyVADModel:
@@ -106,8 +120,13 @@ class VADIteratorB:
             self.model.reset_states()
         else:
             assert bstate.batch_size == n, f'Batch size should be {n}, but got {bstate.batch_size}'
+            if _stateful(self.model):           # SileroVADUtils.py:99
+                h, c = bstate.get_model_state()
+                _inject_state(self.model, h.to(dev), c.to(dev), self.sampling_rate, n)
         window = x.size(1)
         probs = self.model(x.to(dev), self.sampling_rate).to(dev, torch.float32).contiguous()
+        if _stateful(self.model):               # SileroVADUtils.py:131
+            bstate.save_model_state([self.model._c._h, self.model._c._c])
         st = torch.tensor([[int(c.triggered), int(c.temp_end), int(c.current_sample), -1] for c in bstate.channels],
                           dtype=torch.int64, device=dev)
         slot = torch.arange(n, dtype=torch.int32, device=dev)
@@ -143,6 +162,14 @@ class VADChannel:
         self.buf_len = 0          # len(active_buffer) in the reference
         self._slot = None         # row in the owning worker's device tables
         self._owner = None
+        self._fin = None
+
+    def detach(self):
+        """Give the channel's row of the worker's device tables back (call teardown).  Also happens when the
+        channel object is garbage-collected: table size follows the CONCURRENT number of calls."""
+        if self._fin is not None:
+            self._fin()                       # runs SileroVADWorker._release once
+        self._owner = self._slot = self._fin = None
 
     @property
     def active_buffer(self) -> torch.Tensor:
@@ -177,7 +204,8 @@ class SileroVADWorker(InfernBatchedWorker):
         self.input_sr = input_sr
         self.max_vad_frames = input_sr * 30
         self._cap = 0
-        self._nslots = 0
+        self._nslots = 0          # high-water mark of rows ever handed out
+        self._free = []           # released rows, reused before the tables grow
         self._grow(max_channels)
 
     # -- device tables -------------------------------------------------------------------
@@ -187,24 +215,49 @@ class SileroVADWorker(InfernBatchedWorker):
                    st=torch.zeros((cap, 4), dtype=torch.int64, device=dev),
                    blen=torch.zeros(cap, dtype=torch.int32, device=dev),
                    abuf=torch.zeros((cap, ABUF_CAP), dtype=torch.float32, device=dev),
-                   emit=torch.empty((cap, EMIT_CAP), dtype=torch.float32, device=dev))
+                   emit=torch.empty((cap, EMIT_CAP), dtype=torch.float32, device=dev),
+                   # recurrent state of a stateful model, [h|c][2, cap, 64] (SileroVADUtils.py:11: two [2,64] per channel)
+                   mh=torch.zeros((2, cap, 64), dtype=torch.float32, device=dev),
+                   mc=torch.zeros((2, cap, 64), dtype=torch.float32, device=dev))
         new['st'][:, 3] = -1
         if self._cap:
             n = self._cap
-            new['win'][:n] = self._win
-            new['st'][:n] = self._st
-            new['blen'][:n] = self._blen
+            for k, old in (('win', self._win), ('st', self._st), ('blen', self._blen)):
+                new[k][:n] = old
+            new['mh'][:, :n], new['mc'][:, :n] = self._mh, self._mc
             new['abuf'][:n] = self._abuf
-        self._win, self._st, self._blen, self._abuf, self._emit = (new[k] for k in ('win', 'st', 'blen', 'abuf', 'emit'))
+            self._abuf = None                 # (the old rows are released as soon as the copy has been enqueued)
+        self._win, self._st, self._blen, self._abuf, self._emit, self._mh, self._mc = (
+            new[k] for k in ('win', 'st', 'blen', 'abuf', 'emit', 'mh', 'mc'))
         self._cap = cap
 
     def _attach(self, ch: VADChannel):
         if ch._owner is self:
             return
-        if self._nslots == self._cap:
-            self._grow(self._cap * 2)
-        ch._owner, ch._slot = self, self._nslots
-        self._nslots += 1
+        if self._free:
+            slot = self._free.pop()
+            self._st[slot] = torch.tensor([0, 0, 0, -1], dtype=torch.int64, device=self.device)
+            self._blen[slot] = 0
+        else:
+            if self._nslots == self._cap:
+                self._grow(self._cap * 2)
+            slot = self._nslots
+            self._nslots += 1
+        ch._owner, ch._slot = self, slot
+        # the channel's own state object is the authority until now (zeros for a new call)
+        self._mh[:, slot] = ch.state.model_state[0].to(self.device)
+        self._mc[:, slot] = ch.state.model_state[1].to(self.device)
+        ch._fin = weakref.finalize(ch, SileroVADWorker._release, weakref.ref(self), slot)
+
+    @staticmethod
+    def _release(wref, slot):
+        w = wref()
+        if w is not None:
+            w._free.append(slot)
+
+    @property
+    def channels_attached(self) -> int:
+        return self._nslots - len(self._free)
 
     # -- batch processing ------------------------------------------------------------------
     @torch.no_grad()
@@ -226,8 +279,17 @@ class SileroVADWorker(InfernBatchedWorker):
             n = len(chans)
             slot = torch.tensor([ch._slot for ch in chans], dtype=torch.int32, device=dev)
             x = torch.stack([p.audio.to(dev, torch.float32) for p in chunks], dim=0)
-            self._win.index_copy_(0, slot.long(), x)
+            sl = slot.long()
+            self._win.index_copy_(0, sl, x)
+            stateful = _stateful(self.model)
+            if stateful:                      # gather [2,B,64] x 2 by slot (VADBatchFromList.get_model_state, :21-22,99)
+                _inject_state(self.model, self._mh.index_select(1, sl), self._mc.index_select(1, sl), self.input_sr, n)
             probs = self.model(x, self.input_sr).to(dev, torch.float32).contiguous()
+            if stateful:                      # scatter back (save_model_state, :24-26,131)
+                self._mh.index_copy_(1, sl, self.model._c._h.to(dev, torch.float32))
+                self._mc.index_copy_(1, sl, self.model._c._c.to(dev, torch.float32))
+                for ch in chans:              # the reference's per-channel attribute: views of the table rows
+                    ch.state.model_state = [self._mh[:, ch._slot], self._mc[:, ch._slot]]
             ev = torch.empty((n, 8), dtype=torch.int64, device=dev)
             with torch.cuda.device(dev):
                 _lib.check(_lib.lib().ifh_vad_step(
@@ -235,8 +297,8 @@ class SileroVADWorker(InfernBatchedWorker):
                     float(self.vad_iterator.threshold), _lib.ptr(self._st), _lib.ptr(self._blen), _lib.ptr(self._abuf),
                     _lib.ptr(ev), _lib.ptr(self._emit), _lib.stream_ptr(dev)), 'ifh_vad_step')
             ev_h = ev.cpu().tolist()                       # the one host sync per sub-batch
-            st_h = self._st.index_select(0, slot.long()).cpu().tolist()
-            bl_h = self._blen.index_select(0, slot.long()).cpu().tolist()
+            st_h = self._st.index_select(0, sl).cpu().tolist()
+            bl_h = self._blen.index_select(0, sl).cpu().tolist()
             for vc, p, e, s, bl in zip(chans, chunks, ev_h, st_h, bl_h):
                 sd = vc.state
                 sd.triggered, sd.temp_end, sd.current_sample = bool(s[0]), s[1], s[2]

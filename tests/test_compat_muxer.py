@@ -31,15 +31,21 @@ def test_compat_install_aliases():
 def test_torcher_lock_and_timeout():
     import pytest
     from infernos_amd.torcher import InfernTorcher, InfernTorcherDeadlock
+    from infernos_amd.torcher import InfernGlobals, rc_filter
     t = InfernTorcher()
-    with t:
-        pass
+    with t as got:                      # the reference's `with torcher as t` form (InfernTorcher.py:62-64)
+        assert got is t
     assert t.nlocks == 1 and 0.0 <= t.load() <= 1.0
-    t.timeout = 0.05
-    t.acquire()
+    t.lock()
     with pytest.raises(InfernTorcherDeadlock):
-        t.acquire()
-    t.release()
+        t.lock(timeout=0.05)
+    t.unlock()
+    t.acquire(); t.release()
+    f = rc_filter(10, 1.0)              # (x, init_y), applied by calling it (InfernTorcher.py:8-18)
+    a = 1 / (1 + 2 * np.pi * 10)
+    assert abs(f(0.0) - (1 - a)) < 1e-12 and f.last_y == f(f.last_y)
+    with pytest.raises(NotImplementedError):
+        InfernGlobals.get_translator('en', 'pt')
 
 
 def test_output_muxer_trace(golden_dir):

@@ -252,6 +252,102 @@ def test_vad_worker_replays_reference_traces(dev, golden_dir):
                 assert (a['triggered'], a['current_sample']) == (b['triggered'], b['current_sample'])
 
 
+class StatefulFakeModel:
+    """tools/gen_golden.py:_StatefulFakeSilero on device tensors: h += [first sample > 0], c += 1, p from (h + c) mod 5."""
+
+    def __init__(self, dev):
+        import types
+        self.dev = dev
+        self._c = types.SimpleNamespace(_h=None, _c=None, _last_sr=0, _last_batch_size=0)
+
+    def reset_states(self):
+        pass
+
+    def __call__(self, x, sr):
+        mc = self._c
+        assert mc._last_batch_size == x.size(0) and mc._last_sr == sr and tuple(mc._h.shape) == (2, x.size(0), 64)
+        assert mc._h.is_cuda and mc._c.is_cuda
+        e = (x[:, 0] > 0).to(torch.float32)
+        mc._h = mc._h + e[None, :, None]
+        mc._c = mc._c + 1.0
+        k = torch.remainder(mc._h[0, :, 0] + mc._c[1, :, 63], 5.0)
+        return torch.where(k >= 3.0, 0.9, 0.1).to(torch.float32)
+
+
+def test_vad_worker_stateful_model_replays_reference_trace(dev, golden_dir):
+    """Per-channel recurrent model state is injected before and saved after every model call by slot
+    (SileroVADUtils.py:21-26,99,131), with sub-batch membership, order and duplicates changing from batch to batch:
+    events, final FSM state and final model state equal the reference run with the same fake stateful model."""
+    from infernos_amd.codecs import G711Codec
+    from infernos_amd.vad import SileroVADWorker, VADChannel
+    g = json.load(open(os.path.join(golden_dir, 'vad_stateful_trace.json')))
+    w = SileroVADWorker(dev, 8000, model=StatefulFakeModel(dev), max_channels=2)     # forces two table growths
+    codec = G711Codec().to(dev)
+    rng = np.random.default_rng(g['seed'])
+    nch, npkts = g['nch'], g['npkts']
+    events, chans = [], []
+    for ci in range(nch):
+        def a_in(chunk, active, ci=ci):
+            events.append(['raw', ci, bool(active), int(chunk.audio.size(0)), sha16(chunk.audio.cpu().numpy())])
+
+        def v_in(chunk, ci=ci):
+            events.append(['vad', ci, int(chunk.ipos), int(chunk.audio.size(0)), int(chunk.samplerate),
+                           sha16(chunk.audio.cpu().numpy())])
+        chans.append(VADChannel(a_in, v_in, None, dev))
+    pkts = rng.integers(0, 256, (nch, npkts, 160), dtype=np.uint8)
+    orders = list(g['orders'])
+    keep = lambda ci, pi: (pi * 7 + ci * 3) % (ci + 3) != 0
+    for pi in range(npkts):
+        for ci in (range(nch) if pi % 2 == 0 else reversed(range(nch))):
+            if keep(ci, pi):
+                chans[ci].ingest(w, pkts[ci, pi].tobytes(), codec)
+        if pi % 13 not in (2, 5, 12):
+            continue
+        wis = []
+        while not w.inf_queue.empty():
+            wis.append(w.inf_queue.get_nowait())
+        if wis:
+            assert [chans.index(wi[0]) for wi in wis] == orders.pop(0)
+            w.process_batch(wis)
+    assert events == g['events']
+    final = [{'triggered': bool(c.state.triggered), 'temp_end': int(c.state.temp_end),
+              'current_sample': int(c.state.current_sample),
+              'active_start': None if c.active_start is None else int(c.active_start),
+              'buf_len': int(c.buf_len), 'fifo_len': len(c.vad_buffer),
+              'h': float(c.state.model_state[0][0, 0]), 'c': float(c.state.model_state[1][1, 63])} for c in chans]
+    assert final == g['final']
+
+
+def test_vad_worker_slots_follow_concurrent_calls(dev):
+    """Rows of the device tables are released with the channel (detach or garbage collection) and reused with a clean
+    state: table size follows the concurrent, not the cumulative, number of calls."""
+    import gc
+    from infernos_amd.codecs import G711Codec
+    from infernos_amd.vad import SileroVADWorker, VADChannel
+    w = SileroVADWorker(dev, 8000, model=StatefulFakeModel(dev), max_channels=4)
+    codec = G711Codec().to(dev)
+    rng = np.random.default_rng(3)
+    seen = []
+
+    def one_call(n_windows):
+        ch = VADChannel(lambda chunk, active: None, lambda chunk: None, None, dev)
+        for _ in range(n_windows):
+            ch.ingest(w, rng.integers(0, 256, 768, dtype=np.uint8).tobytes(), codec)
+            w.process_batch([w.inf_queue.get_nowait()])
+        return ch
+    for k in range(40):                             # 40 calls one after another, at most 3 alive at a time
+        ch = one_call(2 + k % 3)
+        assert ch.state.current_sample == 768 * (2 + k % 3)              # a reused row starts from a clean FSM state
+        assert float(ch.state.model_state[1][0, 0]) == 2 + k % 3         # ... and a clean model state
+        seen.append(ch)
+        if len(seen) == 3:
+            seen.pop(0).detach()
+            del ch
+            seen.pop(0)                             # dropped without detach(): the finalizer releases the row
+            gc.collect()
+    assert w._cap == 4 and w.channels_attached <= 3
+
+
 def test_vad_iterator_fsm_matches_oracle(dev):
     import ctypes
     from infernos_amd.vad import VADBatchState, VADIteratorB

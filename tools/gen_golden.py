@@ -3,7 +3,7 @@
 
     PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [section ...]
 
-Sections: g711 vad stt batched muxer logmel tts whisper (default: all).
+Sections: g711 vad vad_stateful stt batched muxer logmel tts whisper (default: all).
 Only numbers (inputs/expected outputs) are written, to tests/golden/.  The reference
 cannot travel to the GPU box; these fixtures can.  Third-party arithmetic the reference
 calls (transformers) is exercised through the reference's own call sites wherever the
@@ -181,6 +181,82 @@ def gen_vad():
 
 
 # --------------------------------------------------------------------------------------
+
+class _StatefulFakeSilero:
+    """A fake *stateful* model with the attributes VADIteratorB injects and saves (SileroVADUtils.py:99,131):
+    h += [first sample of the window > 0], c += 1 (exact in f32), p = 0.9 where (h + c) mod 5 >= 3 else 0.1.  A wrong
+    gather/scatter of the per-channel state changes the probabilities and therefore the events.  The same class is
+    restated in tests/test_dsp_gpu.py (on device tensors)."""
+    def __init__(self):
+        import types
+        self._c = types.SimpleNamespace(_h=None, _c=None, _last_sr=0, _last_batch_size=0)
+
+    def reset_states(self):
+        pass
+
+    def __call__(self, x, sr):
+        mc = self._c
+        assert mc._last_batch_size == x.size(0) and mc._last_sr == sr and tuple(mc._h.shape) == (2, x.size(0), 64)
+        e = (x[:, 0] > 0).to(torch.float32)
+        mc._h = mc._h + e[None, :, None]
+        mc._c = mc._c + 1.0
+        k = torch.remainder(mc._h[0, :, 0] + mc._c[1, :, 63], 5.0)
+        return torch.where(k >= 3.0, torch.tensor(0.9), torch.tensor(0.1))
+
+
+def stateful_keep(ci, pi):
+    """which packets a channel receives: channel-dependent gaps, so sub-batch membership and order keep changing"""
+    return (pi * 7 + ci * 3) % (ci + 3) != 0
+
+
+def gen_vad_stateful():
+    from Core.VAD.SileroVAD import VADChannel
+    from Core.VAD.SileroVADUtils import VADIteratorB
+    from Core.Codecs.G711 import G711Codec
+    import contextlib, io
+    nch, npkts, seed = 6, 420, 11
+    w = _mk_vad_worker()
+    w.model = _StatefulFakeSilero()
+    w.vad_iterator = VADIteratorB(w.model, sampling_rate=8000)
+    codec = G711Codec()
+    rng = np.random.default_rng(seed)
+    events, chans, orders = [], [], []
+    for ci in range(nch):
+        def a_in(chunk, active, ci=ci):
+            events.append(['raw', ci, bool(active), int(chunk.audio.size(0)), sha(chunk.audio.numpy())[:16]])
+
+        def v_in(chunk, ci=ci):
+            events.append(['vad', ci, int(chunk.ipos), int(chunk.audio.size(0)), int(chunk.samplerate),
+                           sha(chunk.audio.numpy())[:16]])
+        chans.append(VADChannel(a_in, v_in, None, 'cpu'))
+    pkts = rng.integers(0, 256, (nch, npkts, 160), dtype=np.uint8)
+    for pi in range(npkts):
+        for ci in (range(nch) if pi % 2 == 0 else reversed(range(nch))):      # arrival order alternates too
+            if stateful_keep(ci, pi):
+                chans[ci].ingest(w, pkts[ci, pi].tobytes(), codec)
+        if pi % 13 not in (2, 5, 12):     # let windows pile up: a channel may then be queued twice -> two sub-batches
+            continue
+        wis = []
+        while not w.inf_queue.empty():
+            wis.append(w.inf_queue.get_nowait())
+        if wis:
+            orders.append([chans.index(wi[0]) for wi in wis])
+            with contextlib.redirect_stdout(io.StringIO()):
+                w.process_batch(wis)
+    final = [{'triggered': bool(c.state.triggered), 'temp_end': int(c.state.temp_end),
+              'current_sample': int(c.state.current_sample),
+              'active_start': None if c.active_start is None else int(c.active_start),
+              'buf_len': int(c.active_buffer.size(0)), 'fifo_len': len(c.vad_buffer),
+              'h': float(c.state.model_state[0][0, 0]), 'c': float(c.state.model_state[1][1, 63])} for c in chans]
+    assert any(len(set(o)) < len(o) for o in orders), 'scenario must queue a channel twice in one batch'
+    assert len({tuple(sorted(set(o))) for o in orders}) > 3, 'scenario must vary the sub-batch membership'
+    assert any(e[0] == 'vad' for e in events)
+    dump_json('vad_stateful_trace.json', {
+        'source': 'Core/VAD/SileroVAD.py:27-112 + SileroVADUtils.py:21-26,99,131 with a fake STATEFUL model object '
+                  '(tools/gen_golden.py:_StatefulFakeSilero)', 'nch': nch, 'npkts': npkts, 'seed': seed,
+        'orders': orders, 'events': events, 'final': final})
+
+
 def gen_stt():
     from Cluster.STTSession import STTSession, STTRequest, STTSentinel
     from Core.AudioChunk import VadAudioChunk, AudioChunk
@@ -353,7 +429,7 @@ def gen_logmel():
     dump_json('logmel_meta.json', meta)
 
 
-SECTIONS = {'g711': gen_g711, 'vad': gen_vad, 'stt': gen_stt, 'batched': gen_batched, 'muxer': gen_muxer,
+SECTIONS = {'g711': gen_g711, 'vad': gen_vad, 'vad_stateful': gen_vad_stateful, 'stt': gen_stt, 'batched': gen_batched, 'muxer': gen_muxer,
             'logmel': gen_logmel}
 
 if __name__ == '__main__':
