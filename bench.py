@@ -1,33 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- real-time-factor x concurrent calls of the Infernos speech hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): 64 concurrent synthetic calls per GPU, each a 10 s
-G.711 mu-law utterance in 20 ms / 160 B frames, carried through
-    ingest (decode + 8k->16k + VAD windows) -> Whisper-tiny STT (log-mel, encoder, 32 greedy
-    tokens) -> T2T stub -> SpeechT5 + HiFi-GAN + Amendment TTS (10 infer() calls = 5.12 s of
-    speech at T_text = 64) -> 16k->8k -> mu-law encode,
+Default workload = BASELINE.json configs[2] ("C3", the largest single-GPU configuration): 128 concurrent synthetic
+calls per GPU, each a 10 s G.711 mu-law utterance in 20 ms / 160 B frames, carried through
+    ingest (decode + 8k->16k + VAD windows) -> Whisper-BASE STT (log-mel, encoder, 32 greedy tokens) -> T2T stub
+    -> SpeechT5 + HiFi-GAN + Amendment TTS (10 infer() calls = 5.12 s of speech at T_text = 64) -> 16k->8k -> mu-law,
 bf16 models with seeded random weights (no checkpoints offline), synthetic audio.
+`--config C2` = 64 calls + Whisper-tiny (configs[1]); `--config C4` = the per-GPU share of configs[3]: 256 calls +
+Whisper-tiny.  At N = 1 the default run also measures C2 and the C4 share briefly and reports them as extra keys.
 
-One "step" = one such utterance cycle for every call of every rank.  value = call-seconds of
-inbound audio fully processed per wall second = (N calls x 10 s) / step time: the aggregate
-real-time factor (how many calls' worth of real time the node sustains).  Inputs are resident
-in HBM when the timed region starts.  With N>1 GPUs calls are sharded (64 per GPU, weak
-scaling); rank 0 scatters the frame matrix and gathers the encoded output over RCCL inside the
-timed region.
+One "step" = one such utterance cycle for every call of every rank.  value = call-seconds of inbound audio fully
+processed per wall second = (calls x 10 s) / step time: the aggregate real-time factor.  Inputs are resident in HBM
+when the timed region starts.  With N > 1 GPUs calls are sharded (weak scaling); rank 0 scatters the frame matrix and
+gathers the encoded output over RCCL inside the timed region.
 
-Consecutive cycles are pipelined as a serving loop would: --front-lanes ingest+STT lanes run ahead of
---tts-lanes synthesis lanes, each of which synthesises the utterances of --tts-group consecutive cycles
-as one batch (the path is bound by the dispatch rate of small dependent kernels, DESIGN.md 5, so fewer
-and fatter launches and several independent launch chains in flight are what fill the GPU).  Every
-cycle's whole work -- and the fill and drain of this pipeline -- is inside the timed K steps; outputs
-are byte-identical to the sequential schedule (tests/test_pipeline_gpu.py).
+Batches are formed ACROSS CALLS ONLY (one utterance per call per batch: --tts-group 1); consecutive cycles are
+stage-pipelined the way a serving loop is: --front-lanes ingest+STT lanes run ahead of --tts-lanes synthesis lanes, so
+up to that many utterance batches are in flight on independent launch chains (the path is bound by the dispatch rate of
+small dependent kernels).  Every cycle's whole work -- and the fill and drain of this pipeline -- is inside
+the timed K steps; outputs are byte-identical to the sequential schedule (tests/test_pipeline_gpu.py).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--calls-per-gpu 64] [--no-cpu-baseline]
+p50/p99 tick latency is measured INSIDE the timed region, under that load: a tick thread hands one [N,160] mu-law
+frame matrix (pinned host memory) to the boundary every 20 ms and waits for that tick's ingest outputs (H2D ->
+ifh_ingest_tick -> VAD window/decision when one completes -> ifh_mux_encode_f32_u8 of the next 20 ms of real TTS
+output rows -> D2H) to be back on the host.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C2|C4] [--no-cpu-baseline] [--no-extra-configs]
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -44,6 +48,15 @@ LOGMEL_BYTES_PER_WINDOW = 2.88e6         # 480000*4 read + 80*3000*4 written
 PEAK_BF16_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0                    # MI355X_MICROARCH.md: HBM3E spec
 
+CONFIGS = {   # name -> (calls per GPU, Whisper family, description)
+    'C3': (128, 'whisper_base', 'C3: %d concurrent synthetic 10 s G.711 calls per GPU through ingest+VAD -> Whisper-base STT '
+                                '(32 tokens) -> T2T stub -> SpeechT5+HiFi-GAN TTS (10 infer calls, T_text 64) -> mu-law'),
+    'C2': (64, 'whisper_tiny', 'C2: %d concurrent synthetic 10 s G.711 calls per GPU through ingest+VAD -> Whisper-tiny STT '
+                               '(32 tokens) -> T2T stub -> SpeechT5+HiFi-GAN TTS (10 infer calls, T_text 64) -> mu-law'),
+    'C4': (256, 'whisper_tiny', 'C4 per-GPU share: %d concurrent synthetic 10 s G.711 calls per GPU through ingest+VAD -> '
+                                'Whisper-tiny STT (32 tokens) -> SpeechT5+HiFi-GAN TTS (10 infer calls, T_text 64) -> mu-law'),
+}
+
 
 def make_frames(ncalls, first_call, codec_encode):
     """[TICKS, ncalls, 160] u8 of the SURVEY.md 8(d) synthetic utterances (seed 1000+call)."""
@@ -53,11 +66,12 @@ def make_frames(ncalls, first_call, codec_encode):
     return np.ascontiguousarray(ulaw.reshape(ncalls, TICKS, 160).transpose(1, 0, 2))
 
 
-def cpu_baseline(ncalls=16, threads=32):
-    """The oracle (CPU restatement, kind "port") timed on this host, bounded: one 10 s cycle for `ncalls`
-    calls batched (the reference's own TTS cap is 8): ingest + STT + all 10 TTS infer() calls measured, nothing
-    scaled (about 10 s of CPU work).  Threads capped (a 1-call fp32 graph on 128 threads
-    is slower than on 32)."""
+def cpu_baseline(family='whisper_base', ncalls=16, threads=32):
+    """The oracle (CPU restatement, kind "port") timed on this host, bounded: one 10 s cycle for `ncalls` calls batched
+    (the reference's own TTS cap is 8).  Two TTS legs: the reference's dtype (bf16, `maybe_half`,
+    HelloSippyRTPipe.py:57; 3 of the 10 infer() calls measured, the other 7 priced at their mean) and fp32 (all 10
+    measured); STT is fp32 in both (the reference's CTranslate2 int8 engine is absent).  `value` is the FASTER leg.
+    Threads capped (a small-batch graph on 128 threads is slower than on 32)."""
     from oracle import dsp as odsp, nn as onn
     from infernos_amd.synth import synth_utterance
     from infernos_amd.weights import synth_state_dict
@@ -65,9 +79,10 @@ def cpu_baseline(ncalls=16, threads=32):
     nthreads = max(1, min(threads, os.cpu_count() or 1))
     prev = torch.get_num_threads()
     torch.set_num_threads(nthreads)
+    nheads = 8 if family == 'whisper_base' else 6
     try:
         x = np.stack([synth_utterance(1000 + i, UTT_SECONDS) for i in range(ncalls)])
-        sd_w = synth_state_dict('whisper_tiny', 0)
+        sd_w = synth_state_dict(family, 0)
         sd_t = synth_state_dict('speecht5_tts', 0, stop_bias=-20.0)
         sd_v, sd_a = synth_state_dict('hifigan', 0), synth_state_dict('amendment', 0)
         t0 = time.perf_counter()
@@ -75,29 +90,122 @@ def cpu_baseline(ncalls=16, threads=32):
         x16 = odsp.resample(pcm[:, 8000:72000], 8000, 16000)          # ~8 s of speech per call, as the VAD emits
         mel = torch.from_numpy(odsp.logmel(x16))
         with torch.no_grad():
-            onn.whisper_greedy(sd_w, mel, torch.tensor([[50258, 50259, 50359, 50363]] * ncalls), 32, 6)
+            onn.whisper_greedy(sd_w, mel, torch.tensor([[50258, 50259, 50359, 50363]] * ncalls), 32, nheads)
         t_stt = time.perf_counter() - t0
         g = torch.Generator().manual_seed(2000)
         ids = torch.randint(4, 80, (ncalls, 64), generator=g)
         spk = torch.randn(ncalls, 512, generator=g)
-        t1 = time.perf_counter()
-        with torch.no_grad():
-            st = onn.TTSState(sd_t, ids, torch.ones_like(ids).int(), spk)
-            t_enc = time.perf_counter() - t1
-            masks = (torch.rand(16, 2, 256, generator=g) < 0.5).to(torch.uint8)
-            t2 = time.perf_counter()
-            nmeas = 10
-            for _ in range(nmeas):
-                a = onn.tts_infer(sd_t, sd_v, sd_a, st, masks)
-                odsp.g711_encode(odsp.resample(a.numpy(), 16000, 8000))
-            t_inf = (time.perf_counter() - t2) / nmeas
+        masks = (torch.rand(16, 2, 256, generator=g) < 0.5).to(torch.uint8)
+        legs = {}
+        for name, dtype, nmeas in (('bf16', torch.bfloat16, 3), ('fp32', torch.float32, 10)):
+            sdt = onn._cast(sd_t, dtype)
+            sdv, sda = onn._cast(sd_v, dtype), onn._cast(sd_a, dtype)
+            t1 = time.perf_counter()
+            with torch.no_grad():
+                st = onn.TTSState(sdt, ids, torch.ones_like(ids).int(), spk, dtype=dtype)
+                t_enc = time.perf_counter() - t1
+                t2 = time.perf_counter()
+                for _ in range(nmeas):
+                    a = onn.tts_infer(sdt, sdv, sda, st, masks, dtype=dtype)
+                    odsp.g711_encode(odsp.resample(a.float().numpy(), 16000, 8000))
+                t_inf = (time.perf_counter() - t2) / nmeas
+            legs[name] = dict(total=t_stt + t_enc + 10 * t_inf, t_enc=t_enc, t_inf=t_inf, measured_infer_calls=nmeas)
     finally:
         torch.set_num_threads(prev)
-    total = t_stt + t_enc + nmeas * t_inf
-    return {'value': ncalls * UTT_SECONDS / total, 'unit': 'x real-time (call-seconds/s)', 'cores': nthreads, 'kind': 'port',
-            'sample': '%d calls, one 10 s cycle on the fp32 oracle (oracle/): ingest + log-mel + Whisper-tiny 32 tokens '
-                      '(%.2f s), SpeechT5 encoder (%.2f s), 10 TTS infer() calls + resample + mu-law encode (%.2f s each), all '
-                      'measured; torch threads=%d of os.cpu_count()=%s' % (ncalls, t_stt, t_enc, t_inf, nthreads, os.cpu_count())}
+    best = min(legs, key=lambda k: legs[k]['total'])
+    return {'value': round(ncalls * UTT_SECONDS / legs[best]['total'], 3), 'unit': 'x real-time (call-seconds/s)', 'cores': nthreads,
+            'kind': 'port', 'tts_dtype_of_value': best,
+            'legs_x_realtime': {k: round(ncalls * UTT_SECONDS / v['total'], 3) for k, v in legs.items()},
+            'sample': '%d calls, one 10 s cycle on the oracle (oracle/): ingest + log-mel + %s 32 tokens fp32 (%.2f s); TTS leg bf16 '
+                      '(the reference\'s dtype): SpeechT5 encoder %.2f s + 10 x infer()+resample+mu-law at %.2f s (3 measured); TTS leg '
+                      'fp32: encoder %.2f s + 10 x %.2f s (all measured); value = the faster leg (%s); torch threads=%d of '
+                      'os.cpu_count()=%s' % (ncalls, family, t_stt, legs['bf16']['t_enc'], legs['bf16']['t_inf'], legs['fp32']['t_enc'],
+                                             legs['fp32']['t_inf'], best, nthreads, os.cpu_count())}
+
+
+class TickProbe(threading.Thread):
+    """The per-tick boundary under load (SURVEY.md 8d metric ii): every `period` seconds one [N,160] mu-law frame matrix goes
+    host -> device -> ifh_ingest_tick (+ VAD window step and decision whenever 768 samples complete) and the next 20 ms of
+    TTS output goes ifh_mux_encode_f32_u8 -> host; the latency of a tick is hand-over until both are back on the host."""
+
+    def __init__(self, dev, n, host_frames, tts_pcm, period=0.020):
+        super().__init__(daemon=True)
+        from infernos_amd.frontend import CallTable
+        from infernos_amd.pipeline import BatchedVAD
+        self.dev, self.n, self.period = dev, n, period
+        self.host_frames = host_frames                              # pinned u8 [TICKS, n, 160]
+        self.tts_pcm = tts_pcm                                      # device f32 [n, S]: real TTS output rows
+        with torch.cuda.device(dev):
+            self.calls, self.vad = CallTable(n, dev), BatchedVAD(n, dev)
+            self.stream = torch.cuda.Stream(device=dev)
+            self.slots = torch.arange(n, dtype=torch.int32, device=dev)
+            self.dfr = torch.empty((n, 160), dtype=torch.uint8, device=dev)
+            self.p8, self.p16 = torch.empty((n, 160), device=dev), torch.empty((n, 320), device=dev)
+            self.present = torch.ones((n, 1), dtype=torch.uint8, device=dev)
+            self.ndiv = torch.ones(n, dtype=torch.int32, device=dev)
+            self.enc = torch.empty((n, 160), dtype=torch.uint8, device=dev)
+            self.has = torch.empty(n, dtype=torch.uint8, device=dev)
+        self.host_out = torch.empty((n, 160), dtype=torch.uint8).pin_memory()
+        self.lat, self.windows, self._nb = [], 0, 0
+        self._halt = threading.Event()
+
+    def tick(self, t):
+        from infernos_amd import _lib
+        L, dev, n = _lib.lib(), self.dev, self.n
+        a = time.perf_counter()
+        with torch.cuda.stream(self.stream):
+            self.dfr.copy_(self.host_frames[t % TICKS], non_blocking=True)
+            self.calls.tick(self.dfr, self.slots, self.p8, self.p16, want_ready=False)
+            self._nb += 160
+            if self._nb >= 768:
+                self._nb -= 768
+                self.vad.step(self.calls.win)                       # includes its host sync: the VAD decision is on the host
+                self.windows += 1
+            S = self.tts_pcm.size(1)
+            off = (t * 160) % (S - 160)
+            trk = self.tts_pcm[:, off:off + 160].contiguous()
+            _lib.check(L.ifh_mux_encode_f32_u8(_lib.ptr(trk), _lib.ptr(self.present), _lib.ptr(self.ndiv), n, 1, 160,
+                                               _lib.ptr(self.enc), _lib.ptr(self.has), _lib.stream_ptr(dev)), 'ifh_mux_encode_f32_u8')
+            self.host_out.copy_(self.enc, non_blocking=True)
+            self.stream.synchronize()
+        return (time.perf_counter() - a) * 1e3
+
+    def run(self):
+        torch.cuda.set_device(self.dev)
+        t, t0 = self._t_next, time.perf_counter() - self._t_next * self.period
+        while not self._halt.is_set():
+            due = t0 + t * self.period
+            now = time.perf_counter()
+            if due > now:
+                time.sleep(due - now)
+            self.lat.append(self.tick(t))
+            t += 1
+
+    def stop(self):
+        self._halt.set()
+        self.join(10)
+
+
+def time_steps(pipe, frames_for, nsteps, warmup, world, pipelined, egress, dry, dev, probe=None):
+    if warmup:
+        pipe.run_steps(frames_for, warmup, pipelined=pipelined, on_cycle=egress)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if probe is not None:
+        probe.start()
+    t0 = time.perf_counter()
+    res = pipe.run_steps(frames_for, nsteps, pipelined=pipelined, on_cycle=egress)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if probe is not None:
+        probe.stop()
+    tmax = torch.tensor([dt], dtype=torch.float64, device='cpu' if dry else dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    return float(tmax.item()), res
 
 
 def main():
@@ -105,13 +213,16 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=24)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--calls-per-gpu', type=int, default=64)
+    ap.add_argument('--config', choices=sorted(CONFIGS), default='C3')
+    ap.add_argument('--calls-per-gpu', type=int, default=0, help='override the configuration\'s call count')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--latency-ticks', type=int, default=200)
+    ap.add_argument('--no-extra-configs', action='store_true', help='skip the short C2 / C4-share runs after the main one')
+    ap.add_argument('--no-tick-probe', action='store_true', help='do not run the per-tick latency thread inside the timed region')
     ap.add_argument('--breakdown', action='store_true', help='print per-stage wall times to stderr')
-    ap.add_argument('--tts-lanes', type=int, default=4, help='TTS engine instances whose utterance cycles may overlap')
+    ap.add_argument('--tts-lanes', type=int, default=4, help='TTS engine instances whose utterance batches may be in flight together')
     ap.add_argument('--front-lanes', type=int, default=2, help='ingest+STT lanes (cycles k, k+1 in flight together)')
-    ap.add_argument('--tts-group', type=int, default=4, help='utterance cycles synthesised as one TTS batch')
+    ap.add_argument('--tts-group', type=int, default=1, help='utterance cycles of the SAME calls synthesised as one TTS batch '
+                    '(> 1 is an offline-throughput mode: a live call cannot have utterance k+1 before k has been spoken)')
     ap.add_argument('--no-tts-overlap', action='store_true', help='render on the lane stream instead of a second stream per lane')
     ap.add_argument('--no-pipeline', action='store_true', help='run the stages of consecutive cycles strictly one after another')
     args = ap.parse_args()
@@ -133,6 +244,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    g_in = g_out = None
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         if dry:
@@ -144,52 +256,51 @@ def main():
         g_in, g_out = dist.new_group(), dist.new_group()
     from infernos_amd import _lib
     from infernos_amd.pipeline import SpeechPipeline
-    from infernos_amd.shard import gather_rows, scatter_frames, shard_bounds
+    from infernos_amd.shard import gather_rows, scatter_frames
     from infernos_amd.codecs import G711Codec
 
-    n_local = args.calls_per_gpu
-    n_total = n_local * world
-    pipe = SpeechPipeline(n_local, dev, tts_lanes=args.tts_lanes, tts_overlap=not args.no_tts_overlap, tts_group=args.tts_group, front_lanes=args.front_lanes)
     codec = G711Codec().to(dev)
 
     def enc(x):
         return np.frombuffer(codec.encode(torch.from_numpy(x)), dtype=np.uint8).reshape(x.shape)
-    # every rank builds its own rows for the N=1 path; with N>1 rank 0 holds all rows and scatters
-    if world == 1:
-        frames_all = torch.from_numpy(make_frames(n_local, 0, enc)).to(dev)
-    else:
-        frames_all = torch.from_numpy(make_frames(n_total, 0, enc)).to(dev) if rank == 0 else None
 
-    def reset_state():
-        pipe.reset_calls()
+    def build(cfg, n_local):
+        _, family, _ = CONFIGS[cfg]
+        pipe = SpeechPipeline(n_local, dev, whisper_family=family, tts_lanes=args.tts_lanes, tts_overlap=not args.no_tts_overlap,
+                              tts_group=args.tts_group, front_lanes=args.front_lanes)
+        n_total = n_local * world
+        # every rank builds its own rows for the N=1 path; with N>1 rank 0 holds all rows and scatters
+        if world == 1:
+            frames_all = torch.from_numpy(make_frames(n_local, 0, enc)).to(dev)
+        else:
+            frames_all = torch.from_numpy(make_frames(n_total, 0, enc)).to(dev) if rank == 0 else None
 
-    def frames_for(k):
-        # with N>1 the ingress rank scatters this cycle's frame block over RCCL (inside the timed region)
-        return scatter_frames(frames_all, n_total, TICKS, dev, group=g_in) if world > 1 else frames_all
-
-    def run(nsteps):
+        def frames_for(k):
+            # with N>1 the ingress rank scatters this cycle's frame block over RCCL (inside the timed region)
+            return scatter_frames(frames_all, n_total, TICKS, dev, group=g_in) if world > 1 else frames_all
         egress = (lambda r: gather_rows(r['ulaw'], n_total, group=g_out)) if world > 1 else None
-        return pipe.run_steps(frames_for, nsteps, pipelined=not args.no_pipeline, on_cycle=egress)
+        # priming (untimed, not part of the W warm-up steps): two sequential cycles load every kernel and
+        # capture the hipGraphs of the decode loops, so the timed steps replay them
+        last = pipe.run_steps(frames_for, 2, pipelined=False)
+        pipe.prime(frames_for(0))
+        return pipe, frames_all, frames_for, egress, last
 
-    # priming (untimed, not part of the W warm-up steps): two sequential cycles load every kernel and
-    # capture the hipGraphs of the decode loops, so the timed steps replay them
-    pipe.run_steps(frames_for, 2, pipelined=False)
-    pipe.prime(frames_for(0))
-    if args.warmup:
-        res = run(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    res = run(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device='cpu' if dry else dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    n_local = args.calls_per_gpu or CONFIGS[args.config][0]
+    n_total = n_local * world
+    pipe, frames_all, frames_for, egress, primed = build(args.config, n_local)
+    probe = None
+    if rank == 0 and not args.no_tick_probe:
+        host_frames = (frames_all[:, :n_local] if world > 1 else frames_all).cpu().pin_memory()
+        ul = primed['ulaw']                                         # u8 [n_local, 40960]: the real TTS rows of a primed cycle
+        tts_pcm = torch.empty(ul.shape, dtype=torch.float32, device=dev)
+        _lib.check(_lib.lib().ifh_g711_decode_u8_f32(_lib.ptr(ul.contiguous()), _lib.ptr(tts_pcm), ul.numel(), _lib.stream_ptr(dev)),
+                   'ifh_g711_decode_u8_f32')
+        probe = TickProbe(dev, n_local, host_frames, tts_pcm)
+        for t in range(8):                                          # load its kernels before the timed region
+            probe.tick(t)
+        probe._t_next = 8
+        probe.lat.clear()
+    dt, res = time_steps(pipe, frames_for, args.steps, args.warmup, world, not args.no_pipeline, egress, dry, dev, probe)
     ms_per_step = dt / args.steps * 1e3
     value = n_total * UTT_SECONDS / (dt / args.steps)
 
@@ -199,7 +310,7 @@ def main():
             1e3 * sum(sw['front']) / max(1, len(sw['front'])), len(sw['front']),
             1e3 * sum(sw['tts']) / max(1, len(sw['tts'])), len(sw['tts'])), file=sys.stderr)
     if args.breakdown and rank == 0 and world == 1:
-        reset_state()
+        pipe.reset_calls()
         fr = frames_for(0)
         torch.cuda.synchronize(); a = time.perf_counter()
         ch = pipe.ingest(fr); torch.cuda.synchronize(); b = time.perf_counter()
@@ -217,7 +328,7 @@ def main():
                 fn()
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / n * 1e-3
-        nchunks = 4 * n_local * max(1, args.tts_group)        # the vocoder launch group of the timed region: 4 chunks x (calls x grouped cycles)
+        nchunks = 4 * n_local * max(1, args.tts_group)        # the vocoder launch group of the timed region: 4 chunks per TTS row
         voc_in = torch.randn(nchunks, 12, 80, device=dev).to(torch.bfloat16)
         t_voc = ev_time(lambda: pipe.tts.vocoder(voc_in), n=5)
         ach_tf = nchunks * VOCODER_GFLOP_PER_CHUNK / t_voc / 1e3
@@ -226,69 +337,65 @@ def main():
         mel_out = torch.empty(n_local, 80, 3000, device=dev)
         t_mel = ev_time(lambda: pipe.logmel(x16, lens=lens, out=mel_out), n=5)
         ach_gbs = n_local * LOGMEL_BYTES_PER_WINDOW / t_mel / 1e9
-        # ---- per-tick latency: host frame matrix in, ingest + VAD + encode of one outgoing frame, host bytes out
-        reset_state()
-        host_frames = frames_all[:, :n_local].cpu().pin_memory() if world > 1 else frames_all.cpu().pin_memory()
-        dfr = torch.empty((n_local, 160), dtype=torch.uint8, device=dev)
-        outpcm = torch.zeros((n_local, 160), dtype=torch.float32, device=dev)
-        outenc = torch.empty((n_local, 160), dtype=torch.uint8, device=dev)
-        host_out = torch.empty((n_local, 160), dtype=torch.uint8).pin_memory()
-        lat = []
-        nb = 0
-        L = _lib.lib()
-        for t in range(min(args.latency_ticks, TICKS)):
-            torch.cuda.synchronize()
-            a = time.perf_counter()
-            dfr.copy_(host_frames[t], non_blocking=True)
-            pipe.calls.tick(dfr, pipe.slots, pipe.pcm8k, pipe.pcm16k)
-            nb += 160
-            if nb >= 768:
-                nb -= 768
-                pipe.vad.step(pipe.calls.win)
-            L.ifh_g711_encode_f32_u8(_lib.ptr(outpcm), _lib.ptr(outenc), outpcm.numel(), _lib.stream_ptr(dev))
-            host_out.copy_(outenc, non_blocking=True)
-            torch.cuda.synchronize()
-            lat.append((time.perf_counter() - a) * 1e3)
-        lat = np.array(lat)
-        traffic = None
-        pmc = os.path.join(ROOT, 'profiles', 'r01_vocoder_pmc.json')
-        if os.path.exists(pmc) and n_local == 64:       # PMC counters need their own rocprofv3 run: measured offline
-            pj = json.load(open(pmc))
-            traffic = pj['hbm_bytes_per_pass'] * nchunks / pj.get('chunks_per_pass', 256)
-        traffic_lm = None
-        pmc_lm = os.path.join(ROOT, 'profiles', 'r01_logmel_pmc.json')
-        if os.path.exists(pmc_lm):
-            pj = json.load(open(pmc_lm))
-            traffic_lm = pj['hbm_bytes_per_pass'] * n_local / pj.get('chunks_per_pass', 64)
+        del voc_in, x16, mel_out
+
+        def pmc(name, per):
+            """HBM bytes per launch from a separate rocprofv3 --pmc run (profiles/), scaled by units if the sizes differ"""
+            f = os.path.join(ROOT, 'profiles', name)
+            if not os.path.exists(f):
+                return None
+            pj = json.load(open(f))
+            return pj['hbm_bytes_per_pass'] * per / pj['chunks_per_pass']
+        lat = np.array(probe.lat) if probe is not None and probe.lat else None
         out = {
             'metric': 'real-time-factor x concurrent calls (STT+TTS on 20 ms G.711 frames)',
             'value': round(value, 2), 'unit': 'x real-time (call-seconds/s)', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': 'C2: %d concurrent synthetic 10 s G.711 calls per GPU through ingest+VAD -> Whisper-tiny '
-                                   'STT (32 tokens) -> T2T stub -> SpeechT5+HiFi-GAN TTS (10 infer calls, T_text 64) -> '
-                                   'mu-law' % n_local, 'calls_per_gpu': n_local, 'calls_total': n_total,
+            'config': {'workload': CONFIGS[args.config][2] % n_local, 'calls_per_gpu': n_local, 'calls_total': n_total,
                        'utterance_seconds': UTT_SECONDS, 'weights': 'seeded random (HF shapes)',
                        'parallelism': 'calls sharded %d/GPU, models replicated; RCCL scatter/gather of frames/output' % n_local,
+                       'batching': 'across calls only (one utterance per call per batch)' if args.tts_group == 1 else
+                                   'OFFLINE mode: %d consecutive utterances of the same calls per TTS batch' % args.tts_group,
                        'stage_pipelining': not args.no_pipeline, 'front_lanes': args.front_lanes, 'tts_lanes': args.tts_lanes,
-                       'tts_group_cycles': args.tts_group},
-            'p50_tick_latency_ms': round(float(np.percentile(lat, 50)), 4),
-            'p99_tick_latency_ms': round(float(np.percentile(lat, 99)), 4),
+                       'tts_rows_per_batch': n_local * args.tts_group},
             'stt_audio_seconds_per_call': round(float(res['stt_seconds'].mean()), 3),
             'tts_samples_per_call': int(res['tts_samples'].float().mean()),
-            'roofline': {'kernel': 'HiFi-GAN vocoder pass = k_resblock_pair<*> + k_igemm<*> (%d chunks x 12 frames per launch group)' % nchunks,
+            'roofline': {'kernel': 'HiFi-GAN vocoder pass (%d chunks x 12 frames per launch group)' % nchunks,
                          'bound': 'mfma', 'achieved': round(ach_tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': traffic,
-                         'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r01_vocoder_pmc.json (scaled by chunks if the pass sizes differ)',
+                         'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': pmc('r02_vocoder_pmc.json', nchunks),
+                         'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r02_vocoder_pmc.json (scaled by chunks if the pass sizes differ)',
                          'seconds_per_vocoder_pass': t_voc},
-            'roofline_logmel': {'kernel': 'k_logmel_fft+k_logmel_finish (%d x 30 s windows)' % n_local, 'bound': 'hbm',
+            'roofline_logmel': {'kernel': 'log-mel (%d x 30 s windows)' % n_local, 'bound': 'hbm',
                                 'achieved': round(ach_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                'frac': round(ach_gbs / PEAK_HBM_GBS, 4), 'traffic': traffic_lm,
-                                'traffic_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r01_logmel_pmc.json',
+                                'frac': round(ach_gbs / PEAK_HBM_GBS, 4), 'traffic': pmc('r02_logmel_pmc.json', n_local),
+                                'traffic_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r02_logmel_pmc.json',
                                 'seconds': t_mel},
         }
+        if lat is not None:
+            out.update({'p50_tick_latency_ms': round(float(np.percentile(lat, 50)), 4),
+                        'p99_tick_latency_ms': round(float(np.percentile(lat, 99)), 4),
+                        'tick_latency_note': '%d ticks of [%d,160] paced at 20 ms INSIDE the timed region (H2D -> ingest_tick -> VAD '
+                                             'window+decision on %d of them -> mux_encode of real TTS rows -> D2H, host to host), '
+                                             'while the TTS/STT lanes were running' % (len(lat), n_local, probe.windows)})
+    # ---- the other single-GPU configurations, briefly (N = 1 only: extra keys, not the headline)
+    if world == 1 and not args.no_extra_configs and not args.calls_per_gpu:
+        del pipe, frames_all, probe
+        torch.cuda.empty_cache()
+        extra = {}
+        for cfg in [c for c in ('C2', 'C4', 'C3') if c != args.config]:
+            n2 = CONFIGS[cfg][0]
+            p2, fa2, ff2, eg2, _ = build(cfg, n2)
+            k2 = max(4, min(args.steps, 12))
+            dt2, _ = time_steps(p2, ff2, k2, 2, 1, not args.no_pipeline, eg2, dry, dev)
+            extra[cfg] = {'workload': CONFIGS[cfg][2] % n2, 'value': round(n2 * UTT_SECONDS / (dt2 / k2), 2), 'steps': k2,
+                          'ms_per_step': round(dt2 / k2 * 1e3, 2), 'tts_rows_per_batch': n2 * args.tts_group}
+            del p2, fa2
+            torch.cuda.empty_cache()
+        out['other_configs'] = extra
+    if rank == 0:
         if not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline()
+            out['cpu_baseline'] = cpu_baseline(CONFIGS[args.config][1])
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

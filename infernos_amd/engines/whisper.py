@@ -247,6 +247,32 @@ class Whisper:
         g.replay()
         return bufs['logits']
 
+    def forced_logits(self, enc: torch.Tensor, tokens: torch.Tensor, rows=None, use_graphs=True) -> torch.Tensor:
+        """Teacher-forced decode: feed `tokens` int [B,L] position by position through the same per-token step
+        (and hipGraph) `generate` uses and return the f32 logits after every position for the batch rows `rows`
+        (default all): [len(rows), L, vocab].  What `self.model(**inputs, decoder_input_ids=tokens).logits`
+        (Cluster/InfernSTTWorker.py:83-88) returns, computed incrementally through the KV cache."""
+        dev, d = self.device, self.d
+        Bn, L = tokens.shape
+        assert L <= self.max_tokens
+        bufs = self._dec(Bn)
+        use_graphs = use_graphs and bufs['eager_runs'] >= 1
+        for li, Lr in enumerate(self.dec_layers):
+            C = Lr['cross']
+            ops.linear(enc, C['wkv'], C['bkv'], bufs['cross'][li], rows=Bn * N_CTX, k=d, n=2 * d)
+        toks = bufs['toks']
+        toks.zero_()
+        toks[:L] = tokens.to(dev, torch.int32).t()
+        bufs['pos'].zero_()
+        bufs['stats'].zero_()
+        sel = torch.arange(Bn, device=dev) if rows is None else torch.as_tensor(rows, device=dev)
+        out = torch.empty((sel.numel(), L, self.vocab), dtype=torch.float32, device=dev)
+        for pos in range(L):
+            logits = self._step(bufs, Bn, False, use_graphs and pos > 0)
+            out[:, pos] = logits.index_select(0, sel)
+        bufs['eager_runs'] += 1
+        return out
+
     def generate(self, enc: torch.Tensor, prompts: torch.Tensor, n_new: int, no_speech_id=None, keep_logits=False,
                  eos_id=None, check_every=16, early_exit_nsp=None, use_graphs=True):
         """Greedy decode up to n_new tokens after the prompt.

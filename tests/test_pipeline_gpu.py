@@ -201,3 +201,82 @@ def test_full_size_cycle_properties(built_lib):
     assert np.isfinite(audio).all() and 1e-4 < np.abs(audio).mean() < 0.5
     for a, b in zip(outs[0][:5], outs[1][:5]):
         assert torch.equal(a, b)
+
+
+class _RecMasks:
+    def __init__(self, dev, seed):
+        self.g, self.dev, self.log = torch.Generator().manual_seed(seed), dev, []
+
+    def __call__(self, nsteps):
+        m = torch.randint(0, 2, (nsteps, 2, 256), generator=self.g, dtype=torch.uint8)
+        self.log.append(m)
+        return m.to(self.dev)
+
+
+@pytest.mark.parametrize('name,N,family,nheads', [('C3', 128, 'whisper_base', 8), ('C4-share', 256, 'whisper_tiny', 6)])
+def test_baseline_config_full_cycle(built_lib, name, N, family, nheads):
+    """BASELINE config 3 (128 calls, Whisper-base STT -> T2T stub -> TTS) and the per-GPU share of config 4 (256 calls):
+    one full 10 s utterance cycle through SpeechPipeline at full size.  (i) size-independent properties: calls i and
+    i + N/2 carry the same audio, speaker and text and must give identical results wherever they sit in the batch; the
+    expected amount of speech reaches STT; TTS output length; a second cycle reproduces the first.  (ii) three calls
+    stage by stage against the oracle on the same intermediate data: VAD chunks are slices of the oracle's decode, the
+    first greedy token equals the fp32 oracle's where its top-2 margin exceeds the logit error, and the synthesised
+    audio of the first three infer() calls is within the bf16 bar of oracle.tts_infer + resample + mu-law."""
+    from infernos_amd import _lib
+    from infernos_amd.pipeline import SpeechPipeline
+    from infernos_amd.synth import synth_utterance
+    from infernos_amd.weights import synth_state_dict
+    dev = _lib.require_device('cuda:0')
+    H = N // 2
+    pipe = SpeechPipeline(N, dev, whisper_family=family, tts_lanes=1, n_new_tokens=8)
+    pipe.speakers[H:] = pipe.speakers[:H]
+    pipe.text_ids[H:] = pipe.text_ids[:H]
+    masks = _RecMasks(dev, 31)
+    pipe.tts.mask_source = masks
+    x = np.stack([synth_utterance(1000 + (i % H), 10.0) for i in range(N)])
+    ulaw = odsp.g711_encode(x)
+    frames = torch.from_numpy(np.ascontiguousarray(ulaw.reshape(N, 500, 160).transpose(1, 0, 2))).to(dev)
+    outs = []
+    for rep in range(2):
+        masks.g.manual_seed(31)
+        masks.log.clear()
+        r = pipe.run_steps(lambda k: frames, 1, pipelined=False)
+        outs.append((r['tokens'].cpu(), r['no_speech_prob'].cpu(), r['stt_seconds'].clone(), r['ulaw'].cpu(),
+                     r['tts_samples'].clone(), r['chunks']))
+    toks, nsp, secs, ul, valid, chunks = outs[0]
+    # (i) properties
+    assert torch.equal(toks[:H], toks[H:]) and torch.equal(nsp[:H], nsp[H:]) and chunks[:H] == chunks[H:]
+    assert torch.equal(ul[:H], ul[H:])
+    assert bool((secs > 6.5).all()) and bool((secs < 9.5).all())
+    assert ul.shape == (N, 10 * 4096) and valid.tolist() == [10 * 4096 - 256] * N
+    for a, b in zip(outs[0][:5], outs[1][:5]):
+        assert torch.equal(a, b)
+    # (ii) three calls against the oracle
+    rows = [0, H // 3, H - 1]
+    pcm = odsp.g711_decode(ulaw)
+    sd_w = synth_state_dict(family, 0)
+    for i in rows:
+        lo, hi = chunks[i][0][0], chunks[i][-1][0] + chunks[i][-1][1]
+        merged = np.zeros(hi - lo, np.float32)
+        for (p, n) in chunks[i]:
+            merged[p - lo + 240:p - lo + n] = pcm[i, p + 240:p + n]       # (the 240-sample start pad is stale audio, SileroVAD.py:90)
+        assert abs(float(secs[i]) - merged.size / 8000.0) < 1e-6
+        mel = torch.from_numpy(odsp.logmel(odsp.resample(merged, 8000, 16000)))[None]
+        with torch.no_grad():
+            o_toks, o_first, _, _ = onn.whisper_greedy(sd_w, mel, pipe.prompt[:1].long(), 2, nheads)
+        top2 = o_first.topk(2).values[0]
+        if float(top2[0] - top2[1]) > 0.3:                # the start pad differs by <= 240 stale samples: allow for it
+            assert int(toks[i, 0]) == int(o_toks[0, 0]), (name, i, toks[i].tolist(), o_toks.tolist())
+    W = {k: synth_state_dict(k, 0, **({'stop_bias': -20.0} if k == 'speecht5_tts' else {})) for k in ('speecht5_tts', 'hifigan', 'amendment')}
+    ost = onn.TTSState(W['speecht5_tts'], pipe.text_ids[rows].long(), torch.ones(len(rows), pipe.n_text, dtype=torch.int32),
+                       pipe.speakers[rows])
+    dev_pcm = odsp.g711_decode(ul[rows].numpy())
+    for c in range(3):
+        with torch.no_grad():
+            a = onn.tts_infer(W['speecht5_tts'], W['hifigan'], W['amendment'], ost, masks.log[c])
+        ref = odsp.g711_decode(odsp.g711_encode(odsp.resample(a.numpy(), 16000, 8000)))
+        got = dev_pcm[:, c * 4096:(c + 1) * 4096]
+        lo = 256 if c == 0 else 0                          # the first call's first 512 samples @16 k are never dispatched
+        e = float(np.linalg.norm(got[:, lo:] - ref[:, lo:]) / np.linalg.norm(ref[:, lo:]))
+        print('%s: TTS call %d decoded-mu-law rel_l2 vs oracle %.3e' % (name, c, e))
+        assert e < 6e-2, (name, c, e)          # bf16 model error (<= 1.5 x the reference's own 1.3e-2) + two mu-law quantisations

@@ -228,4 +228,62 @@ def gen_whisper():
     print('wrote whisper.npz')
 
 
-SECTIONS = {'tts': gen_tts, 'whisper': gen_whisper}
+def gen_whisper_tf():
+    """Teacher-forced decoder logits at every one of 36 positions (4 prompt + 32 forced tokens) from the engine the
+    reference's torch path drives (HF WhisperForConditionalGeneration, Cluster/InfernSTTWorker.py:83-88
+    `self.model(**inputs, decoder_input_ids=...)`), in fp32 and in bf16 -- the latter is the yardstick for the bf16
+    device path: the device is held to <= 1.5x the error the same engine makes when it merely runs in bf16.
+    tiny (BASELINE configs 1-2) keeps logit slices; base (config 3) keeps the per-position error norms."""
+    import json
+    from transformers import WhisperConfig, WhisperForConditionalGeneration, WhisperFeatureExtractor
+    from infernos_amd.weights import synth_state_dict
+    from oracle import nn as onn, dsp
+    sys.path.insert(0, HERE)
+    from gen_golden import synth_utterance
+    fe = WhisperFeatureExtractor()
+    PROMPT = [50258, 50259, 50359, 50363]
+    meta, arrays = {}, {}
+    base_cfg = dict(d_model=512, encoder_layers=6, decoder_layers=6, encoder_attention_heads=8, decoder_attention_heads=8,
+                    encoder_ffn_dim=2048, decoder_ffn_dim=2048)
+    for fam, seed, cfg, nh, aseeds in (('whisper_tiny', 0, WhisperConfig(), 6, [1000, 1001]),
+                                       ('whisper_base', 1, WhisperConfig(**base_cfg), 8, [1000, 1001])):
+        sd = synth_state_dict(fam, seed)
+        model = WhisperForConditionalGeneration(cfg)
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        vocab = sd['model.decoder.embed_tokens.weight'].shape[0]
+        g = torch.Generator().manual_seed(4242)
+        forced = torch.randint(0, 50257, (len(aseeds), 32), generator=g)
+        toks = torch.cat([torch.tensor([PROMPT] * len(aseeds)), forced], 1)               # [2, 36]
+        auds = [dsp.resample(synth_utterance(a, 10.0), 8000, 16000) for a in aseeds]
+        mel = torch.from_numpy(fe(auds, sampling_rate=16000, return_tensors='np').input_features)
+        with torch.no_grad():
+            l32 = model(input_features=mel, decoder_input_ids=toks).logits                # [2, 36, V]
+            mb = model.to(torch.bfloat16)
+            l16 = mb(input_features=mel.to(torch.bfloat16), decoder_input_ids=toks).logits.float()
+            model.to(torch.float32)
+            # the oracle (oracle/nn.py) on the same inputs: pins it for teacher-forced steps as well
+            enc = onn.whisper_encoder(sd, mel, nh)
+            nl = len([k for k in sd if k.startswith('model.decoder.layers.') and k.endswith('.fc1.weight')])
+            caches = [{'self': {}, 'cross': {}} for _ in range(nl)]
+            lo = onn.whisper_decoder(sd, toks, 0, enc, nh, caches)
+        rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+        e16 = [rel(l16[:, t], l32[:, t]) for t in range(toks.size(1))]
+        eo = max(rel(lo[:, t], l32[:, t]) for t in range(toks.size(1)))
+        print(fam, 'oracle vs HF fp32 (max over positions) %.2e ; HF bf16 vs fp32 per position: min %.2e max %.2e' % (eo, min(e16), max(e16)))
+        assert eo < 1e-4
+        meta[fam] = {'weights_seed': seed, 'audio_seeds': aseeds, 'tokens': toks.tolist(), 'nheads': nh,
+                     'bf16_vs_fp32_rel_l2': e16, 'oracle_vs_hf_fp32_rel_l2_max': eo, 'vocab': vocab}
+        if fam == 'whisper_tiny':
+            arrays['tiny_logits_fp32_slice'] = l32[:, :, ::97].numpy()
+            arrays['tiny_logits_bf16_slice'] = l16[:, :, ::97].numpy()
+        else:
+            arrays['base_logits_fp32_slice'] = l32[:, :, ::389].numpy()
+    meta['source'] = ('transformers 5.15.0 WhisperForConditionalGeneration holding synth_state_dict weights, called as '
+                      'Cluster/InfernSTTWorker.py:83-88 does (input_features + decoder_input_ids), fp32 and bf16')
+    np.savez_compressed(os.path.join(GOLD, 'whisper_tf.npz'), **arrays)
+    json.dump(meta, open(os.path.join(GOLD, 'whisper_tf_meta.json'), 'w'), indent=1, sort_keys=True)
+    print('wrote whisper_tf.npz')
+
+
+SECTIONS = {'tts': gen_tts, 'whisper': gen_whisper, 'whisper_tf': gen_whisper_tf}
