@@ -235,6 +235,16 @@ int ifh_logmel_filters_host(ifh_logmel_t h, float *out201xnmel_host);          /
 int64_t ifh_logmel_workspace_floats(ifh_logmel_t h, int nbatch, int out_bf16);  /* B (+ B*n_mel*3000 if bf16) */
 int ifh_logmel_run(ifh_logmel_t h, const float *audio, int64_t stride, const int32_t *lens, int nbatch,
                    void *out, int out_bf16, float *workspace, ifh_stream_t stream);
+/* The same transform with the normalisation left to the consumer: raw f32 [B][n_mel][3000] = log10(max(mel power,
+ * 1e-10)) and win_max int32 [B] = the per-utterance maximum of it, in the order-preserving integer encoding of a float
+ * (i >= 0 ? i : i ^ 0x7fffffff).  ifh_logmel_finish_transpose_bf16 applies max(x, max - 8), (x + 4) / 4 while it
+ * produces the bf16 channels-last [B][3000][n_mel] input of Whisper's first convolution: the normalised f32 plane is
+ * never written (1.92 MB of the 4.8 MB per window ifh_logmel_run moves).  Bit-identical to ifh_logmel_run (f32) followed
+ * by ifh_transpose_to_bf16. */
+int ifh_logmel_run_raw(ifh_logmel_t h, const float *audio, int64_t stride, const int32_t *lens, int nbatch, float *raw,
+                       int32_t *win_max, ifh_stream_t stream);
+int ifh_logmel_finish_transpose_bf16(ifh_logmel_t h, const float *raw, const int32_t *win_max, int nbatch, void *out,
+                                     ifh_stream_t stream);
 
 
 /* ---------------------------------------------------------------------------------
@@ -333,6 +343,36 @@ typedef struct ifh_resblock_desc {
     int64_t out_bstride;
 } ifh_resblock_desc;
 int ifh_resblock_pair_bf16(const ifh_resblock_desc *desc, ifh_stream_t stream);
+
+/* One whole HiFi-GAN residual block (HifiGanResidualBlock.forward, modeling_speecht5.py; three dilation pairs) in a
+ * single launch, bit-identical to three ifh_resblock_pair_bf16 launches with dilations 1, 3, 5:
+ *     for d in (1, 3, 5): x = x + conv2_d(lrelu(conv1_d(lrelu(x); taps, d)); taps, 1)
+ *     out = x * out_scale  (+ out if accumulate)
+ * x, out bf16 [nbatch][t][c] channels-last (batch strides in elements, % 4 == 0); c in {32, 64, 128} (t <= 192 at
+ * c = 128), taps in {3, 7, 11}.  wstream: the six convolutions' weights as one stream of MFMA fragments, padded with
+ * zeros to whole 8 KB units -- for convolution q = 2*pair + {0: dilated, 1: plain}, k-step s (32 consecutive
+ * k = tap*c + channel), fragment i (16 output channels), lane l: the 8 bf16
+ *     w_q[16*i + (l & 15)][32*s + 8*(l >> 4) + 0..7]           (w_q as [c][taps][c] = [out][tap][in])
+ * at element ((ks_q + s) * (c/16) + i) * 512 + l * 8, ks_q = 6 convolutions' k-steps before q; nunits =
+ * ceil(6 * taps * (c/32) * (c/16) * 1024 / 8192).  bias f32 [6][c] in the same order.  (host packing:
+ * infernos_amd.ops.w_chain_pack) */
+typedef struct ifh_chain_desc {
+    const void *x;
+    int64_t x_bstride;
+    int32_t c, taps, t, nbatch;
+    const void *wstream;
+    int32_t nunits;
+    const float *bias;
+    float slope;            /* LeakyReLU slope ahead of every convolution, (0, 1] */
+    float out_scale;
+    int32_t accumulate;
+    void *out;
+    int64_t out_bstride;
+    void *debug_prof;       /* NULL, or device uint64[16] (zeroed by the caller): diagnostic shader-clock sums of wave 0 of every
+                             * workgroup -- [0] tile set-up, [1+2q] K loop / [2+2q] epilogue+barrier of convolution q, [13] tiles,
+                             * [14] workgroup lifetime, [15] workgroups (tools/probe_chain.py) */
+} ifh_chain_desc;
+int ifh_resblock_chain_bf16(const ifh_chain_desc *desc, ifh_stream_t stream);
 
 /* y = LayerNorm(x (+ resid)) * gamma + beta; rows of `dim` bf16, dim <= 1024, dim % 4 == 0 */
 int ifh_layernorm_bf16(const void *x, const void *resid, const float *gamma, const float *beta, void *out,

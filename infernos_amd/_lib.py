@@ -52,6 +52,8 @@ SIGNATURES = {
     'ifh_logmel_filters_host': (_i, [_vp, _vp]),
     'ifh_logmel_workspace_floats': (_i64, [_vp, _i, _i]),
     'ifh_logmel_run': (_i, [_vp, _vp, _i64, _vp, _i, _vp, _i, _vp, _vp]),
+    'ifh_logmel_run_raw': (_i, [_vp, _vp, _i64, _vp, _i, _vp, _vp, _vp]),
+    'ifh_logmel_finish_transpose_bf16': (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
 }
 
 
@@ -77,6 +79,13 @@ class ResblockDesc(ctypes.Structure):
     _fields_ = [('x', _vp), ('x_bstride', _i64), ('c', ctypes.c_int32), ('taps', ctypes.c_int32), ('dil', ctypes.c_int32),
                 ('t', ctypes.c_int32), ('nbatch', ctypes.c_int32), ('w1', _vp), ('bias1', _vp), ('w2', _vp), ('bias2', _vp),
                 ('slope', _f), ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp), ('out_bstride', _i64)]
+
+
+class ChainDesc(ctypes.Structure):
+    """ifh_chain_desc (include/infernos_hip.h)"""
+    _fields_ = [('x', _vp), ('x_bstride', _i64), ('c', ctypes.c_int32), ('taps', ctypes.c_int32), ('t', ctypes.c_int32),
+                ('nbatch', ctypes.c_int32), ('wstream', _vp), ('nunits', ctypes.c_int32), ('bias', _vp), ('slope', _f),
+                ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp), ('out_bstride', _i64), ('debug_prof', _vp)]
 
 
 class RtpHdr(ctypes.Structure):
@@ -111,6 +120,7 @@ class AttnDesc(ctypes.Structure):
 SIGNATURES.update({
     'ifh_conv_bf16': (_i, [ctypes.POINTER(ConvDesc), _vp]),
     'ifh_resblock_pair_bf16': (_i, [ctypes.POINTER(ResblockDesc), _vp]),
+    'ifh_resblock_chain_bf16': (_i, [ctypes.POINTER(ChainDesc), _vp]),
     'ifh_layernorm_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     'ifh_transpose_to_bf16': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     'ifh_attn_prefill_bf16': (_i, [ctypes.POINTER(AttnDesc), _vp]),

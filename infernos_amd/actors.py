@@ -9,8 +9,22 @@ reference's decorator arguments when ray is importable, so the app layer keeps c
 from typing import Dict, Union
 from uuid import UUID
 
+from .shard import SessionRouter
 from .stt import InfernSTTWorker, STTRequest, STTSentinel, STTSession
 from .tts import InfernTTSWorker, TTSRequest, TTSSession
+
+
+def _devices(device):
+    """'cuda' / 'cuda:3' / None -> one device; a list or tuple -> those; 'cuda:*' -> every visible GPU.  With several
+    devices an actor runs one worker (thread, stream, replicated weights) per GPU and pins each new session to the least
+    loaded one (SessionRouter): the in-process form of the reference's one-actor-replica-per-GPU-share round robin
+    (Cluster/InfernBenchActor.py:218-221)."""
+    if isinstance(device, (list, tuple)):
+        return list(device)
+    if isinstance(device, str) and device.endswith(':*'):
+        import torch
+        return ['%s:%d' % (device[:-2], i) for i in range(torch.cuda.device_count())]
+    return [device]
 
 
 class InfernSessNotFoundErr(Exception):
@@ -26,15 +40,23 @@ class InfernSTTActor:
         self.sessions = {}
         self._worker_kwa = worker_kwa
 
+    worker_cls = InfernSTTWorker
+
     def start(self, device='cuda'):
-        self.stt = InfernSTTWorker(device, **self._worker_kwa)      # no CPU fallback: raises without a HIP device
-        self.stt.start()
+        # no CPU fallback: a worker raises without a HIP device
+        self.workers = [self.worker_cls(dev, **self._worker_kwa) for dev in _devices(device)]
+        self.router = SessionRouter(len(self.workers))
+        self.stt = self.workers[0]
+        for w in self.workers:
+            w.start()
 
     def stop(self):
-        self.stt.stop()
+        for w in self.workers:
+            w.stop()
 
     def new_stt_session(self, keep_context: bool = False):
-        sess = STTSession(self.stt, keep_context)
+        sess = STTSession(None, keep_context)
+        sess.stt = self.workers[self.router.assign(sess.id)]        # sticky: the session's chunks all go to this GPU
         self.sessions[sess.id] = sess
         return sess.id
 
@@ -42,6 +64,7 @@ class InfernSTTActor:
         sess = self.sessions[sess_id]
         sess.stop()
         del self.sessions[sess_id]
+        self.router.release(sess_id)
 
     def stt_session_soundin(self, sess_id, req: Union[STTRequest, STTSentinel]):
         self.sessions[sess_id].soundin(req)
@@ -56,19 +79,26 @@ class InfernTTSActor:
         self.sessions = {}
         self._worker_kwa = worker_kwa
 
+    worker_cls = InfernTTSWorker
+
     def start(self, lang: str = 'en', output_sr: int = 16000, device=None):
-        self.tts = InfernTTSWorker(lang, output_sr, device, **self._worker_kwa)
-        self.tts.start()
+        self.workers = [self.worker_cls(lang, output_sr, dev, **self._worker_kwa) for dev in _devices(device)]
+        self.router = SessionRouter(len(self.workers))
+        self.tts = self.workers[0]
+        for w in self.workers:
+            w.start()
         self.tts_actr = getattr(self, '_self_handle', self)
 
     def stop(self):
-        self.tts.stop()
+        for w in self.workers:
+            w.stop()
 
     def get_rand_voice_id(self) -> int:
         return self.tts.get_rand_voice_id()
 
     def new_tts_session(self):
         rgen = TTSSession(self.tts, self.tts_actr)
+        rgen.tts = self.workers[self.router.assign(rgen.id)]        # sticky: KV caches / carry frames live on that GPU
         self.sessions[rgen.id] = rgen
         return rgen.id
 
@@ -84,6 +114,7 @@ class InfernTTSActor:
     def tts_session_end(self, rgen_id):
         self.sessions[rgen_id].stop()
         del self.sessions[rgen_id]
+        self.router.release(rgen_id)
 
 
 class RemoteTTSSession:

@@ -35,6 +35,18 @@ class HifiGan:
                              ops.w_conv(sd[R + 'convs2.%d.weight' % d], dev), ops.w_bias(sd[R + 'convs2.%d.bias' % d], dev))
                             for d in range(3)])
             self.res.append(lvl)
+        # whole residual blocks as one launch each (csrc/chain.hip) where the channel count allows: the six convolutions'
+        # weights as one pre-packed fragment stream per block
+        self.chain = {}
+        self.fused_chain = os.environ.get('IFH_NO_CHAIN') is None           # tuning switch
+        for i in range(1, 4):
+            for j, k in enumerate((3, 7, 11)):
+                R = 'resblocks.%d.' % (i * 3 + j)
+                convs = []
+                for d in range(3):
+                    convs.append((sd[R + 'convs1.%d.weight' % d], sd[R + 'convs1.%d.bias' % d]))
+                    convs.append((sd[R + 'convs2.%d.weight' % d], sd[R + 'convs2.%d.bias' % d]))
+                self.chain[(i, j)] = ops.w_chain_pack(convs, dev)
         self.post_w = sd['conv_post.weight'].float()[0].t().contiguous().to(dev)     # [7][32]
         self.post_b = float(sd['conv_post.bias'].float()[0])
         self._bufs = {}
@@ -84,6 +96,11 @@ class HifiGan:
             rbuf = (B['r0%d' % i], B['r1%d' % i])
             for j, k in enumerate((3, 7, 11)):
                 cur = u
+                if self.fused_chain and (i, j) in self.chain and (c < 128 or t <= 192):
+                    ws, nunits, bias = self.chain[(i, j)]
+                    ops.resblock_chain(u, ws, nunits, bias, xn, nbatch=n, t=t, c=c, taps=k, slope=0.1, scale=1.0 / 3.0,
+                                       accumulate=(j > 0))
+                    continue
                 for di, d in enumerate((1, 3, 5)):
                     w1, b1, w2, b2 = self.res[i][j][di]
                     # both convolutions in one launch, intermediate kept in LDS (same bits) -- except at C = 256 with

@@ -101,10 +101,12 @@ class Whisper:
         self.logit_fold = (w, c2, c1)
 
     # ---- encoder ------------------------------------------------------------------------------
-    def encode(self, mel: torch.Tensor) -> torch.Tensor:
-        """mel [B, n_mel, 3000] f32 or bf16 (ifh_logmel_run layout) -> bf16 [B, 1500, d]"""
+    def encode(self, mel: torch.Tensor = None, raw=None) -> torch.Tensor:
+        """mel [B, n_mel, 3000] f32 or bf16 (ifh_logmel_run layout) -> bf16 [B, 1500, d].
+        raw = (WhisperLogMel, raw f32 [B, n_mel, 3000], win_max int32 [B]) instead of mel: the normalisation of the
+        features is applied by the layout change in front of conv1 (ifh_logmel_finish_transpose_bf16), same bits."""
         dev, d, H, FF = self.device, self.d, self.h, self.ff
-        Bn = mel.size(0)
+        Bn = mel.size(0) if raw is None else raw[1].size(0)
         if Bn not in self._enc_bufs:
             e = lambda *s: torch.empty(s, dtype=BF16, device=dev)
             rows = Bn * N_CTX
@@ -114,7 +116,10 @@ class Whisper:
                                       qkv=e(rows, 3 * d), att=e(rows, d), ff=e(rows, FF), out=e(rows, d))
         b = self._enc_bufs[Bn]
         rows = Bn * N_CTX
-        ops.transpose_to_bf16(mel.contiguous(), b['mt'], Bn, self.n_mel, 3000)
+        if raw is None:
+            ops.transpose_to_bf16(mel.contiguous(), b['mt'], Bn, self.n_mel, 3000)
+        else:
+            raw[0].to_conv_input(raw[1], raw[2], out=b['mt'])
         ops.conv(b['mt'], *self.c1, b['c1'], nbatch=Bn, t_in=3000, t_out=3000, cin=self.n_mel, n=d, taps=3, pad=1, act=ACT_GELU)
         ops.conv(b['c1'], *self.c2, b['x'], nbatch=Bn, t_in=3000, t_out=N_CTX, cin=d, n=d, taps=3, stride=2, pad=1,
                  act=ACT_GELU, resid=self.enc_pos, resid_ld=d, resid_bstride=0)

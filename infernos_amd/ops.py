@@ -67,6 +67,19 @@ def resblock_pair(x, w1, b1, w2, b2, out, *, nbatch, t, c, taps, dil, slope=0.1,
     return out
 
 
+def resblock_chain(x, wstream, nunits, bias, out, *, nbatch, t, c, taps, slope=0.1, scale=1.0, accumulate=False, prof=None):
+    """out = chain(x) * scale (+ out): the three dilation pairs (1, 3, 5) of one HiFi-GAN residual block in ONE launch
+    (ifh_resblock_chain_bf16), bit-identical to three resblock_pair launches.  wstream/nunits/bias from w_chain_pack."""
+    d = _lib.ChainDesc()
+    d.x, d.x_bstride = _addr(x), t * c
+    d.c, d.taps, d.t, d.nbatch = c, taps, t, nbatch
+    d.wstream, d.nunits, d.bias = _addr(wstream), nunits, _addr(bias)
+    d.slope, d.out_scale, d.accumulate = slope, scale, int(accumulate)
+    d.out, d.out_bstride, d.debug_prof = _addr(out), t * c, _addr(prof)
+    _lib.check(_lib.lib().ifh_resblock_chain_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_resblock_chain_bf16')
+    return out
+
+
 def linear(x, w, bias, out, *, rows, k, n, **kw):
     """out[rows, n] = epi(x[rows, k] @ w[n, k]^T + bias)"""
     return conv(x, w, bias, out, nbatch=1, t_in=rows, t_out=rows, cin=k, n=n, **kw)
@@ -163,6 +176,30 @@ def w_conv(w, device, scale_per_out=None):
     if scale_per_out is not None:
         w = w * scale_per_out[:, None, None]
     return w.permute(0, 2, 1).to(BF16).contiguous().to(device)
+
+
+def w_chain_pack(convs, device):
+    """The six convolutions of one HiFi-GAN residual block -- [(conv1_d1, b), (conv2_d1, b), (conv1_d3, b), ...], each
+    weight in Conv1d layout [Cout, Cin, k] -- as the fragment stream ifh_resblock_chain_bf16 DMAs into LDS (layout in
+    include/infernos_hip.h: per k-step of 32, per 16 output channels, 64 lanes x 8 bf16 in MFMA A-operand order), zero
+    padded to whole 8 KB units.  -> (bf16 stream on `device`, units, f32 bias [6][C] on `device`)"""
+    parts, biases = [], []
+    for w, b in convs:
+        w = w.float()
+        cout, cin, k = w.shape
+        assert cout == cin and cout % 32 == 0
+        wk = w.permute(0, 2, 1).reshape(cout, k * cin).to(BF16)              # [out][tap*C + ci]
+        ks = k * cin // 32
+        f = wk.reshape(cout // 16, 16, ks, 4, 8).permute(2, 0, 3, 1, 4)       # [s][i][fg][fr][e]: lane = fg*16 + fr
+        parts.append(f.reshape(-1))
+        biases.append(torch.zeros(cout) if b is None else b.float())
+    stream = torch.cat(parts)
+    unit = 8192 // 2
+    nunits = -(-stream.numel() // unit)
+    pad = nunits * unit - stream.numel()
+    if pad:
+        stream = torch.cat([stream, torch.zeros(pad, dtype=BF16)])
+    return stream.contiguous().to(device), nunits, torch.stack(biases).contiguous().to(device)
 
 
 def w_convT_fused(w, bias, device):

@@ -181,8 +181,8 @@ class SpeechPipeline:
             x8[i, :m.numel()] = m
         x16 = self.up(x8, lens=lens8)
         lens16 = (lens8 * 2).to(dev)
-        mel = fl.logmel(x16, lens=lens16)
-        enc = fl.whisper.encode(mel)
+        raw, wmax = fl.logmel.raw(x16, lens=lens16)        # normalisation fused into conv1's layout change
+        enc = fl.whisper.encode(raw=(fl.logmel, raw, wmax))
         prompt = self.prompt if nrow == self.n else self.prompt.repeat(nrow // self.n, 1)
         toks, nsp, _ = fl.whisper.generate(enc, prompt, self.n_new, no_speech_id=50362)
         return toks, nsp, (lens8.float() / 8000.0)
@@ -370,11 +370,10 @@ class SpeechPipeline:
             self.stage_wall['tts'].append(time.perf_counter() - t0)
             return rs, ev
 
-        fronts, ttss = {}, {}
-        out = None
         import sys
         swi = sys.getswitchinterval()
         sys.setswitchinterval(2e-4)        # several launch threads: hand the GIL over quickly
+        ttss = {}
 
         def retire(gi):
             rs, ev = ttss.pop(gi).result()
@@ -386,18 +385,10 @@ class SpeechPipeline:
                 if on_cycle is not None:
                     on_cycle(r)                                    # e.g. egress gather of this cycle's output rows
             return rs[-1]
-        ngroups = (nsteps + G - 1) // G
-        nfront = 0                                                 # groups whose front-end job has been submitted
-        for gi in range(ngroups):
-            while nfront < min(ngroups, gi + 1 + L):               # the front end runs up to L groups ahead
-                lo, hi = nfront * G, min(nsteps, (nfront + 1) * G)
-                fronts[nfront] = self._pool.submit(job, nfront, [fetch(k) for k in range(lo, hi)])
-                nfront += 1
-            ttss[gi] = self._tts_pool.submit(tts_job, gi % L, fronts.pop(gi))
-            if gi >= L - 1:
-                out = retire(gi - (L - 1))
-        for gi in range(max(0, ngroups - (L - 1)), ngroups):
-            out = retire(gi)
+
+        def submit_tts(gi, front_fut):
+            ttss[gi] = self._tts_pool.submit(tts_job, gi % L, front_fut)
+        out = schedule_cycles(nsteps, G, L, fetch, lambda gi, frs: self._pool.submit(job, gi, frs), submit_tts, retire)
         sys.setswitchinterval(swi)
         return out
 
@@ -408,6 +399,29 @@ class SpeechPipeline:
         ulaw, valid, spans = self.synthesize()
         return dict(tokens=toks, no_speech_prob=nsp, stt_seconds=secs, ulaw=ulaw, tts_samples=valid, spans=spans,
                     chunks=[[(c.ipos, c.audio.numel()) for c in lst] for lst in chunks])
+
+
+def schedule_cycles(nsteps, group, lanes, fetch, submit_front, submit_tts, retire):
+    """The order in which SpeechPipeline.run_steps hands work to its stage threads -- pure Python, no device calls, so that
+    the multi-GPU collective order can be tested on CPU (tests/test_shard_cpu.py).  Cycles are grouped `group` at a time;
+    fetch(k) (the ingress collective) and retire(g) (the egress collective of every cycle of group g) run on the CALLING
+    thread, each in increasing order, so every rank issues the collectives of each communicator in the same order;
+    the front-end jobs run up to `lanes` groups ahead of the synthesis jobs, which retire `lanes - 1` groups behind.
+    submit_front(g, [fetch(k) ...]) -> future; submit_tts(g, front_future); retire(g) -> result of the last cycle."""
+    ngroups = (nsteps + group - 1) // group
+    fronts, out = {}, None
+    nfront = 0                                                 # groups whose front-end job has been submitted
+    for gi in range(ngroups):
+        while nfront < min(ngroups, gi + 1 + lanes):           # the front end runs up to `lanes` groups ahead
+            lo, hi = nfront * group, min(nsteps, (nfront + 1) * group)
+            fronts[nfront] = submit_front(nfront, [fetch(k) for k in range(lo, hi)])
+            nfront += 1
+        submit_tts(gi, fronts.pop(gi))
+        if gi >= lanes - 1:
+            out = retire(gi - (lanes - 1))
+    for gi in range(max(0, ngroups - (lanes - 1)), ngroups):
+        out = retire(gi)
+    return out
 
 
 class _FrontLane:

@@ -9,10 +9,51 @@ blocks are moved in one collective each way rather than one per tick.  Ingress a
 threads (the serving loop pipelines its stages): give each its own process group (`group=`) so that
 the per-communicator issue order is the same on every rank.
 """
-from typing import List, Optional
+import threading
+from typing import Hashable, List, Optional
 
 import torch
 import torch.distributed as dist
+
+
+class SessionRouter:
+    """Sticky session -> shard assignment, least loaded at session start: per-session device state (VAD
+    model state, resampler carry, pending STT chunk, TTS KV cache and carry frames) must stay where it was created, so a
+    session keeps its shard until it ends.  A shard is a GPU of this process (the actor facades, one worker thread per
+    device) or a rank of the torch.distributed job (the batched pipeline).  The reference's counterpart is the round-robin
+    over Ray actor replicas (Cluster/InfernBenchActor.py:218-221, InfernSTTActor.py:12)."""
+
+    def __init__(self, n_shards: int):
+        assert n_shards >= 1
+        self.load = [0] * n_shards
+        self._owner = {}
+        self._lock = threading.Lock()
+
+    def assign(self, session_id: Hashable) -> int:
+        with self._lock:
+            if session_id in self._owner:
+                return self._owner[session_id]
+            k = min(range(len(self.load)), key=lambda i: (self.load[i], i))
+            self.load[k] += 1
+            self._owner[session_id] = k
+            return k
+
+    def shard_of(self, session_id: Hashable) -> int:
+        with self._lock:
+            return self._owner[session_id]
+
+    def release(self, session_id: Hashable) -> None:
+        with self._lock:
+            k = self._owner.pop(session_id)
+            self.load[k] -= 1
+
+    def rows_by_shard(self) -> List[list]:
+        """live sessions grouped by shard, in assignment order: the row order of the ingress scatter"""
+        with self._lock:
+            out = [[] for _ in self.load]
+            for sid, k in self._owner.items():
+                out[k].append(sid)
+            return out
 
 
 def _stage(group):

@@ -241,6 +241,54 @@ def test_resblock_pair_is_bit_identical_to_two_convs(dev, case):
         'max abs diff %g' % float((out.float() - ref.float()).abs().max())
 
 
+@pytest.mark.parametrize('case', [
+    dict(B=3, T=192, c=128, k=3), dict(B=2, T=192, c=128, k=7), dict(B=5, T=192, c=128, k=11), dict(B=2, T=100, c=128, k=11),
+    dict(B=2, T=768, c=64, k=3), dict(B=3, T=768, c=64, k=7), dict(B=2, T=768, c=64, k=11), dict(B=2, T=300, c=64, k=11),
+    dict(B=2, T=3072, c=32, k=3), dict(B=2, T=3072, c=32, k=7), dict(B=3, T=3072, c=32, k=11), dict(B=2, T=1000, c=32, k=7),
+    dict(B=2, T=17, c=32, k=11), dict(B=300, T=768, c=64, k=7, acc=True), dict(B=2, T=3072, c=32, k=11, acc=True),
+    dict(B=3, T=192, c=128, k=7, acc=True),
+])
+def test_resblock_chain_is_bit_identical_to_three_pairs(dev, case):
+    """ifh_resblock_chain_bf16 (a whole HifiGanResidualBlock in one launch: activations resident in LDS, residual stream in
+    registers, weights DMA'd as pre-packed fragments) against the three ifh_resblock_pair_bf16 launches it replaces
+    (themselves bit-identical to separate convolutions, which are checked against torch): same rounding points and the same
+    accumulation order, so the bits must agree -- including tiles cut with recomputed margins, sequence edges (zero
+    padding), ragged last tiles, several tiles per persistent block, and the scaled accumulate epilogue."""
+    from infernos_amd import ops
+    B, T, c, k = case['B'], case['T'], case['c'], case['k']
+    acc = case.get('acc', False)
+    g = torch.Generator().manual_seed(T * 3 + c + k + B)
+    x = torch.randn(B, T, c, generator=g).to(BF).to(dev)
+    convs, dev_w = [], []
+    for d in (1, 3, 5):
+        for _ in range(2):
+            w = bfr(torch.randn(c, c, k, generator=g) / (c * k) ** 0.5)
+            b = torch.randn(c, generator=g) * 0.1
+            convs.append((w, b))
+            dev_w.append((ops.w_conv(w, dev), b.to(dev)))
+    prev = torch.randn(B, T, c, generator=g).to(BF).to(dev)
+    ref = prev.clone()
+    cur = x
+    tmp = [torch.empty_like(x), torch.empty_like(x)]
+    for di, d in enumerate((1, 3, 5)):
+        (w1, b1), (w2, b2) = dev_w[2 * di], dev_w[2 * di + 1]
+        last = di == 2
+        nxt = ref if last else tmp[di]
+        ops.resblock_pair(cur, w1, b1, w2, b2, nxt, nbatch=B, t=T, c=c, taps=k, dil=d, slope=0.1,
+                          scale=(1.0 / 3.0 if last else 1.0), accumulate=(last and acc))
+        cur = nxt
+    ws, nunits, bias = ops.w_chain_pack(convs, dev)
+    out = prev.clone()
+    ops.resblock_chain(x, ws, nunits, bias, out, nbatch=B, t=T, c=c, taps=k, slope=0.1, scale=1.0 / 3.0, accumulate=acc)
+    torch.cuda.synchronize()
+    same = torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    if not same:
+        diff = (out.float() - ref.float()).abs()
+        bad = torch.nonzero(diff.amax(dim=2) > 0)
+        raise AssertionError('chain differs from pairs: max abs %g at %d rows, first (batch,row) %s' % (
+            float(diff.max()), bad.size(0), bad[:6].tolist()))
+
+
 def test_layernorm_and_transpose(dev):
     from infernos_amd import ops
     g = torch.Generator().manual_seed(6)
