@@ -163,67 +163,77 @@ __global__ __launch_bounds__(512, 2) void k_resblock_chain(const ChainParams p)
     }
 
     f32x4 acc[NT][MT];
-    // Fragments of one k-step: A = this wave's NT weight tiles (ring), B = its MT row tiles of the operand image.  Every
-    // LDS access of the main loop goes through inline asm with hand-counted s_waitcnt: as ordinary loads the compiler waits
-    // lgkmcnt(0) in front of the MFMAs (the reads just issued for the NEXT k-step included) and vmcnt(0) in front of any LDS
-    // access while a weight DMA is pending -- either one serialises the pipeline.
-    auto load_frags = [&](int src, int dd, int s, bf16x8_t (&fa)[NT], bf16x8_t (&fb)[MT]) {
+    static_assert(NT == 2, "the read/MFMA interleave below is written for two channel tiles per wave");
+    constexpr int NR = NT + MT;                        // fragment reads per k-step
+    // Fragments of one k-step: A = this wave's NT weight tiles (ring), B = its MT row tiles of the operand image, read in
+    // the order the MFMAs want them: q0 = A0, q1..qMT = B0..B(MT-1), q(MT+1) = A1.  Every LDS access of the main loop goes
+    // through inline asm with hand-counted s_waitcnt: as ordinary loads the compiler waits lgkmcnt(0) in front of the MFMAs
+    // (the reads just issued for the NEXT k-step included) and vmcnt(0) in front of any LDS access while a weight DMA is
+    // pending -- either one serialises the pipeline.
+    int nxt_a = 0, nxt_b = 0;                          // byte addresses of the fragments being fetched
+    auto frag_addr = [&](int src, int dd, int s) {     // k-step s of the current convolution: enter its unit, fix the addresses
         if (ks_in_unit == 0) CHAIN_ENTER_UNIT()
         const int tap = s / KSUB, cs = s - tap * KSUB;
-        const int aoff = ab + ring_read * kUnitBytes + ks_in_unit * (FRAGS * 1024);
-        const int boff = src + (tap - H) * dd * SB + cs * 64;
-#pragma unroll
-        for (int i = 0; i < NT; i++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[i]) : "v"(aoff), "n"(i * 1024));
-#pragma unroll
-        for (int j = 0; j < MT; j++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[j]) : "v"(boff), "n"(j * 16 * SB));
+        nxt_a = ab + ring_read * kUnitBytes + ks_in_unit * (FRAGS * 1024);
+        nxt_b = src + (tap - H) * dd * SB + cs * 64;
         if (++ks_in_unit == UK) {
             ks_in_unit = 0;
             ring_read = (ring_read + 1 == NRING) ? 0 : ring_read + 1;
         }
     };
-    auto mfma_all = [&](const bf16x8_t (&fa)[NT], const bf16x8_t (&fb)[MT]) {
-#pragma unroll
-        for (int i = 0; i < NT; i++)
-#pragma unroll
-            for (int j = 0; j < MT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    };
-    // wait until at most KEEP of this wave's LDS reads are outstanding (they return in order), and keep the compiler from
-    // moving the MFMAs that consume the older ones above the wait
-#define CHAIN_WAIT_LDS(KEEP)                                              \
-    {                                                                     \
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(KEEP));                \
-        __builtin_amdgcn_sched_barrier(0);                                \
+#define CHAIN_READ(Q, FA, FB)                                                                                             \
+    {                                                                                                                     \
+        if ((Q) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(FA[0]) : "v"(nxt_a));                                     \
+        else if ((Q) == MT + 1) asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(FA[1]) : "v"(nxt_a));               \
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FB[(Q) - 1]) : "v"(nxt_b), "n"(((Q) - 1) * 16 * SB));    \
     }
-    // one convolution over the image at `src` with dilation dd: two fragment sets, the next k-step's reads in flight
-    // behind this k-step's MFMAs
+    // One k-step: the MFMAs on the fragments in (ca, cb) in the order (A0 x B0..B(MT-1)), (A1 x B0..B(MT-1)), with the NR
+    // reads of the NEXT k-step into (na, nb) issued one per MFMA in front of the first NR of them -- all eight waves run
+    // in step, so reads issued as one burst would occupy the LDS for ~250 cycles in which no MFMA issues.  LDS reads return
+    // in order: in front of MFMA k (k <= MT) the fragment it needs is back once at most NR - 2 reads are outstanding.
+    auto kstep = [&](const bf16x8_t (&ca)[NT], const bf16x8_t (&cb)[MT], bf16x8_t (&na)[NT], bf16x8_t (&nb)[MT], auto has_next) {
+        constexpr bool NEXT = decltype(has_next)::value;
+        if (!NEXT) {
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 0; k < NT * MT; k++) {
+            if (NEXT && k < NR) {
+                if (k <= MT) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 2));
+                CHAIN_READ(k, na, nb)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int i = k / MT, j = k - i * MT;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // one convolution over the image at `src` with dilation dd, two fragment sets
     auto conv = [&](int src, int dd) {
 #pragma unroll
         for (int i = 0; i < NT; i++)
 #pragma unroll
             for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         bf16x8_t fa0[NT], fb0[MT], fa1[NT], fb1[MT];
-        load_frags(src, dd, 0, fa0, fb0);
+        frag_addr(src, dd, 0);
+#pragma unroll
+        for (int q = 0; q < NR; q++) CHAIN_READ(q, fa0, fb0)
+        __builtin_amdgcn_sched_barrier(0);
         int s = 0;
 #pragma unroll 1
         for (; s + 2 < KS; s += 2) {
-            load_frags(src, dd, s + 1, fa1, fb1);
-            CHAIN_WAIT_LDS(NT + MT)
-            mfma_all(fa0, fb0);
-            __builtin_amdgcn_sched_barrier(0);
-            load_frags(src, dd, s + 2, fa0, fb0);
-            CHAIN_WAIT_LDS(NT + MT)
-            mfma_all(fa1, fb1);
-            __builtin_amdgcn_sched_barrier(0);
+            frag_addr(src, dd, s + 1);
+            kstep(fa0, fb0, fa1, fb1, std::true_type{});
+            frag_addr(src, dd, s + 2);
+            kstep(fa1, fb1, fa0, fb0, std::true_type{});
         }
         if (s + 1 < KS) {
-            load_frags(src, dd, s + 1, fa1, fb1);
-            CHAIN_WAIT_LDS(NT + MT)
-            mfma_all(fa0, fb0);
-            CHAIN_WAIT_LDS(0)
-            mfma_all(fa1, fb1);
+            frag_addr(src, dd, s + 1);
+            kstep(fa0, fb0, fa1, fb1, std::true_type{});
+            kstep(fa1, fb1, fa0, fb0, std::false_type{});
         } else {
-            CHAIN_WAIT_LDS(0)
-            mfma_all(fa0, fb0);
+            kstep(fa0, fb0, fa1, fb1, std::false_type{});
         }
     };
     // this lane's biases of convolution q: read through inline asm -- as an ordinary LDS read the compiler puts an
@@ -365,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void k_resblock_chain(const ChainParams p)
         atomicAdd(p.prof + 15, 1ull);
     }
 #undef CHAIN_STAMP
-#undef CHAIN_WAIT_LDS
+#undef CHAIN_READ
 #undef CHAIN_LDS_STORE
 #undef CHAIN_ENTER_UNIT
 #undef CHAIN_DMA

@@ -198,8 +198,8 @@ class InfernSTTWorker(InfernBatchedWorker):
             for i, a in enumerate(audios):
                 a = torch.as_tensor(a)
                 x[i, :lens[i]] = a[:lens[i]].to(dev, torch.float32)
-            mel = self.logmel(x, lens=lens.to(dev))
-            enc = self.model.encode(mel)
+            raw, wmax = self.logmel.raw(x, lens=lens.to(dev))        # normalisation fused into conv1's layout change
+            enc = self.model.encode(raw=(self.logmel, raw, wmax))
             P = max(len(p) for p in prompts)
             assert all(len(p) == P for p in prompts), 'prompts of one batch must have equal length'
             pr = torch.tensor(prompts, dtype=torch.int32)
@@ -223,7 +223,20 @@ class InfernSTTWorker(InfernBatchedWorker):
         audios = [wi[0].chunk.audio for wi in wis]
         prompts = self.get_prompt(tuple((wi[0].lang, wi[0].mode, wi[0].timestamps) for wi in wis))
         max_nsps = [wi[0].max_ns_prob for wi in wis]
-        results = self.transcribe_batch(audios, [list(p) for p in prompts], max_nsps)
+        prompts = [list(p) for p in prompts]
+        try:
+            results = self.transcribe_batch(audios, prompts, max_nsps)
+        except RuntimeError as e:
+            # the reference's recovery (InfernSTTWorker.py:66-72): out of device memory on a batch -> release the
+            # caching allocator's blocks and run the requests one by one; anything else, or a batch of one, re-raises
+            if 'out of memory' not in str(e).lower() or len(wis) == 1:
+                raise
+            self.model._enc_bufs.clear()
+            self.model._dec_bufs.clear()
+            torch.cuda.empty_cache()
+            results = []
+            for a, pr, nsp in zip(audios, prompts, max_nsps):
+                results.extend(self.transcribe_batch([a], [pr], [nsp]))
         for (req, text_cb, ctx), (text, nsp, toks) in zip(wis, results):
             if len(text) > 0 and text[0] == ' ':
                 text = text[1:]

@@ -121,3 +121,93 @@ def test_tts_worker_through_sessions(built_lib):
             assert all(torch.isfinite(c.audio.float()).all() for c in chunks)
     finally:
         w.stop()
+
+
+def test_stt_worker_out_of_memory_retries_one_by_one(built_lib):
+    """The reference's recovery at Cluster/InfernSTTWorker.py:66-72: a batch that runs out of device memory is retried
+    request by request after the allocator's cache has been dropped; results and their order are those of the batch."""
+    from infernos_amd import _lib
+    from infernos_amd.audio import AudioChunk
+    from infernos_amd.stt import InfernSTTWorker, STTRequest
+    from infernos_amd.synth import synth_utterance
+    from infernos_amd.weights import synth_state_dict
+    dev = _lib.require_device('cuda:0')
+    w = InfernSTTWorker(dev, weights=synth_state_dict('whisper_tiny', 0), tokenizer=StubTokenizer(), fixed_new_tokens=5)
+    aud = [torch.from_numpy(odsp.resample(synth_utterance(1000 + i, 3.0)[8000:20000], 8000, 16000)) for i in range(3)]
+
+    def run():
+        got = []
+        wis = [(STTRequest(AudioChunk(a, 16000), None, 'en'), (lambda result, i=i: got.append((i, result.text, result.no_speech_prob))), None)
+               for i, a in enumerate(aud)]
+        w.process_batch(wis)
+        return got
+    ref = run()
+    calls, real = [], w.transcribe_batch
+
+    def flaky(audios, prompts, max_nsps):
+        calls.append(len(audios))
+        if len(audios) > 1:
+            raise RuntimeError('HIP out of memory. Tried to allocate 20.00 MiB')
+        return real(audios, prompts, max_nsps)
+    w.transcribe_batch = flaky
+    got = run()
+    assert calls == [3, 1, 1, 1]
+    assert [g[:2] for g in got] == [r[:2] for r in ref]
+    for g, r in zip(got, ref):
+        assert abs(g[2] - r[2]) <= 1e-3 * abs(r[2]) + 1e-12
+    w.transcribe_batch = lambda *a: (_ for _ in ()).throw(RuntimeError('something else'))
+    with pytest.raises(RuntimeError, match='something else'):
+        run()
+
+
+def test_tts_worker_audio_matches_oracle(built_lib):
+    """InfernTTSWorker through TTSSession (process_batch -> infer -> unbatch_and_dispatch -> TTSSndDispatch -> soundout):
+    the audio that reaches `soundout` is the oracle's tts_infer output for the same text, voice and dropout masks, cut at
+    the reference's dispatch offsets, within the bf16 bar of test_tts_pipe_matches_reference_run."""
+    from infernos_amd import _lib
+    from infernos_amd.audio import AudioChunk
+    from infernos_amd.muxer import ASMarkerNewSent
+    from infernos_amd.tts import InfernTTSWorker, TTSRequest, TTSSession
+    from infernos_amd.weights import synth_state_dict
+    dev = _lib.require_device('cuda:0')
+    W = {'speecht5_tts': synth_state_dict('speecht5_tts', 0, stop_bias=-20.0), 'hifigan': synth_state_dict('hifigan', 0),
+         'amendment': synth_state_dict('amendment', 0)}
+    g = torch.Generator().manual_seed(1)
+    voices = [torch.randn(1, 512, generator=g) for _ in range(4)]
+    mg = torch.Generator().manual_seed(8)
+    masks = []
+
+    def mask_source(n):
+        m = torch.randint(0, 2, (n, 2, 256), generator=mg, dtype=torch.uint8)
+        masks.append(m)
+        return m.to(dev)
+    w = InfernTTSWorker('en', 16000, dev, weights=W, processor=IdsProcessor(), speaker_embeddings=voices, mask_source=mask_source)
+    w.start()
+    try:
+        out, fin = [], threading.Event()
+
+        def soundout(chunk):
+            out.append(chunk)
+            if isinstance(chunk, ASMarkerNewSent):
+                fin.set()
+        sess = TTSSession(w, None)
+        sess.start(soundout)
+        text = '5 17 33 8 61'                                   # 5 tokens: the length rule stops it at step 50 (-> ends_at 52)
+        sess.say(TTSRequest(text, speaker_id=2))
+        assert fin.wait(180)
+    finally:
+        w.stop()
+    got = torch.cat([c.audio.float() for c in out if isinstance(c, AudioChunk)])
+    ids = torch.tensor([[int(t) for t in text.split()]])
+    st = onn.TTSState(W['speecht5_tts'], ids, torch.ones_like(ids).int(), voices[2])
+    ref = []
+    with torch.no_grad():
+        for c in range(len(masks)):
+            a = onn.tts_infer(W['speecht5_tts'], W['hifigan'], W['amendment'], st, masks[c])
+            (s0, e0, _), = onn.tts_dispatch_offsets(st.idx, st.starts_at.tolist(), st.ends_at.tolist())[0]
+            ref.append(a[0, s0:e0])
+    ref = torch.cat(ref)
+    assert got.numel() == ref.numel() == (52 - 1) * 512, (got.numel(), ref.numel())
+    e = float((got.double() - ref.double()).norm() / ref.double().norm())
+    print('TTS worker through session: rel_l2 vs oracle %.3e over %d samples, %d infer calls' % (e, got.numel(), len(masks)))
+    assert e < 3e-2, e

@@ -32,6 +32,18 @@ def main():
     dev = _lib.require_device('cuda:0')
     g = torch.Generator().manual_seed(0)
     tot_c = tot_p = 0.0
+    only = os.environ.get('ONLY')              # e.g. ONLY=128:11 -> that chain alone, 5 launches (for rocprofv3 --pmc)
+    if only:
+        c, k = (int(v) for v in only.split(':'))
+        T = {128: 192, 64: 768, 32: 3072}[c]
+        x = torch.randn(n, T, c, generator=g).to(BF).to(dev)
+        convs = [((torch.randn(c, c, k, generator=g) / (c * k) ** 0.5).to(BF).float(), torch.randn(c, generator=g) * 0.1) for _ in range(6)]
+        ws, nu, bias = ops.w_chain_pack(convs, dev)
+        out = torch.zeros_like(x)
+        for _ in range(5):
+            ops.resblock_chain(x, ws, nu, bias, out, nbatch=n, t=T, c=c, taps=k, scale=1 / 3)
+        torch.cuda.synchronize()
+        return
     for c, T in ((128, 192), (64, 768), (32, 3072)):
         x = torch.randn(n, T, c, generator=g).to(BF).to(dev)
         for k in (3, 7, 11):

@@ -31,9 +31,9 @@ def main():
         nF, sF, bF = pmc_sum(dF, 'FETCH_SIZE', passes)
         nW, sW, bW = pmc_sum(dW, 'WRITE_SIZE', passes)
         res = {
-            'command': 'rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 tools/probe_%s.py %d  (tools/pmc_%s.sh; last of %d passes)' % (what, passes, 'vocoder' if what == 'vocoder' else 'logmel_hbm', passes),
+            'command': 'rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 tools/probe_%s.py %d %d  (tools/prof_r02.sh; last of %d passes)' % (what, passes, chunks, passes),
             'workload': ('one HiFi-GAN vocoder pass, %d chunks x 12 frames (bench.py roofline leg)' % chunks) if what == 'vocoder'
-                        else ('one log-mel launch, %d windows of 30 s -> [80,3000] f32 (bench.py roofline_logmel leg)' % chunks),
+                        else ('one log-mel launch (ifh_logmel_run_raw), %d windows of 30 s -> raw [80,3000] f32 + window maxima (bench.py roofline_logmel leg)' % chunks),
             'chunks_per_pass': chunks,
             'correction': 'gfx950: FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads -> x2 (MI355X_MICROARCH.md, HBM); WRITE_SIZE exact; both in KB',
             'fetch_bytes_corrected': sF * 1024 * 2, 'write_bytes': sW * 1024,
