@@ -137,7 +137,9 @@ class TickProbe(threading.Thread):
         self.tts_pcm = tts_pcm                                      # device f32 [n, S]: real TTS output rows
         with torch.cuda.device(dev):
             self.calls, self.vad = CallTable(n, dev), BatchedVAD(n, dev)
-            self.stream = torch.cuda.Stream(device=dev)
+            # the per-tick path is the real-time one: its few small kernels go to a high-priority hardware queue so that they
+            # do not wait behind a lane's whole queued decode graph
+            self.stream = torch.cuda.Stream(device=dev, priority=-1)
             self.slots = torch.arange(n, dtype=torch.int32, device=dev)
             self.dfr = torch.empty((n, 160), dtype=torch.uint8, device=dev)
             self.p8, self.p16 = torch.empty((n, 160), device=dev), torch.empty((n, 320), device=dev)

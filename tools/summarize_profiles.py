@@ -9,7 +9,7 @@ import csv, glob, json, os, sys
 
 
 def pmc_sum(d, counter, passes):
-    f = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)[0]
+    f = max(glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True), key=os.path.getmtime)   # newest run
     rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     # keep only the vocoder's own kernels (ifh::), split evenly into passes, take the last pass
