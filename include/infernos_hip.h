@@ -374,6 +374,28 @@ typedef struct ifh_chain_desc {
 } ifh_chain_desc;
 int ifh_resblock_chain_bf16(const ifh_chain_desc *desc, ifh_stream_t stream);
 
+/* One stride-1 "same" convolution with 256 input and 256 output channels on short sequences (t <= 48: the first
+ * HiFi-GAN level), two sequences per workgroup, weights DMA'd as pre-packed fragments (the stream layout of
+ * ifh_chain_desc for ONE convolution: taps * 8 k-steps of 16 fragments = taps * 8 units of 16 KB, no padding):
+ *     out = ((conv(lrelu(x, pre_slope); taps, dil) + bias) (+ resid)) * out_scale  (+ out if accumulate)
+ * i.e. what ifh_conv_bf16 computes for these shapes, with the same k order and the same rounding point (same bits).
+ * (taps-1)/2 * dil <= 25. */
+typedef struct ifh_ring256_desc {
+    const void *x;
+    int64_t x_bstride;
+    int32_t taps, dil, t, nbatch;
+    const void *wstream;
+    const float *bias;      /* [256] or NULL */
+    float pre_slope;        /* LeakyReLU slope on the input, (0, 1] (1 = none) */
+    const void *resid;      /* bf16 [nbatch][t][256] or NULL */
+    int64_t resid_bstride;
+    float out_scale;
+    int32_t accumulate;
+    void *out;
+    int64_t out_bstride;
+} ifh_ring256_desc;
+int ifh_conv_ring256_bf16(const ifh_ring256_desc *desc, ifh_stream_t stream);
+
 /* y = LayerNorm(x (+ resid)) * gamma + beta; rows of `dim` bf16, dim <= 1024, dim % 4 == 0 */
 int ifh_layernorm_bf16(const void *x, const void *resid, const float *gamma, const float *beta, void *out,
                        int rows, int dim, float eps, ifh_stream_t stream);

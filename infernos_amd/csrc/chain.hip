@@ -419,6 +419,187 @@ static int launch_chain(ChainParams &p, hipStream_t st)
     return IFH_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_conv_ring256 -- one stride-1 convolution with C = Cin = Cout = 256 on short sequences (the first HiFi-GAN level:
+// T = 48 rows per chunk), out = ((conv(lrelu(x); taps, dil) + bias) [+ resid]) * scale [+ out].
+//
+// At C = 256 a residual pair does not fit the chain kernel (two operand images of even ONE extra chunk exceed the LDS), and
+// the round-1 kernel (conv.hip, 48..96 rows per workgroup, weights through a register prefetch) is bound by the L2 -> CU
+// weight stream: every workgroup re-reads all of W (0.4-1.4 MB) for 48 rows.  Here a workgroup takes TWO chunks -- the x
+// image holds [25 zero rows | chunk a | 25 zero rows | chunk b | zero rows], so the gap is both chunks' zero padding -- as
+// 128 rows x 256 channels of MFMA work (8 waves x 32 output channels x 8 row tiles; 75 % of the rows are real), and the
+// weights arrive through the same DMA ring as above: a k-step is 16 fragments = one 16 KB unit = two global_load_lds per
+// wave, four units in the ring, fragment reads of unit v+1 never wait.  Workgroups are persistent over the chunk pairs.
+struct Ring256Params {
+    const uint16_t *x;
+    int64_t x_bstride;
+    const uint16_t *wstream;     // packed fragments of the convolution: taps * 8 units of 16 KB
+    const float *bias;           // [256] or null
+    const uint16_t *resid;       // [nbatch][T][256] or null
+    int64_t resid_bstride;
+    int T, nbatch, taps, dil;
+    float pre_slope, out_scale;
+    int accumulate;
+    uint16_t *out;
+    int64_t out_bstride;
+};
+
+__global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
+{
+    constexpr int C = 256, NT = 2, MT = 8, NR = NT + MT, NRING = 4, GX = 25;
+    constexpr int SB = (C + 16) * 2;                   // 544-byte rows: stride = 2 (mod 4) sixteen-byte slots
+    constexpr int RT = MT * 16;                        // 128 rows computed
+    constexpr int XROWS = RT + 2 * GX;
+    constexpr int UNIT = 16384;                        // one k-step: 16 fragments of 1 KB
+    constexpr int RING_OFF = XROWS * SB;
+    constexpr int BIAS_OFF = RING_OFF + NRING * UNIT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int T = p.T, pitch = T + GX;                 // chunk b starts `pitch` rows after chunk a
+    const int H = (p.taps - 1) / 2, KS = p.taps * 8;
+
+    for (int i = tid * 16; i < RING_OFF; i += 512 * 16) *reinterpret_cast<uint4 *>(lds + i) = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < C; i += 512) reinterpret_cast<float *>(lds + BIAS_OFF)[i] = p.bias ? p.bias[i] : 0.0f;
+    const unsigned char *wsrc = reinterpret_cast<const unsigned char *>(p.wstream) + wid * 2048 + lane * 16;
+    int u_issue = 0, ring_issue = 0, ring_read = 0;
+#define RING_DMA()                                                                                                       \
+    {                                                                                                                    \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; h_++)                                                                 \
+            __builtin_amdgcn_global_load_lds(                                                                            \
+                (const __attribute__((address_space(1))) void *)(wsrc + (int64_t)u_issue * UNIT + h_ * 1024),            \
+                (__attribute__((address_space(3))) void *)(lds + RING_OFF + ring_issue * UNIT + wid * 2048 + h_ * 1024), 16, 0, 0); \
+        u_issue = (u_issue + 1 == KS) ? 0 : u_issue + 1;                                                                 \
+        ring_issue = (ring_issue + 1 == NRING) ? 0 : ring_issue + 1;                                                     \
+    }
+#pragma unroll
+    for (int d = 0; d < NRING - 1; d++) RING_DMA()
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int ab = RING_OFF + wid * NT * 1024 + lane * 16;               // wave w owns output channels 32w .. 32w+31
+    const int xb = (GX + fr) * SB + fg * 16;
+    const int cw = (wid * NT * 16 + 4 * fg) * 2;
+    const int bias_b = BIAS_OFF + (wid * NT * 16 + 4 * fg) * 4;
+    f32x4 acc[NT][MT];
+    int nxt_a = 0, nxt_b = 0;
+    // entering a unit (= a k-step here): this wave's two pieces of the NEXT unit have landed (all DMAs but the youngest
+    // unit's two), everybody's have after the barrier, the slot of the previous unit is refilled three units ahead
+    auto frag_addr = [&](int s) {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        RING_DMA()
+        const int tap = s >> 3, cs = s & 7;
+        nxt_a = ab + ring_read * UNIT;
+        nxt_b = xb + (tap - H) * p.dil * SB + cs * 64;
+        ring_read = (ring_read + 1 == NRING) ? 0 : ring_read + 1;
+    };
+#define RING_READ(Q, FA, FB)                                                                                              \
+    {                                                                                                                     \
+        if ((Q) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(FA[0]) : "v"(nxt_a));                                     \
+        else if ((Q) == MT + 1) asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(FA[1]) : "v"(nxt_a));               \
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FB[(Q) - 1]) : "v"(nxt_b), "n"(((Q) - 1) * 16 * SB));    \
+    }
+    auto kstep = [&](const bf16x8_t (&ca)[NT], const bf16x8_t (&cb)[MT], bf16x8_t (&na)[NT], bf16x8_t (&nb)[MT], auto has_next) {
+        constexpr bool NEXT = decltype(has_next)::value;
+        if (!NEXT) {
+            asm volatile("s_waitcnt lgkmcnt(0)");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int k = 0; k < NT * MT; k++) {
+            if (NEXT && k < NR) {
+                if (k <= MT) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 2));
+                RING_READ(k, na, nb)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int i = k / MT, j = k - i * MT;
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int npairs = (p.nbatch + 1) / 2;
+    for (int tile = blockIdx.x; tile < npairs; tile += gridDim.x) {
+        const int b0 = tile * 2;
+        const int nb = min(2, p.nbatch - b0);
+        // x image: rows of chunk e at GX + e * pitch + t, LeakyReLU applied once here, 16 bytes per thread per step
+        for (int v = tid; v < nb * T * (C / 8); v += 512) {
+            const int rowi = v / (C / 8), c8 = v - rowi * (C / 8);
+            const int e = rowi / T, t = rowi - e * T;
+            const uint4 xv = *reinterpret_cast<const uint4 *>(p.x + (int64_t)(b0 + e) * p.x_bstride + (int64_t)t * C + c8 * 8);
+            *reinterpret_cast<uint4 *>(lds + (GX + e * pitch + t) * SB + c8 * 16) = p.pre_slope != 1.0f ? lrelu8(xv, p.pre_slope) : xv;
+        }
+        if (nb == 1)                                   // a lone last chunk: the second chunk's rows of the previous tile are stale
+            for (int v = tid; v < T * (C / 8); v += 512)
+                *reinterpret_cast<uint4 *>(lds + (GX + pitch + v / (C / 8)) * SB + (v % (C / 8)) * 16) = make_uint4(0, 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int i = 0; i < NT; i++)
+#pragma unroll
+            for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8_t fa0[NT], fb0[MT], fa1[NT], fb1[MT];
+        frag_addr(0);
+#pragma unroll
+        for (int q = 0; q < NR; q++) RING_READ(q, fa0, fb0)
+        __builtin_amdgcn_sched_barrier(0);
+        int s = 0;
+#pragma unroll 1
+        for (; s + 2 < KS; s += 2) {                   // KS = 8 * taps is even
+            frag_addr(s + 1);
+            kstep(fa0, fb0, fa1, fb1, std::true_type{});
+            frag_addr(s + 2);
+            kstep(fa1, fb1, fa0, fb0, std::true_type{});
+        }
+        frag_addr(s + 1);
+        kstep(fa0, fb0, fa1, fb1, std::true_type{});
+        kstep(fa1, fb1, fa0, fb0, std::false_type{});
+        // epilogue: + bias (+ residual) * scale (+ previous out) -> global, 8 bytes per lane
+        f32x4 bv[NT];
+#pragma unroll
+        for (int i = 0; i < NT; i++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[i]) : "v"(bias_b), "n"(i * 64));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < MT; j++) {
+            const int q = j * 16 + fr;
+            const int e = q >= pitch ? 1 : 0, t = q - e * pitch;
+            if (t < T && e < nb) {
+#pragma unroll
+                for (int i = 0; i < NT; i++) {
+                    const int64_t off = (int64_t)t * C + (wid * NT + i) * 16 + 4 * fg;
+                    const f32x4 a = acc[i][j];
+                    float v0 = a[0] + bv[i][0], v1 = a[1] + bv[i][1], v2 = a[2] + bv[i][2], v3 = a[3] + bv[i][3];
+                    if (p.resid) {
+                        const uint2 rv = *reinterpret_cast<const uint2 *>(p.resid + (int64_t)(b0 + e) * p.resid_bstride + off);
+                        v0 += __uint_as_float(rv.x << 16);
+                        v1 += __uint_as_float(rv.x & 0xffff0000u);
+                        v2 += __uint_as_float(rv.y << 16);
+                        v3 += __uint_as_float(rv.y & 0xffff0000u);
+                    }
+                    v0 *= p.out_scale; v1 *= p.out_scale; v2 *= p.out_scale; v3 *= p.out_scale;
+                    uint16_t *dst = p.out + (int64_t)(b0 + e) * p.out_bstride + off;
+                    if (p.accumulate) {
+                        const uint2 q2 = *reinterpret_cast<const uint2 *>(dst);
+                        v0 += __uint_as_float(q2.x << 16);
+                        v1 += __uint_as_float(q2.x & 0xffff0000u);
+                        v2 += __uint_as_float(q2.y << 16);
+                        v3 += __uint_as_float(q2.y & 0xffff0000u);
+                    }
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(f32x2_to_bf16x2(v0, v1), f32x2_to_bf16x2(v2, v3));
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // every wave is done with the x image before the next tile overwrites it
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef RING_READ
+#undef RING_DMA
+}
+
 }  // namespace ifh
 
 using namespace ifh;
@@ -471,5 +652,53 @@ extern "C" int ifh_resblock_chain_bf16(const ifh_chain_desc *d, ifh_stream_t str
 #undef CHAIN_CASE
     if (rc != IFH_OK) return rc;
     IFH_LAUNCH_CHECK("resblock_chain_bf16");
+    return IFH_OK;
+}
+
+extern "C" int ifh_conv_ring256_bf16(const ifh_ring256_desc *d, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(d);
+    IFH_CHECK_ARG(d->x && d->wstream && d->out);
+    IFH_CHECK_ARG(d->nbatch >= 0 && d->t >= 0);
+    if (d->nbatch == 0 || d->t == 0) return IFH_OK;
+    IFH_CHECK_ARG(d->t <= 48 && d->taps >= 1 && d->taps <= 11 && (d->taps & 1) == 1 && d->dil >= 1 && (d->taps - 1) / 2 * d->dil <= 25);
+    IFH_CHECK_ARG((((uintptr_t)d->x) & 15) == 0 && (((uintptr_t)d->out) & 7) == 0 && (((uintptr_t)d->wstream) & 15) == 0 &&
+                  (!d->resid || (((uintptr_t)d->resid) & 7) == 0) && (!d->bias || (((uintptr_t)d->bias) & 3) == 0) &&
+                  d->x_bstride % 8 == 0 && d->out_bstride % 4 == 0 && d->resid_bstride % 4 == 0);
+    IFH_CHECK_ARG(d->pre_slope > 0.0f && d->pre_slope <= 1.0f);
+    Ring256Params p;
+    p.x = (const uint16_t *)d->x;
+    p.x_bstride = d->x_bstride;
+    p.wstream = (const uint16_t *)d->wstream;
+    p.bias = d->bias;
+    p.resid = (const uint16_t *)d->resid;
+    p.resid_bstride = d->resid_bstride;
+    p.T = d->t;
+    p.nbatch = d->nbatch;
+    p.taps = d->taps;
+    p.dil = d->dil;
+    p.pre_slope = d->pre_slope;
+    p.out_scale = d->out_scale;
+    p.accumulate = d->accumulate;
+    p.out = (uint16_t *)d->out;
+    p.out_bstride = d->out_bstride;
+    constexpr size_t bytes = (size_t)(128 + 50) * 544 + 4 * 16384 + 256 * sizeof(float);
+    static_assert(bytes <= 160 * 1024, "ring256 tile");
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)k_conv_ring256, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return check_hip(e, "conv_ring256 lds attr");
+        attr_set = true;
+    }
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(IFH_EHIP, "conv_ring256: device query");
+        ncu = prop.multiProcessorCount;
+    }
+    const int npairs = (d->nbatch + 1) / 2;
+    hipLaunchKernelGGL(k_conv_ring256, dim3(npairs < ncu ? npairs : ncu), dim3(512), bytes, as_stream(stream), p);
+    IFH_LAUNCH_CHECK("conv_ring256_bf16");
     return IFH_OK;
 }

@@ -47,6 +47,16 @@ class HifiGan:
                     convs.append((sd[R + 'convs1.%d.weight' % d], sd[R + 'convs1.%d.bias' % d]))
                     convs.append((sd[R + 'convs2.%d.weight' % d], sd[R + 'convs2.%d.bias' % d]))
                 self.chain[(i, j)] = ops.w_chain_pack(convs, dev)
+        # the C = 256 level: every convolution as its own fragment stream for ifh_conv_ring256_bf16 (two chunks per workgroup)
+        self.ring = {}
+        self.fused_ring = os.environ.get('IFH_NO_RING256') is None          # tuning switch
+        for j in range(3):
+            R = 'resblocks.%d.' % j
+            for d in range(3):
+                for which in (1, 2):
+                    ws, _, b = ops.w_chain_pack([(sd[R + 'convs%d.%d.weight' % (which, d)], sd[R + 'convs%d.%d.bias' % (which, d)])],
+                                                dev, unit_bytes=16384)
+                    self.ring[(j, d, which)] = (ws, b.reshape(-1))
         self.post_w = sd['conv_post.weight'].float()[0].t().contiguous().to(dev)     # [7][32]
         self.post_b = float(sd['conv_post.bias'].float()[0])
         self._bufs = {}
@@ -103,6 +113,15 @@ class HifiGan:
                     continue
                 for di, d in enumerate((1, 3, 5)):
                     w1, b1, w2, b2 = self.res[i][j][di]
+                    if self.fused_ring and c == 256 and t <= 48 and i == 0:
+                        last = di == 2
+                        nxt = xn if last else rbuf[di]
+                        (ws1, rb1), (ws2, rb2) = self.ring[(j, di, 1)], self.ring[(j, di, 2)]
+                        ops.conv_ring256(cur, ws1, rb1, h, nbatch=n, t=t, taps=k, dil=d, pre_slope=0.1)
+                        ops.conv_ring256(h, ws2, rb2, nxt, nbatch=n, t=t, taps=k, dil=1, pre_slope=0.1, resid=cur,
+                                         scale=(1.0 / 3.0 if last else 1.0), accumulate=(last and j > 0))
+                        cur = nxt
+                        continue
                     # both convolutions in one launch, intermediate kept in LDS (same bits) -- except at C = 256 with
                     # >= 512 batch entries, where two launches measure 1.2-1.35x faster (tools/probe_resblock.py 768)
                     if self.fused_pairs and not (c == 256 and n >= 512):

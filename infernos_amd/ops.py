@@ -80,6 +80,20 @@ def resblock_chain(x, wstream, nunits, bias, out, *, nbatch, t, c, taps, slope=0
     return out
 
 
+def conv_ring256(x, wstream, bias, out, *, nbatch, t, taps, dil=1, pre_slope=1.0, resid=None, scale=1.0, accumulate=False):
+    """One 256 -> 256 channel "same" convolution on sequences of t <= 48 rows (ifh_conv_ring256_bf16: two sequences per
+    workgroup, weights DMA'd as fragments from w_chain_pack([(w, b)], unit_bytes=16384)); same bits as conv()."""
+    d = _lib.Ring256Desc()
+    d.x, d.x_bstride = _addr(x), t * 256
+    d.taps, d.dil, d.t, d.nbatch = taps, dil, t, nbatch
+    d.wstream, d.bias, d.pre_slope = _addr(wstream), _addr(bias), pre_slope
+    d.resid, d.resid_bstride = _addr(resid), t * 256
+    d.out_scale, d.accumulate = scale, int(accumulate)
+    d.out, d.out_bstride = _addr(out), t * 256
+    _lib.check(_lib.lib().ifh_conv_ring256_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_conv_ring256_bf16')
+    return out
+
+
 def linear(x, w, bias, out, *, rows, k, n, **kw):
     """out[rows, n] = epi(x[rows, k] @ w[n, k]^T + bias)"""
     return conv(x, w, bias, out, nbatch=1, t_in=rows, t_out=rows, cin=k, n=n, **kw)
@@ -178,7 +192,7 @@ def w_conv(w, device, scale_per_out=None):
     return w.permute(0, 2, 1).to(BF16).contiguous().to(device)
 
 
-def w_chain_pack(convs, device):
+def w_chain_pack(convs, device, unit_bytes=8192):
     """The six convolutions of one HiFi-GAN residual block -- [(conv1_d1, b), (conv2_d1, b), (conv1_d3, b), ...], each
     weight in Conv1d layout [Cout, Cin, k] -- as the fragment stream ifh_resblock_chain_bf16 DMAs into LDS (layout in
     include/infernos_hip.h: per k-step of 32, per 16 output channels, 64 lanes x 8 bf16 in MFMA A-operand order), zero
@@ -194,7 +208,7 @@ def w_chain_pack(convs, device):
         parts.append(f.reshape(-1))
         biases.append(torch.zeros(cout) if b is None else b.float())
     stream = torch.cat(parts)
-    unit = 8192 // 2
+    unit = unit_bytes // 2
     nunits = -(-stream.numel() // unit)
     pad = nunits * unit - stream.numel()
     if pad:

@@ -270,13 +270,29 @@ class cleanup_text_eu:
         return text.translate(self.table)
 
 
+def get_ja_T5Processor(device, model_name):
+    """The 'ja' processor hook of Cluster/InfernTTSWorker.py:9-20 (OpenJTalk tokenizer + SpeechT5 feature extractor).  Its
+    tokenizer lives in `utils.speecht5_openjtalk_tokenizer`, a module the reference imports but does not ship; it is
+    picked up from the host application when that provides it."""
+    try:
+        from utils.speecht5_openjtalk_tokenizer import SpeechT5OpenjtalkTokenizer
+    except ImportError as e:
+        raise ImportError("lang 'ja' needs utils.speecht5_openjtalk_tokenizer (imported by the reference at "
+                          "Cluster/InfernTTSWorker.py:10 but absent from its tree): provide it on sys.path") from e
+    from transformers import SpeechT5FeatureExtractor, SpeechT5Processor
+    tok = SpeechT5OpenjtalkTokenizer.from_pretrained(model_name)
+    tok._in_target_context_manager, tok.split_special_tokens, tok._added_tokens_encoder, tok._unk_token = False, True, {}, None
+    return SpeechT5Processor(SpeechT5FeatureExtractor.from_pretrained(model_name), tok)
+
+
 lang2model = {'en': {'cleanup_text': cleanup_text_eu()},
               'it': {'model': 'Sandiago21/speecht5_finetuned_voxpopuli_it', 'cleanup_text': cleanup_text_eu()},
               'es': {'model': 'Sandiago21/speecht5_finetuned_facebook_voxpopuli_spanish', 'cleanup_text': cleanup_text_eu()},
               'fr': {'model': 'Sandiago21/speecht5_finetuned_facebook_voxpopuli_french', 'cleanup_text': cleanup_text_eu()},
               'de': {'model': 'JFuellem/speecht5_finetuned_voxpopuli_de', 'cleanup_text': cleanup_text_eu()},
               'pt': {'model': 'evertonaleixo/speecht5_finetuned_fleurs_ptbr', 'cleanup_text': cleanup_text_eu()},
-              'ru': {'model': 'zaebee/speecht5_tts_common_ru'}}
+              'ru': {'model': 'zaebee/speecht5_tts_common_ru'},
+              'ja': {'model': 'esnya/japanese_speecht5_tts', 'get_processor': get_ja_T5Processor}}
 
 
 class InfernTTSWorker(InfernBatchedWorker):

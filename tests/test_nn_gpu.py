@@ -289,6 +289,40 @@ def test_resblock_chain_is_bit_identical_to_three_pairs(dev, case):
             float(diff.max()), bad.size(0), bad[:6].tolist()))
 
 
+@pytest.mark.parametrize('case', [
+    dict(B=4, T=48, k=3, d=1), dict(B=5, T=48, k=7, d=3, resid=True), dict(B=7, T=48, k=11, d=5, resid=True, scale=1 / 3, acc=True),
+    dict(B=1, T=48, k=11, d=1), dict(B=3, T=37, k=7, d=5, resid=True), dict(B=600, T=48, k=11, d=3, resid=True),
+    dict(B=2, T=48, k=3, d=5, pre=1.0),
+])
+def test_conv_ring256_is_bit_identical_to_conv(dev, case):
+    """ifh_conv_ring256_bf16 (two chunks per workgroup around a shared zero gap, weights through the DMA fragment ring,
+    persistent workgroups) against ifh_conv_bf16 on the same operands: same k order and rounding point, so the same bits --
+    odd chunk counts (a lone last chunk after a full pair), short sequences, residual / scale / accumulate epilogues."""
+    from infernos_amd import ops
+    B, T, k, d = case['B'], case['T'], case['k'], case['d']
+    pre = case.get('pre', 0.1)
+    g = torch.Generator().manual_seed(B * 11 + T + k + d)
+    x = torch.randn(B, T, 256, generator=g).to(BF).to(dev)
+    w = bfr(torch.randn(256, 256, k, generator=g) / (256 * k) ** 0.5)
+    b = torch.randn(256, generator=g) * 0.1
+    resid = torch.randn(B, T, 256, generator=g).to(BF).to(dev) if case.get('resid') else None
+    prev = torch.randn(B, T, 256, generator=g).to(BF).to(dev)
+    scale, acc = case.get('scale', 1.0), case.get('acc', False)
+    ref = prev.clone()
+    ops.conv(x, ops.w_conv(w, dev), b.to(dev), ref, nbatch=B, t_in=T, t_out=T, cin=256, n=256, taps=k, dil=d, pad=(k - 1) // 2 * d,
+             pre_slope=pre, resid=resid, scale=scale, accumulate=acc)
+    ws, nunits, bias = ops.w_chain_pack([(w, b)], dev, unit_bytes=16384)
+    assert nunits == 8 * k
+    out = prev.clone()
+    ops.conv_ring256(x, ws, bias.reshape(-1), out, nbatch=B, t=T, taps=k, dil=d, pre_slope=pre, resid=resid, scale=scale, accumulate=acc)
+    torch.cuda.synchronize()
+    if not torch.equal(out.view(torch.int16), ref.view(torch.int16)):
+        diff = (out.float() - ref.float()).abs()
+        bad = torch.nonzero(diff.amax(dim=2) > 0)
+        raise AssertionError('ring256 differs from conv: max abs %g at %d rows, first (batch,row) %s' % (
+            float(diff.max()), bad.size(0), bad[:6].tolist()))
+
+
 def test_layernorm_and_transpose(dev):
     from infernos_amd import ops
     g = torch.Generator().manual_seed(6)

@@ -81,15 +81,30 @@ def main():
                       ' '.join('K%d %.0f E%d %.0f' % (q, per[1 + 2 * q], q, per[2 + 2 * q]) for q in range(6)) +
                       ' | sum %.0f, block life/tile %.0f, tiles/block %.1f' % (sum(per), pr[14] / max(nt, 1), nt / max(nb, 1)), flush=True)
     print('levels 1-3, 9 residual blocks: pairs %.3f ms, chain %.3f ms' % (tot_p * 1e3, tot_c * 1e3))
+    # the C = 256 level: ifh_conv_ring256_bf16 against ifh_conv_bf16, per convolution
+    x = torch.randn(n, 48, 256, generator=g).to(BF).to(dev)
+    o1, o2 = torch.zeros_like(x), torch.zeros_like(x)
+    for k in (3, 7, 11):
+        for d in (1, 5):
+            w = (torch.randn(256, 256, k, generator=g) / (256 * k) ** 0.5).to(BF).float()
+            b = torch.randn(256, generator=g) * 0.1
+            wd, bd = ops.w_conv(w, dev), b.to(dev)
+            ws, nu, bias = ops.w_chain_pack([(w, b)], dev, unit_bytes=16384)
+            t0 = ev_time(lambda: ops.conv(x, wd, bd, o1, nbatch=n, t_in=48, t_out=48, cin=256, n=256, taps=k, dil=d, pad=(k - 1) // 2 * d,
+                                          pre_slope=0.1, resid=x))
+            t1 = ev_time(lambda: ops.conv_ring256(x, ws, bias.reshape(-1), o2, nbatch=n, t=48, taps=k, dil=d, pre_slope=0.1, resid=x))
+            gf = 2 * 48 * 256 * 256 * k * n / 1e9
+            print('C=256 k=%2d d=%d: conv %7.1f us (%6.0f TF/s)   ring256 %7.1f us (%6.0f TF/s)   x%.2f  same bits: %s' % (
+                k, d, t0 * 1e6, gf / t0 / 1e3, t1 * 1e6, gf / t1 / 1e3, t0 / t1, torch.equal(o1.view(torch.int16), o2.view(torch.int16))), flush=True)
     from infernos_amd.engines.vocoder import HifiGan
     from infernos_amd.weights import synth_state_dict
     voc = HifiGan(synth_state_dict('hifigan', 0), dev)
     vin = torch.randn(n, 12, 80, generator=g).to(BF).to(dev)
-    for fused in (False, True):
-        voc.fused_chain = fused
+    for fused, ring in ((False, False), (True, False), (True, True)):
+        voc.fused_chain, voc.fused_ring = fused, ring
         t = ev_time(lambda: voc(vin), n=5)
-        print('vocoder pass, %d chunks, chain=%s: %.3f ms = %.0f TFLOP/s (%.1f %% of 2.5 PF)' % (
-            n, fused, t * 1e3, n * 3.28 / t / 1e3, n * 3.28 / t / 1e3 / 25))
+        print('vocoder pass, %d chunks, chain=%s ring256=%s: %.3f ms = %.0f TFLOP/s (%.1f %% of 2.5 PF)' % (
+            n, fused, ring, t * 1e3, n * 3.28 / t / 1e3, n * 3.28 / t / 1e3 / 25))
 
 
 if __name__ == '__main__':
