@@ -9,6 +9,8 @@ import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libinfernos_hip.so')
+if os.environ.get('IFH_LIB_PATH'):          # tools/ only: an experimental build of the same library
+    LIB_PATH = os.environ['IFH_LIB_PATH']
 
 c_i32p = ctypes.POINTER(ctypes.c_int32)
 _vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double

@@ -31,6 +31,11 @@
 
 #include "igemm.h"
 
+// CHAIN_ABL (tools/ builds only, wrong results): 1 = no MFMAs, 2 = no fragment reads, 4 = no weight-unit sync
+#ifndef CHAIN_ABL
+#define CHAIN_ABL 0
+#endif
+
 namespace ifh {
 
 struct ChainParams {
@@ -46,6 +51,7 @@ struct ChainParams {
     uint16_t *out;
     int64_t out_bstride;
     unsigned long long *prof;    // optional diagnostic: shader-clock sums per phase (wave 0 of every block), see ifh_chain_desc
+    int exp;                     // PROF builds only (env IFH_CHAIN_EXP): ablations -- 1 no unit sync, 2 no fragment reads, 4 no MFMAs (wrong results)
 };
 
 __device__ __forceinline__ uint2 chain_lrelu4(uint2 v, float slope)
@@ -57,6 +63,44 @@ __device__ __forceinline__ uint2 chain_lrelu4(uint2 v, float slope)
     c = fmaxf(c, c * slope);
     d = fmaxf(d, d * slope);
     return make_uint2(f32x2_to_bf16x2(a, b), f32x2_to_bf16x2(c, d));
+}
+
+// s_waitcnt lgkmcnt(n) with n known only after loop unrolling (the immediate must be a literal)
+__device__ __forceinline__ void wait_lgkm(int n)
+{
+    switch (n) {
+    case 0: asm volatile("s_waitcnt lgkmcnt(0)"); break;
+    case 1: asm volatile("s_waitcnt lgkmcnt(1)"); break;
+    case 2: asm volatile("s_waitcnt lgkmcnt(2)"); break;
+    case 3: asm volatile("s_waitcnt lgkmcnt(3)"); break;
+    case 4: asm volatile("s_waitcnt lgkmcnt(4)"); break;
+    case 5: asm volatile("s_waitcnt lgkmcnt(5)"); break;
+    case 6: asm volatile("s_waitcnt lgkmcnt(6)"); break;
+    case 7: asm volatile("s_waitcnt lgkmcnt(7)"); break;
+    case 8: asm volatile("s_waitcnt lgkmcnt(8)"); break;
+    case 9: asm volatile("s_waitcnt lgkmcnt(9)"); break;
+    case 10: asm volatile("s_waitcnt lgkmcnt(10)"); break;
+    case 11: asm volatile("s_waitcnt lgkmcnt(11)"); break;
+    case 12: asm volatile("s_waitcnt lgkmcnt(12)"); break;
+    default: asm volatile("s_waitcnt lgkmcnt(13)"); break;
+    }
+}
+// The NR fragment reads of the next k-step are spread evenly over the NM MFMAs of this one: read i sits in front of
+// MFMA i*NM/NR.  (In front of the first NR MFMAs they kept the LDS 100 % busy for two thirds of the k-step -- every
+// wave issues at the same time -- and idle for the rest; an LDS instruction that finds the queue full stalls its wave's
+// MFMA issue.)  rd_at(k): the read in front of MFMA k or -1; rd_before(k): reads issued in front of MFMAs 0..k-1.
+constexpr int rd_at(int k, int nr, int nm)
+{
+    for (int i = 0; i < nr; i++)
+        if (i * nm / nr == k) return i;
+    return -1;
+}
+constexpr int rd_before(int k, int nr, int nm)
+{
+    int n = 0;
+    for (int i = 0; i < nr; i++)
+        if (i * nm / nr < k) n++;
+    return n;
 }
 
 constexpr int kUnitBytes = 8192;     // 8 waves x 64 lanes x 16 B: one global_load_lds per wave
@@ -170,9 +214,11 @@ __global__ __launch_bounds__(512, 2) void k_resblock_chain(const ChainParams p)
     // through inline asm with hand-counted s_waitcnt: as ordinary loads the compiler waits lgkmcnt(0) in front of the MFMAs
     // (the reads just issued for the NEXT k-step included) and vmcnt(0) in front of any LDS access while a weight DMA is
     // pending -- either one serialises the pipeline.
-    int nxt_a = 0, nxt_b = 0;                          // byte addresses of the fragments being fetched
-    auto frag_addr = [&](int src, int dd, int s) {     // k-step s of the current convolution: enter its unit, fix the addresses
-        if (ks_in_unit == 0) CHAIN_ENTER_UNIT()
+    int nxt_a = 0, nxt_b = 0;                          // byte addresses of the fragments to fetch next
+    bool nxt_enter = false;                            // ... and whether that k-step is the first of a weight unit
+    // addresses of k-step s of the current convolution; no synchronisation here, so that it can sit in the shadow of MFMAs
+    auto advance = [&](int src, int dd, int s) {
+        nxt_enter = ks_in_unit == 0;
         const int tap = s / KSUB, cs = s - tap * KSUB;
         nxt_a = ab + ring_read * kUnitBytes + ks_in_unit * (FRAGS * 1024);
         nxt_b = src + (tap - H) * dd * SB + cs * 64;
@@ -188,25 +234,45 @@ __global__ __launch_bounds__(512, 2) void k_resblock_chain(const ChainParams p)
         else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FB[(Q) - 1]) : "v"(nxt_b), "n"(((Q) - 1) * 16 * SB));    \
     }
     // One k-step: the MFMAs on the fragments in (ca, cb) in the order (A0 x B0..B(MT-1)), (A1 x B0..B(MT-1)), with the NR
-    // reads of the NEXT k-step into (na, nb) issued one per MFMA in front of the first NR of them -- all eight waves run
-    // in step, so reads issued as one burst would occupy the LDS for ~250 cycles in which no MFMA issues.  LDS reads return
-    // in order: in front of MFMA k (k <= MT) the fragment it needs is back once at most NR - 2 reads are outstanding.
-    auto kstep = [&](const bf16x8_t (&ca)[NT], const bf16x8_t (&cb)[MT], bf16x8_t (&na)[NT], bf16x8_t (&nb)[MT], auto has_next) {
+    // reads of the NEXT k-step (addresses already in nxt_*) into (na, nb) issued one per MFMA in front of the first NR of
+    // them -- all eight waves run in step, so reads issued as one burst would occupy the LDS for ~250 cycles in which no MFMA
+    // issues.  LDS reads return in order: in front of MFMA k (k <= MT) the fragment it needs is back once at most NR - 2
+    // reads are outstanding.  If the next k-step opens a weight unit the waves meet first (CHAIN_ENTER_UNIT without its
+    // DMA); everything that is not needed for the first MFMA -- the refill DMA, the addresses of the k-step after next
+    // (s_after, or < 0) -- is issued behind MFMAs, because between the barrier and the first MFMA the matrix pipe idles.
+    auto kstep = [&](const bf16x8_t (&ca)[NT], const bf16x8_t (&cb)[MT], bf16x8_t (&na)[NT], bf16x8_t (&nb)[MT], auto has_next,
+                     int src, int dd, int s_after) {
         constexpr bool NEXT = decltype(has_next)::value;
+        const bool enter = NEXT && nxt_enter;
+        if (enter && !(CHAIN_ABL & 4) && !(PROF && (p.exp & 1))) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRING - 3) : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         if (!NEXT) {
             asm volatile("s_waitcnt lgkmcnt(0)");
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int k = 0; k < NT * MT; k++) {
-            if (NEXT && k < NR) {
-                if (k <= MT) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 2));
-                CHAIN_READ(k, na, nb)
+            if (NEXT && !(CHAIN_ABL & 2) && !(PROF && (p.exp & 2))) {
+                // MFMA k <= MT needs fragment q(k+1) (q0 too for k = 0) of the current set: reads return in order, so it is
+                // back once no more than [reads of this set behind it] + [reads of the next set issued so far] are outstanding
+                if (k <= MT) wait_lgkm(NR - 2 - (k < MT ? k : MT) + rd_before(k, NR, NT * MT) + (k == MT ? NT - 2 : 0));
+                if (rd_at(k, NR, NT * MT) >= 0) CHAIN_READ(rd_at(k, NR, NT * MT), na, nb)
                 __builtin_amdgcn_sched_barrier(0);
             }
             const int i = k / MT, j = k - i * MT;
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
+            if (!(CHAIN_ABL & 1) && !(PROF && (p.exp & 4))) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (k == 1 && enter) {
+                CHAIN_DMA()
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (k == NT * MT - 1 && s_after >= 0) {      // every read of the next set has its address: move on to the one after
+                advance(src, dd, s_after);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
     // one convolution over the image at `src` with dilation dd, two fragment sets
@@ -216,24 +282,23 @@ __global__ __launch_bounds__(512, 2) void k_resblock_chain(const ChainParams p)
 #pragma unroll
             for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         bf16x8_t fa0[NT], fb0[MT], fa1[NT], fb1[MT];
-        frag_addr(src, dd, 0);
+        advance(src, dd, 0);
+        if (nxt_enter) CHAIN_ENTER_UNIT()
 #pragma unroll
         for (int q = 0; q < NR; q++) CHAIN_READ(q, fa0, fb0)
         __builtin_amdgcn_sched_barrier(0);
+        if (KS > 1) advance(src, dd, 1);
         int s = 0;
 #pragma unroll 1
         for (; s + 2 < KS; s += 2) {
-            frag_addr(src, dd, s + 1);
-            kstep(fa0, fb0, fa1, fb1, std::true_type{});
-            frag_addr(src, dd, s + 2);
-            kstep(fa1, fb1, fa0, fb0, std::true_type{});
+            kstep(fa0, fb0, fa1, fb1, std::true_type{}, src, dd, s + 2);
+            kstep(fa1, fb1, fa0, fb0, std::true_type{}, src, dd, s + 3 < KS ? s + 3 : -1);
         }
         if (s + 1 < KS) {
-            frag_addr(src, dd, s + 1);
-            kstep(fa0, fb0, fa1, fb1, std::true_type{});
-            kstep(fa1, fb1, fa0, fb0, std::false_type{});
+            kstep(fa0, fb0, fa1, fb1, std::true_type{}, src, dd, -1);
+            kstep(fa1, fb1, fa0, fb0, std::false_type{}, src, dd, -1);
         } else {
-            kstep(fa0, fb0, fa1, fb1, std::false_type{});
+            kstep(fa0, fb0, fa1, fb1, std::false_type{}, src, dd, -1);
         }
     };
     // this lane's biases of convolution q: read through inline asm -- as an ordinary LDS read the compiler puts an
@@ -483,13 +548,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
     const int bias_b = BIAS_OFF + (wid * NT * 16 + 4 * fg) * 4;
     f32x4 acc[NT][MT];
     int nxt_a = 0, nxt_b = 0;
-    // entering a unit (= a k-step here): this wave's two pieces of the NEXT unit have landed (all DMAs but the youngest
-    // unit's two), everybody's have after the barrier, the slot of the previous unit is refilled three units ahead
-    auto frag_addr = [&](int s) {
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        RING_DMA()
+    // addresses of k-step s (= weight unit s): no synchronisation, so it can sit behind MFMAs
+    auto advance = [&](int s) {
         const int tap = s >> 3, cs = s & 7;
         nxt_a = ab + ring_read * UNIT;
         nxt_b = xb + (tap - H) * p.dil * SB + cs * 64;
@@ -501,22 +561,41 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
         else if ((Q) == MT + 1) asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(FA[1]) : "v"(nxt_a));               \
         else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FB[(Q) - 1]) : "v"(nxt_b), "n"(((Q) - 1) * 16 * SB));    \
     }
-    auto kstep = [&](const bf16x8_t (&ca)[NT], const bf16x8_t (&cb)[MT], bf16x8_t (&na)[NT], bf16x8_t (&nb)[MT], auto has_next) {
+    // entering a unit (= a k-step here): this wave's two pieces of the NEXT unit have landed (all DMAs but the youngest
+    // unit's two), everybody's have after the barrier; the slot of the previous unit is refilled three units ahead, behind
+    // the first MFMAs (as in k_resblock_chain: nothing but the barrier sits between two k-steps' MFMAs)
+#define RING_ENTER()                                            \
+    {                                                           \
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+        __builtin_amdgcn_s_barrier();                           \
+    }
+    auto kstep = [&](const bf16x8_t (&ca)[NT], const bf16x8_t (&cb)[MT], bf16x8_t (&na)[NT], bf16x8_t (&nb)[MT], auto has_next,
+                     int s_after) {
         constexpr bool NEXT = decltype(has_next)::value;
+        if (NEXT) RING_ENTER()
         if (!NEXT) {
             asm volatile("s_waitcnt lgkmcnt(0)");
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int k = 0; k < NT * MT; k++) {
-            if (NEXT && k < NR) {
-                if (k <= MT) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR - 2));
-                RING_READ(k, na, nb)
+            if (NEXT) {
+                if (k <= MT) wait_lgkm(NR - 2 - (k < MT ? k : MT) + rd_before(k, NR, NT * MT));
+                if (rd_at(k, NR, NT * MT) >= 0) RING_READ(rd_at(k, NR, NT * MT), na, nb)
                 __builtin_amdgcn_sched_barrier(0);
             }
             const int i = k / MT, j = k - i * MT;
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if (k == 1 && NEXT) {
+                RING_DMA()
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (k == NT * MT - 1 && s_after >= 0) {
+                advance(s_after);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 
@@ -541,21 +620,21 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
 #pragma unroll
             for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         bf16x8_t fa0[NT], fb0[MT], fa1[NT], fb1[MT];
-        frag_addr(0);
+        advance(0);
+        RING_ENTER()
+        RING_DMA()
 #pragma unroll
         for (int q = 0; q < NR; q++) RING_READ(q, fa0, fb0)
         __builtin_amdgcn_sched_barrier(0);
+        advance(1);
         int s = 0;
 #pragma unroll 1
         for (; s + 2 < KS; s += 2) {                   // KS = 8 * taps is even
-            frag_addr(s + 1);
-            kstep(fa0, fb0, fa1, fb1, std::true_type{});
-            frag_addr(s + 2);
-            kstep(fa1, fb1, fa0, fb0, std::true_type{});
+            kstep(fa0, fb0, fa1, fb1, std::true_type{}, s + 2);
+            kstep(fa1, fb1, fa0, fb0, std::true_type{}, s + 3);
         }
-        frag_addr(s + 1);
-        kstep(fa0, fb0, fa1, fb1, std::true_type{});
-        kstep(fa1, fb1, fa0, fb0, std::false_type{});
+        kstep(fa0, fb0, fa1, fb1, std::true_type{}, -1);
+        kstep(fa1, fb1, fa0, fb0, std::false_type{}, -1);
         // epilogue: + bias (+ residual) * scale (+ previous out) -> global, 8 bytes per lane
         f32x4 bv[NT];
 #pragma unroll
@@ -596,6 +675,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
         __builtin_amdgcn_s_barrier();                  // every wave is done with the x image before the next tile overwrites it
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef RING_ENTER
 #undef RING_READ
 #undef RING_DMA
 }
@@ -629,6 +709,7 @@ extern "C" int ifh_resblock_chain_bf16(const ifh_chain_desc *d, ifh_stream_t str
     p.out = (uint16_t *)d->out;
     p.out_bstride = d->out_bstride;
     p.prof = (unsigned long long *)d->debug_prof;
+    p.exp = (p.prof && getenv("IFH_CHAIN_EXP")) ? atoi(getenv("IFH_CHAIN_EXP")) : 0;
     hipStream_t st = as_stream(stream);
     int rc = IFH_EINVAL;
     //                      <C, TAPS, WGM, WGN, MT, NT, HC, NRING, GX>

@@ -44,9 +44,12 @@ def main():
             ops.resblock_chain(x, ws, nu, bias, out, nbatch=n, t=T, c=c, taps=k, scale=1 / 3)
         torch.cuda.synchronize()
         return
-    for c, T in ((128, 192), (64, 768), (32, 3072)):
+    shapes = ((128, 192), (64, 768), (32, 3072))
+    if os.environ.get('SHAPES'):
+        shapes = tuple(sh for sh in shapes if str(sh[0]) in os.environ['SHAPES'].split(','))
+    for c, T in shapes:
         x = torch.randn(n, T, c, generator=g).to(BF).to(dev)
-        for k in (3, 7, 11):
+        for k in ((11,) if os.environ.get('K11') else (3, 7, 11)):
             convs, dw = [], []
             for d in (1, 3, 5):
                 for _ in range(2):
@@ -81,6 +84,8 @@ def main():
                       ' '.join('K%d %.0f E%d %.0f' % (q, per[1 + 2 * q], q, per[2 + 2 * q]) for q in range(6)) +
                       ' | sum %.0f, block life/tile %.0f, tiles/block %.1f' % (sum(per), pr[14] / max(nt, 1), nt / max(nb, 1)), flush=True)
     print('levels 1-3, 9 residual blocks: pairs %.3f ms, chain %.3f ms' % (tot_p * 1e3, tot_c * 1e3))
+    if os.environ.get('K11'):
+        return
     # the C = 256 level: ifh_conv_ring256_bf16 against ifh_conv_bf16, per convolution
     x = torch.randn(n, 48, 256, generator=g).to(BF).to(dev)
     o1, o2 = torch.zeros_like(x), torch.zeros_like(x)
