@@ -54,9 +54,15 @@ class InfernSTTActor:
         for w in self.workers:
             w.stop()
 
+    def _pool(self):
+        if not hasattr(self, 'workers'):          # `.stt` set directly, the reference's attribute: a pool of one
+            self.workers, self.router = [self.stt], SessionRouter(1)
+        return self.workers, self.router
+
     def new_stt_session(self, keep_context: bool = False):
+        workers, router = self._pool()
         sess = STTSession(None, keep_context)
-        sess.stt = self.workers[self.router.assign(sess.id)]        # sticky: the session's chunks all go to this GPU
+        sess.stt = workers[router.assign(sess.id)]                  # sticky: the session's chunks all go to this GPU
         self.sessions[sess.id] = sess
         return sess.id
 
@@ -64,7 +70,7 @@ class InfernSTTActor:
         sess = self.sessions[sess_id]
         sess.stop()
         del self.sessions[sess_id]
-        self.router.release(sess_id)
+        self._pool()[1].release(sess_id)
 
     def stt_session_soundin(self, sess_id, req: Union[STTRequest, STTSentinel]):
         self.sessions[sess_id].soundin(req)
@@ -96,9 +102,15 @@ class InfernTTSActor:
     def get_rand_voice_id(self) -> int:
         return self.tts.get_rand_voice_id()
 
+    def _pool(self):
+        if not hasattr(self, 'workers'):          # `.tts` set directly, the reference's attribute: a pool of one
+            self.workers, self.router = [self.tts], SessionRouter(1)
+        return self.workers, self.router
+
     def new_tts_session(self):
+        workers, router = self._pool()
         rgen = TTSSession(self.tts, self.tts_actr)
-        rgen.tts = self.workers[self.router.assign(rgen.id)]        # sticky: KV caches / carry frames live on that GPU
+        rgen.tts = workers[router.assign(rgen.id)]                  # sticky: KV caches / carry frames live on that GPU
         self.sessions[rgen.id] = rgen
         return rgen.id
 
@@ -114,7 +126,7 @@ class InfernTTSActor:
     def tts_session_end(self, rgen_id):
         self.sessions[rgen_id].stop()
         del self.sessions[rgen_id]
-        self.router.release(rgen_id)
+        self._pool()[1].release(rgen_id)
 
 
 class RemoteTTSSession:
