@@ -54,15 +54,24 @@ struct ChainParams {
     int exp;                     // PROF builds only (env IFH_CHAIN_EXP): ablations -- 1 no unit sync, 2 no fragment reads, 4 no MFMAs (wrong results)
 };
 
+// LeakyReLU of four packed bf16, rounded back to bf16: max(a, a * slope) for 0 < slope <= 1 (the values of lrelu8 /
+// fmaxf(a, a * slope), bit for bit).  fmaxf() costs a canonicalising v_max x,x per operand that comes out of bit
+// operations; the epilogues are VALU-issue-bound and run in no MFMA's shadow, so the maximum is one v_max_f32 by hand
+// and the products are packed (v_pk_mul_f32).
+__device__ __forceinline__ float chain_max(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ uint2 chain_lrelu4(uint2 v, float slope)
 {
-    float a = __uint_as_float(v.x << 16), b = __uint_as_float(v.x & 0xffff0000u);
-    float c = __uint_as_float(v.y << 16), d = __uint_as_float(v.y & 0xffff0000u);
-    a = fmaxf(a, a * slope);
-    b = fmaxf(b, b * slope);
-    c = fmaxf(c, c * slope);
-    d = fmaxf(d, d * slope);
-    return make_uint2(f32x2_to_bf16x2(a, b), f32x2_to_bf16x2(c, d));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 lo = {__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u)};
+    const f32x2 hi = {__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+    const f32x2 ls = lo * slope, hs = hi * slope;
+    return make_uint2(f32x2_to_bf16x2(chain_max(lo.x, ls.x), chain_max(lo.y, ls.y)),
+                      f32x2_to_bf16x2(chain_max(hi.x, hs.x), chain_max(hi.y, hs.y)));
 }
 
 // s_waitcnt lgkmcnt(n) with n known only after loop unrolling (the immediate must be a literal)

@@ -280,3 +280,28 @@ def test_baseline_config_full_cycle(built_lib, name, N, family, nheads):
         e = float(np.linalg.norm(got[:, lo:] - ref[:, lo:]) / np.linalg.norm(ref[:, lo:]))
         print('%s: TTS call %d decoded-mu-law rel_l2 vs oracle %.3e' % (name, c, e))
         assert e < 6e-2, (name, c, e)          # bf16 model error (<= 1.5 x the reference's own 1.3e-2) + two mu-law quantisations
+
+
+def test_bench_two_ranks_on_one_gpu_dry_run(built_lib):
+    """The N > 1 bench path end to end -- torch.distributed.run with two ranks, sticky shards, ingress scatter / egress gather
+    on two communicators issued from the pipelined schedule, barrier + MAX-over-ranks timing, one JSON line from rank 0 -- on
+    a single-GPU box: IFH_DRYRUN_ONE_GPU=1 puts both ranks on cuda:0 and runs the collectives over gloo."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, IFH_DRYRUN_ONE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+           '--config', 'C2', '--calls-per-gpu', '4', '--tts-lanes', '2', '--no-cpu-baseline', '--no-extra-configs']
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 3 and d['config']['calls_total'] == 8 and d['config']['calls_per_gpu'] == 4
+    assert d['value'] > 0 and d['scaling'] == 'weak' and abs(d['value'] - 8 * 10.0 / (d['ms_per_step'] * 1e-3)) < 0.01 * d['value']
+    assert d['tts_samples_per_call'] == 10 * 4096 - 256 and 6.5 < d['stt_audio_seconds_per_call'] < 9.5
