@@ -466,15 +466,16 @@ static int launch_chain(ChainParams &p, hipStream_t st)
     if (HC == 0 && p.T > R) return fail(IFH_EINVAL, "resblock_chain: whole-sequence tile, t too large");
     const int ksteps = 6 * TAPS * (C / 32);
     if (p.nunits != (ksteps + UK - 1) / UK) return fail(IFH_EINVAL, "resblock_chain: weight stream length does not match c/taps");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_mask = 0;
+    int attr_dev = 0;
+    if (attr_needed_on_this_device(attr_mask, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_resblock_chain<C, TAPS, WGM, WGN, MT, NT, HC, NRING, GX, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)k_resblock_chain<C, TAPS, WGM, WGN, MT, NT, HC, NRING, GX, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return check_hip(e, "resblock_chain lds attr");
-        attr_set = true;
+        attr_mask |= 1ull << attr_dev;
     }
     p.tiles_per_seq = (p.T + R - 1) / R;
     p.ntiles = p.tiles_per_seq * p.nbatch;
@@ -774,11 +775,12 @@ extern "C" int ifh_conv_ring256_bf16(const ifh_ring256_desc *d, ifh_stream_t str
     p.out_bstride = d->out_bstride;
     constexpr size_t bytes = (size_t)(128 + 50) * 544 + 4 * 16384 + 256 * sizeof(float);
     static_assert(bytes <= 160 * 1024, "ring256 tile");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static unsigned long long attr_mask = 0;
+    int attr_dev = 0;
+    if (attr_needed_on_this_device(attr_mask, &attr_dev)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_conv_ring256, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return check_hip(e, "conv_ring256 lds attr");
-        attr_set = true;
+        attr_mask |= 1ull << attr_dev;
     }
     static int ncu = 0;
     if (!ncu) {

@@ -25,6 +25,16 @@ int check_hip(hipError_t e, const char *what);
 
 static inline hipStream_t as_stream(ifh_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// hipFuncSetAttribute acts on the CURRENT device: a process that drives several GPUs (one worker thread per device behind the
+// actors) must set a kernel's dynamic-LDS limit once per device, not once per process.  `mask` is a per-call-site static.
+static inline bool attr_needed_on_this_device(unsigned long long &mask, int *dev_out)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
+    *dev_out = dev;
+    return !((mask >> dev) & 1ull);
+}
+
 constexpr int kWave = 64;
 
 // ---- bf16 helpers (raw uint16 storage) ------------------------------------------------

@@ -219,12 +219,13 @@ static bool launch_direct(const IgemmParams &p, hipStream_t st)
     static_assert(EPB == 1 || BM * (BN + 8) <= BM * XS, "the store16 staging of a group lies inside its own input tile");
     const size_t bytes = ((size_t)EPB * ((R * XS + 7) & ~7) + (size_t)BN * (KW + 8)) * sizeof(uint16_t);
     if (bytes > 160 * 1024) return false;
-    static size_t attr_bytes = 0;
-    if (bytes > 64 * 1024 && bytes > attr_bytes) {
+    static unsigned long long attr_mask = 0;
+    int attr_dev = 0;
+    if (bytes > 64 * 1024 && attr_needed_on_this_device(attr_mask, &attr_dev)) {
         if (hipFuncSetAttribute((const void *)k_conv_direct<CIN, WGM, MT, NT, RESIDENT, KC, EPB>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return false;
-        attr_bytes = 160 * 1024;
+        attr_mask |= 1ull << attr_dev;
     }
     dim3 grid((p.T_out + BM - 1) / BM, (p.nbatch + EPB - 1) / EPB);
     hipLaunchKernelGGL((k_conv_direct<CIN, WGM, MT, NT, RESIDENT, KC, EPB>), grid, dim3(256 * EPB), bytes, st, p);

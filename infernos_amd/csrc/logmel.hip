@@ -1100,17 +1100,18 @@ static int logmel_transform(ifh_logmel_t h, const float *audio, int64_t stride, 
     hipError_t e = hipMemsetD32Async((hipDeviceptr_t)gmax, (int)0x80000000, (size_t)nbatch, st);
     if (e != hipSuccess) return check_hip(e, "logmel memset");
     const size_t ldsb = (size_t)kLdsFloats * sizeof(float);
-    static bool attr_set = false;
+    static unsigned long long attr_mask = 0;
+    int attr_dev = 0;
     static const bool use_v1 = getenv("IFH_LOGMEL_V1") != nullptr;      // tuning switch: f32-MFMA formulation
     static const bool use_dft = getenv("IFH_LOGMEL_DFT") != nullptr;    // tuning switch: bf16x3-MFMA DFT instead of the FFT
-    if (!attr_set) {
+    if (attr_needed_on_this_device(attr_mask, &attr_dev)) {
         e = hipFuncSetAttribute((const void *)k_logmel_dft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)k_logmel_dft2, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2Bytes + 8192);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)k_logmel_fft, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsFftBytes + 8192);
         if (e != hipSuccess) return check_hip(e, "logmel set lds attr");
-        attr_set = true;
+        attr_mask |= 1ull << attr_dev;
     }
     dim3 grid((kFrames + kFT - 1) / kFT, nbatch);
     if (!use_v1 && !use_dft) {

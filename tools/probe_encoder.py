@@ -1,4 +1,4 @@
-"""Whisper-tiny encoder alone (B windows): python tools/probe_encoder.py [B]"""
+"""Whisper encoder alone (B windows): python tools/probe_encoder.py [B] [whisper_tiny|whisper_base]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,7 +7,9 @@ from infernos_amd.engines.whisper import Whisper
 from infernos_amd.weights import synth_state_dict
 dev = _lib.require_device('cuda:0')
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-w = Whisper(synth_state_dict('whisper_tiny', 0), dev)
+fam = sys.argv[2] if len(sys.argv) > 2 else 'whisper_tiny'
+GF = {'whisper_tiny': 36.9e9, 'whisper_base': 87.4e9}[fam]
+w = Whisper(synth_state_dict(fam, 0), dev)
 mel = torch.randn(B, 80, 3000, device=dev)
 for _ in range(2): w.encode(mel)
 torch.cuda.synchronize()
@@ -15,4 +17,4 @@ t0 = time.perf_counter()
 for _ in range(5): w.encode(mel)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 5
-print(f'encoder B={B}: {dt*1e3:.2f} ms -> {B*36.9e9/dt/1e12:.0f} TF/s')
+print(f'{fam} encoder B={B}: {dt*1e3:.2f} ms -> {B*GF/dt/1e12:.0f} TF/s')
