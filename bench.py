@@ -226,6 +226,8 @@ def main():
     ap.add_argument('--tts-group', type=int, default=1, help='utterance cycles of the SAME calls synthesised as one TTS batch '
                     '(> 1 is an offline-throughput mode: a live call cannot have utterance k+1 before k has been spoken)')
     ap.add_argument('--no-tts-overlap', action='store_true', help='render on the lane stream instead of a second stream per lane')
+    ap.add_argument('--stt-beam', type=int, default=5, help='Whisper decode: 5 = the reference default engine\'s beam search '
+                    '(ctranslate2 defaults, InfernSTTWorker.py:61-75); 1 = greedy (its torch engine)')
     ap.add_argument('--no-pipeline', action='store_true', help='run the stages of consecutive cycles strictly one after another')
     args = ap.parse_args()
 
@@ -269,7 +271,7 @@ def main():
     def build(cfg, n_local):
         _, family, _ = CONFIGS[cfg]
         pipe = SpeechPipeline(n_local, dev, whisper_family=family, tts_lanes=args.tts_lanes, tts_overlap=not args.no_tts_overlap,
-                              tts_group=args.tts_group, front_lanes=args.front_lanes)
+                              tts_group=args.tts_group, front_lanes=args.front_lanes, stt_beam=args.stt_beam)
         n_total = n_local * world
         # every rank builds its own rows for the N=1 path; with N>1 rank 0 holds all rows and scatters
         if world == 1:
@@ -362,7 +364,9 @@ def main():
                        'batching': 'across calls only (one utterance per call per batch)' if args.tts_group == 1 else
                                    'OFFLINE mode: %d consecutive utterances of the same calls per TTS batch' % args.tts_group,
                        'stage_pipelining': not args.no_pipeline, 'front_lanes': args.front_lanes, 'tts_lanes': args.tts_lanes,
-                       'tts_rows_per_batch': n_local * args.tts_group},
+                       'tts_rows_per_batch': n_local * args.tts_group,
+                       'stt_decode': ('beam search, %d beams (%d decode rows), 32 tokens' % (args.stt_beam, n_local * args.stt_beam))
+                                     if args.stt_beam > 1 else 'greedy, 32 tokens'},
             'stt_audio_seconds_per_call': round(float(res['stt_seconds'].mean()), 3),
             'tts_samples_per_call': int(res['tts_samples'].float().mean()),
             'roofline': {'kernel': 'HiFi-GAN vocoder pass (%d chunks x 12 frames per launch group)' % nchunks,

@@ -422,6 +422,58 @@ int ifh_attn_decode_bf16(const void *q, int64_t q_bs, const void *k, const void 
                          void *out, int64_t o_bs, const int32_t *key_len, int max_keys, int nbatch, int nheads,
                          int head_dim, const int32_t *dyn_len, int dyn_add, ifh_stream_t stream);
 
+/* ifh_attn_decode_bf16 for query rows that share cache rows: row b reads K/V row b / kv_group (the beams of one
+ * utterance over its one cross-attention cache); every row attends over max_keys keys. */
+int ifh_attn_decode_shared_bf16(const void *q, int64_t q_bs, const void *k, const void *v, int64_t kv_bs, int64_t kv_ts,
+                                void *out, int64_t o_bs, int max_keys, int nbatch, int nheads, int head_dim, int kv_group,
+                                ifh_stream_t stream);
+
+/* ---- beam search over the per-token decode step ----
+ * The search ctranslate2.models.Whisper.generate runs by default for Cluster/InfernSTTWorker.py:61-75 (beam_size 5,
+ * length_penalty 1; the wheel is not vendored by the reference -- the bookkeeping is the one oracle/nn.py:beam_search
+ * restates and pins).  Decode rows are batch-major: row = b * beams + k.  One call = one step at cur_len = pos[0]
+ * tokens (prompt_len <= cur_len < max_length; other values are a no-op so that graph replays past the end are
+ * harmless):
+ *   log p = log_softmax(logits[row]) (+ suppress) (+ begin_suppress when cur_len == prompt_len);
+ *   the 2*beams best of run_scores[b,k] + log p over (k, token), ties to the lower (k, token);
+ *   a candidate ends when its token is eos_id or cur_len + 1 == max_length; the best `beams` that did not end become
+ *   the running beams: their columns of toks (int32 [>= max_length][nbatch*beams], position-major) are permuted in
+ *   place, the new token is written at toks[cur_len], run_scores updated, beam_src[row] = the row (of this step)
+ *   each running row continues -- what ifh_kv_gather_bf16 consumes;
+ *   ended candidates ranked inside the first `beams` compete, on score / (cur_len + 1 - prompt_len) ** length_penalty,
+ *   with the finished hypotheses kept so far: fin_scores f32 / is_fin u8 / fin_len i32 [nbatch, beams] and fin_seqs i32
+ *   [nbatch, beams, max_length - prompt_len] (generated tokens, eos included), best first;
+ *   unsat[b] (int32, 1 on entry of the first step) drops to 0 once the best running beam of b cannot beat its worst
+ *   finished hypothesis: from then on b's finished list is frozen;
+ *   alive[cur_len] = 1 (int32 [max_length], zeroed by the caller) if any b is still unsat and can continue.
+ * Caller initialises run_scores = {0, -1e9, ...} per b, fin_scores = -1e9, is_fin = 0, unsat = 1.
+ * scratch: nbatch * beams * 132 bytes.  beams <= 8; beams * (2*max_length - prompt_len) * 4 <= 60 KB. */
+typedef struct ifh_beam_desc {
+    const float *logits;
+    int64_t ld;
+    int32_t vocab, nbatch, beams;
+    const float *suppress;        /* optional f32[vocab], 0 or -inf */
+    const float *begin_suppress;  /* optional f32[vocab], applied at the first generated position only */
+    int32_t *toks;
+    const int32_t *pos;
+    int32_t prompt_len, max_length, eos_id;
+    float length_penalty;
+    float *run_scores;
+    float *fin_scores;
+    int32_t *fin_seqs;
+    int32_t *fin_len;
+    uint8_t *is_fin;
+    int32_t *unsat;
+    int32_t *beam_src;
+    int32_t *alive;
+    void *scratch;
+} ifh_beam_desc;
+int ifh_beam_step(const ifh_beam_desc *desc, ifh_stream_t stream);
+/* dst[row] = src[row_src[row]] for the first min(len[0], max_len) tokens of a KV cache laid out [nrows][max_len][tok_elems]
+ * bf16 (row_stride elements between rows); src != dst (ping-pong).  tok_elems % 8 == 0. */
+int ifh_kv_gather_bf16(const void *src, void *dst, const int32_t *row_src, const int32_t *len, int max_len, int nrows,
+                       int64_t row_stride, int tok_elems, ifh_stream_t stream);
+
 /* out[i] = table[ids[i]] + pos_table[pos0 + i % seq_len] (pos_table may be NULL); bf16, dim % 8 == 0.
  * dyn_pos (device scalar, optional): pos0 += dyn_pos[0], ids += dyn_pos[0]*dyn_ids_mul */
 int ifh_embed_bf16(const int32_t *ids, const void *table, const void *pos_table, int pos0, int seq_len, int dim,

@@ -97,6 +97,15 @@ class Ring256Desc(ctypes.Structure):
                 ('resid_bstride', _i64), ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp), ('out_bstride', _i64)]
 
 
+class BeamDesc(ctypes.Structure):
+    """ifh_beam_desc (include/infernos_hip.h)"""
+    _fields_ = [('logits', _vp), ('ld', _i64), ('vocab', ctypes.c_int32), ('nbatch', ctypes.c_int32), ('beams', ctypes.c_int32),
+                ('suppress', _vp), ('begin_suppress', _vp), ('toks', _vp), ('pos', _vp), ('prompt_len', ctypes.c_int32),
+                ('max_length', ctypes.c_int32), ('eos_id', ctypes.c_int32), ('length_penalty', _f), ('run_scores', _vp),
+                ('fin_scores', _vp), ('fin_seqs', _vp), ('fin_len', _vp), ('is_fin', _vp), ('unsat', _vp), ('beam_src', _vp),
+                ('alive', _vp), ('scratch', _vp)]
+
+
 class RtpHdr(ctypes.Structure):
     """ifh_rtp_hdr (include/infernos_hip.h)"""
     _fields_ = [(n, ctypes.c_int32) for n in ('version', 'padding', 'extension', 'cc', 'marker', 'pt')] + \
@@ -137,6 +146,9 @@ SIGNATURES.update({
     'ifh_attn_decode_bf16': (_i, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     'ifh_embed_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     'ifh_add_i32': (_i, [_vp, _i, _vp, _i64, _vp]),
+    'ifh_attn_decode_shared_bf16': (_i, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
+    'ifh_beam_step': (_i, [ctypes.POINTER(BeamDesc), _vp]),
+    'ifh_kv_gather_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp]),
     'ifh_argmax_pick_f32': (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     'ifh_tts_stop_update': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp]),
     'ifh_tts_stop_advance': (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp, _i64, _vp, _vp]),

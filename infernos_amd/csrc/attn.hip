@@ -204,7 +204,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_decode(const uint16_t *__restr
                                                          const uint16_t *__restrict__ k, const uint16_t *__restrict__ v,
                                                          int64_t kv_bs, int64_t kv_ts, uint16_t *__restrict__ out,
                                                          int64_t o_bs, const int32_t *__restrict__ key_len, int S,
-                                                         const int32_t *__restrict__ dyn_len, int dyn_add)
+                                                         const int32_t *__restrict__ dyn_len, int dyn_add, int kv_group)
 {
     __shared__ float comb[NW][8][10];
     const int b = blockIdx.y, h = blockIdx.x;
@@ -221,8 +221,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn_decode(const uint16_t *__restr
             qv[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
         }
     }
-    const uint16_t *kb = k + (int64_t)b * kv_bs + h * HD + 8 * c;
-    const uint16_t *vb = v + (int64_t)b * kv_bs + h * HD + 8 * c;
+    const uint16_t *kb = k + (int64_t)(b / kv_group) * kv_bs + h * HD + 8 * c;      // kv_group query rows share a cache row
+    const uint16_t *vb = v + (int64_t)(b / kv_group) * kv_bs + h * HD + 8 * c;
     float m = -1e30f, l = 0.0f, o[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) o[i] = 0.0f;
@@ -320,6 +320,160 @@ __global__ __launch_bounds__(NW * 64) void k_attn_decode(const uint16_t *__restr
     }
 }
 
+// k_attn_decode for G query rows that share one cache row (the beams of an utterance over its cross-attention K/V):
+// one workgroup per (cache row, head) serves the G queries, so every key and value is loaded once instead of G times.
+// Key assignment, iteration order and arithmetic per query are those of k_attn_decode: same bits.
+template <int NW, int G>
+__global__ __launch_bounds__(NW * 64) void k_attn_decode_group(const uint16_t *__restrict__ q, int64_t q_bs,
+                                                               const uint16_t *__restrict__ k,
+                                                               const uint16_t *__restrict__ v, int64_t kv_bs,
+                                                               int64_t kv_ts, uint16_t *__restrict__ out, int64_t o_bs,
+                                                               int S)
+{
+    __shared__ float comb[NW][G][8][10];
+    const int bg = blockIdx.y, h = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 7, g = lane >> 3;
+    const int klen = S;
+    float qv[G][8];
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+        const uint4 t = *reinterpret_cast<const uint4 *>(q + (int64_t)(bg * G + r) * q_bs + h * HD + 8 * c);
+        const uint32_t *u = reinterpret_cast<const uint32_t *>(&t);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            qv[r][2 * e] = __uint_as_float(u[e] << 16);
+            qv[r][2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+        }
+    }
+    const uint16_t *kb = k + (int64_t)bg * kv_bs + h * HD + 8 * c;
+    const uint16_t *vb = v + (int64_t)bg * kv_bs + h * HD + 8 * c;
+    float m[G], l[G], o[G][8];
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+        m[r] = -1e30f;
+        l[r] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[r][i] = 0.0f;
+    }
+    constexpr int KU = 4;
+    for (int key0 = wid * 8 + g; key0 < klen; key0 += 8 * NW * KU) {
+        uint4 kk[KU], vv[KU];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int key = key0 + u * 8 * NW;
+            kk[u] = make_uint4(0, 0, 0, 0);
+            vv[u] = make_uint4(0, 0, 0, 0);
+            if (key < klen) {
+                kk[u] = *reinterpret_cast<const uint4 *>(kb + (int64_t)key * kv_ts);
+                vv[u] = *reinterpret_cast<const uint4 *>(vb + (int64_t)key * kv_ts);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < G; r++) {
+            float sc[KU];
+            float mn = m[r];
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const uint32_t *ku = reinterpret_cast<const uint32_t *>(&kk[u]);
+                float s = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    s = __fmaf_rn(qv[r][2 * e], __uint_as_float(ku[e] << 16), s);
+                    s = __fmaf_rn(qv[r][2 * e + 1], __uint_as_float(ku[e] & 0xffff0000u), s);
+                }
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 4, 64);
+                s = (key0 + u * 8 * NW < klen) ? s : -1e30f;
+                sc[u] = s;
+                mn = fmaxf(mn, s);
+            }
+            const float a = __expf(m[r] - mn);
+            l[r] *= a;
+#pragma unroll
+            for (int i = 0; i < 8; i++) o[r][i] *= a;
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const float pr = (key0 + u * 8 * NW < klen) ? __expf(sc[u] - mn) : 0.0f;
+                l[r] += pr;
+                const uint32_t *vu = reinterpret_cast<const uint32_t *>(&vv[u]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    o[r][2 * e] = __fmaf_rn(pr, __uint_as_float(vu[e] << 16), o[r][2 * e]);
+                    o[r][2 * e + 1] = __fmaf_rn(pr, __uint_as_float(vu[e] & 0xffff0000u), o[r][2 * e + 1]);
+                }
+            }
+            m[r] = mn;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            const float m2 = __shfl_xor(m[r], off, 64), l2 = __shfl_xor(l[r], off, 64);
+            const float mn = fmaxf(m[r], m2);
+            const float a = __expf(m[r] - mn), a2 = __expf(m2 - mn);
+            l[r] = l[r] * a + l2 * a2;
+#pragma unroll
+            for (int i = 0; i < 8; i++) o[r][i] = o[r][i] * a + __shfl_xor(o[r][i], off, 64) * a2;
+            m[r] = mn;
+        }
+    }
+    if (NW > 1) {
+        if (g == 0) {
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+                comb[wid][r][c][0] = m[r];
+                comb[wid][r][c][1] = l[r];
+#pragma unroll
+                for (int i = 0; i < 8; i++) comb[wid][r][c][2 + i] = o[r][i];
+            }
+        }
+        __syncthreads();
+        if (wid == 0 && g == 0) {
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+#pragma unroll
+                for (int w = 1; w < NW; w++) {
+                    const float m2 = comb[w][r][c][0], l2 = comb[w][r][c][1];
+                    const float mn = fmaxf(m[r], m2);
+                    const float a = __expf(m[r] - mn), a2 = __expf(m2 - mn);
+                    l[r] = l[r] * a + l2 * a2;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) o[r][i] = o[r][i] * a + comb[w][r][c][2 + i] * a2;
+                    m[r] = mn;
+                }
+            }
+        }
+    }
+    if (wid == 0 && g == 0) {
+#pragma unroll
+        for (int r = 0; r < G; r++) {
+            const float inv = l[r] > 0.0f ? 1.0f / l[r] : 0.0f;
+            uint4 pk;
+            pk.x = pack2(o[r][0] * inv, o[r][1] * inv);
+            pk.y = pack2(o[r][2] * inv, o[r][3] * inv);
+            pk.z = pack2(o[r][4] * inv, o[r][5] * inv);
+            pk.w = pack2(o[r][6] * inv, o[r][7] * inv);
+            *reinterpret_cast<uint4 *>(out + (int64_t)(bg * G + r) * o_bs + h * HD + 8 * c) = pk;
+        }
+    }
+}
+
+template <int G>
+static void attn_decode_group_launch(const void *q, int64_t q_bs, const void *k, const void *v, int64_t kv_bs, int64_t kv_ts,
+                                     void *out, int64_t o_bs, int max_keys, int ngroups, int nheads, hipStream_t st)
+{
+    dim3 grid(nheads, ngroups);
+    if (max_keys > 256)
+        hipLaunchKernelGGL((k_attn_decode_group<4, G>), grid, dim3(256), 0, st, (const uint16_t *)q, q_bs, (const uint16_t *)k,
+                           (const uint16_t *)v, kv_bs, kv_ts, (uint16_t *)out, o_bs, max_keys);
+    else
+        hipLaunchKernelGGL((k_attn_decode_group<1, G>), grid, dim3(64), 0, st, (const uint16_t *)q, q_bs, (const uint16_t *)k,
+                           (const uint16_t *)v, kv_bs, kv_ts, (uint16_t *)out, o_bs, max_keys);
+}
+
 }  // namespace ifh
 
 using namespace ifh;
@@ -359,24 +513,58 @@ extern "C" int ifh_attn_prefill_bf16(const ifh_attn_desc *d, ifh_stream_t stream
     return IFH_OK;
 }
 
+static int attn_decode_launch(const void *q, int64_t q_bs, const void *k, const void *v, int64_t kv_bs, int64_t kv_ts,
+                              void *out, int64_t o_bs, const int32_t *key_len, int max_keys, int nbatch, int nheads,
+                              int head_dim, const int32_t *dyn_len, int dyn_add, int kv_group, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(nbatch >= 0);
+    if (nbatch == 0) return IFH_OK;
+    IFH_CHECK_ARG(q && k && v && out && nheads > 0 && head_dim == HD && max_keys >= 1 && kv_group >= 1);
+    IFH_CHECK_ARG(q_bs % 8 == 0 && kv_bs % 8 == 0 && kv_ts % 8 == 0 && o_bs % 8 == 0 && nbatch < 65536);
+    IFH_CHECK_ARG(kv_group == 1 || !key_len);       // per-row key counts belong to query rows, not to shared cache rows
+    dim3 grid(nheads, nbatch);
+    if (max_keys > 256)      // long caches: 4 waves per (batch, head) (measured faster from ~160 keys up)
+        hipLaunchKernelGGL(k_attn_decode<4>, grid, dim3(256), 0, as_stream(stream), (const uint16_t *)q, q_bs,
+                           (const uint16_t *)k, (const uint16_t *)v, kv_bs, kv_ts, (uint16_t *)out, o_bs, key_len, max_keys,
+                           dyn_len, dyn_add, kv_group);
+    else
+        hipLaunchKernelGGL(k_attn_decode<1>, grid, dim3(64), 0, as_stream(stream), (const uint16_t *)q, q_bs,
+                           (const uint16_t *)k, (const uint16_t *)v, kv_bs, kv_ts, (uint16_t *)out, o_bs, key_len, max_keys,
+                           dyn_len, dyn_add, kv_group);
+    IFH_LAUNCH_CHECK("attn_decode");
+    return IFH_OK;
+}
+
 extern "C" int ifh_attn_decode_bf16(const void *q, int64_t q_bs, const void *k, const void *v, int64_t kv_bs,
                                     int64_t kv_ts, void *out, int64_t o_bs, const int32_t *key_len, int max_keys,
                                     int nbatch, int nheads, int head_dim, const int32_t *dyn_len, int dyn_add,
                                     ifh_stream_t stream)
 {
-    IFH_CHECK_ARG(nbatch >= 0);
+    return attn_decode_launch(q, q_bs, k, v, kv_bs, kv_ts, out, o_bs, key_len, max_keys, nbatch, nheads, head_dim, dyn_len,
+                              dyn_add, 1, stream);
+}
+
+extern "C" int ifh_attn_decode_shared_bf16(const void *q, int64_t q_bs, const void *k, const void *v, int64_t kv_bs,
+                                           int64_t kv_ts, void *out, int64_t o_bs, int max_keys, int nbatch, int nheads,
+                                           int head_dim, int kv_group, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(nbatch >= 0 && kv_group >= 1);
     if (nbatch == 0) return IFH_OK;
+    if (kv_group == 1 || kv_group > 8 || nbatch % kv_group != 0)       // general form: one workgroup per query row
+        return attn_decode_launch(q, q_bs, k, v, kv_bs, kv_ts, out, o_bs, nullptr, max_keys, nbatch, nheads, head_dim,
+                                  nullptr, 0, kv_group, stream);
     IFH_CHECK_ARG(q && k && v && out && nheads > 0 && head_dim == HD && max_keys >= 1);
-    IFH_CHECK_ARG(q_bs % 8 == 0 && kv_bs % 8 == 0 && kv_ts % 8 == 0 && o_bs % 8 == 0 && nbatch < 65536);
-    dim3 grid(nheads, nbatch);
-    if (max_keys > 256)      // long caches: 4 waves per (batch, head) (measured faster from ~160 keys up)
-        hipLaunchKernelGGL(k_attn_decode<4>, grid, dim3(256), 0, as_stream(stream), (const uint16_t *)q, q_bs,
-                           (const uint16_t *)k, (const uint16_t *)v, kv_bs, kv_ts, (uint16_t *)out, o_bs, key_len, max_keys,
-                           dyn_len, dyn_add);
-    else
-        hipLaunchKernelGGL(k_attn_decode<1>, grid, dim3(64), 0, as_stream(stream), (const uint16_t *)q, q_bs,
-                           (const uint16_t *)k, (const uint16_t *)v, kv_bs, kv_ts, (uint16_t *)out, o_bs, key_len, max_keys,
-                           dyn_len, dyn_add);
-    IFH_LAUNCH_CHECK("attn_decode");
+    IFH_CHECK_ARG(q_bs % 8 == 0 && kv_bs % 8 == 0 && kv_ts % 8 == 0 && o_bs % 8 == 0 && nbatch / kv_group < 65536);
+    const int ng = nbatch / kv_group;
+    hipStream_t st = as_stream(stream);
+    switch (kv_group) {
+#define IFH_AG(G)                                                                                             \
+    case G:                                                                                                   \
+        attn_decode_group_launch<G>(q, q_bs, k, v, kv_bs, kv_ts, out, o_bs, max_keys, ng, nheads, st);        \
+        break;
+        IFH_AG(2) IFH_AG(3) IFH_AG(4) IFH_AG(5) IFH_AG(6) IFH_AG(7) IFH_AG(8)
+#undef IFH_AG
+    }
+    IFH_LAUNCH_CHECK("attn_decode_group");
     return IFH_OK;
 }

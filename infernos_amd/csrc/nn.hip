@@ -576,8 +576,18 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         launch_igemm<64, 32, 2>(p, pre, st);
     else if (d->n <= 64)
         launch_igemm<128, 64, 2>(p, pre, st);
-    else
-        launch_igemm<128, 128, 2>(p, pre, st);
+    else {
+        // a few hundred rows x a narrow layer (the 640 decode rows of a 5-beam search over 128 utterances: 20 tiles of
+        // 128 x 128 at n = 512) leaves most of the 256 CUs idle: take the tile that yields at least one workgroup per CU.
+        // The k order per output element does not depend on the tile: same bits.
+        const int64_t mt = (M + 127) / 128;
+        if (mt * ((d->n + 127) / 128) >= 256)
+            launch_igemm<128, 128, 2>(p, pre, st);
+        else if (mt * ((d->n + 63) / 64) >= 256 || M > 4096)
+            launch_igemm<128, 64, 2>(p, pre, st);
+        else
+            launch_igemm<64, 32, 2>(p, pre, st);
+    }
     IFH_LAUNCH_CHECK("conv_bf16");
     return IFH_OK;
 }

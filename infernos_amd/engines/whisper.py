@@ -137,25 +137,59 @@ class Whisper:
         return b['out'].view(Bn, N_CTX, d)
 
     # ---- decoder ------------------------------------------------------------------------------
-    def _dec(self, Bn):
-        if Bn not in self._dec_bufs:
+    def _dec(self, Bn, beams=0):
+        """Decode buffers for Bn rows.  beams >= 1: Bn = utterances * beams rows that share the utterances' cross-attention
+        K/V (one cache row per utterance) and own a second self-attention cache set for the per-step beam gather."""
+        key = Bn if beams == 0 else (Bn, beams)
+        if key not in self._dec_bufs:
             dev, d = self.device, self.d
             e = lambda *s, dt=BF16: torch.empty(s, dtype=dt, device=dev)
             while len(self._dec_bufs) >= 3:
                 self._dec_bufs.pop(next(iter(self._dec_bufs)))
-            self._dec_bufs[Bn] = dict(
-                cross=[e(Bn * N_CTX, 2 * d) for _ in self.dec_layers],
+            self._dec_bufs[key] = dict(
+                cross=[e(Bn // max(1, beams) * N_CTX, 2 * d) for _ in self.dec_layers],
                 kv=[torch.zeros((Bn, self.max_tokens, 2 * d), dtype=BF16, device=dev) for _ in self.dec_layers],
                 x=e(Bn, d), hn=e(Bn, d), q=e(Bn, d), att=e(Bn, d), ff=e(Bn, self.ff),
                 logits_full=e(Bn, self.vpad, dt=torch.float32),
                 stats=torch.zeros((3 * len(self.dec_layers), max(64, -(-Bn // 16) * 16), 2), dtype=torch.int64, device=dev),
                 toks=torch.zeros((self.max_tokens + 1, Bn), dtype=torch.int32, device=dev),
                 pos=torch.zeros(1, dtype=torch.int32, device=dev), graphs={}, eager_runs=0)
-            b = self._dec_bufs[Bn]
+            b = self._dec_bufs[key]
             b['logits'] = b['logits_full'][:, :self.vocab]         # [Bn, vocab] view, row stride vpad
-        return self._dec_bufs[Bn]
+            if beams >= 1:
+                b['cross_group'] = beams
+                b['kv2'] = [torch.zeros_like(t) for t in b['kv']]
+        return self._dec_bufs[key]
 
-    def decoder_step(self, bufs, Bn: int, argmax: bool):
+    def _cross_attn(self, bufs, li, Bn):
+        d, H = self.d, self.h
+        ck = bufs['cross'][li]
+        g = bufs.get('cross_group', 1)
+        if g == 1:
+            ops.attn_decode(bufs['q'], ck, ck, bufs['att'], nbatch=Bn, nheads=H, max_keys=N_CTX, q_bs=d,
+                            kv_bs=N_CTX * 2 * d, kv_ts=2 * d, o_bs=d, v_off=d)
+        else:                                      # beams: g consecutive rows share one utterance's cross K/V
+            ops.attn_decode_shared(bufs['q'], ck, ck, bufs['att'], nbatch=Bn, nheads=H, max_keys=N_CTX, q_bs=d,
+                                   kv_bs=N_CTX * 2 * d, kv_ts=2 * d, o_bs=d, v_off=d, kv_group=g)
+
+    def _tail(self, bufs, Bn, mode):
+        """What follows the logits of a step: nothing (False), greedy pick (True), or one beam-search step + the KV
+        gather into the other cache set (('beam', parity, ...): see generate_beam).  Runs after pos was advanced."""
+        if mode is True or mode is False:
+            return
+        bm = bufs['beam']
+        ops.beam_step(bufs['logits_full'], bm['state'], bufs['toks'], bufs['pos'], vocab=self.vocab, ld=self.vpad,
+                      prompt_len=bm['P'], max_length=bm['max_length'], eos_id=bm['eos'], length_penalty=bm['lp'],
+                      suppress=bm['suppress'], begin_suppress=bm['begin_suppress'])
+        src, dst = (bufs['kv'], bufs['kv2']) if mode[1] == 0 else (bufs['kv2'], bufs['kv'])
+        for a, b in zip(src, dst):
+            ops.kv_gather(a, b, bm['state'].beam_src, bufs['pos'], nrows=Bn, max_len=self.max_tokens, tok_elems=2 * self.d)
+
+    @staticmethod
+    def _kvsel(bufs, mode):
+        return bufs['kv2'] if (mode is not True and mode is not False and mode[1] == 1) else bufs['kv']
+
+    def decoder_step(self, bufs, Bn: int, argmax):
         """One token per sequence at the position held in bufs['pos'] (device scalar): embeds
         toks[pos], appends K/V at pos, attends over pos+1 keys, optionally writes
         argmax(logits) to toks[pos+1], then advances pos.  Identical launches for every position,
@@ -164,9 +198,10 @@ class Whisper:
         x, pos, toks = bufs['x'], bufs['pos'], bufs['toks']
         ops.embed(toks, self.tok, self.dec_pos, x, n=Bn, dim=d, pos0=0, seq_len=1, dyn_pos=pos, dyn_ids_mul=Bn)
         smax = self.max_tokens
+        kvs = self._kvsel(bufs, argmax)
         for li, L in enumerate(self.dec_layers):
             S, C = L['self'], L['cross']
-            kv = bufs['kv'][li]
+            kv = kvs[li]
             ops.layernorm(x, *L['ln1'], bufs['hn'], Bn, d)
             ops.conv(bufs['hn'], S['wqkv'], S['bqkv'], bufs['q'], nbatch=Bn, t_in=1, t_out=1, cin=d, n=3 * d, ldc=d,
                      out_bstride=d, dyn_pos=pos, n_split=d, out2=kv, out2_bstride=smax * 2 * d, ldc2=2 * d, dyn_ooff2_mul=1)
@@ -175,19 +210,18 @@ class Whisper:
             ops.linear(bufs['att'], S['wo'], S['bo'], x, rows=Bn, k=d, n=d, resid=x)
             ops.layernorm(x, *L['ln2'], bufs['hn'], Bn, d)
             ops.linear(bufs['hn'], C['wq'], C['bq'], bufs['q'], rows=Bn, k=d, n=d)
-            ck = bufs['cross'][li]
-            ops.attn_decode(bufs['q'], ck, ck, bufs['att'], nbatch=Bn, nheads=H, max_keys=N_CTX, q_bs=d,
-                            kv_bs=N_CTX * 2 * d, kv_ts=2 * d, o_bs=d, v_off=d)
+            self._cross_attn(bufs, li, Bn)
             ops.linear(bufs['att'], C['wo'], C['bo'], x, rows=Bn, k=d, n=d, resid=x)
             ops.layernorm(x, *L['ln3'], bufs['hn'], Bn, d)
             ops.linear(bufs['hn'], L['w1'], L['b1'], bufs['ff'], rows=Bn, k=d, n=self.ff, act=ACT_GELU)
             ops.linear(bufs['ff'], L['w2'], L['b2'], x, rows=Bn, k=self.ff, n=d, resid=x)
         ops.layernorm(x, *self.dec_ln, bufs['hn'], Bn, d)
         ops.linear(bufs['hn'], self.tok, None, bufs['logits_full'], rows=Bn, k=d, n=self.vocab, ldc=self.vpad)
-        if argmax:
+        if argmax is True:
             ops.argmax_pick(bufs['logits_full'], vocab=self.vocab, nrows=Bn, ld=self.vpad, argmax_out=toks, out_off=Bn,
                             dyn_pos=pos, dyn_out_mul=Bn)
         ops.add_i32(pos, 1)
+        self._tail(bufs, Bn, argmax)
         return bufs['logits']
 
     def decoder_step_folded(self, bufs, Bn: int, argmax: bool):
@@ -199,9 +233,10 @@ class Whisper:
         SO = stats.size(1) * 2                 # zero on entry: cleared by the last launch of the previous token
         ops.embed(toks, self.tok, self.dec_pos, x, n=Bn, dim=d, pos0=0, seq_len=1, dyn_pos=pos, dyn_ids_mul=Bn)
         smax = self.max_tokens
+        kvs = self._kvsel(bufs, argmax)
         for li, (L, F) in enumerate(zip(self.dec_layers, self.dec_fold)):
             S, C = L['self'], L['cross']
-            kv = bufs['kv'][li]
+            kv = kvs[li]
             s1, s2, s3, s3p = (3 * li) * SO, (3 * li + 1) * SO, (3 * li + 2) * SO, (3 * li - 1) * SO
             kvargs = dict(nbatch=Bn, t_in=1, t_out=1, cin=d, n=3 * d, ldc=d, out_bstride=d, dyn_pos=pos, n_split=d, out2=kv,
                           out2_bstride=smax * 2 * d, ldc2=2 * d, dyn_ooff2_mul=1)
@@ -216,9 +251,7 @@ class Whisper:
             ops.linear(bufs['att'], S['wo'], S['bo'], x, rows=Bn, k=d, n=d, resid=x, stats_out=stats, stats_off=s1, ln_dim=d)
             w, c2, c1 = F['cq']
             ops.linear(x, w, c2, bufs['q'], rows=Bn, k=d, n=d, aln=(stats, s1, c1), ln_dim=d)
-            ck = bufs['cross'][li]
-            ops.attn_decode(bufs['q'], ck, ck, bufs['att'], nbatch=Bn, nheads=H, max_keys=N_CTX, q_bs=d,
-                            kv_bs=N_CTX * 2 * d, kv_ts=2 * d, o_bs=d, v_off=d)
+            self._cross_attn(bufs, li, Bn)
             ops.linear(bufs['att'], C['wo'], C['bo'], x, rows=Bn, k=d, n=d, resid=x, stats_out=stats, stats_off=s2, ln_dim=d)
             w, c2, c1 = F['ff1']
             ops.linear(x, w, c2, bufs['ff'], rows=Bn, k=d, n=self.ff, act=ACT_GELU, aln=(stats, s2, c1), ln_dim=d)
@@ -226,10 +259,11 @@ class Whisper:
         w, c2, c1 = self.logit_fold
         ops.linear(x, w, c2, bufs['logits_full'], rows=Bn, k=d, n=self.vpad, aln=(stats, (3 * len(self.dec_layers) - 1) * SO, c1),
                    ln_dim=d)
-        if argmax:
+        if argmax is True:
             ops.argmax_pick(bufs['logits_full'], vocab=self.vocab, nrows=Bn, ld=self.vpad, argmax_out=toks, out_off=Bn,
                             dyn_pos=pos, dyn_out_mul=Bn)
         ops.add_i32(pos, 1, zero=stats)
+        self._tail(bufs, Bn, argmax)
         return bufs['logits']
 
     def _step(self, bufs, Bn, argmax, use_graphs):
@@ -323,3 +357,70 @@ class Whisper:
                         break
         bufs['eager_runs'] += 1
         return toks[P:P + n_new].t().contiguous(), nsp, first
+
+    def generate_beam(self, enc: torch.Tensor, prompts: torch.Tensor, n_new: int, beams: int = 5, eos_id: int = 50257,
+                      length_penalty: float = 1.0, suppress=None, begin_suppress=None, no_speech_id=None, check_every=8,
+                      use_graphs=True):
+        """Beam search (the decode ctranslate2's Whisper.generate runs by default, Cluster/InfernSTTWorker.py:61-75:
+        beam_size 5, length_penalty 1, return_no_speech_prob) over the same per-token step `generate` uses, on
+        B * beams decode rows that share each utterance's cross-attention K/V.  Search bookkeeping, token-matrix
+        permutation and the per-step self-attention KV gather all run on the device (ifh_beam_step,
+        ifh_kv_gather_bf16) inside the replayed hipGraph; the host only polls `alive` every `check_every` tokens.
+        enc bf16 [B,1500,d]; prompts int [B,P] (same P for every row); suppress / begin_suppress: optional f32 [vocab]
+        additive masks (0 / -inf) on the log-probs (every step / first generated position).
+        -> (tokens int32 [B, n_new] padded with eos_id, lengths int32 [B] (eos included), scores f32 [B]
+        = sum log p / length ** length_penalty, no_speech_prob f32 [B] or None)."""
+        dev, d = self.device, self.d
+        B, P = prompts.shape
+        K = int(beams)
+        assert 1 <= K <= 8
+        n_new = min(n_new, self.max_tokens - P)
+        rows = B * K
+        bufs = self._dec(rows, K)
+        use_graphs = use_graphs and bufs['eager_runs'] >= 1
+        for li, L in enumerate(self.dec_layers):
+            C = L['cross']
+            ops.linear(enc, C['wkv'], C['bkv'], bufs['cross'][li], rows=B * N_CTX, k=d, n=2 * d)
+        st = bufs.get('beam_state')
+        if st is None or st.max_new != n_new:
+            st = bufs['beam_state'] = ops.BeamState(B, K, n_new, dev)
+        st.reset()
+        masks = []
+        for name, m in (('sup_buf', suppress), ('bsup_buf', begin_suppress)):     # fixed device buffers: graphs hold them
+            if m is None:
+                masks.append(None)
+                continue
+            if name not in bufs:
+                bufs[name] = torch.zeros(self.vocab, dtype=torch.float32, device=dev)
+            bufs[name].copy_(m.to(torch.float32))
+            masks.append(bufs[name])
+        bufs['beam'] = dict(state=st, P=P, max_length=P + n_new, eos=int(eos_id), lp=float(length_penalty),
+                            suppress=masks[0], begin_suppress=masks[1])
+        mkey = (P, n_new, int(eos_id), float(length_penalty), suppress is None, begin_suppress is None)
+        if bufs.get('beam_key') != mkey:           # graphs bake these by value: drop the ones captured for another search
+            for k in [k for k in bufs['graphs'] if isinstance(k, tuple)]:
+                del bufs['graphs'][k]
+            bufs['beam_key'] = mkey
+        toks = bufs['toks']
+        toks.fill_(int(eos_id))
+        toks[:P] = prompts.to(dev, torch.int32).repeat_interleave(K, 0).t()
+        bufs['pos'].zero_()
+        bufs['stats'].zero_()
+        nsp = torch.empty(B, dtype=torch.float32, device=dev) if no_speech_id is not None else None
+        for pos in range(P + n_new - 1):
+            gen = pos >= P - 1
+            mode = ('beam', (pos - (P - 1)) & 1) if gen else False
+            self._step(bufs, rows, mode, use_graphs and pos > 0)
+            if pos == 0 and nsp is not None:       # rows b * K: the first beam of every utterance
+                ops.argmax_pick(bufs['logits_full'], vocab=self.vocab, nrows=B, ld=K * self.vpad, pick_token=no_speech_id,
+                                pick_prob_out=nsp)
+            if gen:
+                done = pos - (P - 1) + 1
+                if done % check_every == 0 and done < n_new:
+                    if int(st.alive[pos + 1].item()) == 0:           # this step ran at cur_len = pos + 1
+                        break
+        bufs['eager_runs'] += 1
+        lens = st.fin_len[:, 0].clone()
+        out = st.fin_seqs[:, 0, :].clone()
+        out.masked_fill_(torch.arange(n_new, device=dev)[None, :] >= lens[:, None], int(eos_id))
+        return out, lens, st.fin_scores[:, 0].clone(), nsp

@@ -134,6 +134,64 @@ def attn_decode(q, k, v, out, *, nbatch, nheads, max_keys, q_bs, kv_bs, kv_ts, o
     return out
 
 
+def attn_decode_shared(q, k, v, out, *, nbatch, nheads, max_keys, q_bs, kv_bs, kv_ts, o_bs, kv_group, k_off=0, v_off=0):
+    """attn_decode where query row b reads cache row b // kv_group (beams of one utterance over its cross-attention K/V)"""
+    _lib.check(_lib.lib().ifh_attn_decode_shared_bf16(_addr(q), q_bs, _addr(k, k_off), _addr(v, v_off), kv_bs, kv_ts,
+                                                      _addr(out), o_bs, max_keys, nbatch, nheads, 64, kv_group,
+                                                      _lib.stream_ptr(out.device)), 'ifh_attn_decode_shared_bf16')
+    return out
+
+
+class BeamState:
+    """Device-resident state of ifh_beam_step for `nbatch` utterances x `beams` (include/infernos_hip.h: ifh_beam_desc)."""
+
+    def __init__(self, nbatch, beams, max_new, device):
+        import torch
+        z = lambda *s, dt: torch.zeros(s, dtype=dt, device=device)
+        self.nbatch, self.beams, self.max_new = nbatch, beams, max_new
+        self.run_scores = z(nbatch, beams, dt=torch.float32)
+        self.fin_scores = z(nbatch, beams, dt=torch.float32)
+        self.fin_seqs = z(nbatch, beams, max_new, dt=torch.int32)
+        self.fin_len = z(nbatch, beams, dt=torch.int32)
+        self.is_fin = z(nbatch, beams, dt=torch.uint8)
+        self.unsat = z(nbatch, dt=torch.int32)
+        self.beam_src = z(nbatch * beams, dt=torch.int32)
+        self.alive = z(2048, dt=torch.int32)
+        self.scratch = z(nbatch * beams * 132, dt=torch.uint8)
+
+    def reset(self):
+        self.run_scores.fill_(-1.0e9)
+        self.run_scores[:, 0] = 0.0
+        self.fin_scores.fill_(-1.0e9)
+        self.fin_seqs.zero_()
+        self.fin_len.zero_()
+        self.is_fin.zero_()
+        self.unsat.fill_(1)
+        self.alive.zero_()
+
+
+def beam_step(logits, st: BeamState, toks, pos, *, vocab, ld, prompt_len, max_length, eos_id, length_penalty=1.0,
+              suppress=None, begin_suppress=None):
+    """One beam-search step at cur_len = pos[0] (ifh_beam_step)."""
+    assert max_length - prompt_len <= st.max_new and max_length <= st.alive.numel()
+    assert st.fin_seqs.size(2) == max_length - prompt_len, 'fin_seqs rows are max_length - prompt_len long'
+    d = _lib.BeamDesc()
+    d.logits, d.ld, d.vocab, d.nbatch, d.beams = _addr(logits), ld, vocab, st.nbatch, st.beams
+    d.suppress, d.begin_suppress = _addr(suppress), _addr(begin_suppress)
+    d.toks, d.pos = _addr(toks), _addr(pos)
+    d.prompt_len, d.max_length, d.eos_id, d.length_penalty = prompt_len, max_length, eos_id, length_penalty
+    d.run_scores, d.fin_scores, d.fin_seqs, d.fin_len = _addr(st.run_scores), _addr(st.fin_scores), _addr(st.fin_seqs), _addr(st.fin_len)
+    d.is_fin, d.unsat, d.beam_src, d.alive, d.scratch = _addr(st.is_fin), _addr(st.unsat), _addr(st.beam_src), _addr(st.alive), _addr(st.scratch)
+    _lib.check(_lib.lib().ifh_beam_step(ctypes.byref(d), _lib.stream_ptr(logits.device)), 'ifh_beam_step')
+
+
+def kv_gather(src, dst, row_src, length, *, nrows, max_len, tok_elems):
+    """dst[row] = src[row_src[row]] for the first length[0] tokens of a [nrows, max_len, tok_elems] bf16 cache"""
+    _lib.check(_lib.lib().ifh_kv_gather_bf16(_addr(src), _addr(dst), _addr(row_src), _addr(length), max_len, nrows,
+                                             max_len * tok_elems, tok_elems, _lib.stream_ptr(dst.device)),
+               'ifh_kv_gather_bf16')
+
+
 def embed(ids, table, pos_table, out, *, n, dim, pos0=0, seq_len=1, ids_off=0, dyn_pos=None, dyn_ids_mul=0):
     _lib.check(_lib.lib().ifh_embed_bf16(_addr(ids, ids_off), _addr(table), _addr(pos_table), pos0, seq_len, dim, n,
                                          _addr(out), _addr(dyn_pos), dyn_ids_mul, _lib.stream_ptr(out.device)),

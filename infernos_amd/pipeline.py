@@ -82,7 +82,7 @@ class BatchedVAD:
 class SpeechPipeline:
     def __init__(self, ncalls: int, device=None, whisper_family='whisper_tiny', seed=0, n_text=64, n_infer=10,
                  n_new_tokens=32, tts_output_sr=8000, weights=None, tts_lanes=2, tts_overlap=True, tts_group=1,
-                 front_lanes=1):
+                 front_lanes=1, stt_beam=1):
         from .engines.whisper import Whisper
         from .features import WhisperLogMel
         from .tts import HelloSippyRTPipe
@@ -92,6 +92,7 @@ class SpeechPipeline:
         self.tts_overlap = tts_overlap      # render of chunk c on a second stream while chunk c+1 decodes (within a lane)
         self.tts_group = max(1, tts_group)  # utterance cycles synthesised as one TTS batch (rows = group * ncalls)
         self.block_ingest = os.environ.get('IFH_TICK_INGEST') is None
+        self.stt_beam = int(stt_beam)      # 1: greedy (the reference's torch engine); 5: its default engine's beam search
         with torch.cuda.device(dev):
             self.calls = CallTable(ncalls, dev)
             self.vad = BatchedVAD(ncalls, dev)
@@ -184,7 +185,11 @@ class SpeechPipeline:
         raw, wmax = fl.logmel.raw(x16, lens=lens16)        # normalisation fused into conv1's layout change
         enc = fl.whisper.encode(raw=(fl.logmel, raw, wmax))
         prompt = self.prompt if nrow == self.n else self.prompt.repeat(nrow // self.n, 1)
-        toks, nsp, _ = fl.whisper.generate(enc, prompt, self.n_new, no_speech_id=50362)
+        if self.stt_beam > 1:
+            toks, _, _, nsp = fl.whisper.generate_beam(enc, prompt, self.n_new, beams=self.stt_beam, eos_id=50257,
+                                                       no_speech_id=50362, check_every=self.n_new + 1)
+        else:
+            toks, nsp, _ = fl.whisper.generate(enc, prompt, self.n_new, no_speech_id=50362)
         return toks, nsp, (lens8.float() / 8000.0)
 
     # ---- stage 3 -----------------------------------------------------------------------------

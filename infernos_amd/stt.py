@@ -151,14 +151,22 @@ class InfernSTTWorker(InfernBatchedWorker):
     max_batch_size is the reference's tuning knob (4 there); the MI355X default is 64 because a
     batch is one set of large GEMMs here.  Constructor extras (all optional): `weights` (HF-format
     state dict; default: download `model_name`), `tokenizer` (needs convert_tokens_to_ids / decode;
-    default: WhisperTokenizer.from_pretrained), `max_new_tokens`."""
+    default: WhisperTokenizer.from_pretrained), `max_new_tokens`.
+
+    beam_size selects the reference's decode: 5 (default) is what its default engine runs --
+    ctranslate2.models.Whisper.generate(features, prompts, return_no_speech_prob=True) with that library's defaults
+    (beam_size 5, length_penalty 1; InfernSTTWorker.py:61-75): every request is decoded, no_speech_prob is reported;
+    1 is its torch engine (infer_and_decode_torch, :77-107): greedy, and nothing is generated when every request of
+    the batch is above its max_ns_prob (:91-92).  suppress_tokens / begin_suppress_tokens: token ids masked at every /
+    at the first generated position (the model's generation config; ctranslate2 applies them by default)."""
     max_batch_size: int = 64
     max_chunk_duration: float = 32.0
     sample_rate: int = 16000
     debug = False
 
     def __init__(self, device: str, model_name: str = 'openai/whisper-large-v3', weights=None, tokenizer=None,
-                 max_new_tokens: int = 224, fixed_new_tokens=None):
+                 max_new_tokens: int = 224, fixed_new_tokens=None, beam_size: int = 5, length_penalty: float = 1.0,
+                 suppress_tokens=None, begin_suppress_tokens=None):
         super().__init__()
         from .engines.whisper import Whisper
         from .features import WhisperLogMel
@@ -177,6 +185,19 @@ class InfernSTTWorker(InfernBatchedWorker):
         self.eos_token_id = getattr(tokenizer, 'eos_token_id', None)
         self.max_new_tokens = max_new_tokens
         self.fixed_new_tokens = fixed_new_tokens
+        self.beam_size, self.length_penalty = int(beam_size), float(length_penalty)
+        self._suppress = self._begin_suppress = None
+        V = self.model.vocab
+        if self.beam_size > 1 and self.eos_token_id is None:
+            raise ValueError('beam search needs the tokenizer\'s eos_token_id')
+        if suppress_tokens or (fixed_new_tokens and self.beam_size > 1):
+            self._suppress = torch.zeros(V, dtype=torch.float32)
+            self._suppress[list(suppress_tokens or [])] = float('-inf')
+            if fixed_new_tokens:                     # fixed-length workloads: the end token can never win
+                self._suppress[self.eos_token_id] = float('-inf')
+        if begin_suppress_tokens:
+            self._begin_suppress = torch.zeros(V, dtype=torch.float32)
+            self._begin_suppress[list(begin_suppress_tokens)] = float('-inf')
         self._prompt_cache = {}
 
     def get_prompt(self, options):
@@ -204,6 +225,20 @@ class InfernSTTWorker(InfernBatchedWorker):
             assert all(len(p) == P for p in prompts), 'prompts of one batch must have equal length'
             pr = torch.tensor(prompts, dtype=torch.int32)
             n_new = self.fixed_new_tokens or self.max_new_tokens
+            if self.beam_size > 1:
+                toks, tlens, _, nsp = self.model.generate_beam(enc, pr, n_new, beams=self.beam_size, eos_id=self.eos_token_id,
+                                                               length_penalty=self.length_penalty, suppress=self._suppress,
+                                                               begin_suppress=self._begin_suppress,
+                                                               no_speech_id=self.no_speech_token_id)
+                nsp = nsp.cpu().tolist()
+                toks, tlens = toks.cpu().tolist(), tlens.cpu().tolist()
+                out = []
+                for row, n, p in zip(toks, tlens, nsp):
+                    row = row[:n]
+                    if row and row[-1] == self.eos_token_id:
+                        row = row[:-1]
+                    out.append((self.tokenizer.decode(row, skip_special_tokens=True), p, row))
+                return out
             toks, nsp, _ = self.model.generate(enc, pr, n_new, no_speech_id=self.no_speech_token_id,
                                                eos_id=None if self.fixed_new_tokens else self.eos_token_id,
                                                early_exit_nsp=max_nsps)

@@ -367,3 +367,95 @@ def whisper_greedy(sd, mel, prompt, n_new, nheads, no_speech_id=None, dtype=torc
         if s + 1 < n_new:
             cur = whisper_decoder(sd, nxt[:, None], prompt.size(1) + s, enc, nheads, caches)[:, -1]
     return torch.stack(out, 1), first, logits0, enc
+
+
+# =========================================================================================
+# Beam search (the decode CTranslate2's Whisper.generate runs by default for InfernSTTWorker.infer_and_decode_ct2,
+# Cluster/InfernSTTWorker.py:61-75: beam_size 5, length_penalty 1).  ctranslate2 is a wheel the reference does not
+# vendor, so the search is restated from the transformers 5.15 implementation the fixtures are generated with
+# (GenerationMixin._beam_search, generation/utils.py: do_sample False, early_stopping False) and pinned against it
+# in tests/golden/whisper_beam.npz.
+# =========================================================================================
+def beam_search(step_logits, prompt, n_new, num_beams, eos_id, length_penalty=1.0, suppress=None, begin_suppress=None):
+    """step_logits(seqs [R, cur_len] int64, beam_src [R] or None) -> logits [R, V] for the next token of every row
+    (rows are batch-major: row = b * num_beams + k; beam_src names the previous-step row each row continues, for a
+    KV-cached model).  prompt int64 [B, P].  Returns (sequences [B][list of new tokens, eos included], scores [B]
+    = sum of log-probs / generated length ** length_penalty, all_fin (sequences, scores, is_fin) per batch item)."""
+    B, P = prompt.shape
+    K, KK = num_beams, 2 * num_beams
+    max_length = P + n_new
+    NEG = -1.0e9
+    run_seqs = prompt[:, None, :].repeat(1, K, 1)                       # [B, K, cur_len]
+    run_scores = torch.zeros(B, K)
+    run_scores[:, 1:] = NEG
+    fin_seqs = [[[] for _ in range(K)] for _ in range(B)]
+    fin_scores = torch.full((B, K), NEG)
+    is_fin = torch.zeros(B, K, dtype=torch.bool)
+    unsat = torch.ones(B, dtype=torch.bool)
+    beam_src = None
+    cur_len = P
+    while True:
+        logits = step_logits(run_seqs.reshape(B * K, cur_len), beam_src).float()
+        V = logits.size(-1)
+        logp = torch.log_softmax(logits, -1)
+        if suppress is not None:
+            logp = logp + suppress
+        if begin_suppress is not None and cur_len == P:
+            logp = logp + begin_suppress
+        acc = (logp.view(B, K, V) + run_scores[:, :, None]).reshape(B, K * V)
+        top_s, top_i = torch.topk(acc, KK)                              # sorted descending
+        top_b, top_t = top_i // V, top_i % V
+        cand_seqs = torch.cat([torch.gather(run_seqs, 1, top_b[:, :, None].expand(B, KK, cur_len)), top_t[:, :, None]], 2)
+        hits = (top_t == eos_id) | (cur_len + 1 >= max_length)
+        # running beams of the next step: the best K candidates that did not just finish
+        run_pick = torch.topk(top_s + hits.float() * NEG, K)[1]
+        run_seqs = torch.gather(cand_seqs, 1, run_pick[:, :, None].expand(B, K, cur_len + 1))
+        run_scores = torch.gather(top_s + hits.float() * NEG, 1, run_pick)
+        beam_src = (torch.gather(top_b, 1, run_pick) + torch.arange(B)[:, None] * K).reshape(-1)
+        # finished hypotheses: only candidates ranked inside the first K may finish
+        just = hits.clone()
+        just[:, K:] = False
+        fs = top_s / float(cur_len + 1 - P) ** length_penalty
+        fs = fs + (~unsat)[:, None].float() * NEG + (~just).float() * NEG
+        merged = torch.cat([fin_scores, fs], 1)
+        pick = torch.topk(merged, K)[1]
+        new_fin = []
+        for b in range(B):
+            row = []
+            for j in pick[b].tolist():
+                row.append(fin_seqs[b][j] if j < K else cand_seqs[b, j - K, P:].tolist())
+            new_fin.append(row)
+        fin_seqs = new_fin
+        fin_scores = torch.gather(merged, 1, pick)
+        is_fin = torch.gather(torch.cat([is_fin, just], 1), 1, pick)
+        cur_len += 1
+        best_possible = run_scores[:, 0] / float(cur_len - P) ** length_penalty
+        worst = torch.where(is_fin, fin_scores.min(1, keepdim=True)[0], torch.full((B, K), NEG))
+        unsat = unsat & (best_possible[:, None] > worst).any(1)
+        if not bool(unsat.any()) or bool(hits.all()):
+            break
+    return [fin_seqs[b][0] for b in range(B)], fin_scores[:, 0].clone(), (fin_seqs, fin_scores, is_fin)
+
+
+def whisper_beam(sd, mel, prompt, n_new, nheads, num_beams=5, eos_id=50257, length_penalty=1.0, suppress=None,
+                 begin_suppress=None, dtype=torch.float32):
+    """Encoder + beam search over the KV-cached decoder.  Returns (sequences, scores, enc)."""
+    sd = _cast(sd, dtype)
+    enc = whisper_encoder(sd, mel, nheads, dtype)
+    nl = 0
+    while ('model.decoder.layers.%d.fc1.weight' % nl) in sd:
+        nl += 1
+    K = num_beams
+    encK = enc.repeat_interleave(K, 0)
+    state = {'caches': None}
+
+    def step(seqs, beam_src):
+        if beam_src is None:
+            state['caches'] = [{'self': {}, 'cross': {}} for _ in range(nl)]
+            return whisper_decoder(sd, seqs, 0, encK, nheads, state['caches'])[:, -1]
+        for c in state['caches']:
+            c['self']['k'] = c['self']['k'].index_select(0, beam_src)
+            c['self']['v'] = c['self']['v'].index_select(0, beam_src)
+        return whisper_decoder(sd, seqs[:, -1:], seqs.size(1) - 1, encK, nheads, state['caches'])[:, -1]
+    seqs, scores, _ = beam_search(step, prompt, n_new, K, eos_id, length_penalty, suppress, begin_suppress)
+    return seqs, scores, enc

@@ -105,3 +105,36 @@ def test_whisper_matches_reference_run(golden_dir):
     assert np.array_equal(toks.numpy(), g['greedy'])
     nsp = torch.softmax(l0, -1)[:, meta['no_speech_id']].tolist()
     np.testing.assert_allclose(nsp, meta['no_speech_prob'], rtol=1e-2)
+
+
+def test_beam_search_matches_transformers(golden_dir):
+    """oracle/nn.py:beam_search against transformers' GenerationMixin beam search on the seeded whisper_tiny
+    (tools/gen_golden_nn.py:gen_whisper_beam): 13 cases over beams, eos id, length, length_penalty, begin-suppression,
+    two of them ending early on a finished hypothesis."""
+    from oracle import dsp
+    from infernos_amd.synth import synth_utterance
+    g = np.load(os.path.join(golden_dir, 'whisper_beam.npz'))
+    meta = json.load(open(os.path.join(golden_dir, 'whisper_beam_meta.json')))
+    sd = synth_state_dict('whisper_tiny', 0)
+    auds = [dsp.resample(synth_utterance(s, 10.0), 8000, 16000) for s in meta['audio_seeds']]
+    mel = torch.from_numpy(dsp.logmel(np.stack(auds)))
+    prompt = torch.tensor([meta['prompt']] * 2)
+    V = 51865
+    early = 0
+    for ci, c in enumerate(meta['cases']):
+        sup = torch.zeros(V)
+        sup[50257:] = float('-inf')
+        sup[c['eos']] = 0.0
+        bs = None
+        if c['begin']:
+            bs = torch.zeros(V)
+            bs[c['begin']] = float('-inf')
+        with torch.no_grad():
+            seqs, scores, _ = onn.whisper_beam(sd, mel, prompt, c['n_new'], 6, c['beams'], c['eos'], c['lp'], suppress=sup,
+                                               begin_suppress=bs)
+        lens = g['len%d' % ci]
+        for b in range(2):
+            assert seqs[b] == g['seq%d' % ci][b, :lens[b]].tolist(), (ci, b)
+            early += int(lens[b] < c['n_new'])
+        np.testing.assert_allclose(scores.numpy(), g['score%d' % ci], atol=2e-4)
+    assert early >= 2

@@ -37,7 +37,7 @@ def test_stt_worker_through_sessions(built_lib):
     from infernos_amd.weights import synth_state_dict
     dev = _lib.require_device('cuda:0')
     sd = synth_state_dict('whisper_tiny', 0)
-    w = InfernSTTWorker(dev, weights=sd, tokenizer=StubTokenizer(), fixed_new_tokens=6)
+    w = InfernSTTWorker(dev, weights=sd, tokenizer=StubTokenizer(), fixed_new_tokens=6, beam_size=1)     # the torch engine's path
     w.start()
     try:
         results, done = {}, threading.Event()
@@ -211,3 +211,48 @@ def test_tts_worker_audio_matches_oracle(built_lib):
     e = float((got.double() - ref.double()).norm() / ref.double().norm())
     print('TTS worker through session: rel_l2 vs oracle %.3e over %d samples, %d infer calls' % (e, got.numel(), len(masks)))
     assert e < 3e-2, e
+
+
+def test_stt_worker_default_decode_is_beam_search(built_lib):
+    """The worker's default decode is the reference's default engine's: beam search with 5 beams
+    (Cluster/InfernSTTWorker.py:61-75 through ctranslate2's defaults), every request decoded whatever its
+    max_ns_prob, no_speech_prob reported.  Checked against the oracle's search on the same audio."""
+    from infernos_amd import _lib
+    from infernos_amd.audio import AudioChunk
+    from infernos_amd.stt import InfernSTTWorker, STTRequest
+    from infernos_amd.synth import synth_utterance
+    from infernos_amd.weights import synth_state_dict
+    dev = _lib.require_device('cuda:0')
+    sd = synth_state_dict('whisper_tiny', 0)
+    V = 51865
+    specials = [i for i in range(50257, V) if i != 50257]
+    w = InfernSTTWorker(dev, weights=sd, tokenizer=StubTokenizer(), max_new_tokens=7, suppress_tokens=specials,
+                        begin_suppress_tokens=[220, 50257])
+    assert w.beam_size == 5
+    aud = [odsp.resample(synth_utterance(1000 + i, 3.0)[8000:20000], 8000, 16000) for i in range(3)]
+    got = []
+    wis = []
+    for i, a in enumerate(aud):
+        req = STTRequest(AudioChunk(torch.from_numpy(a), 16000), None, 'en')
+        req.max_ns_prob = -1.0                 # would suppress generation on the torch engine's path; not here
+        wis.append((req, (lambda result, i=i: got.append((i, result))), None))
+    w.process_batch(wis)
+    assert [g[0] for g in got] == [0, 1, 2]
+    sup = torch.zeros(V)
+    sup[specials] = float('-inf')
+    bs = torch.zeros(V)
+    bs[[220, 50257]] = float('-inf')
+    same = 0
+    for i, r in got:
+        toks = [int(t) for t in r.text.split()]
+        mel = torch.from_numpy(odsp.logmel(aud[i][None]))
+        with torch.no_grad():
+            seqs, scores, enc = onn.whisper_beam(sd, mel, torch.tensor([[50258, 50259, 50359, 50363]]), 7, 6, 5, 50257, 1.0,
+                                                 suppress=sup, begin_suppress=bs)
+            o_l0 = onn.whisper_decoder(sd, torch.tensor([[50258]]), 0, enc, 6, [{'self': {}, 'cross': {}} for _ in range(4)])[:, 0]
+        ref = [t for t in seqs[0] if t != 50257]
+        same += int(toks == ref)
+        assert len(toks) == len(ref) == 7
+        nsp = float(torch.softmax(o_l0, -1)[0, 50362])
+        assert abs(r.no_speech_prob - nsp) <= 0.5 * nsp + 1e-12
+    assert same >= 2, same

@@ -286,4 +286,77 @@ def gen_whisper_tf():
     print('wrote whisper_tf.npz')
 
 
-SECTIONS = {'tts': gen_tts, 'whisper': gen_whisper, 'whisper_tf': gen_whisper_tf}
+def gen_whisper_beam():
+    """Beam-search fixtures: transformers' GenerationMixin.generate(num_beams=K) (the base class, not Whisper's
+    long-form override) on the seeded whisper_tiny, with the special-token range suppressed so that the search has
+    real alternatives, for several (K, eos, length, length_penalty) cases; oracle/nn.py:beam_search is pinned to
+    them."""
+    import json
+    from transformers import WhisperConfig, WhisperForConditionalGeneration, WhisperFeatureExtractor
+    from transformers.generation.utils import GenerationMixin
+    from infernos_amd.weights import synth_state_dict
+    from oracle import nn as onn, dsp
+    sys.path.insert(0, HERE)
+    from gen_golden import synth_utterance
+    sd = synth_state_dict('whisper_tiny', 0)
+    model = WhisperForConditionalGeneration(WhisperConfig())
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    fe = WhisperFeatureExtractor()
+    PROMPT = [50258, 50259, 50359, 50363]
+    V = 51865
+    auds = [dsp.resample(synth_utterance(1000 + i, 10.0), 8000, 16000) for i in range(2)]
+    mel = torch.from_numpy(fe(auds, sampling_rate=16000, return_tensors='np').input_features)
+    prompt = torch.tensor([PROMPT, PROMPT])
+    cases = [dict(beams=5, eos=50257, n_new=12, lp=1.0, begin=[]),
+             dict(beams=5, eos=5880, n_new=12, lp=1.0, begin=[]),
+             dict(beams=5, eos=21251, n_new=12, lp=1.0, begin=[]),
+             dict(beams=5, eos=21251, n_new=10, lp=2.0, begin=[6435]),
+             dict(beams=5, eos=6435, n_new=8, lp=0.5, begin=[220, 6435]),
+             dict(beams=3, eos=23249, n_new=9, lp=1.0, begin=[]),
+             dict(beams=2, eos=5880, n_new=6, lp=1.0, begin=[5880]),
+             dict(beams=4, eos=9923, n_new=16, lp=1.0, begin=[]),
+             dict(beams=5, eos=5880, n_new=12, lp=0.0, begin=[]),          # un-normalised scores: short hypotheses win
+             dict(beams=5, eos=6435, n_new=12, lp=0.0, begin=[]),
+             dict(beams=3, eos=21251, n_new=12, lp=0.0, begin=[]),
+             dict(beams=5, eos=5880, n_new=12, lp=0.3, begin=[]),
+             dict(beams=5, eos=21251, n_new=12, lp=0.2, begin=[5880])]
+    arrays, meta = {}, []
+    for ci, c in enumerate(cases):
+        sup_ids = [i for i in range(50257, V) if i != c['eos']]
+        with torch.no_grad():
+            out = GenerationMixin.generate(model, input_features=mel, decoder_input_ids=prompt, num_beams=c['beams'],
+                                           do_sample=False, max_new_tokens=c['n_new'], eos_token_id=c['eos'],
+                                           pad_token_id=50256, length_penalty=c['lp'], early_stopping=False,
+                                           return_dict_in_generate=True, output_scores=True, suppress_tokens=sup_ids,
+                                           begin_suppress_tokens=c['begin'] or None, forced_decoder_ids=None)
+        seq = out.sequences[:, len(PROMPT):]
+        # generated length per row: up to and including the first eos (the rest is padding)
+        lens = []
+        for r in seq.tolist():
+            lens.append(r.index(c['eos']) + 1 if c['eos'] in r else len(r))
+        sup = torch.zeros(V)
+        sup[sup_ids] = float('-inf')
+        bs = None
+        if c['begin']:
+            bs = torch.zeros(V)
+            bs[c['begin']] = float('-inf')
+        o_seq, o_sc, _ = onn.whisper_beam(sd, mel, prompt, c['n_new'], 6, c['beams'], c['eos'], c['lp'], suppress=sup,
+                                          begin_suppress=bs)
+        same = all(o_seq[b] == seq[b, :lens[b]].tolist() for b in range(2))
+        print('beam case', ci, c, 'lens', lens, 'tokens equal', same, 'score diff',
+              float((o_sc - out.sequences_scores).abs().max()))
+        arrays['seq%d' % ci] = seq.numpy().astype(np.int32)
+        arrays['len%d' % ci] = np.asarray(lens, np.int32)
+        arrays['score%d' % ci] = out.sequences_scores.numpy()
+        meta.append(c)
+    np.savez_compressed(os.path.join(GOLD, 'whisper_beam.npz'), **arrays)
+    json.dump({'source': 'transformers 5.15.0 GenerationMixin.generate(num_beams=K, do_sample=False, early_stopping=False) '
+                         'on WhisperForConditionalGeneration(WhisperConfig()) holding synth_state_dict(whisper_tiny, 0); '
+                         'ids >= 50257 other than eos suppressed (suppress_tokens), `begin` = begin_suppress_tokens',
+               'prompt': PROMPT, 'audio_seeds': [1000, 1001], 'cases': meta},
+              open(os.path.join(GOLD, 'whisper_beam_meta.json'), 'w'), indent=1, sort_keys=True)
+    print('wrote whisper_beam.npz')
+
+
+SECTIONS = {'tts': gen_tts, 'whisper': gen_whisper, 'whisper_tf': gen_whisper_tf, 'whisper_beam': gen_whisper_beam}
