@@ -486,6 +486,41 @@ int ifh_argmax_pick_f32(const float *logits, int64_t ld, int vocab, int nrows, i
  * zero_bytes (% 16 == 0, 16-byte aligned, may be 0) at zero_buf: the LayerNorm statistics the NEXT step accumulates into */
 int ifh_add_i32(int32_t *value, int delta, void *zero_buf, int64_t zero_bytes, ifh_stream_t stream);
 
+/* ---- decoder-only LLM step (InfernLLMWorker, Cluster/InfernLLMWorker.py:60-119: Qwen2.5 through transformers' generate;
+ * layer maths of transformers/models/qwen2/modeling_qwen2.py).  The projections are ifh_conv_bf16 GEMMs; these are the
+ * kernels between them. ---- */
+/* out = x * rsqrt(mean(x^2) + eps) * gamma   (Qwen2RMSNorm); x, out bf16 [rows, dim], gamma f32 [dim]; dim % 8 == 0 */
+int ifh_rmsnorm_bf16(const void *x, const float *gamma, void *out, int rows, int dim, float eps, ifh_stream_t stream);
+/* Rotary embedding + KV append on the fused projection qkv bf16 [nrows * tokens_per_row, qkv_ld] = q (nheads*head_dim) |
+ * k (nkv*head_dim) | v (nkv*head_dim).  Token t of row b sits at position pos0[b] + t; tokens with t >= nvalid[b] are
+ * padding and are skipped.  q is rotated in place; rotated k and v go to cache bf16 [nrows][max_pos][cache_ts] at
+ * (b, position): k heads first, then v heads.  cos_sin f32 [max_pos][head_dim/2][2] (cos, sin of position * theta^(-2j/hd));
+ * pairing (j, j + head_dim/2) as apply_rotary_pos_emb / rotate_half. */
+int ifh_rope_append_bf16(void *qkv, int64_t qkv_ld, const float *cos_sin, int max_pos, void *cache, int64_t cache_bs,
+                         int64_t cache_ts, const int32_t *pos0, const int32_t *nvalid, int nrows, int tokens_per_row,
+                         int nheads, int nkv, int head_dim, ifh_stream_t stream);
+/* Grouped-query attention of single query tokens against the KV cache: token i (of ntokens = rows * tokens_per_row)
+ * attends over keys 0 .. key_len[i]-1 of cache row i / tokens_per_row; the nheads/nkv (<= 8) query heads of a kv head
+ * share its K/V loads.  Prefill = one call over all prompt tokens with key_len[i] = position + 1 (causal); decode =
+ * tokens_per_row 1.  head_dim 64 or 128.  out[i] bf16 [nheads*head_dim]; softmax(scale * q.k) v, fp32 accumulation. */
+typedef struct ifh_gqa_desc {
+    const void *q;
+    int64_t q_ts;
+    const void *cache;
+    int64_t cache_bs, cache_ts;
+    int32_t v_off;             /* element offset of the v heads inside a cache token (nkv * head_dim) */
+    void *out;
+    int64_t o_ts;
+    const int32_t *key_len;    /* int32 [ntokens] */
+    int32_t ntokens, tokens_per_row, nheads, nkv, head_dim, max_keys;
+    float scale;
+} ifh_gqa_desc;
+int ifh_attn_gqa_bf16(const ifh_gqa_desc *desc, ifh_stream_t stream);
+/* out[r, j] = silu(gate_up[r, j]) * gate_up[r, ffn + j]   (Qwen2MLP); bf16, ffn % 8 == 0 */
+int ifh_silu_mul_bf16(const void *gate_up, void *out, int64_t rows, int ffn, ifh_stream_t stream);
+/* values[i] += delta where mask[i] != 0 (mask optional): per-row sequence lengths advanced between graph replays */
+int ifh_add_i32_vec(int32_t *values, const int32_t *mask, int n, int delta, ifh_stream_t stream);
+
 /* ---- TTS streaming glue, HelloSippyRTPipe.infer (HelloSippyRTPipe.py:191-240) ---- */
 /* stop rule (:227-228) on the 2 stop logits per utterance (row stride logits_ld floats); ends_at int64[n].
  * dyn_minmax (optional, device int32[2] = {minlen, maxlen}) overrides the by-value lengths: a launch captured in a

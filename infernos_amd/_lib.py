@@ -106,6 +106,14 @@ class BeamDesc(ctypes.Structure):
                 ('alive', _vp), ('scratch', _vp)]
 
 
+class GqaDesc(ctypes.Structure):
+    """ifh_gqa_desc (include/infernos_hip.h)"""
+    _fields_ = [('q', _vp), ('q_ts', _i64), ('cache', _vp), ('cache_bs', _i64), ('cache_ts', _i64), ('v_off', ctypes.c_int32),
+                ('out', _vp), ('o_ts', _i64), ('key_len', _vp), ('ntokens', ctypes.c_int32), ('tokens_per_row', ctypes.c_int32),
+                ('nheads', ctypes.c_int32), ('nkv', ctypes.c_int32), ('head_dim', ctypes.c_int32), ('max_keys', ctypes.c_int32),
+                ('scale', _f)]
+
+
 class RtpHdr(ctypes.Structure):
     """ifh_rtp_hdr (include/infernos_hip.h)"""
     _fields_ = [(n, ctypes.c_int32) for n in ('version', 'padding', 'extension', 'cc', 'marker', 'pt')] + \
@@ -149,6 +157,11 @@ SIGNATURES.update({
     'ifh_attn_decode_shared_bf16': (_i, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     'ifh_beam_step': (_i, [ctypes.POINTER(BeamDesc), _vp]),
     'ifh_kv_gather_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp]),
+    'ifh_rmsnorm_bf16': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
+    'ifh_rope_append_bf16': (_i, [_vp, _i64, _vp, _i, _vp, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'ifh_attn_gqa_bf16': (_i, [ctypes.POINTER(GqaDesc), _vp]),
+    'ifh_silu_mul_bf16': (_i, [_vp, _vp, _i64, _i, _vp]),
+    'ifh_add_i32_vec': (_i, [_vp, _vp, _i, _i, _vp]),
     'ifh_argmax_pick_f32': (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     'ifh_tts_stop_update': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp]),
     'ifh_tts_stop_advance': (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp, _i64, _vp, _vp]),

@@ -1,0 +1,368 @@
+// Decoder-only LLM step kernels for InfernLLMWorker (Cluster/InfernLLMWorker.py:60-119: Qwen2.5 through
+// transformers' generate): the pieces around the GEMMs (nn.hip) of a Qwen2 layer
+// (transformers/models/qwen2/modeling_qwen2.py: Qwen2RMSNorm, apply_rotary_pos_emb, Qwen2Attention with grouped-query
+// heads, Qwen2MLP).
+//   k_rmsnorm        one wave per token row: x * rsqrt(mean(x^2) + eps) * gamma, fp32 statistics.
+//   k_rope_append    rotary embedding of the fused q|k|v projection: q rotated in place, k rotated and v copied into the
+//                    KV cache at the token's own position (ragged prompts: every row has its own length).
+//   k_attn_gqa       one query token per (token, kv head): the G query heads of a kv head share every K/V load; keys
+//                    0 .. key_len[token]-1 of the token's cache row.  The same kernel serves prefill (one launch over all
+//                    prompt tokens, key_len = position + 1: causal) and decode.
+//   k_silu_mul       silu(gate) * up on the fused gate|up projection.
+#include "common.h"
+
+namespace ifh {
+
+__global__ __launch_bounds__(256) void k_rmsnorm(const uint16_t *__restrict__ x, const float *__restrict__ gamma,
+                                                 uint16_t *__restrict__ out, int rows, int dim, float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const uint4 *xr = reinterpret_cast<const uint4 *>(x + (int64_t)row * dim);
+    uint4 *orow = reinterpret_cast<uint4 *>(out + (int64_t)row * dim);
+    const int nv = dim >> 3;
+    float ss = 0.0f;
+    for (int j = lane; j < nv; j += 64) {
+        const uint4 t = xr[j];
+        const uint32_t *u = reinterpret_cast<const uint32_t *>(&t);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float a = __uint_as_float(u[e] << 16), b = __uint_as_float(u[e] & 0xffff0000u);
+            ss = __fmaf_rn(a, a, ss);
+            ss = __fmaf_rn(b, b, ss);
+        }
+    }
+    ss = wave_sum(ss);
+    const float r = rsqrtf(ss / (float)dim + eps);
+    for (int j = lane; j < nv; j += 64) {
+        const uint4 t = xr[j];
+        const uint32_t *u = reinterpret_cast<const uint32_t *>(&t);
+        const float4 g0 = *reinterpret_cast<const float4 *>(gamma + 8 * j);
+        const float4 g1 = *reinterpret_cast<const float4 *>(gamma + 8 * j + 4);
+        uint4 o;
+        o.x = f32x2_to_bf16x2(__uint_as_float(u[0] << 16) * r * g0.x, __uint_as_float(u[0] & 0xffff0000u) * r * g0.y);
+        o.y = f32x2_to_bf16x2(__uint_as_float(u[1] << 16) * r * g0.z, __uint_as_float(u[1] & 0xffff0000u) * r * g0.w);
+        o.z = f32x2_to_bf16x2(__uint_as_float(u[2] << 16) * r * g1.x, __uint_as_float(u[2] & 0xffff0000u) * r * g1.y);
+        o.w = f32x2_to_bf16x2(__uint_as_float(u[3] << 16) * r * g1.z, __uint_as_float(u[3] & 0xffff0000u) * r * g1.w);
+        orow[j] = o;
+    }
+}
+
+// token i = b * T + t sits at position pos0[b] + t of cache row b; tokens with t >= nvalid[b] are padding (skipped).
+// One thread per (token, head slot, pair j < hd/2); head slots: nh query heads, nkv key heads, nkv value heads.
+__global__ __launch_bounds__(256) void k_rope_append(uint16_t *__restrict__ qkv, int64_t qkv_ld,
+                                                     const float *__restrict__ cs /* [max_pos][hd/2][2] cos, sin */,
+                                                     uint16_t *__restrict__ cache, int64_t cache_bs, int64_t cache_ts,
+                                                     const int32_t *__restrict__ pos0, const int32_t *__restrict__ nvalid,
+                                                     int T, int nh, int nkv, int hd, int max_pos, int64_t total)
+{
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int half = hd >> 1;
+    const int j = (int)(idx % half);
+    const int slot = (int)((idx / half) % (nh + 2 * nkv));
+    const int64_t i = idx / ((int64_t)half * (nh + 2 * nkv));
+    const int b = (int)(i / T), t = (int)(i % T);
+    if (t >= nvalid[b]) return;
+    const int pos = pos0[b] + t;
+    if (pos >= max_pos) return;
+    uint16_t *src = qkv + i * qkv_ld + (int64_t)slot * hd;
+    if (slot >= nh + nkv) {                 // value head: plain copy of the pair's two elements
+        uint16_t *dst = cache + (int64_t)b * cache_bs + (int64_t)pos * cache_ts + (int64_t)(slot - nh) * hd;
+        dst[j] = src[j];
+        dst[j + half] = src[j + half];
+        return;
+    }
+    const float c = cs[((int64_t)pos * half + j) * 2], s = cs[((int64_t)pos * half + j) * 2 + 1];
+    const float a = bf16_to_f32(src[j]), bb = bf16_to_f32(src[j + half]);
+    const uint16_t r0 = f32_to_bf16(a * c - bb * s), r1 = f32_to_bf16(bb * c + a * s);
+    if (slot < nh) {
+        src[j] = r0;
+        src[j + half] = r1;
+    } else {
+        uint16_t *dst = cache + (int64_t)b * cache_bs + (int64_t)pos * cache_ts + (int64_t)(slot - nh) * hd;
+        dst[j] = r0;
+        dst[j + half] = r1;
+    }
+}
+
+// Grouped-query decode attention.  A wave is 8 key-groups x 8 lanes; a lane owns 8*HDV of the 64*HDV head dims (HDV
+// 16-byte loads per key for K and for V).  Structure of k_attn_decode (attn.hip): per key-group online softmax over its
+// keys, merged over the 8 groups and the NW waves at the end.
+template <int NW, int G, int HDV>
+__global__ __launch_bounds__(NW * 64) void k_attn_gqa(const uint16_t *__restrict__ q, int64_t q_ts,
+                                                      const uint16_t *__restrict__ cache, int64_t cache_bs,
+                                                      int64_t cache_ts, int v_off, uint16_t *__restrict__ out,
+                                                      int64_t o_ts, const int32_t *__restrict__ key_len, int T,
+                                                      float scale)
+{
+    constexpr int HD = 64 * HDV, DV = 8 * HDV;
+    __shared__ float comb[NW][G][8][2 + DV];
+    const int i = blockIdx.y, kvh = blockIdx.x;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int c = lane & 7, g = lane >> 3;
+    const int klen = key_len[i];
+    float qv[G][DV];
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+#pragma unroll
+        for (int hv = 0; hv < HDV; hv++) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(q + (int64_t)i * q_ts + (kvh * G + r) * HD + hv * 64 + 8 * c);
+            const uint32_t *u = reinterpret_cast<const uint32_t *>(&t);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                qv[r][hv * 8 + 2 * e] = __uint_as_float(u[e] << 16) * scale;
+                qv[r][hv * 8 + 2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u) * scale;
+            }
+        }
+    }
+    const uint16_t *kb = cache + (int64_t)(i / T) * cache_bs + kvh * HD + 8 * c;
+    const uint16_t *vb = kb + v_off;
+    float m[G], l[G], o[G][DV];
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+        m[r] = -1e30f;
+        l[r] = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DV; d++) o[r][d] = 0.0f;
+    }
+    constexpr int KU = 2;
+    for (int key0 = wid * 8 + g; key0 < klen; key0 += 8 * NW * KU) {
+        uint4 kk[KU][HDV], vv[KU][HDV];
+#pragma unroll
+        for (int u = 0; u < KU; u++) {
+            const int key = key0 + u * 8 * NW;
+#pragma unroll
+            for (int hv = 0; hv < HDV; hv++) {
+                kk[u][hv] = make_uint4(0, 0, 0, 0);
+                vv[u][hv] = make_uint4(0, 0, 0, 0);
+                if (key < klen) {
+                    kk[u][hv] = *reinterpret_cast<const uint4 *>(kb + (int64_t)key * cache_ts + hv * 64);
+                    vv[u][hv] = *reinterpret_cast<const uint4 *>(vb + (int64_t)key * cache_ts + hv * 64);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < G; r++) {
+            float sc[KU];
+            float mn = m[r];
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                float s = 0.0f;
+#pragma unroll
+                for (int hv = 0; hv < HDV; hv++) {
+                    const uint32_t *ku = reinterpret_cast<const uint32_t *>(&kk[u][hv]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        s = __fmaf_rn(qv[r][hv * 8 + 2 * e], __uint_as_float(ku[e] << 16), s);
+                        s = __fmaf_rn(qv[r][hv * 8 + 2 * e + 1], __uint_as_float(ku[e] & 0xffff0000u), s);
+                    }
+                }
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 4, 64);
+                s = (key0 + u * 8 * NW < klen) ? s : -1e30f;
+                sc[u] = s;
+                mn = fmaxf(mn, s);
+            }
+            const float a = __expf(m[r] - mn);
+            l[r] *= a;
+#pragma unroll
+            for (int d = 0; d < DV; d++) o[r][d] *= a;
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const float pr = (key0 + u * 8 * NW < klen) ? __expf(sc[u] - mn) : 0.0f;
+                l[r] += pr;
+#pragma unroll
+                for (int hv = 0; hv < HDV; hv++) {
+                    const uint32_t *vu = reinterpret_cast<const uint32_t *>(&vv[u][hv]);
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        o[r][hv * 8 + 2 * e] = __fmaf_rn(pr, __uint_as_float(vu[e] << 16), o[r][hv * 8 + 2 * e]);
+                        o[r][hv * 8 + 2 * e + 1] = __fmaf_rn(pr, __uint_as_float(vu[e] & 0xffff0000u), o[r][hv * 8 + 2 * e + 1]);
+                    }
+                }
+            }
+            m[r] = mn;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < G; r++) {
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) {
+            const float m2 = __shfl_xor(m[r], off, 64), l2 = __shfl_xor(l[r], off, 64);
+            const float mn = fmaxf(m[r], m2);
+            const float a = __expf(m[r] - mn), a2 = __expf(m2 - mn);
+            l[r] = l[r] * a + l2 * a2;
+#pragma unroll
+            for (int d = 0; d < DV; d++) o[r][d] = o[r][d] * a + __shfl_xor(o[r][d], off, 64) * a2;
+            m[r] = mn;
+        }
+    }
+    if (NW > 1) {
+        if (g == 0) {
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+                comb[wid][r][c][0] = m[r];
+                comb[wid][r][c][1] = l[r];
+#pragma unroll
+                for (int d = 0; d < DV; d++) comb[wid][r][c][2 + d] = o[r][d];
+            }
+        }
+        __syncthreads();
+        if (wid == 0 && g == 0) {
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+#pragma unroll
+                for (int w = 1; w < NW; w++) {
+                    const float m2 = comb[w][r][c][0], l2 = comb[w][r][c][1];
+                    const float mn = fmaxf(m[r], m2);
+                    const float a = __expf(m[r] - mn), a2 = __expf(m2 - mn);
+                    l[r] = l[r] * a + l2 * a2;
+#pragma unroll
+                    for (int d = 0; d < DV; d++) o[r][d] = o[r][d] * a + comb[w][r][c][2 + d] * a2;
+                    m[r] = mn;
+                }
+            }
+        }
+    }
+    if (wid == 0 && g == 0) {
+#pragma unroll
+        for (int r = 0; r < G; r++) {
+            const float inv = l[r] > 0.0f ? 1.0f / l[r] : 0.0f;
+#pragma unroll
+            for (int hv = 0; hv < HDV; hv++) {
+                uint4 pk;
+                pk.x = f32x2_to_bf16x2(o[r][hv * 8 + 0] * inv, o[r][hv * 8 + 1] * inv);
+                pk.y = f32x2_to_bf16x2(o[r][hv * 8 + 2] * inv, o[r][hv * 8 + 3] * inv);
+                pk.z = f32x2_to_bf16x2(o[r][hv * 8 + 4] * inv, o[r][hv * 8 + 5] * inv);
+                pk.w = f32x2_to_bf16x2(o[r][hv * 8 + 6] * inv, o[r][hv * 8 + 7] * inv);
+                *reinterpret_cast<uint4 *>(out + (int64_t)i * o_ts + (kvh * G + r) * HD + hv * 64 + 8 * c) = pk;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_silu_mul(const uint16_t *__restrict__ gu, uint16_t *__restrict__ out, int64_t rows,
+                                                  int ffn)
+{
+    const int nv = ffn >> 3;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= rows * nv) return;
+    const int64_t row = idx / nv;
+    const int j = (int)(idx % nv);
+    const uint4 a = *reinterpret_cast<const uint4 *>(gu + row * 2 * ffn + 8 * j);
+    const uint4 b = *reinterpret_cast<const uint4 *>(gu + row * 2 * ffn + ffn + 8 * j);
+    const uint32_t *ua = reinterpret_cast<const uint32_t *>(&a), *ub = reinterpret_cast<const uint32_t *>(&b);
+    uint32_t r[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const float g0 = __uint_as_float(ua[e] << 16), g1 = __uint_as_float(ua[e] & 0xffff0000u);
+        const float u0 = __uint_as_float(ub[e] << 16), u1 = __uint_as_float(ub[e] & 0xffff0000u);
+        r[e] = f32x2_to_bf16x2(g0 / (1.0f + __expf(-g0)) * u0, g1 / (1.0f + __expf(-g1)) * u1);
+    }
+    *reinterpret_cast<uint4 *>(out + row * ffn + 8 * j) = make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+__global__ void k_add_i32_vec(int32_t *__restrict__ v, const int32_t *__restrict__ mask, int n, int delta)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && (!mask || mask[i])) v[i] += delta;
+}
+
+template <int G, int HDV>
+static void attn_gqa_launch(const ifh_gqa_desc *d, hipStream_t st)
+{
+    dim3 grid(d->nkv, d->ntokens);
+    if (d->max_keys > 256)
+        hipLaunchKernelGGL((k_attn_gqa<4, G, HDV>), grid, dim3(256), 0, st, (const uint16_t *)d->q, d->q_ts,
+                           (const uint16_t *)d->cache, d->cache_bs, d->cache_ts, d->v_off, (uint16_t *)d->out, d->o_ts,
+                           d->key_len, d->tokens_per_row, d->scale);
+    else
+        hipLaunchKernelGGL((k_attn_gqa<1, G, HDV>), grid, dim3(64), 0, st, (const uint16_t *)d->q, d->q_ts,
+                           (const uint16_t *)d->cache, d->cache_bs, d->cache_ts, d->v_off, (uint16_t *)d->out, d->o_ts,
+                           d->key_len, d->tokens_per_row, d->scale);
+}
+
+}  // namespace ifh
+
+using namespace ifh;
+
+extern "C" int ifh_rmsnorm_bf16(const void *x, const float *gamma, void *out, int rows, int dim, float eps,
+                                ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(rows >= 0);
+    if (rows == 0) return IFH_OK;
+    IFH_CHECK_ARG(x && gamma && out && dim > 0 && dim % 8 == 0 && eps > 0.0f);
+    IFH_CHECK_ARG(((((uintptr_t)x) | ((uintptr_t)out) | ((uintptr_t)gamma)) & 15) == 0);
+    hipLaunchKernelGGL(k_rmsnorm, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), (const uint16_t *)x, gamma,
+                       (uint16_t *)out, rows, dim, eps);
+    IFH_LAUNCH_CHECK("rmsnorm");
+    return IFH_OK;
+}
+
+extern "C" int ifh_rope_append_bf16(void *qkv, int64_t qkv_ld, const float *cos_sin, int max_pos, void *cache,
+                                    int64_t cache_bs, int64_t cache_ts, const int32_t *pos0, const int32_t *nvalid,
+                                    int nrows, int tokens_per_row, int nheads, int nkv, int head_dim, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(nrows >= 0 && tokens_per_row >= 1);
+    if (nrows == 0) return IFH_OK;
+    IFH_CHECK_ARG(qkv && cos_sin && cache && pos0 && nvalid && max_pos >= 1);
+    IFH_CHECK_ARG(nheads >= 1 && nkv >= 1 && head_dim >= 2 && head_dim % 2 == 0);
+    IFH_CHECK_ARG(qkv_ld >= (int64_t)(nheads + 2 * nkv) * head_dim && cache_ts >= (int64_t)2 * nkv * head_dim &&
+                  cache_bs >= cache_ts * max_pos);
+    const int64_t total = (int64_t)nrows * tokens_per_row * (nheads + 2 * nkv) * (head_dim / 2);
+    IFH_CHECK_ARG(total / 256 < (1ll << 31));
+    hipLaunchKernelGGL(k_rope_append, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       (uint16_t *)qkv, qkv_ld, cos_sin, (uint16_t *)cache, cache_bs, cache_ts, pos0, nvalid,
+                       tokens_per_row, nheads, nkv, head_dim, max_pos, total);
+    IFH_LAUNCH_CHECK("rope_append");
+    return IFH_OK;
+}
+
+extern "C" int ifh_attn_gqa_bf16(const ifh_gqa_desc *d, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(d && d->ntokens >= 0);
+    if (d->ntokens == 0) return IFH_OK;
+    IFH_CHECK_ARG(d->q && d->cache && d->out && d->key_len && d->nheads >= 1 && d->nkv >= 1 && d->nheads % d->nkv == 0);
+    IFH_CHECK_ARG(d->head_dim == 64 || d->head_dim == 128);
+    IFH_CHECK_ARG(d->tokens_per_row >= 1 && d->max_keys >= 1 && d->ntokens < 65536 * 16);
+    IFH_CHECK_ARG(d->q_ts % 8 == 0 && d->o_ts % 8 == 0 && d->cache_bs % 8 == 0 && d->cache_ts % 8 == 0 && d->v_off % 8 == 0);
+    const int G = d->nheads / d->nkv;
+    IFH_CHECK_ARG(G <= 8);
+    hipStream_t st = as_stream(stream);
+#define IFH_GQA(GG)                                                      \
+    case GG:                                                             \
+        if (d->head_dim == 128) attn_gqa_launch<GG, 2>(d, st);           \
+        else attn_gqa_launch<GG, 1>(d, st);                              \
+        break;
+    switch (G) {
+        IFH_GQA(1) IFH_GQA(2) IFH_GQA(3) IFH_GQA(4) IFH_GQA(5) IFH_GQA(6) IFH_GQA(7) IFH_GQA(8)
+    }
+#undef IFH_GQA
+    IFH_LAUNCH_CHECK("attn_gqa");
+    return IFH_OK;
+}
+
+extern "C" int ifh_silu_mul_bf16(const void *gate_up, void *out, int64_t rows, int ffn, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(rows >= 0);
+    if (rows == 0) return IFH_OK;
+    IFH_CHECK_ARG(gate_up && out && ffn > 0 && ffn % 8 == 0);
+    const int64_t total = rows * (ffn / 8);
+    IFH_CHECK_ARG(total / 256 < (1ll << 31));
+    hipLaunchKernelGGL(k_silu_mul, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       (const uint16_t *)gate_up, (uint16_t *)out, rows, ffn);
+    IFH_LAUNCH_CHECK("silu_mul");
+    return IFH_OK;
+}
+
+extern "C" int ifh_add_i32_vec(int32_t *values, const int32_t *mask, int n, int delta, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(n >= 0);
+    if (n == 0) return IFH_OK;
+    IFH_CHECK_ARG(values);
+    hipLaunchKernelGGL(k_add_i32_vec, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), values, mask, n, delta);
+    IFH_LAUNCH_CHECK("add_i32_vec");
+    return IFH_OK;
+}

@@ -1,0 +1,188 @@
+"""Qwen2 decoder-only LLM engine (InfernLLMWorker's model: Cluster/InfernLLMWorker.py:60-119 loads
+Qwen/Qwen2.5-*-Instruct through transformers and calls generate with a streamer).
+
+Layer maths: transformers/models/qwen2/modeling_qwen2.py (RMSNorm, rotary embedding with rotate_half pairing,
+grouped-query attention, SiLU-gated MLP, tied or separate lm_head).  Everything runs through the C ABI: projections are
+ifh_conv_bf16 GEMMs (q|k|v and gate|up fused into one weight each), the rest are the llm.hip kernels.
+
+Batches are ragged by construction: every row keeps its own length (device int32), prompts are prefilled in one pass
+over the padded [B, T] token block with per-token key counts (causal) and padding skipped, and each decode step
+advances all rows by one token at their own positions -- the per-token launch sequence is identical for every step, so it
+is captured into a hipGraph after the first eager step and replayed.
+"""
+import torch
+
+from .. import _lib, ops
+
+BF16 = torch.bfloat16
+
+
+class Qwen2:
+    def __init__(self, sd, cfg, device, max_tokens=2048):
+        self.device = dev = _lib.require_device(device)
+        self.cfg = cfg
+        self.d, self.hd, self.nh, self.nkv, self.ff = cfg['hidden'], cfg['head_dim'], cfg['heads'], cfg['kv_heads'], cfg['ffn']
+        self.vocab = cfg['vocab']
+        self.vpad = -(-self.vocab // 16) * 16
+        self.max_tokens = min(max_tokens, cfg['max_pos'])
+        self.eps = cfg['rms_eps']
+        self.nq = (self.nh + 2 * self.nkv) * self.hd
+        f32 = lambda t: t.float().contiguous().to(dev)
+        self.tok = sd['model.embed_tokens.weight'].to(BF16).contiguous().to(dev)
+        self.head = sd['lm_head.weight'].to(BF16).contiguous().to(dev) if 'lm_head.weight' in sd and not cfg['tie'] else self.tok
+        self.norm = f32(sd['model.norm.weight'])
+        self.layers = []
+        for i in range(cfg['layers']):
+            L = 'model.layers.%d.' % i
+            A = L + 'self_attn.'
+            self.layers.append(dict(
+                ln1=f32(sd[L + 'input_layernorm.weight']), ln2=f32(sd[L + 'post_attention_layernorm.weight']),
+                wqkv=ops.w_linear(torch.cat([sd[A + 'q_proj.weight'], sd[A + 'k_proj.weight'], sd[A + 'v_proj.weight']]), dev),
+                bqkv=ops.w_bias(torch.cat([sd[A + 'q_proj.bias'], sd[A + 'k_proj.bias'], sd[A + 'v_proj.bias']]), dev),
+                wo=ops.w_linear(sd[A + 'o_proj.weight'], dev),
+                wgu=ops.w_linear(torch.cat([sd[L + 'mlp.gate_proj.weight'], sd[L + 'mlp.up_proj.weight']]), dev),
+                wd=ops.w_linear(sd[L + 'mlp.down_proj.weight'], dev)))
+        # cos/sin of position * theta^(-2j/hd), f32 [max_tokens][hd/2][2] (Qwen2RotaryEmbedding, computed in fp32)
+        inv = 1.0 / (cfg['rope_theta'] ** (torch.arange(0, self.hd, 2, dtype=torch.int64).float() / self.hd))
+        fr = torch.arange(self.max_tokens).float()[:, None] * inv[None, :]
+        self.cos_sin = torch.stack([fr.cos(), fr.sin()], -1).contiguous().to(dev)
+        self._bufs = {}
+
+    # ---- buffers ------------------------------------------------------------------------------
+    def _state(self, B):
+        if B not in self._bufs:
+            dev, d = self.device, self.d
+            e = lambda *s, dt=BF16: torch.empty(s, dtype=dt, device=dev)
+            while len(self._bufs) >= 2:
+                self._bufs.pop(next(iter(self._bufs)))
+            self._bufs[B] = dict(
+                kv=[torch.zeros((B, self.max_tokens, 2 * self.nkv * self.hd), dtype=BF16, device=dev) for _ in self.layers],
+                x=e(B, d), h=e(B, d), qkv=e(B, self.nq), att=e(B, self.nh * self.hd), gu=e(B, 2 * self.ff), ff=e(B, self.ff),
+                logits_full=e(B, self.vpad, dt=torch.float32),
+                lens=torch.zeros((2, B), dtype=torch.int32, device=dev),        # [0]: tokens in the cache, [1]: that + 1
+                ones=torch.ones(B, dtype=torch.int32, device=dev),
+                toks=torch.zeros(B, dtype=torch.int32, device=dev), graph=None, eager_steps=0)
+            b = self._bufs[B]
+            b['logits'] = b['logits_full'][:, :self.vocab]
+        return self._bufs[B]
+
+    # ---- one layer stack over `rows` tokens -----------------------------------------------------
+    def _layers(self, x, h, qkv, att, gu, ff, kv, rows, nrows, T, pos0, nvalid, key_len, max_keys):
+        d = self.d
+        for L, cache in zip(self.layers, kv):
+            ops.rmsnorm(x, L['ln1'], h, rows, d, self.eps)
+            ops.linear(h, L['wqkv'], L['bqkv'], qkv, rows=rows, k=d, n=self.nq)
+            ops.rope_append(qkv, self.cos_sin, cache, pos0, nvalid, nrows=nrows, tokens_per_row=T, nheads=self.nh, nkv=self.nkv,
+                            head_dim=self.hd, max_pos=self.max_tokens)
+            ops.attn_gqa(qkv, cache, att, key_len, ntokens=rows, tokens_per_row=T, nheads=self.nh, nkv=self.nkv,
+                         head_dim=self.hd, max_pos=self.max_tokens, max_keys=max_keys)
+            ops.linear(att, L['wo'], None, x, rows=rows, k=self.nh * self.hd, n=d, resid=x)
+            ops.rmsnorm(x, L['ln2'], h, rows, d, self.eps)
+            ops.linear(h, L['wgu'], None, gu, rows=rows, k=d, n=2 * self.ff)
+            ops.silu_mul(gu, ff, rows, self.ff)
+            ops.linear(ff, L['wd'], None, x, rows=rows, k=self.ff, n=d, resid=x)
+
+    def _head(self, st, x, B, argmax):
+        ops.rmsnorm(x, self.norm, st['h'], B, self.d, self.eps)
+        ops.linear(st['h'], self.head, None, st['logits_full'], rows=B, k=self.d, n=self.vocab, ldc=self.vpad)
+        if argmax:
+            ops.argmax_pick(st['logits_full'], vocab=self.vocab, nrows=B, ld=self.vpad, argmax_out=st['toks'])
+
+    # ---- prefill ------------------------------------------------------------------------------
+    def prefill(self, prompts, all_logits=False, argmax=True):
+        """prompts: list of B token-id lists (1 <= len <= max_tokens - 1).  Fills the KV caches and leaves the logits of
+        every row's last prompt token in state['logits'] (and their argmax in state['toks'] if `argmax`).  all_logits:
+        also return f32 [B, T, vocab] logits of every prompt position (padding rows undefined) -- a test hook."""
+        dev, d = self.device, self.d
+        B = len(prompts)
+        lens = [len(p) for p in prompts]
+        assert min(lens) >= 1 and max(lens) < self.max_tokens
+        T = max(lens)
+        st = self._state(B)
+        ids = torch.zeros((B, T), dtype=torch.int32)
+        for i, p in enumerate(prompts):
+            ids[i, :len(p)] = torch.as_tensor(p, dtype=torch.int32)
+        ids = ids.to(dev)
+        lens_t = torch.tensor(lens, dtype=torch.int32, device=dev)
+        pos0 = torch.zeros(B, dtype=torch.int32, device=dev)
+        t_idx = torch.arange(T, dtype=torch.int32, device=dev)[None, :].expand(B, T)
+        key_len = torch.where(t_idx < lens_t[:, None], t_idx + 1, torch.ones_like(t_idx)).contiguous()
+        rows = B * T
+        e = lambda *s: torch.empty(s, dtype=BF16, device=dev)
+        x, h, qkv, att, gu, ff = e(rows, d), e(rows, d), e(rows, self.nq), e(rows, self.nh * self.hd), e(rows, 2 * self.ff), e(rows, self.ff)
+        ops.embed(ids, self.tok, None, x, n=rows, dim=d)
+        self._layers(x, h, qkv, att, gu, ff, st['kv'], rows, B, T, pos0, lens_t, key_len, T)
+        last = (torch.arange(B, device=dev) * T + (lens_t.long() - 1))
+        st['x'].copy_(x.index_select(0, last))
+        st['lens'][0].copy_(lens_t)
+        st['lens'][1].copy_(lens_t + 1)
+        self._head(st, st['x'], B, argmax)
+        out = None
+        if all_logits:
+            out = torch.empty((rows, self.vocab), dtype=torch.float32, device=dev)
+            ops.rmsnorm(x, self.norm, h, rows, d, self.eps)
+            ops.linear(h, self.head, None, out, rows=rows, k=d, n=self.vocab)
+            out = out.view(B, T, self.vocab)
+        return st, out
+
+    # ---- decode -------------------------------------------------------------------------------
+    def _step_launches(self, st, B, argmax):
+        ops.embed(st['toks'], self.tok, None, st['x'], n=B, dim=self.d)
+        self._layers(st['x'], st['h'], st['qkv'], st['att'], st['gu'], st['ff'], st['kv'], B, B, 1, st['lens'][0], st['ones'],
+                     st['lens'][1], self.max_tokens)
+        self._head(st, st['x'], B, argmax)
+        ops.add_i32_vec(st['lens'], 1)
+
+    def step(self, st, B, argmax=True, use_graphs=True):
+        """Feed state['toks'] (one token per row) at every row's own position; logits of the next token land in
+        state['logits'], their argmax in state['toks'] when `argmax` (greedy chaining without a host round trip)."""
+        if not use_graphs or st['eager_steps'] < 1:
+            st['eager_steps'] += 1
+            return self._step_launches(st, B, argmax)
+        key = 'graph%d' % int(argmax)
+        if st.get(key) is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
+                self._step_launches(st, B, argmax)
+            st[key] = g
+        st[key].replay()
+
+    def generate(self, prompts, max_new_tokens, eos_ids=(), pad_id=0, on_tokens=None, sampler=None, use_graphs=True,
+                 keep_logits=False):
+        """Continue every prompt for up to max_new_tokens tokens; a row stops at one of eos_ids (kept in its output) and is
+        fed pad_id afterwards, as transformers' generate does; the loop ends when every row has stopped or a row's
+        cache is full.  on_tokens(int64 [B] CPU tensor) is called once per step with the tokens just chosen (pad_id for
+        stopped rows): the streamer hook of InfernLLMWorker.py:113-118.  sampler(logits f32 [B, vocab] device, step) ->
+        int tensor [B] replaces the greedy pick.  Returns (list of per-row generated id lists, per-step logits list
+        if keep_logits)."""
+        B = len(prompts)
+        st, _ = self.prefill(prompts, argmax=sampler is None)
+        done = [False] * B
+        out = [[] for _ in range(B)]
+        eos = set(int(e) for e in eos_ids)
+        budget = min(max_new_tokens, self.max_tokens - max(len(p) for p in prompts))
+        kept = []
+        for s in range(budget):
+            if keep_logits:
+                kept.append(st['logits'].clone())
+            if sampler is not None:
+                st['toks'].copy_(sampler(st['logits'], s).to(torch.int32))
+            toks = st['toks'].cpu().tolist()
+            step_toks = []
+            for i, t in enumerate(toks):
+                if done[i]:
+                    step_toks.append(pad_id)
+                    continue
+                out[i].append(t)
+                step_toks.append(t)
+                if t in eos:
+                    done[i] = True
+            if on_tokens is not None:
+                on_tokens(torch.tensor(step_toks, dtype=torch.long))
+            if all(done) or s + 1 == budget:
+                break
+            if any(done):           # stopped rows are fed the pad token (their later outputs are dropped)
+                st['toks'].copy_(torch.tensor(step_toks, dtype=torch.int32))
+            self.step(st, B, argmax=sampler is None, use_graphs=use_graphs)
+        return out, kept

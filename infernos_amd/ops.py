@@ -142,6 +142,43 @@ def attn_decode_shared(q, k, v, out, *, nbatch, nheads, max_keys, q_bs, kv_bs, k
     return out
 
 
+def rmsnorm(x, gamma, out, rows, dim, eps=1e-6):
+    _lib.check(_lib.lib().ifh_rmsnorm_bf16(_addr(x), _addr(gamma), _addr(out), rows, dim, eps, _lib.stream_ptr(out.device)),
+               'ifh_rmsnorm_bf16')
+    return out
+
+
+def rope_append(qkv, cos_sin, cache, pos0, nvalid, *, nrows, tokens_per_row, nheads, nkv, head_dim, max_pos):
+    """rotary embedding of q (in place) and k, KV append at every token's own position (ifh_rope_append_bf16)"""
+    ts = 2 * nkv * head_dim
+    _lib.check(_lib.lib().ifh_rope_append_bf16(_addr(qkv), (nheads + 2 * nkv) * head_dim, _addr(cos_sin), max_pos, _addr(cache),
+                                               max_pos * ts, ts, _addr(pos0), _addr(nvalid), nrows, tokens_per_row, nheads, nkv,
+                                               head_dim, _lib.stream_ptr(qkv.device)), 'ifh_rope_append_bf16')
+
+
+def attn_gqa(qkv, cache, out, key_len, *, ntokens, tokens_per_row, nheads, nkv, head_dim, max_pos, max_keys):
+    """grouped-query attention of single query tokens against the KV cache (ifh_attn_gqa_bf16); q = the first
+    nheads*head_dim columns of the fused projection"""
+    d = _lib.GqaDesc()
+    d.q, d.q_ts = _addr(qkv), (nheads + 2 * nkv) * head_dim
+    d.cache, d.cache_bs, d.cache_ts, d.v_off = _addr(cache), max_pos * 2 * nkv * head_dim, 2 * nkv * head_dim, nkv * head_dim
+    d.out, d.o_ts, d.key_len = _addr(out), nheads * head_dim, _addr(key_len)
+    d.ntokens, d.tokens_per_row, d.nheads, d.nkv, d.head_dim = ntokens, tokens_per_row, nheads, nkv, head_dim
+    d.max_keys, d.scale = max_keys, head_dim ** -0.5
+    _lib.check(_lib.lib().ifh_attn_gqa_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_attn_gqa_bf16')
+    return out
+
+
+def silu_mul(gate_up, out, rows, ffn):
+    _lib.check(_lib.lib().ifh_silu_mul_bf16(_addr(gate_up), _addr(out), rows, ffn, _lib.stream_ptr(out.device)), 'ifh_silu_mul_bf16')
+    return out
+
+
+def add_i32_vec(values, delta, mask=None):
+    _lib.check(_lib.lib().ifh_add_i32_vec(_addr(values), _addr(mask), values.numel(), delta, _lib.stream_ptr(values.device)),
+               'ifh_add_i32_vec')
+
+
 class BeamState:
     """Device-resident state of ifh_beam_step for `nbatch` utterances x `beams` (include/infernos_hip.h: ifh_beam_desc)."""
 

@@ -18,6 +18,39 @@ SCHEMA_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'nn_schem
 
 FAMILIES = ('speecht5_tts', 'hifigan', 'amendment', 'whisper_tiny', 'whisper_base')
 
+# Qwen2 decoder-only configurations (InfernLLMWorker, Cluster/InfernLLMWorker.py:60: Qwen/Qwen2.5-*-Instruct).  Key names
+# and shapes are a pure function of the configuration (qwen2_schema); 'qwen2_tiny' is the parity-test size, whose schema
+# is also captured from transformers' Qwen2ForCausalLM into nn_schema.json and compared in the tests; 'qwen2_1p5b' is
+# Qwen2.5-1.5B-Instruct's config.json (BASELINE configuration 5).
+QWEN2_CONFIGS = {
+    'qwen2_tiny': dict(vocab=1000, hidden=512, ffn=1024, layers=2, heads=4, kv_heads=2, head_dim=128, rope_theta=1.0e6,
+                       rms_eps=1e-6, tie=True, max_pos=512),
+    'qwen2_tiny64': dict(vocab=777, hidden=256, ffn=640, layers=3, heads=4, kv_heads=1, head_dim=64, rope_theta=1.0e4,
+                         rms_eps=1e-5, tie=False, max_pos=512),
+    'qwen2_1p5b': dict(vocab=151936, hidden=1536, ffn=8960, layers=28, heads=12, kv_heads=2, head_dim=128, rope_theta=1.0e6,
+                       rms_eps=1e-6, tie=True, max_pos=32768),
+}
+
+
+def qwen2_schema(cfg):
+    """state-dict names -> (shape, dtype) of transformers' Qwen2ForCausalLM for a QWEN2_CONFIGS entry"""
+    d, hd, nh, nkv, ffn = cfg['hidden'], cfg['head_dim'], cfg['heads'], cfg['kv_heads'], cfg['ffn']
+    sc = {'model.embed_tokens.weight': ([cfg['vocab'], d], 'float32'), 'model.norm.weight': ([d], 'float32')}
+    if not cfg['tie']:
+        sc['lm_head.weight'] = ([cfg['vocab'], d], 'float32')
+    for i in range(cfg['layers']):
+        L = 'model.layers.%d.' % i
+        sc[L + 'input_layernorm.weight'] = ([d], 'float32')
+        sc[L + 'post_attention_layernorm.weight'] = ([d], 'float32')
+        for n, rows in (('q_proj', nh * hd), ('k_proj', nkv * hd), ('v_proj', nkv * hd)):
+            sc[L + 'self_attn.%s.weight' % n] = ([rows, d], 'float32')
+            sc[L + 'self_attn.%s.bias' % n] = ([rows], 'float32')
+        sc[L + 'self_attn.o_proj.weight'] = ([d, nh * hd], 'float32')
+        sc[L + 'mlp.gate_proj.weight'] = ([ffn, d], 'float32')
+        sc[L + 'mlp.up_proj.weight'] = ([ffn, d], 'float32')
+        sc[L + 'mlp.down_proj.weight'] = ([d, ffn], 'float32')
+    return sc
+
 
 def load_schema():
     with open(SCHEMA_FILE) as f:
@@ -53,7 +86,7 @@ def synth_tensor(name, shape, dtype, seed):
     if dtype == 'int64':
         return torch.zeros(shape, dtype=torch.int64)
     leaf = name.rsplit('.', 1)[-1]
-    norm_like = ('layer_norm' in name or 'batch_norm' in name or 'layernorm' in name)
+    norm_like = ('layer_norm' in name or 'batch_norm' in name or 'layernorm' in name or name == 'model.norm.weight')
     if leaf == 'alpha':
         return torch.ones(shape)
     if leaf == 'running_var':
@@ -75,7 +108,7 @@ def synth_state_dict(family: str, seed: int = 0, stop_bias=None):
     """Seeded random HF-format state dict (CPU, float32) for one model family.
     stop_bias: value for speech_decoder_postnet.prob_out.bias (e.g. -20 disables the stop
     head)."""
-    schema = load_schema()[family]
+    schema = qwen2_schema(QWEN2_CONFIGS[family]) if family in QWEN2_CONFIGS else load_schema()[family]
     sd = {}
     for name in sorted(schema):
         shape, dtype = schema[name]

@@ -459,3 +459,83 @@ def whisper_beam(sd, mel, prompt, n_new, nheads, num_beams=5, eos_id=50257, leng
         return whisper_decoder(sd, seqs[:, -1:], seqs.size(1) - 1, encK, nheads, state['caches'])[:, -1]
     seqs, scores, _ = beam_search(step, prompt, n_new, K, eos_id, length_penalty, suppress, begin_suppress)
     return seqs, scores, enc
+
+
+# =========================================================================================
+# Qwen2 (decoder-only LLM of InfernLLMWorker, Cluster/InfernLLMWorker.py:60-119)
+# transformers/models/qwen2/modeling_qwen2.py: Qwen2RMSNorm, Qwen2RotaryEmbedding + apply_rotary_pos_emb (rotate_half),
+# Qwen2Attention (grouped-query heads: repeat_kv), Qwen2MLP, Qwen2ForCausalLM (tied or separate lm_head)
+# =========================================================================================
+def rms_norm(w, x, eps):
+    return w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+
+
+def rope_cos_sin(max_pos, head_dim, theta):
+    """f32 [max_pos, head_dim/2] cos and sin of position * theta^(-2j/head_dim)"""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+    fr = torch.arange(max_pos).float()[:, None] * inv[None, :]
+    return fr.cos(), fr.sin()
+
+
+def _rope(x, cos, sin):
+    """x [B, H, T, hd]; cos/sin [T, hd/2]: x * cat(cos, cos) + rotate_half(x) * cat(sin, sin)"""
+    h = x.size(-1) // 2
+    x1, x2 = x[..., :h], x[..., h:]
+    return torch.cat([x1 * cos - x2 * sin, x2 * cos + x1 * sin], -1)
+
+
+def qwen2_forward(sd, cfg, tokens, pos0, caches):
+    """tokens int64 [B, T] starting at position pos0 (same for every row; ragged batches are run row by row);
+    caches: list per layer of {} / {'k','v'} [B, kv_heads, S, hd].  Returns logits f32 [B, T, vocab]."""
+    d, hd, nh, nkv = cfg['hidden'], cfg['head_dim'], cfg['heads'], cfg['kv_heads']
+    B, T = tokens.shape
+    cos, sin = rope_cos_sin(pos0 + T, hd, cfg['rope_theta'])
+    cos, sin = cos[pos0:], sin[pos0:]
+    x = F.embedding(tokens, sd['model.embed_tokens.weight'])
+    for i in range(cfg['layers']):
+        L = 'model.layers.%d.' % i
+        h = rms_norm(sd[L + 'input_layernorm.weight'], x, cfg['rms_eps'])
+        q = linear(sd, L + 'self_attn.q_proj', h).view(B, T, nh, hd).transpose(1, 2)
+        k = linear(sd, L + 'self_attn.k_proj', h).view(B, T, nkv, hd).transpose(1, 2)
+        v = linear(sd, L + 'self_attn.v_proj', h).view(B, T, nkv, hd).transpose(1, 2)
+        q, k = _rope(q, cos, sin), _rope(k, cos, sin)
+        c = caches[i]
+        if 'k' in c:
+            k, v = torch.cat([c['k'], k], 2), torch.cat([c['v'], v], 2)
+        c['k'], c['v'] = k, v
+        S = k.size(2)
+        kr, vr = k.repeat_interleave(nh // nkv, 1), v.repeat_interleave(nh // nkv, 1)
+        w = (q @ kr.transpose(-1, -2)) * hd ** -0.5
+        m = torch.ones(T, S, dtype=torch.bool).tril(S - T)
+        w = w.masked_fill(~m, float('-inf'))
+        o = (torch.softmax(w, -1) @ vr).transpose(1, 2).reshape(B, T, nh * hd)
+        x = x + F.linear(o, sd[L + 'self_attn.o_proj.weight'])
+        h = rms_norm(sd[L + 'post_attention_layernorm.weight'], x, cfg['rms_eps'])
+        x = x + F.linear(F.silu(F.linear(h, sd[L + 'mlp.gate_proj.weight'])) * F.linear(h, sd[L + 'mlp.up_proj.weight']),
+                         sd[L + 'mlp.down_proj.weight'])
+    x = rms_norm(sd['model.norm.weight'], x, cfg['rms_eps'])
+    return F.linear(x, sd.get('lm_head.weight', sd['model.embed_tokens.weight']))
+
+
+def qwen2_greedy(sd, cfg, prompts, n_new, eos_ids=()):
+    """Greedy continuation of every prompt (list of token-id lists, decoded at their own lengths: what a left-padded
+    batch through transformers' generate yields) for up to n_new tokens, stopping a row at an eos id (kept).
+    Returns (list of generated id lists, list of f32 [len(prompt)+generated-1, vocab] logits per row)."""
+    outs, logs = [], []
+    for p in prompts:
+        caches = [{} for _ in range(cfg['layers'])]
+        lg = qwen2_forward(sd, cfg, torch.tensor([p]), 0, caches)[0]
+        allg = [lg]
+        new = []
+        cur = lg[-1]
+        for s in range(n_new):
+            t = int(cur.argmax())
+            new.append(t)
+            if t in eos_ids or s + 1 == n_new:
+                break
+            lg = qwen2_forward(sd, cfg, torch.tensor([[t]]), len(p) + s, caches)[0]
+            allg.append(lg)
+            cur = lg[-1]
+        outs.append(new)
+        logs.append(torch.cat(allg, 0))
+    return outs, logs

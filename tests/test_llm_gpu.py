@@ -1,0 +1,197 @@
+"""GPU parity tests for the LLM row (InfernLLMWorker's Qwen2 decode), through the C ABI: the
+kernels between the GEMMs against plain PyTorch fp32, the engine's logits at every prompt and generated position
+against transformers' fp32 run of the same seeded weights (tests/golden/qwen2.npz, which the oracle is pinned to),
+held to 1.5x the error transformers' own bf16 run has against its fp32 run (recorded in the fixture)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import nn as onn  # noqa: E402  (checker only)
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope='module')
+def dev(built_lib):
+    from infernos_amd import _lib
+    return _lib.require_device('cuda:0')
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize('rows,dim', [(1, 1536), (7, 512), (130, 256), (5, 8192)])
+def test_rmsnorm(dev, rows, dim):
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, dim, generator=g) * 3).to(BF)
+    w = 1 + 0.1 * torch.randn(dim, generator=g)
+    out = torch.empty(rows, dim, dtype=BF, device=dev)
+    ops.rmsnorm(x.to(dev), w.to(dev), out, rows, dim, 1e-6)
+    ref = onn.rms_norm(w, x.float(), 1e-6)
+    assert torch.equal(out.cpu(), ref.to(BF)) or rel_l2(out.float().cpu(), ref) < 3e-3
+    assert float((out.float().cpu() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize('nh,nkv,hd,B,T', [(12, 2, 128, 3, 1), (4, 2, 128, 2, 9), (4, 1, 64, 5, 4), (7, 7, 64, 2, 3)])
+def test_rope_append(dev, nh, nkv, hd, B, T):
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(nh * 100 + T)
+    max_pos = 40
+    nq = (nh + 2 * nkv) * hd
+    qkv = torch.randn(B * T, nq, generator=g).to(BF)
+    pos0 = torch.randint(0, 20, (B,), generator=g).int()
+    nvalid = torch.randint(1, T + 1, (B,), generator=g).int()
+    cos, sin = onn.rope_cos_sin(max_pos, hd, 1.0e6)
+    cs = torch.stack([cos, sin], -1).contiguous()
+    cache0 = torch.randn(B, max_pos, 2 * nkv * hd, generator=g).to(BF)
+    dq, cache = qkv.clone().to(dev), cache0.clone().to(dev)
+    ops.rope_append(dq, cs.to(dev), cache, pos0.to(dev), nvalid.to(dev), nrows=B, tokens_per_row=T, nheads=nh, nkv=nkv,
+                    head_dim=hd, max_pos=max_pos)
+    dq, cache = dq.cpu(), cache.cpu()
+    exp_cache = cache0.clone()
+    for b in range(B):
+        for t in range(T):
+            i = b * T + t
+            if t >= int(nvalid[b]):
+                assert torch.equal(dq[i], qkv[i])              # padding token: untouched
+                continue
+            p = int(pos0[b]) + t
+            x = qkv[i].float()
+            q = onn._rope(x[:nh * hd].view(1, nh, 1, hd), cos[p:p + 1], sin[p:p + 1]).reshape(-1)
+            k = onn._rope(x[nh * hd:(nh + nkv) * hd].view(1, nkv, 1, hd), cos[p:p + 1], sin[p:p + 1]).reshape(-1)
+            assert torch.equal(dq[i, :nh * hd], q.to(BF))
+            assert torch.equal(dq[i, nh * hd:], qkv[i, nh * hd:])
+            exp_cache[b, p, :nkv * hd] = k.to(BF)
+            exp_cache[b, p, nkv * hd:] = qkv[i, (nh + nkv) * hd:]
+    assert torch.equal(cache, exp_cache)
+
+
+@pytest.mark.parametrize('nh,nkv,hd,B,T,S', [(12, 2, 128, 3, 1, 300), (4, 2, 128, 2, 6, 40), (4, 1, 64, 3, 5, 33),
+                                             (7, 1, 128, 2, 1, 700), (8, 1, 64, 1, 3, 20), (5, 5, 64, 2, 2, 17),
+                                             (3, 1, 128, 4, 1, 9)])
+def test_attn_gqa(dev, nh, nkv, hd, B, T, S):
+    """single-token grouped-query attention against softmax(q k^T / sqrt(hd)) v in fp32, ragged key counts, one and four
+    waves per (token, kv head), prefill-style (T tokens per cache row) and decode-style addressing"""
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(nh + S)
+    nq = (nh + 2 * nkv) * hd
+    qkv = torch.randn(B * T, nq, generator=g).to(BF)
+    cache = torch.randn(B, S, 2 * nkv * hd, generator=g).to(BF)
+    key_len = torch.randint(1, S + 1, (B * T,), generator=g).int()
+    key_len[0] = S
+    out = torch.empty(B * T, nh * hd, dtype=BF, device=dev)
+    ops.attn_gqa(qkv.to(dev), cache.to(dev), out, key_len.to(dev), ntokens=B * T, tokens_per_row=T, nheads=nh, nkv=nkv,
+                 head_dim=hd, max_pos=S, max_keys=S)
+    out = out.float().cpu()
+    G = nh // nkv
+    for i in range(B * T):
+        b, n = i // T, int(key_len[i])
+        q = qkv[i, :nh * hd].float().view(nh, hd)
+        k = cache[b, :n, :nkv * hd].float().view(n, nkv, hd).repeat_interleave(G, 1)
+        v = cache[b, :n, nkv * hd:].float().view(n, nkv, hd).repeat_interleave(G, 1)
+        w = torch.softmax(torch.einsum('hd,nhd->hn', q, k) * hd ** -0.5, -1)
+        ref = torch.einsum('hn,nhd->hd', w, v).reshape(-1)
+        assert float((out[i] - ref).abs().max()) < 2e-2 * max(1.0, float(ref.abs().max())), i
+    print('attn_gqa ok', nh, nkv, hd, T, S)
+
+
+def test_silu_mul_and_lengths(dev):
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(5)
+    rows, ffn = 37, 8960
+    gu = (torch.randn(rows, 2 * ffn, generator=g) * 2).to(BF)
+    out = torch.empty(rows, ffn, dtype=BF, device=dev)
+    ops.silu_mul(gu.to(dev), out, rows, ffn)
+    ref = F.silu(gu[:, :ffn].float()) * gu[:, ffn:].float()
+    assert float((out.float().cpu() - ref).abs().max()) <= 2 ** -7 * float(ref.abs().max())
+    assert rel_l2(out.float().cpu(), ref) < 3e-3
+    v = torch.arange(10, dtype=torch.int32, device=dev)
+    ops.add_i32_vec(v, 3)
+    assert v.tolist() == list(range(3, 13))
+    ops.add_i32_vec(v, -1, mask=torch.tensor([1, 0] * 5, dtype=torch.int32, device=dev))
+    assert v.tolist() == [2, 4, 4, 6, 6, 8, 8, 10, 10, 12]
+
+
+@pytest.mark.parametrize('family', ['qwen2_tiny', 'qwen2_tiny64'])
+def test_qwen2_engine_logits_and_greedy(dev, golden_dir, family):
+    from infernos_amd.engines.qwen2 import Qwen2
+    from infernos_amd.weights import synth_state_dict, QWEN2_CONFIGS
+    g = np.load(os.path.join(golden_dir, 'qwen2.npz'))
+    meta = json.load(open(os.path.join(golden_dir, 'qwen2_meta.json')))[family]
+    cfg = QWEN2_CONFIGS[family]
+    sd = synth_state_dict(family, meta['seed'])
+    model = Qwen2(sd, cfg, dev, max_tokens=64)
+    prompts = meta['prompts']
+    bar = 1.5 * meta['hf_bf16_rel_l2']
+    # prompt positions: every row at its own length, one padded prefill pass
+    st, logits = model.prefill(prompts, all_logits=True)
+    logits = logits.cpu()
+    worst = 0.0
+    for i, p in enumerate(prompts):
+        ref = torch.from_numpy(g['%s_prompt_logits%d' % (family, i)])
+        worst = max(worst, rel_l2(logits[i, :len(p), ::7], ref))
+    print(family, 'prompt logits rel-L2 %.3e (bar %.3e)' % (worst, bar))
+    assert worst < bar
+    # teacher-forced continuation: feed the fixture's greedy tokens, compare the logits of every generated position
+    gen = g[family + '_gen']
+    ref_steps = torch.from_numpy(g[family + '_step_logits'])
+    B = len(prompts)
+    got = [st['logits'].cpu().clone()]
+    for s in range(gen.shape[1] - 1):
+        st['toks'].copy_(torch.from_numpy(gen[:, s].copy()).int())
+        model.step(st, B, argmax=False)
+        got.append(st['logits'].cpu().clone())
+    got = torch.stack(got, 1)
+    e = rel_l2(got[:, :, ::7], ref_steps)
+    print(family, 'generated-position logits rel-L2 %.3e' % e)
+    assert e < bar
+    # full-vocabulary check against the oracle on one row, and greedy tokens where the margin allows
+    with torch.no_grad():
+        o_new, o_logs = onn.qwen2_greedy(sd, cfg, prompts, gen.shape[1])
+    assert [o == gen[i].tolist() for i, o in enumerate(o_new)] == [True] * B
+    assert rel_l2(got[1], o_logs[1][len(prompts[1]) - 1:]) < bar
+    out, kept = model.generate(prompts, gen.shape[1], keep_logits=True)
+    out2, _ = model.generate(prompts, gen.shape[1], use_graphs=False)
+    assert out == out2                                  # replayed graph == eager launches
+    for i in range(B):
+        for s in range(gen.shape[1]):
+            if out[i][s] != int(gen[i, s]):
+                top2 = o_logs[i][len(prompts[i]) - 1 + s].topk(2).values
+                assert float(top2[0] - top2[1]) < 0.1 * float(o_logs[i].std()), (i, s)
+                break                                   # after a near-tie flip the continuations differ legitimately
+
+
+def test_qwen2_generate_eos_padding_and_callbacks(dev):
+    """rows stop at their own eos, are fed the pad token afterwards, and the per-step callback sees what
+    transformers' streamer protocol delivers (pad for stopped rows)"""
+    from infernos_amd.engines.qwen2 import Qwen2
+    from infernos_amd.weights import synth_state_dict, QWEN2_CONFIGS
+    cfg = QWEN2_CONFIGS['qwen2_tiny64']
+    sd = synth_state_dict('qwen2_tiny64', 1)
+    model = Qwen2(sd, cfg, dev, max_tokens=64)
+    prompts = [[3, 1, 4, 1, 5], [9, 2, 6], [5, 3, 5, 8, 9, 7, 9]]
+    free, _ = model.generate(prompts, 12)
+    eos = {free[0][3], free[1][6]}
+    seen = []
+    out, _ = model.generate(prompts, 12, eos_ids=eos, pad_id=0, on_tokens=lambda t: seen.append(t.tolist()))
+    with torch.no_grad():
+        o_new, _ = onn.qwen2_greedy(sd, cfg, prompts, 12, eos_ids=eos)
+    for i in range(3):
+        n = min(len(out[i]), len(free[i]))
+        assert out[i] == free[i][:len(out[i])]
+        assert out[i][-1] in eos or len(out[i]) == 12
+        assert all(t not in eos for t in out[i][:-1])
+    assert len(out[0]) <= 4 and len(out[1]) <= 7
+    cols = list(zip(*seen))
+    for i in range(3):
+        assert list(cols[i][:len(out[i])]) == out[i] and all(t == 0 for t in cols[i][len(out[i]):])
+    print('eos test lens', [len(o) for o in out], 'oracle', [len(o) for o in o_new])

@@ -359,4 +359,77 @@ def gen_whisper_beam():
     print('wrote whisper_beam.npz')
 
 
-SECTIONS = {'tts': gen_tts, 'whisper': gen_whisper, 'whisper_tf': gen_whisper_tf, 'whisper_beam': gen_whisper_beam}
+def _hf_qwen2(family, seed):
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+    from infernos_amd.weights import synth_state_dict, QWEN2_CONFIGS
+    c = QWEN2_CONFIGS[family]
+    hc = Qwen2Config(vocab_size=c['vocab'], hidden_size=c['hidden'], intermediate_size=c['ffn'], num_hidden_layers=c['layers'],
+                     num_attention_heads=c['heads'], num_key_value_heads=c['kv_heads'], head_dim=c['head_dim'],
+                     max_position_embeddings=c['max_pos'], rms_norm_eps=c['rms_eps'], tie_word_embeddings=c['tie'],
+                     rope_parameters={'rope_theta': c['rope_theta'], 'rope_type': 'default'}, use_sliding_window=False,
+                     attention_dropout=0.0, pad_token_id=0, bos_token_id=None, eos_token_id=None)
+    model = Qwen2ForCausalLM(hc)
+    sd = synth_state_dict(family, seed)
+    full = dict(sd)
+    if c['tie']:
+        full['lm_head.weight'] = sd['model.embed_tokens.weight']
+    model.load_state_dict(full, strict=True)
+    model.eval()
+    return model, sd, c
+
+
+def gen_qwen2():
+    """Qwen2 fixtures: transformers' Qwen2ForCausalLM holding the seeded weights, called the way
+    InfernLLMWorker.process_batch does (Cluster/InfernLLMWorker.py:108-118: a padded batch + attention mask through
+    generate); the state-dict schema of the parity-test configurations goes to nn_schema.json."""
+    import json
+    from oracle import nn as onn
+    arrays, meta = {}, {}
+    schema_path = os.path.join(ROOT, 'infernos_amd', 'nn_schema.json')
+    schema = json.load(open(schema_path))
+    for family, seed, prompts in (('qwen2_tiny', 0, [[11, 22, 33, 44, 55, 66, 77], [5, 9, 2], [901, 17, 4, 4, 250]]),
+                                  ('qwen2_tiny64', 1, [[3, 1, 4, 1, 5, 9, 2, 6], [700, 2], [10, 20, 30, 40, 50, 60]])):
+        model, sd, c = _hf_qwen2(family, seed)
+        schema[family] = {k: [list(v.shape), 'float32'] for k, v in model.state_dict().items()
+                          if not (c['tie'] and k == 'lm_head.weight')}
+        T = max(len(p) for p in prompts)
+        ids = torch.zeros((len(prompts), T), dtype=torch.long)
+        mask = torch.zeros((len(prompts), T), dtype=torch.long)
+        for i, p in enumerate(prompts):                        # left padding: generation continues from the last real token
+            ids[i, T - len(p):] = torch.tensor(p)
+            mask[i, T - len(p):] = 1
+        n_new = 10
+        with torch.no_grad():
+            out = model.generate(input_ids=ids, attention_mask=mask, max_new_tokens=n_new, do_sample=False,
+                                 return_dict_in_generate=True, output_logits=True, pad_token_id=0)
+            fwd = model(input_ids=ids, attention_mask=mask).logits
+        gen = out.sequences[:, T:]
+        step_logits = torch.stack(out.logits, 1)                # [B, n_new, V]
+        o_new, o_logs = onn.qwen2_greedy(sd, c, prompts, n_new)
+        ok = all(o_new[i] == gen[i].tolist() for i in range(len(prompts)))
+        dl = max(float((o_logs[i][len(p) - 1:] - step_logits[i]).abs().max()) for i, p in enumerate(prompts))
+        dp = max(float((o_logs[i][:len(p)] - fwd[i, T - len(p):]).abs().max()) for i, p in enumerate(prompts))
+        print(family, 'greedy equal', ok, 'max |logit diff| generated', dl, 'prompt', dp, 'logit std', float(fwd.std()))
+        arrays[family + '_gen'] = gen.numpy().astype(np.int32)
+        arrays[family + '_step_logits'] = step_logits[:, :, ::7].numpy()
+        for i, p in enumerate(prompts):
+            arrays['%s_prompt_logits%d' % (family, i)] = fwd[i, T - len(p):, ::7].numpy()
+        # the same engine in the reference's dtype (torch_dtype="auto" -> bf16 checkpoints): its distance from fp32 is the
+        # bar the device engine is held to
+        with torch.no_grad():
+            fwd16 = model.to(torch.bfloat16)(input_ids=ids, attention_mask=mask).logits.float()
+        model.to(torch.float32)
+        rel16 = max(float((fwd16[i, T - len(p):] - fwd[i, T - len(p):]).norm() / fwd[i, T - len(p):].norm())
+                    for i, p in enumerate(prompts))
+        print(family, 'transformers bf16 vs fp32 prompt logits rel-L2', rel16)
+        meta[family] = {'seed': seed, 'prompts': prompts, 'n_new': n_new, 'hf_bf16_rel_l2': rel16}
+    json.dump(schema, open(schema_path, 'w'), sort_keys=True)
+    json.dump(schema, open(os.path.join(GOLD, 'nn_schema.json'), 'w'), sort_keys=True)
+    meta['source'] = ('transformers 5.15.0 Qwen2ForCausalLM holding synth_state_dict weights; left-padded batch + attention_mask '
+                      'through forward and generate(do_sample=False), fp32')
+    np.savez_compressed(os.path.join(GOLD, 'qwen2.npz'), **arrays)
+    json.dump(meta, open(os.path.join(GOLD, 'qwen2_meta.json'), 'w'), indent=1, sort_keys=True)
+    print('wrote qwen2.npz')
+
+
+SECTIONS = {'tts': gen_tts, 'whisper': gen_whisper, 'whisper_tf': gen_whisper_tf, 'whisper_beam': gen_whisper_beam, 'qwen2': gen_qwen2}
