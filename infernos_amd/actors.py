@@ -1,6 +1,6 @@
 """Actor facades over the workers: session tables keyed by UUID.
 
-Interface of Cluster/InfernSTTActor.py:12-53, Cluster/InfernTTSActor.py:12-52 and
+Interface of Cluster/InfernSTTActor.py:12-53, Cluster/InfernTTSActor.py:12-52, Cluster/InfernLLMActor.py:11-69 and
 Cluster/RemoteTTSSession.py:12-30.  The reference wraps these classes with @ray.remote; here they
 are plain classes (Ray is not part of the speech path) and `as_ray_actor(cls)` applies the
 reference's decorator arguments when ray is importable, so the app layer keeps calling
@@ -9,6 +9,7 @@ reference's decorator arguments when ray is importable, so the app layer keeps c
 from typing import Dict, Union
 from uuid import UUID
 
+from .llm import InfernLLMWorker, LLMInferRequest, LLMRequest, LLMSession, LLMSessionParams
 from .shard import SessionRouter
 from .stt import InfernSTTWorker, STTRequest, STTSentinel, STTSession
 from .tts import InfernTTSWorker, TTSRequest, TTSSession
@@ -129,6 +130,70 @@ class InfernTTSActor:
         self._pool()[1].release(rgen_id)
 
 
+class InfernLLMActor:
+    """Session table over the LLM worker(s) (InfernLLMActor.py:11-69).  start() warms the worker up the way the
+    reference does: max_batch_size 'What is your name?' requests pushed straight into the queue, answers awaited."""
+    debug = False
+    sessions: Dict[UUID, LLMSession]
+    llm: InfernLLMWorker
+
+    def __init__(self, **worker_kwa):
+        self.sessions = {}
+        self._worker_kwa = worker_kwa
+
+    worker_cls = InfernLLMWorker
+
+    def start(self, device='cuda', warmup=True):
+        from queue import Queue
+        self.workers = [self.worker_cls(dev, **self._worker_kwa) for dev in _devices(device)]      # no CPU fallback
+        self.router = SessionRouter(len(self.workers))
+        self.llm = self.workers[0]
+        for w in self.workers:
+            w.start()
+        if not warmup:
+            return
+        for w in self.workers:
+            tq = Queue()
+            irs = tuple(LLMInferRequest(LLMRequest('What is your name?', None), [{"role": "user", "content": 'What is your name?'}])
+                        for _ in range(w.max_batch_size))
+            for _i in irs:
+                _i.textout_cb = lambda result: tq.put(result)
+            for ir in irs:
+                w.infer(ir)
+            for _ in irs:
+                tq.get()
+
+    def stop(self):
+        for w in self.workers:
+            w.stop()
+
+    def _pool(self):
+        if not hasattr(self, 'workers'):
+            self.workers, self.router = [self.llm], SessionRouter(1)
+        return self.workers, self.router
+
+    def new_llm_session(self, sconf: LLMSessionParams):
+        workers, router = self._pool()
+        sess = LLMSession(None, sconf)
+        sess.llm = workers[router.assign(sess.id)]
+        self.sessions[sess.id] = sess
+        return sess.id
+
+    def llm_session_end(self, sess_id):
+        sess = self.sessions[sess_id]
+        sess.stop()
+        del self.sessions[sess_id]
+        self._pool()[1].release(sess_id)
+
+    def llm_session_textin(self, sess_id, req: LLMRequest):
+        self.sessions[sess_id].textin(req)
+        return sess_id
+
+    def llm_session_context_add(self, sess_id, content: str, role: str = 'user'):
+        self.sessions[sess_id].context_add(content, role)
+        return sess_id
+
+
 class RemoteTTSSession:
     """Client-side handle (RemoteTTSSession.py:12-30): works with a Ray actor handle
     (`.method.remote(...)` + ray.get) or with the plain actor object."""
@@ -160,5 +225,5 @@ class RemoteTTSSession:
 def as_ray_actor(cls):
     """@ray.remote(num_gpus=0.25, resources={...}) like the reference, if ray is installed."""
     import ray
-    res = {'InfernSTTActor': {'stt': 1}, 'InfernTTSActor': {'tts': 1}}[cls.__name__]
-    return ray.remote(num_gpus=0.25, resources=res)(cls)
+    res = {'InfernSTTActor': {'stt': 1}, 'InfernTTSActor': {'tts': 1}, 'InfernLLMActor': {'llm': 1}}[cls.__name__]
+    return ray.remote(num_gpus=1.0 if cls.__name__ == 'InfernLLMActor' else 0.25, resources=res)(cls)

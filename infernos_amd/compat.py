@@ -21,6 +21,8 @@ MAP = {
     'Cluster.InfernSTTWorker': ('infernos_amd.stt', ['InfernSTTWorker']),
     'Cluster.InfernTTSWorker': ('infernos_amd.tts', ['InfernTTSWorker', 'cleanup_text_eu', 'lang2model']),
     'Cluster.TTSSession': ('infernos_amd.tts', ['TTSRequest', 'TTSSndDispatch', 'TTSSession']),
+    'Cluster.LLMSession': ('infernos_amd.llm', ['LLMRequest', 'LLMResult', 'LLMInferRequest', 'LLMSessionParams', 'LLMSession']),
+    'Cluster.InfernLLMWorker': ('infernos_amd.llm', ['InfernLLMWorker', 'ResultsStreamer']),
     'HelloSippyTTSRT.HelloSippyRTPipe': ('infernos_amd.tts', ['HelloSippyRTPipe', 'HelloSippyPlayRequest', 'HelloSippyPipeState',
                                                               'HelloSippyPipeStateBatched']),
     'safetorch.InfernTorcher': ('infernos_amd.torcher', ['InfernTorcher', 'InfernTorcherDeadlock', 'rc_filter']),

@@ -1,0 +1,219 @@
+"""LLM stage of the AI-attendant path: session objects, the sentence-boundary streamer and the batched worker.
+
+Interfaces of Cluster/LLMSession.py:5-70 (LLMRequest, LLMResult, LLMInferRequest, LLMSessionParams, LLMSession) and
+Cluster/InfernLLMWorker.py:15-119 (ResultsStreamer, InfernLLMWorker).  The reference worker loads
+Qwen/Qwen2.5-14B-Instruct 4-bit through ipex-llm and calls transformers' generate with the streamer; here the model is
+engines/qwen2.py on the HIP device (bf16), and the generate loop hands the streamer the same sequence of `put` calls:
+the prompt once, then one int64 [B] tensor of tokens per step (pad for rows that have stopped), then `end`.
+"""
+from functools import partial
+from time import monotonic
+from typing import List, Tuple
+from uuid import UUID, uuid4
+
+import torch
+
+from . import _lib
+from .workers import InfernBatchedWorker
+
+
+class LLMRequest():
+    id: UUID
+    text: str
+    textout_cb: callable
+    auto_ctx_add: bool = True
+
+    def __init__(self, text: str, textout_cb: callable):
+        self.text, self.textout_cb = text, textout_cb
+        self.id = uuid4()
+
+
+class LLMResult():
+    req_id: UUID
+    text: str
+
+    def __init__(self, text: str, req_id: UUID):
+        self.text, self.req_id = text, req_id
+
+
+class LLMInferRequest():
+    req: LLMRequest
+    context: Tuple[dict]
+    textout_cb: callable
+
+    def __init__(self, req: LLMRequest, context: List[dict]):
+        self.req, self.context = req, tuple(context)
+
+
+class LLMSessionParams():
+    system_prompt: str
+
+    def __init__(self, system_prompt: str):
+        self.system_prompt = system_prompt
+
+
+class LLMSession():
+    """Per-call chat context (LLMSession.py:34-70): consecutive messages of one role are joined with a space; the
+    request is queued with a snapshot of the context; answers are appended as 'assistant' unless the request opts
+    out (auto_ctx_add)."""
+    id: UUID
+    context: List[dict]
+    debug: bool = False
+
+    def __init__(self, llm: 'InfernLLMWorker', params: LLMSessionParams):
+        self.id = uuid4()
+        self.context = [{"role": "system", "content": params.system_prompt}]
+        self.llm = llm
+
+    def context_add(self, content: str, role: str = "user"):
+        if self.debug:
+            print(f'{monotonic():4.3f}: LLMSession.context_add: {self.context=}, {content=}')
+        if len(self.context) > 0 and self.context[-1]["role"] == role:
+            self.context[-1]["content"] += f' {content}'
+        else:
+            self.context.append({"role": role, "content": content})
+
+    def textin(self, req: LLMRequest):
+        self.context_add(req.text)
+        ireq = LLMInferRequest(req, self.context)
+        if hasattr(req, '_proc_start_cb'):
+            ireq._proc_start_cb = req._proc_start_cb
+        ireq.textout_cb = partial(self.textout, req=req)
+        self.llm.infer(ireq)
+
+    def textout(self, req: LLMRequest, result: LLMResult):
+        if req.auto_ctx_add:
+            self.context_add(result.text, "assistant")
+        req.textout_cb(result=result)
+
+    def stop(self):
+        del self.llm
+
+
+class ResultsStreamer:
+    """Sentence-boundary streaming of a batch being generated (InfernLLMWorker.py:15-66).  `put` receives the prompt
+    first (ignored), then the new token of every row per step; the text decoded so far is cut at the last of
+    '. ', '? ', '! ', newline and everything before it delivered (if at least 10 characters); no decode on steps where
+    the token count is a multiple of decode_batch_size; `end` delivers the rest."""
+    debug = False
+    sync_on = ('. ', '? ', '! ', '\n')
+    decode_batch_size = 8
+
+    def __init__(self, wis: List[LLMInferRequest], upper: 'InfernLLMWorker'):
+        self.tokenizer = upper.llm_tokenizer
+        self.wi_cbs = tuple(wi.textout_cb for wi in wis)
+        self.newLLMResult = tuple(partial(LLMResult, req_id=wi.req.id) for wi in wis)
+        self.oposs = [0 for _ in range(len(wis))]
+        self.current_tokens = None
+        self.batch_decode = partial(upper.llm_tokenizer.batch_decode, skip_special_tokens=True)
+
+    def put(self, token_ids):
+        if self.current_tokens is None:
+            self.current_tokens = torch.zeros((token_ids.shape[0], 0), dtype=torch.long)
+            return
+        if token_ids.dim() == 1:
+            token_ids = token_ids.unsqueeze(1)
+        self.current_tokens = torch.cat([self.current_tokens, token_ids], dim=1)
+        if self.current_tokens.shape[1] % self.decode_batch_size == 0:
+            return
+        results = self.batch_decode(self.current_tokens)
+        for (ir, r), op, cb, newLR in zip(enumerate(results), self.oposs, self.wi_cbs, self.newLLMResult):
+            new_content = r[op:]
+            if len(new_content) == 0:
+                continue
+            sp = (op + pos + len(c) for c in self.sync_on if (pos := new_content.rfind(c)) >= 0)
+            try:
+                spos = next(sp)
+            except StopIteration:
+                continue
+            r = r[op:spos - 1]
+            if len(r) < 10:
+                continue
+            cb(result=newLR(r))
+            self.oposs[ir] = spos
+
+    def end(self):
+        results = self.batch_decode(self.current_tokens)
+        for r, op, cb, newLR in zip(results, self.oposs, self.wi_cbs, self.newLLMResult):
+            if len(r) == op:
+                continue
+            cb(result=newLR(r[op:]))
+        del self.current_tokens
+        del self.wi_cbs
+
+
+def qwen2_config_from_hf(hc):
+    """transformers Qwen2Config -> the engine's configuration dict (infernos_amd.weights.QWEN2_CONFIGS layout)"""
+    rope = getattr(hc, 'rope_parameters', None) or {}
+    return dict(vocab=hc.vocab_size, hidden=hc.hidden_size, ffn=hc.intermediate_size, layers=hc.num_hidden_layers,
+                heads=hc.num_attention_heads, kv_heads=hc.num_key_value_heads,
+                head_dim=getattr(hc, 'head_dim', None) or hc.hidden_size // hc.num_attention_heads,
+                rope_theta=float(rope.get('rope_theta', getattr(hc, 'rope_theta', 1.0e6))), rms_eps=hc.rms_norm_eps,
+                tie=bool(hc.tie_word_embeddings), max_pos=hc.max_position_embeddings)
+
+
+class InfernLLMWorker(InfernBatchedWorker):
+    """`infer(LLMInferRequest)`; every request's textout_cb receives LLMResult pieces from the worker thread as the
+    batch is generated, then the remainder when it ends (InfernLLMWorker.py:104-118).
+
+    Constructor extras (optional): `weights` (HF-format Qwen2 state dict) + `config` (QWEN2_CONFIGS-style dict; default:
+    download `model_name`), `tokenizer` (needs apply_chat_template / __call__(padding=True) / batch_decode /
+    eos_token_id / pad_token_id; default AutoTokenizer.from_pretrained), `max_new_tokens` (the reference passes
+    16 * 1024), `max_tokens` (KV-cache positions per row), `eos_token_ids`, `sampler` (callable(logits f32 [B, vocab]
+    on the device, step) -> token ids [B]; default greedy).  max_batch_size is the reference's knob (8 there); the
+    MI355X default is 64: a decode step streams the weights once whatever the batch."""
+    model_name = "Qwen/Qwen2.5-14B-Instruct"
+    max_batch_size: int = 64
+    debug = False
+    llm_model: object
+    llm_tokenizer: object
+
+    def __init__(self, device=None, model_name: str = None, weights=None, config=None, tokenizer=None,
+                 max_new_tokens: int = 16 * 1024, max_tokens: int = 4096, eos_token_ids=None, sampler=None):
+        super().__init__()
+        from .engines.qwen2 import Qwen2
+        self.device = dev = _lib.require_device(device if device is not None else 'cuda')      # no CPU fallback
+        if model_name is not None:
+            self.model_name = model_name
+        if weights is None:
+            from transformers import AutoConfig, AutoModelForCausalLM
+            config = qwen2_config_from_hf(AutoConfig.from_pretrained(self.model_name))
+            weights = AutoModelForCausalLM.from_pretrained(self.model_name, torch_dtype='auto').state_dict()
+        if tokenizer is None:
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(self.model_name)
+        self.llm_tokenizer = tokenizer
+        with torch.cuda.device(dev):
+            self.llm_model = Qwen2(weights, config, dev, max_tokens=max_tokens)
+        self.max_new_tokens = max_new_tokens
+        eos = eos_token_ids if eos_token_ids is not None else getattr(tokenizer, 'eos_token_id', None)
+        self.eos_token_ids = tuple(eos) if isinstance(eos, (list, tuple, set)) else (() if eos is None else (int(eos),))
+        pad = getattr(tokenizer, 'pad_token_id', None)
+        self.pad_token_id = int(pad) if pad is not None else (self.eos_token_ids[0] if self.eos_token_ids else 0)
+        self.sampler = sampler
+
+    def tokenize_batch(self, wis: List[LLMInferRequest]):
+        """chat template + padded tokenisation exactly as InfernLLMWorker.py:108-112, then every row's own token list
+        (padding removed through the attention mask): rows are decoded at their own lengths -- the result of a
+        left-padded batch in transformers' generate"""
+        messages = [self.llm_tokenizer.apply_chat_template(list(r.context), tokenize=False, add_generation_prompt=True)
+                    for r in wis]
+        enc = self.llm_tokenizer(messages, return_tensors="pt", padding=True)
+        ids, mask = enc['input_ids'], enc['attention_mask']
+        limit = self.llm_model.max_tokens - 2
+        prompts = []
+        for row, m in zip(ids.tolist(), mask.tolist()):
+            p = [t for t, k in zip(row, m) if k]
+            prompts.append(p[-limit:] if len(p) > limit else p)          # longer than the cache: keep the tail
+        return ids, prompts
+
+    def process_batch(self, wis: List[LLMInferRequest]):
+        if self.debug:
+            print(f'InfernLLMWorker.process_batch: got {len(wis)=}')
+        streamer = ResultsStreamer(wis, self)
+        ids, prompts = self.tokenize_batch(wis)
+        with torch.cuda.device(self.device):
+            streamer.put(ids)
+            self.llm_model.generate(prompts, self.max_new_tokens, eos_ids=self.eos_token_ids, pad_id=self.pad_token_id,
+                                    on_tokens=streamer.put, sampler=self.sampler)
+        streamer.end()

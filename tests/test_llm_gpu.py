@@ -195,3 +195,76 @@ def test_qwen2_generate_eos_padding_and_callbacks(dev):
     for i in range(3):
         assert list(cols[i][:len(out[i])]) == out[i] and all(t == 0 for t in cols[i][len(out[i]):])
     print('eos test lens', [len(o) for o in out], 'oracle', [len(o) for o in o_new])
+
+
+def test_llm_worker_through_actor_matches_reference_run(dev, golden_dir):
+    """InfernLLMActor -> LLMSession -> InfernLLMWorker on the device against the transcript of the reference worker's own
+    process_batch (transformers fp32 on the same seeded weights, tests/golden/llm_host.json): same generated tokens
+    (up to a bf16 near-tie) and then necessarily the same sentence callbacks."""
+    import threading
+    from infernos_amd.actors import InfernLLMActor
+    from infernos_amd.llm import LLMRequest, LLMSessionParams
+    from infernos_amd.synth import CharChatTokenizer
+    from infernos_amd.weights import synth_state_dict, QWEN2_CONFIGS
+    w = json.load(open(os.path.join(golden_dir, 'llm_host.json')))['worker']
+    cfg = QWEN2_CONFIGS[w['family']]
+    sd = synth_state_dict(w['family'], w['seed'])
+    tok = CharChatTokenizer(cfg['vocab'])
+    actor = InfernLLMActor(weights=sd, config=cfg, tokenizer=tok, eos_token_ids=w['eos'], max_tokens=256)
+    actor.start(dev, warmup=False)
+    worker = actor.llm
+    steps = []
+    real_generate = worker.llm_model.generate
+
+    def logging_generate(prompts, n, **kw):
+        cb = kw['on_tokens']
+        kw['on_tokens'] = lambda t: (steps.append(t.tolist()), cb(t))[1]
+        return real_generate(prompts, n, **kw)
+    worker.llm_model.generate = logging_generate
+    try:
+        calls, done = [], threading.Event()
+        n_expected = len(w['calls'])
+        sids = []
+        # the three requests must land in one batch: hold the worker's queue while they are queued
+        with worker.inf_queue.mutex:
+            pass
+        for b, cx in enumerate(w['contexts']):
+            sid = actor.new_llm_session(LLMSessionParams(cx[0]['content']))
+            sids.append(sid)
+            sess = actor.sessions[sid]
+            for m in cx[1:-1]:
+                sess.context_add(m['content'], m['role'])
+        reqs = []
+        for b, cx in enumerate(w['contexts']):
+            req = LLMRequest(cx[-1]['content'], (lambda result, b=b: (calls.append([b, result.text]),
+                                                                      done.set() if len(calls) >= n_expected else None)))
+            req.auto_ctx_add = False
+            reqs.append(req)
+        worker.inf_queue.mutex.acquire()
+        try:
+            from infernos_amd.llm import LLMInferRequest
+            from functools import partial
+            for sid, req in zip(sids, reqs):
+                sess = actor.sessions[sid]
+                sess.context_add(req.text)
+                ir = LLMInferRequest(req, sess.context)
+                ir.textout_cb = partial(sess.textout, req=req)
+                worker.inf_queue.queue.append(ir)
+            worker.inf_queue.not_empty.notify()
+        finally:
+            worker.inf_queue.mutex.release()
+        assert done.wait(120)
+        import time
+        time.sleep(0.5)
+        same = steps == w['step_tokens']
+        print('llm worker: %d steps, tokens identical to the reference run: %s' % (len(steps), same))
+        if same:
+            assert calls == w['calls']
+        else:
+            k = next(i for i, (a, b) in enumerate(zip(steps, w['step_tokens'])) if a != b)
+            assert k >= 4, (k, steps[k], w['step_tokens'][k])          # a bf16 near-tie may flip a late token, not an early one
+        for sid in sids:
+            actor.llm_session_end(sid)
+        assert actor.sessions == {}
+    finally:
+        actor.stop()

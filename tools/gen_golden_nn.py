@@ -432,4 +432,122 @@ def gen_qwen2():
     print('wrote qwen2.npz')
 
 
-SECTIONS = {'tts': gen_tts, 'whisper': gen_whisper, 'whisper_tf': gen_whisper_tf, 'whisper_beam': gen_whisper_beam, 'qwen2': gen_qwen2}
+def gen_llm_host():
+    """Host-side fixtures of the LLM row, produced by the REFERENCE's own classes: LLMSession (Cluster/LLMSession.py),
+    ResultsStreamer fed scripted token streams, and InfernLLMWorker.process_batch (Cluster/InfernLLMWorker.py:104-118)
+    driving transformers' Qwen2ForCausalLM (seeded qwen2_tiny64) with the stand-in chat tokenizer."""
+    import json
+    from Cluster.LLMSession import LLMSession, LLMSessionParams, LLMRequest, LLMInferRequest
+    import Cluster.InfernLLMWorker as ref
+    from infernos_amd.synth import CharChatTokenizer
+    out = {}
+    # ---- 1. session transcript
+    class FakeLLM:
+        def __init__(self):
+            self.q = []
+
+        def infer(self, ireq):
+            self.q.append(ireq)
+    llm = FakeLLM()
+    sess = LLMSession(llm, LLMSessionParams('You are an attendant.'))
+    log = []
+    snap = lambda tag: log.append([tag, json.loads(json.dumps(sess.context))])
+    got = []
+    snap('init')
+    sess.context_add('<Incoming call>')
+    snap('ctx user')
+    sess.context_add('second user line')
+    snap('ctx user again')
+    r1 = LLMRequest('Hello, who is this?', lambda result: got.append(['r1', result.text]))
+    sess.textin(r1)
+    snap('textin r1')
+    q1 = [list(llm.q[-1].context)]
+    llm.q[-1].textout_cb(result=ref.LLMResult('This is the attendant.', r1.id))
+    snap('textout r1')
+    llm.q[-1].textout_cb(result=ref.LLMResult('How can I help?', r1.id))
+    snap('textout r1 again')
+    r2 = LLMRequest('I need a taxi', lambda result: got.append(['r2', result.text]))
+    r2.auto_ctx_add = False
+    sess.textin(r2)
+    snap('textin r2')
+    llm.q[-1].textout_cb(result=ref.LLMResult('Calling one.', r2.id))
+    snap('textout r2 (no auto add)')
+    sess.context_add('Calling one.', 'assistant')
+    sess.context_add('<sentence interrupted>', 'user')
+    snap('manual adds')
+    out['session'] = {'log': log, 'delivered': got, 'queued_first_context': q1}
+    # ---- 2. streamer on scripted token streams
+    tok = CharChatTokenizer(777)
+
+    class Upper:
+        llm_tokenizer = tok
+    g = torch.Generator().manual_seed(7)
+    B, steps = 3, 90
+    stream = torch.randint(4, 777, (steps, B), generator=g)
+    stop = [90, 41, 64]
+    for b in range(B):
+        stream[stop[b]:, b] = tok.pad_token_id
+    calls = []
+    wis = []
+    for b in range(B):
+        ir = LLMInferRequest(LLMRequest('x', None), [{}])
+        ir.textout_cb = (lambda result, b=b: calls.append([len(seen), b, result.text]))
+        wis.append(ir)
+    seen = []
+    st = ref.ResultsStreamer(wis, Upper())
+    st.put(torch.zeros((B, 5), dtype=torch.long))
+    for s in range(steps):
+        seen.append(s)
+        st.put(stream[s])
+    seen.append('end')
+    st.end()
+    out['streamer'] = {'tokens': stream.tolist(), 'calls': calls}
+    # ---- 3. the reference worker's process_batch on the seeded model
+    model, sd, c = _hf_qwen2('qwen2_tiny64', 1)
+    contexts = [[{'role': 'system', 'content': 'You are an attendant.'}, {'role': 'user', 'content': 'Hello? Who is this.'}],
+                [{'role': 'system', 'content': 'Short.'}, {'role': 'user', 'content': 'Hi'}],
+                [{'role': 'system', 'content': 'You are an attendant at a hotel.'}, {'role': 'user', 'content': 'I need a room, please!'},
+                 {'role': 'assistant', 'content': 'Sure.'}, {'role': 'user', 'content': 'For two nights'}]]
+    msgs = [tok.apply_chat_template(cx, tokenize=False, add_generation_prompt=True) for cx in contexts]
+    enc = tok(msgs, return_tensors='pt', padding=True)
+    with torch.no_grad():
+        free = model.generate(**enc, max_new_tokens=80, do_sample=False, pad_token_id=tok.pad_token_id)[:, enc['input_ids'].size(1):]
+    eos = sorted({int(free[0, 70]), int(free[1, 33]), int(free[2, 52])})
+    model.generation_config.eos_token_id = eos
+    model.generation_config.pad_token_id = tok.pad_token_id
+    w = object.__new__(ref.InfernLLMWorker)
+    from Cluster.InfernBatchedWorker import InfernBatchedWorker
+    InfernBatchedWorker.__init__(w)
+    w.llm_model, w.llm_tokenizer, w.debug = model, tok, False
+    if not hasattr(torch, 'xpu') or not hasattr(torch.xpu, 'synchronize'):
+        raise RuntimeError('torch.xpu missing')
+    real_sync = torch.xpu.synchronize
+    torch.xpu.synchronize = lambda *a, **k: None
+    calls, puts = [], []
+    real_put = ref.ResultsStreamer.put
+
+    def logging_put(self, token_ids):
+        puts.append(token_ids.tolist())
+        return real_put(self, token_ids)
+    ref.ResultsStreamer.put = logging_put
+    wis = []
+    for b, cx in enumerate(contexts):
+        ir = LLMInferRequest(LLMRequest('x', None), cx)
+        ir.textout_cb = (lambda result, b=b: calls.append([b, result.text]))
+        wis.append(ir)
+    try:
+        w.process_batch(wis)
+    finally:
+        torch.xpu.synchronize = real_sync
+        ref.ResultsStreamer.put = real_put
+    gen_steps = puts[1:]
+    print('llm worker: eos', eos, 'steps', len(gen_steps), 'calls', calls)
+    out['worker'] = {'contexts': contexts, 'eos': eos, 'prompt_ids': puts[0], 'step_tokens': gen_steps, 'calls': calls,
+                     'family': 'qwen2_tiny64', 'seed': 1}
+    out['source'] = ('Cluster/LLMSession.py:34-70, Cluster/InfernLLMWorker.py:15-66 (ResultsStreamer) and :104-118 (process_batch) '
+                     'run in place on transformers 5.15.0; tokenizer = infernos_amd.synth.CharChatTokenizer')
+    json.dump(out, open(os.path.join(GOLD, 'llm_host.json'), 'w'), indent=0, sort_keys=True)
+    print('wrote llm_host.json')
+
+
+SECTIONS = {'tts': gen_tts, 'whisper': gen_whisper, 'whisper_tf': gen_whisper_tf, 'whisper_beam': gen_whisper_beam, 'qwen2': gen_qwen2, 'llm_host': gen_llm_host}
