@@ -210,6 +210,58 @@ def time_steps(pipe, frames_for, nsteps, warmup, world, pipelined, egress, dry, 
     return float(tmax.item()), res
 
 
+
+def c5_share(dev, args, build, n_sessions=64, prompt_len=192, first_sentence=16, reply_tokens=48, turns=5):
+    """One GPU's share of BASELINE configuration 5 (512 AI-attendant sessions over 8 GPUs = 64 per GPU): a turn is
+    STT (the C3 front end and decode on the caller's 10 s utterance) -> LLM (Qwen2.5-1.5B shape, random weights, a
+    192-token chat context per session, reply streamed) -> TTS.  Turn latency = end of the caller's speech (utterance
+    ingested, VAD closed) to the first 512 ms of synthesised audio of the reply's first sentence (taken as 16 tokens),
+    with all 64 sessions' turns arriving together (the worst case for a batched worker).  Sequential stages, one stream."""
+    from infernos_amd.engines.qwen2 import Qwen2
+    from infernos_amd.weights import QWEN2_CONFIGS, qwen2_random_on_device
+    cfg = QWEN2_CONFIGS['qwen2_1p5b']
+    pipe, frames_all, frames_for, _, _ = build('C3', n_sessions)
+    llm = Qwen2(qwen2_random_on_device(cfg, dev), cfg, dev, max_tokens=prompt_len + reply_tokens + 8)
+    g = torch.Generator().manual_seed(5)
+    prompts = [torch.randint(10, cfg['vocab'] - 10, (prompt_len - (i % 9),), generator=g).tolist() for i in range(n_sessions)]
+    n_infer = pipe.n_infer
+    lat, parts = [], []
+    for turn in range(turns + 2):
+        fl = pipe.front_lanes[0]
+        pipe.reset_calls(fl)
+        chunks = pipe.ingest(frames_for(turn), fl)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        pipe.stt(chunks, fl)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        marks = []
+        llm.generate(prompts, reply_tokens, on_tokens=lambda t: marks.append(time.perf_counter()))
+        t_first = marks[first_sentence - 1]
+        t2 = time.perf_counter()
+        pipe.n_infer = 1                                   # the first 512 ms chunk of the reply
+        pipe.synthesize()
+        torch.cuda.synchronize(dev)
+        t3 = time.perf_counter()
+        pipe.n_infer = n_infer
+        if turn >= 2:                                      # the first two turns load kernels and capture the graphs
+            lat.append((t1 - t0) + (t_first - t1) + (t3 - t2))
+            parts.append((t1 - t0, t_first - t1, t2 - t1, t3 - t2))
+    pa = np.array(parts)
+    res = {'workload': '%d AI-attendant sessions per GPU (1/8 of configuration 5): Whisper-base STT + Qwen2.5-1.5B-shaped LLM '
+                       '(random weights, %d-token contexts) + SpeechT5/HiFi-GAN TTS, turns of all sessions arriving together' %
+                       (n_sessions, prompt_len),
+           'p50_turn_latency_ms': round(float(np.percentile(lat, 50)) * 1e3, 1),
+           'turn_latency_definition': 'end of caller speech -> first 512 ms of synthesised reply audio (first sentence = %d tokens)' % first_sentence,
+           'stt_ms': round(float(pa[:, 0].mean()) * 1e3, 1), 'llm_first_sentence_ms': round(float(pa[:, 1].mean()) * 1e3, 1),
+           'llm_reply_ms': round(float(pa[:, 2].mean()) * 1e3, 1), 'tts_first_chunk_ms': round(float(pa[:, 3].mean()) * 1e3, 1),
+           'llm_decode_tokens_per_s': round(n_sessions * (reply_tokens - first_sentence) / float((pa[:, 2] - pa[:, 1]).mean()), 0),
+           'turns': turns}
+    del pipe, llm, frames_all
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -400,6 +452,10 @@ def main():
                           'ms_per_step': round(dt2 / k2 * 1e3, 2), 'tts_rows_per_batch': n2 * args.tts_group}
             del p2, fa2
             torch.cuda.empty_cache()
+        try:
+            extra['C5_share'] = c5_share(dev, args, build)
+        except Exception as e:                             # the LLM leg is a "next" row: never take the headline line down
+            extra['C5_share'] = {'error': repr(e)}
         out['other_configs'] = extra
     if rank == 0:
         if not args.no_cpu_baseline:

@@ -486,6 +486,22 @@ int ifh_argmax_pick_f32(const float *logits, int64_t ld, int vocab, int nrows, i
  * zero_bytes (% 16 == 0, 16-byte aligned, may be 0) at zero_buf: the LayerNorm statistics the NEXT step accumulates into */
 int ifh_add_i32(int32_t *value, int delta, void *zero_buf, int64_t zero_bytes, ifh_stream_t stream);
 
+/* ---- sampling a decode step's logits: what transformers' generate does for a checkpoint whose generation config says
+ * do_sample (Qwen2.5-Instruct: repetition_penalty 1.05, temperature 0.7, top_k 20, top_p 0.8), i.e. the reference's
+ * InfernLLMWorker.py:113-118 call with no sampling arguments (generation/logits_process.py order). ---- */
+/* logits[r, t] = l < 0 ? l * penalty : l / penalty for every token t in history[r, 0 .. lens[r]) (each token once);
+ * history int32 [nrows, hist_ld], at most 8192 tokens per row are considered */
+int ifh_repetition_penalty_f32(float *logits, int64_t ld, int vocab, int nrows, const int32_t *history, int64_t hist_ld,
+                               const int32_t *lens, float penalty, ifh_stream_t stream);
+/* per row: logits / temperature, the top_k (<= 32; 0 = 32) best (ties to the lower token id), top-p on their softmax
+ * (a candidate stays iff the mass of it and everything below it exceeds 1 - top_p; the best always stays), renormalise,
+ * draw by inverse CDF over the kept candidates in descending order with uniform[r] in [0, 1).  out_tokens int32 [nrows].
+ * scratch: nrows * 260 bytes.  out_cand / out_probs (optional, [nrows][32]): the sorted candidates and their final
+ * probabilities (0 for dropped ones) -- test hooks. */
+int ifh_sample_topk_f32(const float *logits, int64_t ld, int vocab, int nrows, float temperature, int top_k, float top_p,
+                        const float *uniform, int32_t *out_tokens, void *scratch, int32_t *out_cand, float *out_probs,
+                        ifh_stream_t stream);
+
 /* ---- decoder-only LLM step (InfernLLMWorker, Cluster/InfernLLMWorker.py:60-119: Qwen2.5 through transformers' generate;
  * layer maths of transformers/models/qwen2/modeling_qwen2.py).  The projections are ifh_conv_bf16 GEMMs; these are the
  * kernels between them. ---- */

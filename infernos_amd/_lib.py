@@ -162,6 +162,8 @@ SIGNATURES.update({
     'ifh_attn_gqa_bf16': (_i, [ctypes.POINTER(GqaDesc), _vp]),
     'ifh_silu_mul_bf16': (_i, [_vp, _vp, _i64, _i, _vp]),
     'ifh_add_i32_vec': (_i, [_vp, _vp, _i, _i, _vp]),
+    'ifh_repetition_penalty_f32': (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _f, _vp]),
+    'ifh_sample_topk_f32': (_i, [_vp, _i64, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ifh_argmax_pick_f32': (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     'ifh_tts_stop_update': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp]),
     'ifh_tts_stop_advance': (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp, _i64, _vp, _vp]),

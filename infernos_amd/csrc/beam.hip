@@ -63,6 +63,7 @@ __device__ __forceinline__ void beam_block_best(float &bv, int &bi, float *s_v, 
 //   en masse) takes 16 exhaustive scans instead: always exact.
 // Keeping a sorted top-16 per thread in registers costs 5x more: with 64 lanes a wave takes the insertion branch on
 // practically every element.
+template <int SLOTS>
 __global__ __launch_bounds__(256) void k_beam_rowtop(const float *__restrict__ logits, int64_t ld, int V,
                                                      const float *__restrict__ suppress,
                                                      const float *__restrict__ begin_suppress,
@@ -140,9 +141,9 @@ __global__ __launch_bounds__(256) void k_beam_rowtop(const float *__restrict__ l
             if (s_m[w] != -INFINITY) st += s_s[w] * __expf(s_m[w] - mn);
         row_lse[row] = mn + __logf(st);
     }
-    // threshold: the BEAM_SLOTS-th best thread maximum (-inf if fewer threads hold a finite candidate)
+    // threshold: the SLOTS-th best thread maximum (-inf if fewer threads hold a finite candidate)
     float thr = -INFINITY;
-    for (int r = 0; r < BEAM_SLOTS; r++) {
+    for (int r = 0; r < SLOTS; r++) {
         float bv = best;
         int bi = besti;
         beam_block_best(bv, bi, s_v, s_i);
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void k_beam_rowtop(const float *__restrict__ l
     const int n = l_n;
     if (n <= BEAM_LIST) {
         // thread t owns list entries t, t + 256, ...
-        for (int r = 0; r < BEAM_SLOTS; r++) {
+        for (int r = 0; r < SLOTS; r++) {
             float bv = -INFINITY;
             int bi = 0x7fffffff, at = -1;
             for (int e = tid; e < n; e += 256)
@@ -204,15 +205,15 @@ __global__ __launch_bounds__(256) void k_beam_rowtop(const float *__restrict__ l
                 l_i[at] = 0x7fffffff;
             }
             if (tid == 0) {
-                cand_val[row * BEAM_SLOTS + r] = bv;
-                cand_tok[row * BEAM_SLOTS + r] = bi == 0x7fffffff ? 0 : bi;
+                cand_val[row * SLOTS + r] = bv;
+                cand_tok[row * SLOTS + r] = bi == 0x7fffffff ? 0 : bi;
             }
         }
     } else {
         // exhaustive: round r scans the row for the best candidate after round r-1's pick in (value desc, token asc) order
         float pv = INFINITY;
         int pi = -1;
-        for (int r = 0; r < BEAM_SLOTS; r++) {
+        for (int r = 0; r < SLOTS; r++) {
             float bv = -INFINITY;
             int bi = 0x7fffffff;
             for (int i = tid; i < V; i += 256) {
@@ -229,12 +230,93 @@ __global__ __launch_bounds__(256) void k_beam_rowtop(const float *__restrict__ l
             pv = bv;
             pi = bi;
             if (tid == 0) {
-                cand_val[row * BEAM_SLOTS + r] = bv;
-                cand_tok[row * BEAM_SLOTS + r] = bi == 0x7fffffff ? 0 : bi;
+                cand_val[row * SLOTS + r] = bv;
+                cand_tok[row * SLOTS + r] = bi == 0x7fffffff ? 0 : bi;
             }
             if (bi == 0x7fffffff) pv = -INFINITY;       // exhausted: the remaining slots stay (-inf, 0)
         }
     }
+}
+
+
+// ---- sampling (transformers' generate with do_sample: RepetitionPenaltyLogitsProcessor, then TemperatureLogitsWarper,
+// TopKLogitsWarper, TopPLogitsWarper, softmax, one draw; generation/logits_process.py) ----
+constexpr int SAMPLE_SLOTS = 32;       // top_k <= 32
+constexpr int REP_HIST = 8192;
+
+// logits[row, t] = l < 0 ? l * penalty : l / penalty for every token t of the row's history (each token once however
+// often it occurs: all reads of a row precede its writes)
+__global__ __launch_bounds__(256) void k_rep_penalty(float *__restrict__ logits, int64_t ld, int V,
+                                                     const int32_t *__restrict__ hist, int64_t hist_ld,
+                                                     const int32_t *__restrict__ lens, float penalty)
+{
+    __shared__ float val[REP_HIST];
+    const int row = blockIdx.x;
+    float *x = logits + (int64_t)row * ld;
+    const int32_t *h = hist + (int64_t)row * hist_ld;
+    const int n = min(lens[row], REP_HIST);
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int t = h[i];
+        val[i] = (t >= 0 && t < V) ? x[t] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int t = h[i];
+        if (t >= 0 && t < V) x[t] = val[i] < 0.0f ? val[i] * penalty : val[i] / penalty;
+    }
+}
+
+// One thread per row over the row's SAMPLE_SLOTS best logits (value descending): temperature, top-k, top-p (a candidate
+// stays iff the probability mass of it and everything below it exceeds 1 - top_p, the ascending cumulative sum of
+// TopPLogitsWarper; the best one always stays), renormalise, inverse-CDF draw with the caller's uniform number.
+__global__ __launch_bounds__(64) void k_sample_pick(const float *__restrict__ cand_val, const int32_t *__restrict__ cand_tok,
+                                                    int nrows, float temperature, int top_k, float top_p,
+                                                    const float *__restrict__ uniform, int32_t *__restrict__ out_tok,
+                                                    float *__restrict__ out_probs /* optional [nrows][SAMPLE_SLOTS] */)
+{
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= nrows) return;
+    const float *cv = cand_val + (int64_t)row * SAMPLE_SLOTS;
+    const int32_t *ct = cand_tok + (int64_t)row * SAMPLE_SLOTS;
+    int k = min(top_k > 0 ? top_k : SAMPLE_SLOTS, SAMPLE_SLOTS);
+    while (k > 1 && !(cv[k - 1] > -INFINITY)) k--;
+    float z[SAMPLE_SLOTS], pr[SAMPLE_SLOTS];
+    const float z0 = cv[0] / temperature;
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < SAMPLE_SLOTS; i++) {
+        z[i] = i < k ? cv[i] / temperature : -INFINITY;
+        pr[i] = i < k ? __expf(z[i] - z0) : 0.0f;
+        sum += pr[i];
+    }
+    // top-p on softmax over the top-k set: cumulative sum in ascending order
+    int keep = k;
+    if (top_p < 1.0f) {
+        float cum = 0.0f;
+        keep = 1;
+        for (int i = k - 1; i >= 1; i--) {
+            cum += pr[i] / sum;
+            if (cum > 1.0f - top_p) {
+                keep = i + 1;
+                break;
+            }
+        }
+    }
+    float ks = 0.0f;
+    for (int i = 0; i < keep; i++) ks += pr[i];
+    const float u = uniform[row] * ks;
+    float acc = 0.0f;
+    int pick = keep - 1;
+    for (int i = 0; i < keep; i++) {
+        acc += pr[i];
+        if (acc > u) {
+            pick = i;
+            break;
+        }
+    }
+    out_tok[row] = ct[pick];
+    if (out_probs)
+        for (int i = 0; i < SAMPLE_SLOTS; i++) out_probs[(int64_t)row * SAMPLE_SLOTS + i] = i < keep ? pr[i] / ks : 0.0f;
 }
 
 struct BeamParams {
@@ -408,7 +490,7 @@ extern "C" int ifh_beam_step(const ifh_beam_desc *d, ifh_stream_t stream)
     float *cand_val = (float *)d->scratch;
     int32_t *cand_tok = (int32_t *)(cand_val + (size_t)rows * BEAM_SLOTS);
     float *row_lse = (float *)(cand_tok + (size_t)rows * BEAM_SLOTS);
-    hipLaunchKernelGGL(k_beam_rowtop, dim3(rows), dim3(256), 0, as_stream(stream), d->logits, d->ld, d->vocab,
+    hipLaunchKernelGGL(k_beam_rowtop<BEAM_SLOTS>, dim3(rows), dim3(256), 0, as_stream(stream), d->logits, d->ld, d->vocab,
                        d->suppress, d->begin_suppress, d->pos, d->prompt_len, cand_val, cand_tok, row_lse);
     IFH_LAUNCH_CHECK("beam_rowtop");
     BeamParams p;
@@ -449,5 +531,44 @@ extern "C" int ifh_kv_gather_bf16(const void *src, void *dst, const int32_t *row
     hipLaunchKernelGGL(k_kv_gather, dim3(8, nrows), dim3(256), 0, as_stream(stream), (const uint4 *)src, (uint4 *)dst,
                        row_src, len, max_len, row_stride / 8, tok_elems / 8);
     IFH_LAUNCH_CHECK("kv_gather");
+    return IFH_OK;
+}
+
+extern "C" int ifh_repetition_penalty_f32(float *logits, int64_t ld, int vocab, int nrows, const int32_t *history,
+                                          int64_t hist_ld, const int32_t *lens, float penalty, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(nrows >= 0);
+    if (nrows == 0 || penalty == 1.0f) return IFH_OK;
+    IFH_CHECK_ARG(logits && history && lens && vocab > 0 && ld >= vocab && penalty > 0.0f && hist_ld > 0);
+    hipLaunchKernelGGL(k_rep_penalty, dim3(nrows), dim3(256), 0, as_stream(stream), logits, ld, vocab, history, hist_ld, lens,
+                       penalty);
+    IFH_LAUNCH_CHECK("rep_penalty");
+    return IFH_OK;
+}
+
+extern "C" int ifh_sample_topk_f32(const float *logits, int64_t ld, int vocab, int nrows, float temperature, int top_k,
+                                   float top_p, const float *uniform, int32_t *out_tokens, void *scratch,
+                                   int32_t *out_cand /* optional [nrows][32] */, float *out_probs /* optional [nrows][32] */,
+                                   ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(nrows >= 0);
+    if (nrows == 0) return IFH_OK;
+    IFH_CHECK_ARG(logits && uniform && out_tokens && scratch && vocab > 0 && ld >= vocab);
+    IFH_CHECK_ARG(temperature > 0.0f && top_k >= 0 && top_k <= SAMPLE_SLOTS && top_p > 0.0f && top_p <= 1.0f);
+    float *cand_val = (float *)scratch;
+    int32_t *cand_tok = (int32_t *)(cand_val + (size_t)nrows * SAMPLE_SLOTS);
+    float *row_lse = (float *)(cand_tok + (size_t)nrows * SAMPLE_SLOTS);
+    static const int32_t *no_pos = nullptr;
+    hipLaunchKernelGGL(k_beam_rowtop<SAMPLE_SLOTS>, dim3(nrows), dim3(256), 0, as_stream(stream), logits, ld, vocab,
+                       (const float *)nullptr, (const float *)nullptr, no_pos, 0, cand_val, cand_tok, row_lse);
+    IFH_LAUNCH_CHECK("sample_rowtop");
+    hipLaunchKernelGGL(k_sample_pick, dim3((nrows + 63) / 64), dim3(64), 0, as_stream(stream), cand_val, cand_tok, nrows,
+                       temperature, top_k, top_p, uniform, out_tokens, out_probs);
+    IFH_LAUNCH_CHECK("sample_pick");
+    if (out_cand) {
+        hipError_t e = hipMemcpyAsync(out_cand, cand_tok, (size_t)nrows * SAMPLE_SLOTS * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                                      as_stream(stream));
+        if (e != hipSuccess) return check_hip(e, "sample_topk copy");
+    }
     return IFH_OK;
 }

@@ -204,6 +204,97 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
     }
 }
 
+// ---- weight-streaming GEMM for decode steps of LLM-sized layers (M <= 64 rows, N x K in the tens of MB) ----
+// k_gemm_skinny gives every 16 x 16 output tile its own block: at M = 64 a weight fragment is fetched by four blocks and an
+// activation fragment by N/16 of them, fine for 768-wide speech decoders whose weights live in L2, ~1 TB/s of weight
+// streaming on an 8960 x 1536 layer.  Here one block owns NTB column tiles x ALL (up to 4) row tiles, so every weight
+// byte crosses HBM -> CU exactly once; its four waves split K into contiguous quarters (sequential addresses per
+// wave), keep U k-steps of 16-byte fragment loads in flight, and sum their partial tiles through LDS.
+template <int NTB, int U>
+__global__ __launch_bounds__(256) void k_gemm_m64(const IgemmParams p)
+{
+    constexpr int NW = 4, MT = 4;
+    __shared__ __attribute__((aligned(16))) float red[NW][MT * NTB][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 16 * NTB;
+    const int M = p.nbatch * p.T_out;
+    const int nk = (p.K + 31) / 32;
+    const int per = (nk + NW - 1) / NW;
+    const int kt0 = wid * per, kt1 = min(nk, kt0 + per);
+    const uint16_t *wrow[NTB];
+    bool wok[NTB];
+#pragma unroll
+    for (int t = 0; t < NTB; t++) {
+        const int nrow = n0 + 16 * t + fr;
+        wok[t] = nrow < p.N;
+        wrow[t] = p.w + (int64_t)(wok[t] ? nrow : 0) * p.K + fg * 8;
+    }
+    const uint16_t *xrow[MT];
+    bool xok[MT];
+#pragma unroll
+    for (int r = 0; r < MT; r++) {
+        const int mm0 = 16 * r + fr;
+        xok[r] = mm0 < M;
+        const int mm = xok[r] ? mm0 : 0;
+        const int bb = mm / p.T_out, tt = mm - bb * p.T_out;
+        xrow[r] = p.x + (int64_t)bb * p.x_bstride + (int64_t)tt * p.lda + fg * 8;
+    }
+    f32x4 acc[NTB][MT];
+#pragma unroll
+    for (int t = 0; t < NTB; t++)
+#pragma unroll
+        for (int r = 0; r < MT; r++) acc[t][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int kt = kt0; kt < kt1; kt += U) {
+        uint4 wv[U][NTB], xv[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int kk = kt + u;
+            const bool kok = kk < kt1 && (kk * 32 + fg * 8) < p.K;      // K % 8 == 0
+#pragma unroll
+            for (int t = 0; t < NTB; t++) {
+                wv[u][t] = make_uint4(0, 0, 0, 0);
+                if (wok[t] && kok) wv[u][t] = *reinterpret_cast<const uint4 *>(wrow[t] + kk * 32);
+            }
+#pragma unroll
+            for (int r = 0; r < MT; r++) {
+                xv[u][r] = make_uint4(0, 0, 0, 0);
+                if (xok[r] && kok) xv[u][r] = *reinterpret_cast<const uint4 *>(xrow[r] + kk * 32);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int t = 0; t < NTB; t++) {
+                const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wv[u][t]);
+#pragma unroll
+                for (int r = 0; r < MT; r++)
+                    acc[t][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8_t, xv[u][r]), acc[t][r], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < NTB; t++)
+#pragma unroll
+        for (int r = 0; r < MT; r++) *reinterpret_cast<f32x4 *>(&red[wid][t * MT + r][lane][0]) = acc[t][r];
+    __syncthreads();
+    const int dynv = p.dyn ? p.dyn[0] : 0;
+    // wave w finishes tiles w, w + 4, ...: column tile = tile / MT, row tile = tile % MT
+#pragma unroll
+    for (int i = 0; i < NTB; i++) {
+        const int tile = wid + NW * i;
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w][tile][lane][0]);
+        const int m = 16 * (tile % MT) + fr, n = n0 + 16 * (tile / MT) + 4 * fg;
+        if (m < M && n < p.N) {
+            if (p.fast_epi)
+                igemm_store4<true>(p, m, n, s, dynv);
+            else
+                igemm_store4<false>(p, m, n, s, dynv);
+        }
+    }
+}
+
 template <int BM, int BN, int WGM, bool PRE, bool FAST>
 __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
 {
@@ -538,7 +629,18 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     const int64_t M = (int64_t)d->nbatch * d->t_out;
     IFH_CHECK_ARG(M < (1ll << 31));
     hipStream_t st = as_stream(stream);
-    if (M <= 256 && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre) {
+    const bool ln_fold = d->aln_stats || d->rln_stats || d->stats_out;
+    if (M <= 64 && M > 16 && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre && !ln_fold && d->n >= 8192 &&
+        (int64_t)d->n * p.K >= (int64_t)4096 * 1024) {
+        // LLM-sized wide layer at decode batch (gate|up 17920 x 1536, the vocabulary head): every weight byte once
+        // (k_gemm_m64).  Narrow deep layers (down 1536 x 8960: 96 column tiles) stay with the 16 x 16-tile kernel below:
+        // one block per column tile leaves 160 CUs idle and measured slower (41.8 vs 34.2 us).
+        const int ct = (d->n + 15) / 16;
+        if (ct >= 4 * 256)
+            hipLaunchKernelGGL((k_gemm_m64<4, 2>), dim3((ct + 3) / 4), dim3(256), 0, st, p);
+        else
+            hipLaunchKernelGGL((k_gemm_m64<2, 3>), dim3((ct + 1) / 2), dim3(256), 0, st, p);
+    } else if (M <= 256 && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre) {
         const dim3 grid((d->n + 15) / 16, (unsigned)((M + 15) / 16));
         // waves per block = K split: 2 (12 k-steps each at K = 768) / 4 for deep K.  With several decode loops in
         // flight (SpeechPipeline TTS lanes) fewer, longer waves beat 4/8 short ones by ~6 % end to end; alone the

@@ -17,6 +17,28 @@ from .. import _lib, ops
 BF16 = torch.bfloat16
 
 
+class Sampler:
+    """The draw transformers' generate makes when the checkpoint's generation config says do_sample (Qwen2.5-Instruct:
+    repetition_penalty 1.05, temperature 0.7, top_k 20, top_p 0.8): ifh_repetition_penalty_f32 over the row's prompt and
+    generated tokens, then ifh_sample_topk_f32 with one uniform number per row from a seeded device generator."""
+
+    def __init__(self, temperature=0.7, top_k=20, top_p=0.8, repetition_penalty=1.05, seed=0):
+        assert 0 <= top_k <= 32, 'ifh_sample_topk_f32 keeps at most 32 candidates'
+        self.temperature, self.top_k, self.top_p, self.repetition_penalty = temperature, top_k, top_p, repetition_penalty
+        self.seed, self.gen = seed, None
+
+    def pick(self, model, st, B):
+        dev = model.device
+        if self.gen is None:
+            self.gen = torch.Generator(device=dev).manual_seed(self.seed)
+        u = torch.rand(B, generator=self.gen, device=dev)
+        if self.repetition_penalty != 1.0:
+            ops.repetition_penalty(st['logits_full'], st['hist'], st['lens'][0], vocab=model.vocab, ld=model.vpad,
+                                   penalty=self.repetition_penalty)
+        ops.sample_topk(st['logits_full'], u, st['toks'], st['sscratch'], vocab=model.vocab, ld=model.vpad, nrows=B,
+                        temperature=self.temperature, top_k=self.top_k, top_p=self.top_p)
+
+
 class Qwen2:
     def __init__(self, sd, cfg, device, max_tokens=2048):
         self.device = dev = _lib.require_device(device)
@@ -61,6 +83,8 @@ class Qwen2:
                 logits_full=e(B, self.vpad, dt=torch.float32),
                 lens=torch.zeros((2, B), dtype=torch.int32, device=dev),        # [0]: tokens in the cache, [1]: that + 1
                 ones=torch.ones(B, dtype=torch.int32, device=dev),
+                hist=torch.zeros((B, self.max_tokens), dtype=torch.int32, device=dev),     # prompt + chosen tokens per row
+                sscratch=torch.zeros(B * 260, dtype=torch.uint8, device=dev),
                 toks=torch.zeros(B, dtype=torch.int32, device=dev), graph=None, eager_steps=0)
             b = self._bufs[B]
             b['logits'] = b['logits_full'][:, :self.vocab]
@@ -116,6 +140,7 @@ class Qwen2:
         st['x'].copy_(x.index_select(0, last))
         st['lens'][0].copy_(lens_t)
         st['lens'][1].copy_(lens_t + 1)
+        st['hist'][:, :T].copy_(ids)
         self._head(st, st['x'], B, argmax)
         out = None
         if all_logits:
@@ -153,8 +178,8 @@ class Qwen2:
         """Continue every prompt for up to max_new_tokens tokens; a row stops at one of eos_ids (kept in its output) and is
         fed pad_id afterwards, as transformers' generate does; the loop ends when every row has stopped or a row's
         cache is full.  on_tokens(int64 [B] CPU tensor) is called once per step with the tokens just chosen (pad_id for
-        stopped rows): the streamer hook of InfernLLMWorker.py:113-118.  sampler(logits f32 [B, vocab] device, step) ->
-        int tensor [B] replaces the greedy pick.  Returns (list of per-row generated id lists, per-step logits list
+        stopped rows): the streamer hook of InfernLLMWorker.py:113-118.  sampler (a Sampler) replaces the greedy pick.
+        Returns (list of per-row generated id lists, per-step logits list
         if keep_logits)."""
         B = len(prompts)
         st, _ = self.prefill(prompts, argmax=sampler is None)
@@ -167,7 +192,8 @@ class Qwen2:
             if keep_logits:
                 kept.append(st['logits'].clone())
             if sampler is not None:
-                st['toks'].copy_(sampler(st['logits'], s).to(torch.int32))
+                sampler.pick(self, st, B)
+            st['hist'].scatter_(1, st['lens'][0].long()[:, None], st['toks'][:, None])      # the chosen token's position
             toks = st['toks'].cpu().tolist()
             step_toks = []
             for i, t in enumerate(toks):

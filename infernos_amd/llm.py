@@ -159,9 +159,10 @@ class InfernLLMWorker(InfernBatchedWorker):
     Constructor extras (optional): `weights` (HF-format Qwen2 state dict) + `config` (QWEN2_CONFIGS-style dict; default:
     download `model_name`), `tokenizer` (needs apply_chat_template / __call__(padding=True) / batch_decode /
     eos_token_id / pad_token_id; default AutoTokenizer.from_pretrained), `max_new_tokens` (the reference passes
-    16 * 1024), `max_tokens` (KV-cache positions per row), `eos_token_ids`, `sampler` (callable(logits f32 [B, vocab]
-    on the device, step) -> token ids [B]; default greedy).  max_batch_size is the reference's knob (8 there); the
-    MI355X default is 64: a decode step streams the weights once whatever the batch."""
+    16 * 1024), `max_tokens` (KV-cache positions per row), `eos_token_ids`, `generation_config` (dict: do_sample,
+    temperature, top_k, top_p, repetition_penalty -- what transformers' generate takes from the checkpoint; read from
+    the checkpoint when the weights are downloaded, greedy when weights are passed without it).  max_batch_size is the
+    reference's knob (8 there); the MI355X default is 64: a decode step streams the weights once whatever the batch."""
     model_name = "Qwen/Qwen2.5-14B-Instruct"
     max_batch_size: int = 64
     debug = False
@@ -169,7 +170,7 @@ class InfernLLMWorker(InfernBatchedWorker):
     llm_tokenizer: object
 
     def __init__(self, device=None, model_name: str = None, weights=None, config=None, tokenizer=None,
-                 max_new_tokens: int = 16 * 1024, max_tokens: int = 4096, eos_token_ids=None, sampler=None):
+                 max_new_tokens: int = 16 * 1024, max_tokens: int = 4096, eos_token_ids=None, generation_config=None):
         super().__init__()
         from .engines.qwen2 import Qwen2
         self.device = dev = _lib.require_device(device if device is not None else 'cuda')      # no CPU fallback
@@ -178,7 +179,15 @@ class InfernLLMWorker(InfernBatchedWorker):
         if weights is None:
             from transformers import AutoConfig, AutoModelForCausalLM
             config = qwen2_config_from_hf(AutoConfig.from_pretrained(self.model_name))
-            weights = AutoModelForCausalLM.from_pretrained(self.model_name, torch_dtype='auto').state_dict()
+            hf = AutoModelForCausalLM.from_pretrained(self.model_name, torch_dtype='auto')
+            weights = hf.state_dict()
+            if generation_config is None:
+                gc = hf.generation_config
+                generation_config = dict(do_sample=bool(gc.do_sample), temperature=gc.temperature or 1.0, top_k=gc.top_k or 0,
+                                         top_p=gc.top_p or 1.0, repetition_penalty=gc.repetition_penalty or 1.0)
+                if eos_token_ids is None and gc.eos_token_id is not None:
+                    eos_token_ids = gc.eos_token_id
+            del hf
         if tokenizer is None:
             from transformers import AutoTokenizer
             tokenizer = AutoTokenizer.from_pretrained(self.model_name)
@@ -190,7 +199,12 @@ class InfernLLMWorker(InfernBatchedWorker):
         self.eos_token_ids = tuple(eos) if isinstance(eos, (list, tuple, set)) else (() if eos is None else (int(eos),))
         pad = getattr(tokenizer, 'pad_token_id', None)
         self.pad_token_id = int(pad) if pad is not None else (self.eos_token_ids[0] if self.eos_token_ids else 0)
-        self.sampler = sampler
+        gc = generation_config or {}
+        self.sampler = None
+        if gc.get('do_sample'):
+            from .engines.qwen2 import Sampler
+            self.sampler = Sampler(gc.get('temperature', 1.0), gc.get('top_k', 0), gc.get('top_p', 1.0),
+                                   gc.get('repetition_penalty', 1.0), gc.get('seed', 0))
 
     def tokenize_batch(self, wis: List[LLMInferRequest]):
         """chat template + padded tokenisation exactly as InfernLLMWorker.py:108-112, then every row's own token list

@@ -179,6 +179,19 @@ def add_i32_vec(values, delta, mask=None):
                'ifh_add_i32_vec')
 
 
+def repetition_penalty(logits, history, lens, *, vocab, ld, penalty):
+    _lib.check(_lib.lib().ifh_repetition_penalty_f32(_addr(logits), ld, vocab, history.size(0), _addr(history), history.size(1),
+                                                     _addr(lens), penalty, _lib.stream_ptr(logits.device)),
+               'ifh_repetition_penalty_f32')
+
+
+def sample_topk(logits, uniform, out_tokens, scratch, *, vocab, ld, nrows, temperature=1.0, top_k=0, top_p=1.0, out_cand=None,
+                out_probs=None):
+    _lib.check(_lib.lib().ifh_sample_topk_f32(_addr(logits), ld, vocab, nrows, temperature, top_k, top_p, _addr(uniform),
+                                              _addr(out_tokens), _addr(scratch), _addr(out_cand), _addr(out_probs),
+                                              _lib.stream_ptr(logits.device)), 'ifh_sample_topk_f32')
+
+
 class BeamState:
     """Device-resident state of ifh_beam_step for `nbatch` utterances x `beams` (include/infernos_hip.h: ifh_beam_desc)."""
 

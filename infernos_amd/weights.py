@@ -136,3 +136,20 @@ def scaled_positional_table(max_len, dim):
     pe[:, 0::2] = torch.sin(pos * div)
     pe[:, 1::2] = torch.cos(pos * div)
     return pe
+
+
+def qwen2_random_on_device(cfg, device, seed=0):
+    """Random bf16/f32 tensors of a Qwen2 configuration's shapes generated ON the device (1.5 B parameters take minutes
+    through the seeded CPU generator): for throughput/latency measurements only -- parity tests use synth_state_dict."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for name, (shape, _) in qwen2_schema(cfg).items():
+        if name.endswith('norm.weight') or 'layernorm' in name:
+            sd[name] = 1.0 + 0.1 * torch.randn(shape, generator=g, device=device)
+        elif len(shape) == 1:
+            sd[name] = 0.05 * torch.randn(shape, generator=g, device=device)
+        elif 'embed_tokens' in name:
+            sd[name] = 0.5 * torch.randn(shape, generator=g, device=device, dtype=torch.bfloat16)
+        else:
+            sd[name] = torch.randn(shape, generator=g, device=device, dtype=torch.bfloat16) / shape[1] ** 0.5
+    return sd

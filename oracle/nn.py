@@ -539,3 +539,38 @@ def qwen2_greedy(sd, cfg, prompts, n_new, eos_ids=()):
         outs.append(new)
         logs.append(torch.cat(allg, 0))
     return outs, logs
+
+
+# =========================================================================================
+# Sampling (transformers/generation/logits_process.py: RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
+# TopKLogitsWarper, TopPLogitsWarper in the order generate applies them, then softmax)
+# =========================================================================================
+def sample_warp(logits, history, penalty=1.0, temperature=1.0, top_k=0, top_p=1.0):
+    """logits f32 [V], history: token ids of the row so far -> (token ids by descending probability, their probabilities)
+    of the distribution transformers' generate draws from."""
+    s = logits.clone().float()
+    if penalty != 1.0 and len(history):
+        idx = torch.unique(torch.as_tensor(history, dtype=torch.long))
+        sc = s[idx]
+        s[idx] = torch.where(sc < 0, sc * penalty, sc / penalty)
+    s = s / temperature
+    if top_k and top_k > 0:
+        kth = torch.topk(s, min(top_k, s.numel())).values[-1]
+        s = s.masked_fill(s < kth, float('-inf'))
+    if top_p < 1.0:
+        so, si = torch.sort(s, descending=False)
+        cum = torch.softmax(so, -1).cumsum(-1)
+        rem = cum <= (1 - top_p)
+        rem[-1:] = False
+        s[si[rem]] = float('-inf')
+    p = torch.softmax(s, -1)
+    order = torch.argsort(p, descending=True, stable=True)
+    n = int((p > 0).sum())
+    return order[:n], p[order[:n]]
+
+
+def sample_pick(ids, probs, u):
+    """inverse-CDF draw over the candidates in descending order"""
+    cdf = probs.cumsum(-1)
+    i = int((cdf > u * float(cdf[-1])).nonzero()[0]) if bool((cdf > u * float(cdf[-1])).any()) else len(ids) - 1
+    return int(ids[i])

@@ -138,3 +138,18 @@ def test_beam_search_matches_transformers(golden_dir):
             early += int(lens[b] < c['n_new'])
         np.testing.assert_allclose(scores.numpy(), g['score%d' % ci], atol=2e-4)
     assert early >= 2
+
+
+def test_sampling_distribution_matches_transformers_warpers(golden_dir):
+    """oracle/nn.py:sample_warp against transformers' RepetitionPenalty / Temperature / TopK / TopP chain
+    (tools/gen_golden_nn.py:gen_sampling)"""
+    g = np.load(os.path.join(golden_dir, 'sampling.npz'))
+    meta = json.load(open(os.path.join(golden_dir, 'sampling_meta.json')))
+    logits, hist = torch.from_numpy(g['logits']), g['history']
+    for ci, c in enumerate(meta['cases']):
+        for r in range(logits.size(0)):
+            ids, p = onn.sample_warp(logits[r], hist[r].tolist(), c['penalty'], c['temperature'], c['top_k'], c['top_p'])
+            n = int((g['ids%d' % ci][r] >= 0).sum())
+            assert ids.tolist() == g['ids%d' % ci][r, :n].tolist()
+            np.testing.assert_allclose(p.numpy(), g['probs%d' % ci][r, :n], atol=1e-6)
+            assert onn.sample_pick(ids, p, 0.0) == int(ids[0]) and onn.sample_pick(ids, p, 0.999999) == int(ids[-1])

@@ -550,4 +550,43 @@ def gen_llm_host():
     print('wrote llm_host.json')
 
 
-SECTIONS = {'tts': gen_tts, 'whisper': gen_whisper, 'whisper_tf': gen_whisper_tf, 'whisper_beam': gen_whisper_beam, 'qwen2': gen_qwen2, 'llm_host': gen_llm_host}
+def gen_sampling():
+    """transformers' own logits processors / warpers (the chain generate builds for do_sample with Qwen2.5-Instruct's
+    generation config) on seeded rows: the distribution the draw is made from."""
+    import json
+    from transformers.generation.logits_process import (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper,
+                                                         TopKLogitsWarper, TopPLogitsWarper)
+    from oracle import nn as onn
+    g = torch.Generator().manual_seed(21)
+    V, R = 5003, 6
+    logits = torch.randn(R, V, generator=g) * 4
+    hist = torch.randint(0, V, (R, 40), generator=g)
+    cases = [dict(penalty=1.05, temperature=0.7, top_k=20, top_p=0.8), dict(penalty=1.0, temperature=1.0, top_k=5, top_p=1.0),
+             dict(penalty=1.3, temperature=0.3, top_k=32, top_p=0.95), dict(penalty=1.0, temperature=1.5, top_k=20, top_p=0.5)]
+    arrays = {'logits': logits.numpy(), 'history': hist.numpy().astype(np.int32)}
+    for ci, c in enumerate(cases):
+        s = RepetitionPenaltyLogitsProcessor(c['penalty'])(hist, logits.clone()) if c['penalty'] != 1.0 else logits.clone()
+        s = TemperatureLogitsWarper(c['temperature'])(hist, s)
+        s = TopKLogitsWarper(c['top_k'])(hist, s)
+        if c['top_p'] < 1.0:
+            s = TopPLogitsWarper(c['top_p'])(hist, s)
+        p = torch.softmax(s, -1)
+        ids = torch.full((R, 32), -1, dtype=torch.int32)
+        pr = torch.zeros(R, 32)
+        for r in range(R):
+            o_ids, o_p = onn.sample_warp(logits[r], hist[r].tolist(), c['penalty'], c['temperature'], c['top_k'], c['top_p'])
+            order = torch.argsort(p[r], descending=True, stable=True)
+            n = int((p[r] > 0).sum())
+            ids[r, :n] = order[:n].int()
+            pr[r, :n] = p[r][order[:n]]
+            assert o_ids.tolist() == order[:n].tolist() and float((o_p - pr[r, :n]).abs().max()) < 1e-6, (ci, r)
+        arrays['ids%d' % ci] = ids.numpy()
+        arrays['probs%d' % ci] = pr.numpy()
+        print('sampling case', ci, c, 'kept', [(int((ids[r] >= 0).sum())) for r in range(R)])
+    np.savez_compressed(os.path.join(GOLD, 'sampling.npz'), **arrays)
+    json.dump({'cases': cases, 'source': 'transformers 5.15.0 generation/logits_process.py processors applied in generate\'s order'},
+              open(os.path.join(GOLD, 'sampling_meta.json'), 'w'), indent=1, sort_keys=True)
+    print('wrote sampling.npz')
+
+
+SECTIONS = {'tts': gen_tts, 'whisper': gen_whisper, 'whisper_tf': gen_whisper_tf, 'whisper_beam': gen_whisper_beam, 'qwen2': gen_qwen2, 'llm_host': gen_llm_host, 'sampling': gen_sampling}

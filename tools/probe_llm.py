@@ -1,0 +1,80 @@
+"""Qwen2.5-1.5B-shaped decode on one GPU (BASELINE configuration 5's LLM): prefill and per-token step time at B rows.
+usage: python tools/probe_llm.py [B] [prompt_len] [new_tokens]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from infernos_amd import _lib                                    # noqa: E402
+from infernos_amd.engines.qwen2 import Qwen2                     # noqa: E402
+from infernos_amd.weights import QWEN2_CONFIGS, qwen2_random_on_device, qwen2_schema     # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 192
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+dev = _lib.require_device('cuda:0')
+cfg = QWEN2_CONFIGS['qwen2_1p5b']
+
+
+t0 = time.perf_counter()
+model = Qwen2(qwen2_random_on_device(cfg, dev), cfg, dev, max_tokens=P + N + 8)
+torch.cuda.synchronize()
+print('model built in %.1f s' % (time.perf_counter() - t0))
+g = torch.Generator().manual_seed(1)
+prompts = [torch.randint(10, 150000, (P - (i % 7),), generator=g).tolist() for i in range(B)]
+for rep in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st, _ = model.prefill(prompts)
+    torch.cuda.synchronize()
+    t_pre = time.perf_counter() - t0
+model.step(st, B)
+model.step(st, B)          # captures
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(N):
+    model.step(st, B)
+torch.cuda.synchronize()
+t_step = (time.perf_counter() - t0) / N
+params = sum(int(torch.tensor(s).prod()) for s, _ in qwen2_schema(cfg).values())
+wbytes = 2 * params
+print('Qwen2.5-1.5B shape, B=%d, prompt %d: prefill %.1f ms (%.0f tok/s); decode %.3f ms/step = %.0f tok/s; weights %.2f GB -> '
+      '%.2f TB/s of weight streaming (%.0f %% of 8 TB/s)' % (B, P, t_pre * 1e3, B * P / t_pre, t_step * 1e3, B / t_step, wbytes / 1e9,
+                                                            wbytes / t_step / 1e12, 100 * wbytes / t_step / 8e12))
+
+# ---- the pieces of a decode step on their own (HIP events, 50 launches each) ----
+from infernos_amd import ops                                     # noqa: E402
+
+
+def ev(fn, n=50):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3
+
+
+L = model.layers[0]
+d, ff = model.d, model.ff
+kv = st['kv'][0]
+parts = {
+    'rmsnorm': lambda: ops.rmsnorm(st['x'], L['ln1'], st['h'], B, d, model.eps),
+    'qkv %dx%d' % (model.nq, d): lambda: ops.linear(st['h'], L['wqkv'], L['bqkv'], st['qkv'], rows=B, k=d, n=model.nq),
+    'rope': lambda: ops.rope_append(st['qkv'], model.cos_sin, kv, st['lens'][0], st['ones'], nrows=B, tokens_per_row=1, nheads=model.nh,
+                                    nkv=model.nkv, head_dim=model.hd, max_pos=model.max_tokens),
+    'attn': lambda: ops.attn_gqa(st['qkv'], kv, st['att'], st['lens'][1], ntokens=B, tokens_per_row=1, nheads=model.nh, nkv=model.nkv,
+                                 head_dim=model.hd, max_pos=model.max_tokens, max_keys=model.max_tokens),
+    'o %dx%d' % (d, d): lambda: ops.linear(st['att'], L['wo'], None, st['x'], rows=B, k=d, n=d, resid=st['x']),
+    'gate_up %dx%d' % (2 * ff, d): lambda: ops.linear(st['h'], L['wgu'], None, st['gu'], rows=B, k=d, n=2 * ff),
+    'silu_mul': lambda: ops.silu_mul(st['gu'], st['ff'], B, ff),
+    'down %dx%d' % (d, ff): lambda: ops.linear(st['ff'], L['wd'], None, st['x'], rows=B, k=ff, n=d, resid=st['x']),
+    'head %dx%d' % (model.vocab, d): lambda: ops.linear(st['h'], model.head, None, st['logits_full'], rows=B, k=d, n=model.vocab, ldc=model.vpad),
+    'argmax': lambda: ops.argmax_pick(st['logits_full'], vocab=model.vocab, nrows=B, ld=model.vpad, argmax_out=st['toks']),
+}
+print('per launch (us): ' + ' | '.join('%s %.1f' % (k, ev(f)) for k, f in parts.items()))
