@@ -211,7 +211,7 @@ def time_steps(pipe, frames_for, nsteps, warmup, world, pipelined, egress, dry, 
 
 
 
-def c5_share(dev, args, build, n_sessions=64, prompt_len=192, first_sentence=16, reply_tokens=48, turns=5):
+def c5_share(dev, args, build, n_sessions=64, prompt_len=192, first_sentence=16, reply_tokens=48, turns=5, llm_family='qwen2_1p5b'):
     """One GPU's share of BASELINE configuration 5 (512 AI-attendant sessions over 8 GPUs = 64 per GPU): a turn is
     STT (the C3 front end and decode on the caller's 10 s utterance) -> LLM (Qwen2.5-1.5B shape, random weights, a
     192-token chat context per session, reply streamed) -> TTS.  Turn latency = end of the caller's speech (utterance
@@ -219,7 +219,7 @@ def c5_share(dev, args, build, n_sessions=64, prompt_len=192, first_sentence=16,
     with all 64 sessions' turns arriving together (the worst case for a batched worker).  Sequential stages, one stream."""
     from infernos_amd.engines.qwen2 import Qwen2
     from infernos_amd.weights import QWEN2_CONFIGS, qwen2_random_on_device
-    cfg = QWEN2_CONFIGS['qwen2_1p5b']
+    cfg = QWEN2_CONFIGS[llm_family]
     pipe, frames_all, frames_for, _, _ = build('C3', n_sessions)
     llm = Qwen2(qwen2_random_on_device(cfg, dev), cfg, dev, max_tokens=prompt_len + reply_tokens + 8)
     g = torch.Generator().manual_seed(5)
@@ -280,6 +280,9 @@ def main():
     ap.add_argument('--no-tts-overlap', action='store_true', help='render on the lane stream instead of a second stream per lane')
     ap.add_argument('--stt-beam', type=int, default=5, help='Whisper decode: 5 = the reference default engine\'s beam search '
                     '(ctranslate2 defaults, InfernSTTWorker.py:61-75); 1 = greedy (its torch engine)')
+    ap.add_argument('--c5-only', action='store_true', help='run only the configuration-5 per-GPU share (STT -> LLM -> TTS turn latency) and print it')
+    ap.add_argument('--c5-sessions', type=int, default=64)
+    ap.add_argument('--c5-llm', default='qwen2_1p5b', help='infernos_amd.weights.QWEN2_CONFIGS entry (random weights of that shape)')
     ap.add_argument('--no-pipeline', action='store_true', help='run the stages of consecutive cycles strictly one after another')
     args = ap.parse_args()
 
@@ -341,6 +344,11 @@ def main():
         pipe.prime(frames_for(0))
         return pipe, frames_all, frames_for, egress, last
 
+    if args.c5_only:
+        if rank == 0:
+            print(json.dumps({'C5_share': c5_share(dev, args, build, n_sessions=args.c5_sessions, llm_family=args.c5_llm,
+                                                   turns=max(1, min(args.steps, 5)))}))
+        return
     n_local = args.calls_per_gpu or CONFIGS[args.config][0]
     n_total = n_local * world
     pipe, frames_all, frames_for, egress, primed = build(args.config, n_local)

@@ -260,6 +260,8 @@ int ifh_logmel_finish_transpose_bf16(ifh_logmel_t h, const float *raw, const int
 #define IFH_ACT_TANH 3
 #define IFH_ACT_LRELU 4     /* slope = act_slope */
 #define IFH_ACT_SIGMOID 5
+#define IFH_ACT_SILU_GLU 6  /* weight rows interleaved (gate_j, up_j): out[m, j] = silu(acc[2j]) * acc[2j+1], n/2 columns written;
+                            * decode-batch launches of wide layers only (16 < rows <= 64, n >= 8192), plain bf16 output */
 
 /* One implicit-GEMM launch on the matrix cores: Linear, Conv1d, or one phase of a
  * ConvTranspose1d, channels-last.
@@ -302,7 +304,7 @@ typedef struct ifh_conv_desc {
     void *out2;
     int64_t out2_bstride;
     int32_t ldc2, ooff2, dyn_ooff2_mul;
-    /* LayerNorm folded around a decode-step GEMM (rows <= 256, taps == 1), so that the three LayerNorm launches
+    /* LayerNorm folded around a decode-step GEMM (rows <= 1024, taps == 1), so that the three LayerNorm launches
      * per transformer layer disappear from the latency-bound decode loop:
      *   stats_out int64 [rows][2]: += (sum, sum of squares) of every stored output row in 2^16 fixed point,
      *       by integer atomics (commutative, hence bit-reproducible); the caller zeroes it per step;
@@ -318,6 +320,8 @@ typedef struct ifh_conv_desc {
     void *stats_out;
     int32_t ln_dim;
     float ln_eps;
+    int32_t ln_rms;        /* 1: the folded normalisation is an RMSNorm -- aln: out = rsqrt(mean(x^2) + eps) * acc (aln_c1 unused);
+                            * stats_out as for LayerNorm (only the sum of squares is consumed) */
 } ifh_conv_desc;
 int ifh_conv_bf16(const ifh_conv_desc *desc, ifh_stream_t stream);
 
@@ -532,8 +536,9 @@ typedef struct ifh_gqa_desc {
     float scale;
 } ifh_gqa_desc;
 int ifh_attn_gqa_bf16(const ifh_gqa_desc *desc, ifh_stream_t stream);
-/* out[r, j] = silu(gate_up[r, j]) * gate_up[r, ffn + j]   (Qwen2MLP); bf16, ffn % 8 == 0 */
-int ifh_silu_mul_bf16(const void *gate_up, void *out, int64_t rows, int ffn, ifh_stream_t stream);
+/* out[r, j] = silu(gate[r, j]) * up[r, j]   (Qwen2MLP); bf16, ffn % 8 == 0.  gate_up row = [gate | up] (interleaved 0) or
+ * [gate_0, up_0, gate_1, up_1, ...] (interleaved 1: the layout of a projection packed for IFH_ACT_SILU_GLU) */
+int ifh_silu_mul_bf16(const void *gate_up, void *out, int64_t rows, int ffn, int interleaved, ifh_stream_t stream);
 /* values[i] += delta where mask[i] != 0 (mask optional): per-row sequence lengths advanced between graph replays */
 int ifh_add_i32_vec(int32_t *values, const int32_t *mask, int n, int delta, ifh_stream_t stream);
 

@@ -73,7 +73,7 @@ class ConvDesc(ctypes.Structure):
                 ('n_split', ctypes.c_int32), ('out2', _vp), ('out2_bstride', _i64), ('ldc2', ctypes.c_int32),
                 ('ooff2', ctypes.c_int32), ('dyn_ooff2_mul', ctypes.c_int32),
                 ('aln_stats', _vp), ('aln_c1', _vp), ('rln_stats', _vp), ('rln_gamma', _vp), ('rln_beta', _vp),
-                ('stats_out', _vp), ('ln_dim', ctypes.c_int32), ('ln_eps', _f)]
+                ('stats_out', _vp), ('ln_dim', ctypes.c_int32), ('ln_eps', _f), ('ln_rms', ctypes.c_int32)]
 
 
 class ResblockDesc(ctypes.Structure):
@@ -160,7 +160,7 @@ SIGNATURES.update({
     'ifh_rmsnorm_bf16': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     'ifh_rope_append_bf16': (_i, [_vp, _i64, _vp, _i, _vp, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ifh_attn_gqa_bf16': (_i, [ctypes.POINTER(GqaDesc), _vp]),
-    'ifh_silu_mul_bf16': (_i, [_vp, _vp, _i64, _i, _vp]),
+    'ifh_silu_mul_bf16': (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     'ifh_add_i32_vec': (_i, [_vp, _vp, _i, _i, _vp]),
     'ifh_repetition_penalty_f32': (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _f, _vp]),
     'ifh_sample_topk_f32': (_i, [_vp, _i64, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -50,9 +50,10 @@ struct IgemmParams {
     void *stats_out;          // int64 [M][2] += fixed-point (sum, sumsq) of the stored output rows (caller zeroes)
     int ln_dim;               // LayerNorm width
     float ln_eps;
+    int ln_rms;               // RMSNorm instead of LayerNorm in the folded modes (mean term dropped)
 };
 
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_TANH = 3, ACT_LRELU = 4, ACT_SIGMOID = 5 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_TANH = 3, ACT_LRELU = 4, ACT_SIGMOID = 5, ACT_SILU_GLU = 6 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope)
 {

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
     const int dynv0 = p.dyn ? p.dyn[0] : 0;
     if (ln_mode && xok && nb + 4 * fg < p.N) {
         const int n = nb + 4 * fg;
-        if (p.aln_stats) pc1 = *reinterpret_cast<const float4 *>(p.aln_c1 + n);
+        if (p.aln_stats && !p.ln_rms) pc1 = *reinterpret_cast<const float4 *>(p.aln_c1 + n);
         if (p.bias) pbias = *reinterpret_cast<const float4 *>(p.bias + n);
         if (p.resid) {
             presid = *reinterpret_cast<const uint2 *>(p.resid + epi_row(p, m, n, dynv0).rbase + n);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
         *reinterpret_cast<f32x4 *>(&red[wid][MT * NT - 1][lane][0]) = acc3;
     }
     const float fx = (1.0f / 65536.0f) / (float)p.ln_dim;
-    const float a_mean = (float)st_a.x * fx, r_mean = (float)st_r.x * fx;
+    const float a_mean = p.ln_rms ? 0.0f : (float)st_a.x * fx, r_mean = (float)st_r.x * fx;
     const float a_rstd = rsqrtf(fmaxf((float)st_a.y * fx - a_mean * a_mean, 0.0f) + p.ln_eps);
     const float r_rstd = rsqrtf(fmaxf((float)st_r.y * fx - r_mean * r_mean, 0.0f) + p.ln_eps);
     __syncthreads();
@@ -287,7 +287,29 @@ __global__ __launch_bounds__(256) void k_gemm_m64(const IgemmParams p)
         for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w][tile][lane][0]);
         const int m = 16 * (tile % MT) + fr, n = n0 + 16 * (tile / MT) + 4 * fg;
         if (m < M && n < p.N) {
-            if (p.fast_epi)
+            if (p.aln_stats) {
+                // normalisation of the A rows folded in (ifh_conv_desc.aln_*): the producer left (sum, sum of squares)
+                const longlong2 st = reinterpret_cast<const longlong2 *>(p.aln_stats)[m];
+                const float fx = (1.0f / 65536.0f) / (float)p.ln_dim;
+                const float mean = p.ln_rms ? 0.0f : (float)st.x * fx;
+                const float rstd = rsqrtf(fmaxf((float)st.y * fx - mean * mean, 0.0f) + p.ln_eps);
+                float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!p.ln_rms) c1 = *reinterpret_cast<const float4 *>(p.aln_c1 + n);
+                s[0] = rstd * (s[0] - mean * c1.x);
+                s[1] = rstd * (s[1] - mean * c1.y);
+                s[2] = rstd * (s[2] - mean * c1.z);
+                s[3] = rstd * (s[3] - mean * c1.w);
+            }
+            if (p.act == ACT_SILU_GLU) {
+                // interleaved (gate, up) weight rows: this lane holds two pairs -> two outputs of the half-width result
+                if (p.bias) {
+                    const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
+                    s[0] += bv.x; s[1] += bv.y; s[2] += bv.z; s[3] += bv.w;
+                }
+                const float o0 = s[0] / (1.0f + __expf(-s[0])) * s[1], o1 = s[2] / (1.0f + __expf(-s[2])) * s[3];
+                *reinterpret_cast<uint32_t *>(reinterpret_cast<uint16_t *>(p.out) + (int64_t)m * p.ldc + (n >> 1)) =
+                    f32x2_to_bf16x2(o0, o1);
+            } else if (p.fast_epi)
                 igemm_store4<true>(p, m, n, s, dynv);
             else
                 igemm_store4<false>(p, m, n, s, dynv);
@@ -559,7 +581,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     IFH_CHECK_ARG(d->cin > 0 && d->cin % 8 == 0 && d->taps >= 1 && d->stride >= 1 && d->dil >= 1);
     IFH_CHECK_ARG(d->lda % 8 == 0 && d->x_bstride % 8 == 0 && (((uintptr_t)d->x) & 15) == 0 && (((uintptr_t)d->w) & 15) == 0);
     IFH_CHECK_ARG(d->n > 0 && d->t_in > 0 && d->ldc > 0 && d->ostride >= 1 && d->ooff >= 0);
-    IFH_CHECK_ARG(d->act >= 0 && d->act <= 5);
+    IFH_CHECK_ARG(d->act >= 0 && d->act <= 6);
     IgemmParams p;
     p.x = (const uint16_t *)d->x;
     p.x_bstride = d->x_bstride;
@@ -616,10 +638,12 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     p.stats_out = d->stats_out;
     p.ln_dim = d->ln_dim;
     p.ln_eps = d->ln_eps;
+    p.ln_rms = d->ln_rms;
     if (d->aln_stats || d->rln_stats || d->stats_out) {
-        IFH_CHECK_ARG((int64_t)d->nbatch * d->t_out <= 256 && d->taps == 1 && d->stride == 1 && d->pad == 0 && d->pre_slope == 1.0f);
+        IFH_CHECK_ARG((int64_t)d->nbatch * d->t_out <= 1024 && d->taps == 1 && d->stride == 1 && d->pad == 0 && d->pre_slope == 1.0f);
         IFH_CHECK_ARG(d->n % 16 == 0 && d->ln_dim > 0 && !d->colmask && !d->accumulate && p.vec_ok && p.res_vec_ok);
-        IFH_CHECK_ARG(!d->aln_stats || d->aln_c1);
+        IFH_CHECK_ARG(!d->aln_stats || d->aln_c1 || d->ln_rms);
+        IFH_CHECK_ARG(!d->ln_rms || !d->rln_stats);
         IFH_CHECK_ARG(!d->rln_stats || (d->rln_gamma && d->rln_beta && d->resid));
     }
     p.dyn = d->dyn_pos;
@@ -630,17 +654,27 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     IFH_CHECK_ARG(M < (1ll << 31));
     hipStream_t st = as_stream(stream);
     const bool ln_fold = d->aln_stats || d->rln_stats || d->stats_out;
-    if (M <= 64 && M > 16 && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre && !ln_fold && d->n >= 8192 &&
-        (int64_t)d->n * p.K >= (int64_t)4096 * 1024) {
+    const bool aln_only = d->aln_stats && !d->rln_stats && !d->stats_out;     // k_gemm_m64 can consume row statistics, not produce them
+    const bool glu = d->act == IFH_ACT_SILU_GLU;
+    if (glu)
+        IFH_CHECK_ARG(M <= 64 && M > 16 && d->n >= 8192 && d->n % 16 == 0 && !d->resid && !d->accumulate && !d->out_f32 &&
+                      !d->colmask && d->n_split == 0 && d->t_out == (int)M && d->ostride == 1 && d->ooff == 0 && !d->dyn_pos &&
+                      d->out_scale == 1.0f && !d->rln_stats && !d->stats_out && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre);
+    if (M <= 64 && M > 16 && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre && (!ln_fold || aln_only) && d->n >= 8192 &&
+        ((int64_t)d->n * p.K >= (int64_t)4096 * 1024 || glu)) {
         // LLM-sized wide layer at decode batch (gate|up 17920 x 1536, the vocabulary head): every weight byte once
         // (k_gemm_m64).  Narrow deep layers (down 1536 x 8960: 96 column tiles) stay with the 16 x 16-tile kernel below:
         // one block per column tile leaves 160 CUs idle and measured slower (41.8 vs 34.2 us).
         const int ct = (d->n + 15) / 16;
+        // column tiles per block: 4 wherever that still gives a block per CU.  Fewer (more, smaller blocks) was measured
+        // slower at every size (gate|up 27.9 / 29.2 / 37.4 us, head 159 / 200 / 296 us for 4 / 2 / 1): each block re-reads the
+        // whole activation matrix from L2, and L2 -> CU bytes (~4 TB/s here), not HBM, are what bounds this kernel
         if (ct >= 4 * 256)
             hipLaunchKernelGGL((k_gemm_m64<4, 2>), dim3((ct + 3) / 4), dim3(256), 0, st, p);
         else
             hipLaunchKernelGGL((k_gemm_m64<2, 3>), dim3((ct + 1) / 2), dim3(256), 0, st, p);
-    } else if (M <= 256 && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre) {
+    } else if ((M <= 256 || (ln_fold && M <= 1024)) && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre) {
+        // (LayerNorm-folded launches exist only in this kernel: up to 1024 rows -- the 640 decode rows of a 5-beam search)
         const dim3 grid((d->n + 15) / 16, (unsigned)((M + 15) / 16));
         // waves per block = K split: 2 (12 k-steps each at K = 768) / 4 for deep K.  With several decode loops in
         // flight (SpeechPipeline TTS lanes) fewer, longer waves beat 4/8 short ones by ~6 % end to end; alone the

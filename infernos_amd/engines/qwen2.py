@@ -10,6 +10,8 @@ over the padded [B, T] token block with per-token key counts (causal) and paddin
 advances all rows by one token at their own positions -- the per-token launch sequence is identical for every step, so it
 is captured into a hipGraph after the first eager step and replayed.
 """
+import os
+
 import torch
 
 from .. import _lib, ops
@@ -53,22 +55,34 @@ class Qwen2:
         self.tok = sd['model.embed_tokens.weight'].to(BF16).contiguous().to(dev)
         self.head = sd['lm_head.weight'].to(BF16).contiguous().to(dev) if 'lm_head.weight' in sd and not cfg['tie'] else self.tok
         self.norm = f32(sd['model.norm.weight'])
+        # RMSNorm weights are folded into the projections that consume the normalised rows (W diag(gamma)), so that the
+        # normalisation left to do at run time is the per-row scale rsqrt(mean(x^2) + eps): an explicit RMSNorm with unit
+        # gamma in the prefill, nothing at all in the decode step (the scale is applied in the consumer's epilogue from row
+        # statistics the producer of x accumulated: ifh_conv_desc.aln_stats / stats_out with ln_rms).  gate and up rows are
+        # interleaved (gate_j, up_j) for the fused SiLU-gate epilogue (IFH_ACT_SILU_GLU).
+        self.ones = torch.ones(self.d, dtype=torch.float32, device=dev)
         self.layers = []
         for i in range(cfg['layers']):
             L = 'model.layers.%d.' % i
             A = L + 'self_attn.'
+            g1, g2 = sd[L + 'input_layernorm.weight'].float(), sd[L + 'post_attention_layernorm.weight'].float()
+            wqkv = torch.cat([sd[A + 'q_proj.weight'], sd[A + 'k_proj.weight'], sd[A + 'v_proj.weight']]).float() * g1.to(sd[A + 'q_proj.weight'].device)
+            wg = sd[L + 'mlp.gate_proj.weight'].float() * g2.to(sd[L + 'mlp.gate_proj.weight'].device)
+            wu = sd[L + 'mlp.up_proj.weight'].float() * g2.to(sd[L + 'mlp.up_proj.weight'].device)
+            wgu = torch.stack([wg, wu], 1).reshape(2 * self.ff, self.d)
             self.layers.append(dict(
-                ln1=f32(sd[L + 'input_layernorm.weight']), ln2=f32(sd[L + 'post_attention_layernorm.weight']),
-                wqkv=ops.w_linear(torch.cat([sd[A + 'q_proj.weight'], sd[A + 'k_proj.weight'], sd[A + 'v_proj.weight']]), dev),
+                wqkv=ops.w_linear(wqkv, dev),
                 bqkv=ops.w_bias(torch.cat([sd[A + 'q_proj.bias'], sd[A + 'k_proj.bias'], sd[A + 'v_proj.bias']]), dev),
                 wo=ops.w_linear(sd[A + 'o_proj.weight'], dev),
-                wgu=ops.w_linear(torch.cat([sd[L + 'mlp.gate_proj.weight'], sd[L + 'mlp.up_proj.weight']]), dev),
+                wgu=ops.w_linear(wgu, dev),
                 wd=ops.w_linear(sd[L + 'mlp.down_proj.weight'], dev)))
+            del wqkv, wg, wu, wgu
         # cos/sin of position * theta^(-2j/hd), f32 [max_tokens][hd/2][2] (Qwen2RotaryEmbedding, computed in fp32)
         inv = 1.0 / (cfg['rope_theta'] ** (torch.arange(0, self.hd, 2, dtype=torch.int64).float() / self.hd))
         fr = torch.arange(self.max_tokens).float()[:, None] * inv[None, :]
         self.cos_sin = torch.stack([fr.cos(), fr.sin()], -1).contiguous().to(dev)
         self._bufs = {}
+        self.fuse = os.environ.get('IFH_LLM_NO_FUSE') is None      # tuning switch: explicit RMSNorm / SiLU launches instead
 
     # ---- buffers ------------------------------------------------------------------------------
     def _state(self, B):
@@ -85,6 +99,8 @@ class Qwen2:
                 ones=torch.ones(B, dtype=torch.int32, device=dev),
                 hist=torch.zeros((B, self.max_tokens), dtype=torch.int32, device=dev),     # prompt + chosen tokens per row
                 sscratch=torch.zeros(B * 260, dtype=torch.uint8, device=dev),
+                stats=torch.zeros((2 * len(self.layers), max(64, -(-B // 16) * 16), 2), dtype=torch.int64, device=dev),
+                tick=torch.zeros(1, dtype=torch.int32, device=dev),
                 toks=torch.zeros(B, dtype=torch.int32, device=dev), graph=None, eager_steps=0)
             b = self._bufs[B]
             b['logits'] = b['logits_full'][:, :self.vocab]
@@ -92,19 +108,50 @@ class Qwen2:
 
     # ---- one layer stack over `rows` tokens -----------------------------------------------------
     def _layers(self, x, h, qkv, att, gu, ff, kv, rows, nrows, T, pos0, nvalid, key_len, max_keys):
+        """the layer stack with explicit (unit-gamma) RMSNorm launches: prefill, and decode batches outside 17..64 rows"""
         d = self.d
         for L, cache in zip(self.layers, kv):
-            ops.rmsnorm(x, L['ln1'], h, rows, d, self.eps)
+            ops.rmsnorm(x, self.ones, h, rows, d, self.eps)
             ops.linear(h, L['wqkv'], L['bqkv'], qkv, rows=rows, k=d, n=self.nq)
             ops.rope_append(qkv, self.cos_sin, cache, pos0, nvalid, nrows=nrows, tokens_per_row=T, nheads=self.nh, nkv=self.nkv,
                             head_dim=self.hd, max_pos=self.max_tokens)
             ops.attn_gqa(qkv, cache, att, key_len, ntokens=rows, tokens_per_row=T, nheads=self.nh, nkv=self.nkv,
                          head_dim=self.hd, max_pos=self.max_tokens, max_keys=max_keys)
             ops.linear(att, L['wo'], None, x, rows=rows, k=self.nh * self.hd, n=d, resid=x)
-            ops.rmsnorm(x, L['ln2'], h, rows, d, self.eps)
+            ops.rmsnorm(x, self.ones, h, rows, d, self.eps)
             ops.linear(h, L['wgu'], None, gu, rows=rows, k=d, n=2 * self.ff)
-            ops.silu_mul(gu, ff, rows, self.ff)
+            ops.silu_mul(gu, ff, rows, self.ff, interleaved=True)
             ops.linear(ff, L['wd'], None, x, rows=rows, k=self.ff, n=d, resid=x)
+
+    def _layers_fused(self, st, B):
+        """decode step at 17..64 rows: six launches per layer.  o-proj and down-proj leave the (sum, sum of squares) of the
+        residual-stream rows they store; q|k|v and gate|up apply rsqrt(mean(x^2) + eps) in their epilogues; gate|up also
+        applies SiLU(gate) * up.  Layer 0 reads the embedding rows, which nobody produced statistics for."""
+        d = self.d
+        x, h, qkv, att, ff, stats = st['x'], st['h'], st['qkv'], st['att'], st['ff'], st['stats']
+        SO = stats.size(1) * 2
+        pos0, ones, key_len = st['lens'][0], st['ones'], st['lens'][1]
+        for li, (L, cache) in enumerate(zip(self.layers, st['kv'])):
+            s1, s2 = (2 * li) * SO, (2 * li + 1) * SO
+            if li == 0:
+                ops.rmsnorm(x, self.ones, h, B, d, self.eps)
+                ops.linear(h, L['wqkv'], L['bqkv'], qkv, rows=B, k=d, n=self.nq)
+            else:
+                ops.linear(x, L['wqkv'], L['bqkv'], qkv, rows=B, k=d, n=self.nq, aln=(stats, s1, None), ln_dim=d, ln_eps=self.eps,
+                           ln_rms=True)
+            ops.rope_append(qkv, self.cos_sin, cache, pos0, ones, nrows=B, tokens_per_row=1, nheads=self.nh, nkv=self.nkv,
+                            head_dim=self.hd, max_pos=self.max_tokens)
+            ops.attn_gqa(qkv, cache, att, key_len, ntokens=B, tokens_per_row=1, nheads=self.nh, nkv=self.nkv, head_dim=self.hd,
+                         max_pos=self.max_tokens, max_keys=self.max_tokens)
+            ops.linear(att, L['wo'], None, x, rows=B, k=self.nh * self.hd, n=d, resid=x, stats_out=stats, stats_off=s2, ln_dim=d,
+                       ln_eps=self.eps, ln_rms=True)
+            ops.linear(x, L['wgu'], None, ff, rows=B, k=d, n=2 * self.ff, ldc=self.ff, act=ops.ACT_SILU_GLU, aln=(stats, s2, None),
+                       ln_dim=d, ln_eps=self.eps, ln_rms=True)
+            if li + 1 < len(self.layers):
+                ops.linear(ff, L['wd'], None, x, rows=B, k=self.ff, n=d, resid=x, stats_out=stats, stats_off=s1 + 2 * SO, ln_dim=d,
+                           ln_eps=self.eps, ln_rms=True)
+            else:
+                ops.linear(ff, L['wd'], None, x, rows=B, k=self.ff, n=d, resid=x)
 
     def _head(self, st, x, B, argmax):
         ops.rmsnorm(x, self.norm, st['h'], B, self.d, self.eps)
@@ -153,10 +200,16 @@ class Qwen2:
     # ---- decode -------------------------------------------------------------------------------
     def _step_launches(self, st, B, argmax):
         ops.embed(st['toks'], self.tok, None, st['x'], n=B, dim=self.d)
-        self._layers(st['x'], st['h'], st['qkv'], st['att'], st['gu'], st['ff'], st['kv'], B, B, 1, st['lens'][0], st['ones'],
-                     st['lens'][1], self.max_tokens)
+        fused = self.fuse and 16 < B <= 64 and 2 * self.ff >= 8192 and self.d % 16 == 0
+        if fused:
+            self._layers_fused(st, B)
+        else:
+            self._layers(st['x'], st['h'], st['qkv'], st['att'], st['gu'], st['ff'], st['kv'], B, B, 1, st['lens'][0], st['ones'],
+                         st['lens'][1], self.max_tokens)
         self._head(st, st['x'], B, argmax)
         ops.add_i32_vec(st['lens'], 1)
+        if fused:
+            ops.add_i32(st['tick'], 1, zero=st['stats'])          # the row statistics of this step are spent
 
     def step(self, st, B, argmax=True, use_graphs=True):
         """Feed state['toks'] (one token per row) at every row's own position; logits of the next token land in

@@ -267,7 +267,7 @@ class Whisper:
         return bufs['logits']
 
     def _step(self, bufs, Bn, argmax, use_graphs):
-        if self.fold_ln and Bn <= 256:
+        if self.fold_ln and Bn <= int(os.environ.get('IFH_FOLD_MAX_ROWS', '1024')):
             step = self.decoder_step_folded
         else:
             step = self.decoder_step

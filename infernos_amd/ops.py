@@ -9,7 +9,7 @@ import torch
 from . import _lib
 from ._lib import AttnDesc, ConvDesc
 
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_LRELU, ACT_SIGMOID = range(6)
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH, ACT_LRELU, ACT_SIGMOID, ACT_SILU_GLU = range(7)
 BF16 = torch.bfloat16
 
 
@@ -24,7 +24,7 @@ def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=
          resid=None, resid_off=0, resid_ld=None, resid_bstride=None, scale=1.0, accumulate=False,
          out_off=0, ldc=None, out_bstride=None, ostride=1, ooff=0, dyn_pos=None, dyn_ooff_mul=0, dyn_resid_mul=0,
          n_split=0, out2=None, out2_bstride=0, ldc2=0, ooff2=0, dyn_ooff2_mul=0,
-         aln=None, rln=None, stats_out=None, stats_off=0, ln_dim=0, ln_eps=1e-5):
+         aln=None, rln=None, stats_out=None, stats_off=0, ln_dim=0, ln_eps=1e-5, ln_rms=False):
     # aln = (stats, stats_off, c1); rln = (stats, stats_off, gamma, beta)
     """One implicit-GEMM launch (see ifh_conv_desc).  Strides default to dense [nbatch][t][c]."""
     d = ConvDesc()
@@ -49,7 +49,7 @@ def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=
         d.aln_stats, d.aln_c1 = _addr(aln[0], aln[1]), _addr(aln[2])
     if rln is not None:
         d.rln_stats, d.rln_gamma, d.rln_beta = _addr(rln[0], rln[1]), _addr(rln[2]), _addr(rln[3])
-    d.stats_out, d.ln_dim, d.ln_eps = _addr(stats_out, stats_off), ln_dim, ln_eps
+    d.stats_out, d.ln_dim, d.ln_eps, d.ln_rms = _addr(stats_out, stats_off), ln_dim, ln_eps, int(ln_rms)
     _lib.check(_lib.lib().ifh_conv_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_conv_bf16')
     return out
 
@@ -169,8 +169,9 @@ def attn_gqa(qkv, cache, out, key_len, *, ntokens, tokens_per_row, nheads, nkv, 
     return out
 
 
-def silu_mul(gate_up, out, rows, ffn):
-    _lib.check(_lib.lib().ifh_silu_mul_bf16(_addr(gate_up), _addr(out), rows, ffn, _lib.stream_ptr(out.device)), 'ifh_silu_mul_bf16')
+def silu_mul(gate_up, out, rows, ffn, interleaved=False):
+    _lib.check(_lib.lib().ifh_silu_mul_bf16(_addr(gate_up), _addr(out), rows, ffn, int(interleaved), _lib.stream_ptr(out.device)),
+               'ifh_silu_mul_bf16')
     return out
 
 

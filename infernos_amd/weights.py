@@ -27,6 +27,10 @@ QWEN2_CONFIGS = {
                        rms_eps=1e-6, tie=True, max_pos=512),
     'qwen2_tiny64': dict(vocab=777, hidden=256, ffn=640, layers=3, heads=4, kv_heads=1, head_dim=64, rope_theta=1.0e4,
                          rms_eps=1e-5, tie=False, max_pos=512),
+    # wide MLP: the smallest shape whose decode step takes the fused path (row statistics instead of RMSNorm launches,
+    # SiLU-gate epilogue on the weight-streaming GEMM: gate|up >= 8192 columns); checked against the oracle directly
+    'qwen2_wide': dict(vocab=1000, hidden=512, ffn=4096, layers=3, heads=4, kv_heads=2, head_dim=128, rope_theta=1.0e6,
+                       rms_eps=1e-6, tie=True, max_pos=512),
     'qwen2_1p5b': dict(vocab=151936, hidden=1536, ffn=8960, layers=28, heads=12, kv_heads=2, head_dim=128, rope_theta=1.0e6,
                        rms_eps=1e-6, tie=True, max_pos=32768),
 }

@@ -305,3 +305,22 @@ def test_bench_two_ranks_on_one_gpu_dry_run(built_lib):
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['config']['calls_total'] == 8 and d['config']['calls_per_gpu'] == 4
     assert d['value'] > 0 and d['scaling'] == 'weak' and abs(d['value'] - 8 * 10.0 / (d['ms_per_step'] * 1e-3)) < 0.01 * d['value']
     assert d['tts_samples_per_call'] == 10 * 4096 - 256 and 6.5 < d['stt_audio_seconds_per_call'] < 9.5
+
+
+def test_bench_config5_share_leg(built_lib):
+    """bench.py's configuration-5 leg (STT -> LLM -> TTS turn latency for one GPU's sessions) end to end at a small size:
+    4 sessions, the test-sized LLM configuration."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--c5-only', '--c5-sessions', '4', '--c5-llm', 'qwen2_tiny64', '--steps', '2',
+           '--tts-lanes', '1', '--front-lanes', '1']
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])['C5_share']
+    assert d['turns'] == 2 and d['p50_turn_latency_ms'] > 0
+    parts = d['stt_ms'] + d['llm_first_sentence_ms'] + d['tts_first_chunk_ms']
+    assert abs(parts - d['p50_turn_latency_ms']) < 0.35 * d['p50_turn_latency_ms']
+    assert d['llm_reply_ms'] > d['llm_first_sentence_ms'] and d['llm_decode_tokens_per_s'] > 0

@@ -64,7 +64,7 @@ L = model.layers[0]
 d, ff = model.d, model.ff
 kv = st['kv'][0]
 parts = {
-    'rmsnorm': lambda: ops.rmsnorm(st['x'], L['ln1'], st['h'], B, d, model.eps),
+    'rmsnorm': lambda: ops.rmsnorm(st['x'], model.ones, st['h'], B, d, model.eps),
     'qkv %dx%d' % (model.nq, d): lambda: ops.linear(st['h'], L['wqkv'], L['bqkv'], st['qkv'], rows=B, k=d, n=model.nq),
     'rope': lambda: ops.rope_append(st['qkv'], model.cos_sin, kv, st['lens'][0], st['ones'], nrows=B, tokens_per_row=1, nheads=model.nh,
                                     nkv=model.nkv, head_dim=model.hd, max_pos=model.max_tokens),
@@ -72,7 +72,7 @@ parts = {
                                  head_dim=model.hd, max_pos=model.max_tokens, max_keys=model.max_tokens),
     'o %dx%d' % (d, d): lambda: ops.linear(st['att'], L['wo'], None, st['x'], rows=B, k=d, n=d, resid=st['x']),
     'gate_up %dx%d' % (2 * ff, d): lambda: ops.linear(st['h'], L['wgu'], None, st['gu'], rows=B, k=d, n=2 * ff),
-    'silu_mul': lambda: ops.silu_mul(st['gu'], st['ff'], B, ff),
+    'silu_mul': lambda: ops.silu_mul(st['gu'], st['ff'], B, ff, interleaved=True),
     'down %dx%d' % (d, ff): lambda: ops.linear(st['ff'], L['wd'], None, st['x'], rows=B, k=ff, n=d, resid=st['x']),
     'head %dx%d' % (model.vocab, d): lambda: ops.linear(st['h'], model.head, None, st['logits_full'], rows=B, k=d, n=model.vocab, ldc=model.vpad),
     'argmax': lambda: ops.argmax_pick(st['logits_full'], vocab=model.vocab, nrows=B, ld=model.vpad, argmax_out=st['toks']),
