@@ -66,7 +66,7 @@ def make_frames(ncalls, first_call, codec_encode):
     return np.ascontiguousarray(ulaw.reshape(ncalls, TICKS, 160).transpose(1, 0, 2))
 
 
-def cpu_baseline(family='whisper_base', ncalls=16, threads=32):
+def cpu_baseline(family='whisper_base', ncalls=16, threads=32, beams=5):
     """The oracle (CPU restatement, kind "port") timed on this host, bounded: one 10 s cycle for `ncalls` calls batched
     (the reference's own TTS cap is 8).  Two TTS legs: the reference's dtype (bf16, `maybe_half`,
     HelloSippyRTPipe.py:57; 3 of the 10 infer() calls measured, the other 7 priced at their mean) and fp32 (all 10
@@ -89,8 +89,12 @@ def cpu_baseline(family='whisper_base', ncalls=16, threads=32):
         pcm = odsp.g711_decode(odsp.g711_encode(x))
         x16 = odsp.resample(pcm[:, 8000:72000], 8000, 16000)          # ~8 s of speech per call, as the VAD emits
         mel = torch.from_numpy(odsp.logmel(x16))
-        with torch.no_grad():
-            onn.whisper_greedy(sd_w, mel, torch.tensor([[50258, 50259, 50359, 50363]] * ncalls), 32, nheads)
+        with torch.no_grad():                     # the decode of the timed region: beam search (or greedy with --stt-beam 1)
+            prompt = torch.tensor([[50258, 50259, 50359, 50363]] * ncalls)
+            if beams > 1:
+                onn.whisper_beam(sd_w, mel, prompt, 32, nheads, beams, 50257)
+            else:
+                onn.whisper_greedy(sd_w, mel, prompt, 32, nheads)
         t_stt = time.perf_counter() - t0
         g = torch.Generator().manual_seed(2000)
         ids = torch.randint(4, 80, (ncalls, 64), generator=g)
@@ -116,11 +120,12 @@ def cpu_baseline(family='whisper_base', ncalls=16, threads=32):
     return {'value': round(ncalls * UTT_SECONDS / legs[best]['total'], 3), 'unit': 'x real-time (call-seconds/s)', 'cores': nthreads,
             'kind': 'port', 'tts_dtype_of_value': best,
             'legs_x_realtime': {k: round(ncalls * UTT_SECONDS / v['total'], 3) for k, v in legs.items()},
-            'sample': '%d calls, one 10 s cycle on the oracle (oracle/): ingest + log-mel + %s 32 tokens fp32 (%.2f s); TTS leg bf16 '
-                      '(the reference\'s dtype): SpeechT5 encoder %.2f s + 10 x infer()+resample+mu-law at %.2f s (3 measured); TTS leg '
-                      'fp32: encoder %.2f s + 10 x %.2f s (all measured); value = the faster leg (%s); torch threads=%d of '
-                      'os.cpu_count()=%s' % (ncalls, family, t_stt, legs['bf16']['t_enc'], legs['bf16']['t_inf'], legs['fp32']['t_enc'],
-                                             legs['fp32']['t_inf'], best, nthreads, os.cpu_count())}
+            'sample': ('%d calls, one 10 s cycle on the oracle (oracle/): ingest + log-mel + %s 32 tokens ' % (ncalls, family)) +
+                      ('beam search, %d beams, ' % beams if beams > 1 else 'greedy, ') +
+                      'fp32 (%.2f s); TTS leg bf16 (the reference\'s dtype): SpeechT5 encoder %.2f s + 10 x infer()+resample+mu-law at %.2f s '
+                      '(3 measured); TTS leg fp32: encoder %.2f s + 10 x %.2f s (all measured); value = the faster leg (%s); torch '
+                      'threads=%d of os.cpu_count()=%s' % (t_stt, legs['bf16']['t_enc'], legs['bf16']['t_inf'], legs['fp32']['t_enc'],
+                                                           legs['fp32']['t_inf'], best, nthreads, os.cpu_count())}
 
 
 class TickProbe(threading.Thread):
@@ -467,7 +472,7 @@ def main():
         out['other_configs'] = extra
     if rank == 0:
         if not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(CONFIGS[args.config][1])
+            out['cpu_baseline'] = cpu_baseline(CONFIGS[args.config][1], beams=args.stt_beam)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
