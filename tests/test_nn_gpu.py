@@ -59,6 +59,12 @@ def bfr(x):
     dict(B=1, T=20, cin=1280, cout=768, k=1, act='relu'),               # skinny, 2 row tiles
     dict(B=1, T=33, cin=256, cout=256, k=1, act='relu', colmask=True),  # skinny with dropout mask
     dict(B=1, T=64, cin=768, cout=2, k=1, f32=True),                    # stop logits
+    # large plain linears (thousands of rows: LLM prefill, Whisper / SpeechT5 encoders): k_igemm at full grids, ragged M and N
+    dict(B=1, T=12288, cin=1536, cout=2048, k=1),                       # LLM prefill q|k|v shape
+    dict(B=4, T=3001, cin=512, cout=1536, k=1, act='gelu', resid=True),  # ragged M (12004 rows), N tail-free, epilogue ops
+    dict(B=2, T=8200, cin=384, cout=1000, k=1, scale=0.5),              # N tail (1000 = 7 x 128 + 104), general epilogue
+    dict(B=1, T=16500, cin=96, cout=256, k=1, f32=True),                # K = 96: three k-steps
+    dict(B=1, T=33000, cin=32, cout=128, k=1),                          # K = 32: one k-step
 ])
 def test_conv_kernel_matches_torch(dev, case):
     from infernos_amd import ops

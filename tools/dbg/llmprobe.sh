@@ -1,4 +1,4 @@
 mkdir -p gpurun_out
-for n in 100000 128; do
-echo "NW8 from $n"; IFH_GQA_NW8=$n timeout -k 5 200 python3 tools/probe_llm.py 64 192 64 2>&1 | grep "decode\|per launch" | sed 's/.*decode/decode/' | cut -c1-200
-done
+echo "plain"; IFH_GEMM_DMA=0 timeout -k 5 280 python3 tools/probe_llm.py 64 192 8 2>&1 | grep "prefill per" | cut -c1-300
+echo "remap"; IFH_IGEMM_REMAP=1 IFH_GEMM_DMA=0 timeout -k 5 280 python3 tools/probe_llm.py 64 192 8 2>&1 | grep "prefill per" | cut -c1-300
+IFH_IGEMM_REMAP=1 IFH_GEMM_DMA=0 timeout -k 5 600 python -m pytest tests/test_nn_gpu.py -x -q -k "conv_kernel_matches" 2>&1 | tail -3

@@ -78,3 +78,28 @@ parts = {
     'argmax': lambda: ops.argmax_pick(st['logits_full'], vocab=model.vocab, nrows=B, ld=model.vpad, argmax_out=st['toks']),
 }
 print('per launch (us): ' + ' | '.join('%s %.1f' % (k, ev(f)) for k, f in parts.items()))
+
+# ---- prefill pieces at B x P tokens (one layer) ----
+rows = B * P
+e = lambda *s_: torch.empty(s_, dtype=torch.bfloat16, device=dev)
+x, h, qkv, att, gu, ffb = e(rows, d), e(rows, d), e(rows, model.nq), e(rows, model.nh * model.hd), e(rows, 2 * ff), e(rows, ff)
+x.normal_()
+lens_t = torch.full((B,), P, dtype=torch.int32, device=dev)
+pos0 = torch.zeros(B, dtype=torch.int32, device=dev)
+t_idx = torch.arange(P, dtype=torch.int32, device=dev)[None, :].expand(B, P)
+key_len = (t_idx + 1).contiguous()
+pp = {
+    'rmsnorm': lambda: ops.rmsnorm(x, model.ones, h, rows, d, model.eps),
+    'qkv': lambda: ops.linear(h, L['wqkv'], L['bqkv'], qkv, rows=rows, k=d, n=model.nq),
+    'rope': lambda: ops.rope_append(qkv, model.cos_sin, kv, pos0, lens_t, nrows=B, tokens_per_row=P, nheads=model.nh, nkv=model.nkv,
+                                    head_dim=model.hd, max_pos=model.max_tokens),
+    'attn': lambda: ops.attn_gqa(qkv, kv, att, key_len, ntokens=rows, tokens_per_row=P, nheads=model.nh, nkv=model.nkv,
+                                 head_dim=model.hd, max_pos=model.max_tokens, max_keys=P),
+    'o': lambda: ops.linear(att, L['wo'], None, x, rows=rows, k=d, n=d, resid=x),
+    'gate_up': lambda: ops.linear(h, L['wgu'], None, gu, rows=rows, k=d, n=2 * ff),
+    'silu_mul': lambda: ops.silu_mul(gu, ffb, rows, ff, interleaved=True),
+    'down': lambda: ops.linear(ffb, L['wd'], None, x, rows=rows, k=ff, n=d, resid=x),
+}
+res = {k: ev(f, 5) for k, f in pp.items()}
+print('prefill per layer at %d tokens (us): ' % rows + ' | '.join('%s %.0f' % kv_ for kv_ in res.items()) +
+      ' | sum x %d layers = %.1f ms' % (len(model.layers), sum(res.values()) * len(model.layers) / 1e3))
