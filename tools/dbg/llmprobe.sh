@@ -1,4 +1,2 @@
-mkdir -p gpurun_out
-echo "plain"; IFH_GEMM_DMA=0 timeout -k 5 280 python3 tools/probe_llm.py 64 192 8 2>&1 | grep "prefill per" | cut -c1-300
-echo "remap"; IFH_IGEMM_REMAP=1 IFH_GEMM_DMA=0 timeout -k 5 280 python3 tools/probe_llm.py 64 192 8 2>&1 | grep "prefill per" | cut -c1-300
-IFH_IGEMM_REMAP=1 IFH_GEMM_DMA=0 timeout -k 5 600 python -m pytest tests/test_nn_gpu.py -x -q -k "conv_kernel_matches" 2>&1 | tail -3
+for v in "" 1 "" 1; do echo "NO_DMA=$v"; IFH_NO_GEMM_DMA=$v timeout -k 5 280 python3 tools/probe_llm.py 64 192 8 2>&1 | grep "prefill" | cut -c1-120; done
+for v in "" 1; do echo "NO_DMA=$v"; IFH_NO_GEMM_DMA=$v timeout -k 5 280 python3 tools/probe_encoder.py 128 whisper_base 2>&1 | tail -3 | cut -c1-200; done
