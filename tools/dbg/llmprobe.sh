@@ -1,2 +1,4 @@
-for v in "" 1 "" 1; do echo "NO_DMA=$v"; IFH_NO_GEMM_DMA=$v timeout -k 5 280 python3 tools/probe_llm.py 64 192 8 2>&1 | grep "prefill" | cut -c1-120; done
-for v in "" 1; do echo "NO_DMA=$v"; IFH_NO_GEMM_DMA=$v timeout -k 5 280 python3 tools/probe_encoder.py 128 whisper_base 2>&1 | tail -3 | cut -c1-200; done
+echo "k_gemm_256 random"; timeout -k 5 120 python3 tools/dbg/gemm1.py
+echo "k_igemm random"; IFH_NO_GEMM_DMA=1 timeout -k 5 120 python3 tools/dbg/gemm1.py
+echo "k_gemm_256 zeros"; timeout -k 5 120 python3 tools/dbg/gemm1.py zeros
+echo "k_igemm zeros"; IFH_NO_GEMM_DMA=1 timeout -k 5 120 python3 tools/dbg/gemm1.py zeros
