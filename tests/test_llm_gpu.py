@@ -189,7 +189,6 @@ def test_qwen2_generate_eos_padding_and_callbacks(dev):
     with torch.no_grad():
         o_new, _ = onn.qwen2_greedy(sd, cfg, prompts, 12, eos_ids=eos)
     for i in range(3):
-        n = min(len(out[i]), len(free[i]))
         assert out[i] == free[i][:len(out[i])]
         assert out[i][-1] in eos or len(out[i]) == 12
         assert all(t not in eos for t in out[i][:-1])
@@ -228,9 +227,6 @@ def test_llm_worker_through_actor_matches_reference_run(dev, golden_dir):
         calls, done = [], threading.Event()
         n_expected = len(w['calls'])
         sids = []
-        # the three requests must land in one batch: hold the worker's queue while they are queued
-        with worker.inf_queue.mutex:
-            pass
         for b, cx in enumerate(w['contexts']):
             sid = actor.new_llm_session(LLMSessionParams(cx[0]['content']))
             sids.append(sid)
@@ -243,6 +239,8 @@ def test_llm_worker_through_actor_matches_reference_run(dev, golden_dir):
                                                                       done.set() if len(calls) >= n_expected else None)))
             req.auto_ctx_add = False
             reqs.append(req)
+        # the three requests must land in ONE batch: queue them while holding the worker's queue lock (what
+        # LLMSession.textin does per request, minus the wake-up between them)
         worker.inf_queue.mutex.acquire()
         try:
             from infernos_amd.llm import LLMInferRequest
