@@ -83,13 +83,14 @@ class Qwen2:
         self.cos_sin = torch.stack([fr.cos(), fr.sin()], -1).contiguous().to(dev)
         self._bufs = {}
         self.fuse = os.environ.get('IFH_LLM_NO_FUSE') is None      # tuning switch: explicit RMSNorm / SiLU launches instead
+        self.bucket_batches = True
 
     # ---- buffers ------------------------------------------------------------------------------
     def _state(self, B):
         if B not in self._bufs:
             dev, d = self.device, self.d
             e = lambda *s, dt=BF16: torch.empty(s, dtype=dt, device=dev)
-            while len(self._bufs) >= 2:
+            while len(self._bufs) >= 3:
                 self._bufs.pop(next(iter(self._bufs)))
             self._bufs[B] = dict(
                 kv=[torch.zeros((B, self.max_tokens, 2 * self.nkv * self.hd), dtype=BF16, device=dev) for _ in self.layers],
@@ -234,9 +235,18 @@ class Qwen2:
         stopped rows): the streamer hook of InfernLLMWorker.py:113-118.  sampler (a Sampler) replaces the greedy pick.
         Returns (list of per-row generated id lists, per-step logits list
         if keep_logits)."""
-        B = len(prompts)
+        nreal = len(prompts)
+        # batch sizes are bucketed (1, 2, 4, ... rows; a bucket = one set of KV caches, work buffers and captured step graphs):
+        # a worker that is handed 1..max_batch_size requests per batch would otherwise allocate and capture per size.
+        # Padding rows hold one pad token, count as stopped from the start and never reach the caller.
+        B = 1
+        while B < nreal:
+            B *= 2
+        if not self.bucket_batches or keep_logits:
+            B = nreal
+        prompts = list(prompts) + [[pad_id]] * (B - nreal)
         st, _ = self.prefill(prompts, argmax=sampler is None)
-        done = [False] * B
+        done = [i >= nreal for i in range(B)]
         out = [[] for _ in range(B)]
         eos = set(int(e) for e in eos_ids)
         budget = min(max_new_tokens, self.max_tokens - max(len(p) for p in prompts))
@@ -258,10 +268,11 @@ class Qwen2:
                 if t in eos:
                     done[i] = True
             if on_tokens is not None:
-                on_tokens(torch.tensor(step_toks, dtype=torch.long))
+                on_tokens(torch.tensor(step_toks[:nreal], dtype=torch.long))
             if all(done) or s + 1 == budget:
                 break
             if any(done):           # stopped rows are fed the pad token (their later outputs are dropped)
                 st['toks'].copy_(torch.tensor(step_toks, dtype=torch.int32))
             self.step(st, B, argmax=sampler is None, use_graphs=use_graphs)
+        out = out[:nreal]
         return out, kept

@@ -363,3 +363,22 @@ def test_qwen2_fused_decode_step_matches_oracle_and_unfused(dev):
     agree = sum(int(a[i] == o_new[i]) for i in range(B))
     print('greedy rows identical to the oracle: %d / %d' % (agree, B))
     assert agree >= B // 2
+
+
+def test_qwen2_batch_buckets_share_state_and_results(dev):
+    """5 and 7 prompts both run in the 8-row bucket (one set of caches and graphs); padding rows never surface; tokens are
+    those of the unbucketed run"""
+    from infernos_amd.engines.qwen2 import Qwen2
+    from infernos_amd.weights import synth_state_dict, QWEN2_CONFIGS
+    cfg = QWEN2_CONFIGS['qwen2_tiny64']
+    model = Qwen2(synth_state_dict('qwen2_tiny64', 1), cfg, dev, max_tokens=64)
+    g = torch.Generator().manual_seed(4)
+    prompts = [torch.randint(4, 700, (2 + i,), generator=g).tolist() for i in range(7)]
+    seen = []
+    a5, _ = model.generate(prompts[:5], 6, on_tokens=lambda t: seen.append(t.shape[0]))
+    a7, _ = model.generate(prompts, 6)
+    assert list(model._bufs) == [8] and set(seen) == {5}
+    model.bucket_batches = False
+    b5, _ = model.generate(prompts[:5], 6)
+    b7, _ = model.generate(prompts, 6)
+    assert a5 == b5 and a7 == b7 and a7[:5] == a5
