@@ -251,13 +251,20 @@ class Qwen2:
         eos = set(int(e) for e in eos_ids)
         budget = min(max_new_tokens, self.max_tokens - max(len(p) for p in prompts))
         kept = []
-        for s in range(budget):
-            if keep_logits:
-                kept.append(st['logits'].clone())
-            if sampler is not None:
-                sampler.pick(self, st, B)
-            st['hist'].scatter_(1, st['lens'][0].long()[:, None], st['toks'][:, None])      # the chosen token's position
-            toks = st['toks'].cpu().tolist()
+        # The token loop runs one step ahead of the host: the chosen tokens chain on the device (argmax / sampler -> next
+        # embedding), so step s + 1 is launched before the host has seen the tokens of step s; those arrive through a small
+        # pinned ring and are handed to `on_tokens` one step late.  A row that has stopped keeps decoding its own continuation
+        # on the device (transformers feeds it the pad token instead): rows are independent and its outputs are dropped, so
+        # only the host-side view (pad_id for stopped rows) matters.  The loop ends one step after the host sees the last stop.
+        ring = st.get('tok_ring')
+        if ring is None:
+            ring = st['tok_ring'] = [torch.empty(B, dtype=torch.int32).pin_memory() for _ in range(2)]
+            st['tok_ev'] = [torch.cuda.Event() for _ in range(2)]
+        evs = st['tok_ev']
+
+        def deliver(s):
+            evs[s & 1].synchronize()
+            toks = ring[s & 1].tolist()
             step_toks = []
             for i, t in enumerate(toks):
                 if done[i]:
@@ -269,10 +276,23 @@ class Qwen2:
                     done[i] = True
             if on_tokens is not None:
                 on_tokens(torch.tensor(step_toks[:nreal], dtype=torch.long))
-            if all(done) or s + 1 == budget:
-                break
-            if any(done):           # stopped rows are fed the pad token (their later outputs are dropped)
-                st['toks'].copy_(torch.tensor(step_toks, dtype=torch.int32))
-            self.step(st, B, argmax=sampler is None, use_graphs=use_graphs)
+
+        for s in range(budget):
+            if keep_logits:
+                kept.append(st['logits'].clone())
+            if sampler is not None:
+                sampler.pick(self, st, B)
+            st['hist'].scatter_(1, st['lens'][0].long()[:, None], st['toks'][:, None])      # the chosen token's position
+            ring[s & 1].copy_(st['toks'], non_blocking=True)
+            evs[s & 1].record()
+            if s + 1 < budget:
+                self.step(st, B, argmax=sampler is None, use_graphs=use_graphs)          # step s + 1, ahead of the host
+            if s >= 1:
+                deliver(s - 1)
+                if all(done):
+                    break                      # (the step already in flight is never looked at)
+        else:
+            if budget > 0 and not all(done):
+                deliver(budget - 1)
         out = out[:nreal]
         return out, kept

@@ -116,6 +116,28 @@ def test_actors_pin_sessions_to_least_loaded_device():
     assert t.router.load == [1, 1]
     t.stop()
 
+    # configuration 5's LLM stage: the same routing (one InfernLLMWorker per device, sessions sticky to the least loaded)
+    from infernos_amd.llm import LLMRequest, LLMSessionParams
+
+    class FakeLLM(FakeSTT):
+        max_batch_size = 4
+
+    class LLMActor(actors.InfernLLMActor):
+        worker_cls = FakeLLM
+    m = LLMActor()
+    m.start(device=['cuda:0', 'cuda:1', 'cuda:2', 'cuda:3'], warmup=False)
+    lids = [m.new_llm_session(LLMSessionParams('system %d' % i)) for i in range(6)]
+    assert [m.router.shard_of(i) for i in lids] == [0, 1, 2, 3, 0, 1]
+    for i in lids:
+        m.llm_session_textin(i, LLMRequest('hello', lambda result: None))
+        m.llm_session_context_add(i, 'more', 'user')
+    assert [len(w.items) for w in m.workers] == [2, 2, 1, 1]
+    assert m.workers[0].items[0].context == ({'role': 'system', 'content': 'system 0'}, {'role': 'user', 'content': 'hello'})
+    assert m.sessions[lids[0]].context[-1] == {'role': 'user', 'content': 'hello more'}
+    m.llm_session_end(lids[1])
+    assert m.router.load == [2, 1, 1, 1]
+    m.stop()
+
 
 def _pipelined_worker(rank, world, port, n_total, nsteps, group, lanes, q):
     """SpeechPipeline.run_steps' schedule (pipeline.schedule_cycles) over two gloo communicators: the ingress scatter is issued
