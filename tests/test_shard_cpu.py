@@ -132,7 +132,9 @@ def test_actors_pin_sessions_to_least_loaded_device():
         m.llm_session_textin(i, LLMRequest('hello', lambda result: None))
         m.llm_session_context_add(i, 'more', 'user')
     assert [len(w.items) for w in m.workers] == [2, 2, 1, 1]
-    assert m.workers[0].items[0].context == ({'role': 'system', 'content': 'system 0'}, {'role': 'user', 'content': 'hello'})
+    # the queued request holds a shallow snapshot (tuple of the same dicts), as Cluster/LLMSession.py:31 does: text added to
+    # the last message before the worker picks the request up is seen by it
+    assert m.workers[0].items[0].context == ({'role': 'system', 'content': 'system 0'}, {'role': 'user', 'content': 'hello more'})
     assert m.sessions[lids[0]].context[-1] == {'role': 'user', 'content': 'hello more'}
     m.llm_session_end(lids[1])
     assert m.router.load == [2, 1, 1, 1]
