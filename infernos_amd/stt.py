@@ -173,7 +173,16 @@ class InfernSTTWorker(InfernBatchedWorker):
         self.device = dev = _lib.require_device(device)
         if weights is None:
             from transformers import WhisperForConditionalGeneration
-            weights = WhisperForConditionalGeneration.from_pretrained(model_name).state_dict()
+            hf = WhisperForConditionalGeneration.from_pretrained(model_name)
+            weights = hf.state_dict()
+            # the checkpoint's generation config carries the token lists ctranslate2's converter bakes into its model
+            # (suppress_ids / suppress_ids_begin) and applies by default (suppress_tokens=[-1], suppress_blank=True)
+            gc = getattr(hf, 'generation_config', None)
+            if suppress_tokens is None and gc is not None and getattr(gc, 'suppress_tokens', None):
+                suppress_tokens = list(gc.suppress_tokens)
+            if begin_suppress_tokens is None and gc is not None and getattr(gc, 'begin_suppress_tokens', None):
+                begin_suppress_tokens = list(gc.begin_suppress_tokens)
+            del hf
         if tokenizer is None:
             from transformers import WhisperTokenizer
             tokenizer = WhisperTokenizer.from_pretrained(model_name)
