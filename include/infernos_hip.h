@@ -46,6 +46,19 @@ int ifh_device_count(void);            /* does not initialise a context */
 /* _ulaw_to_pcm_ct / _pcm_to_ulaw_ct (G711.py:7-19): the two tables, computed on the host
  * by the same closed form the kernels use. out256_host: int16[256]; out65536_host: u8[65536]. */
 int ifh_g711_tables_host(int16_t *out256_host, uint8_t *out65536_host);
+
+/* ---- G.722 (Core/Codecs/G722.py:8-56: the reference's second negotiated codec, SIP/InfernUAS.py:50; it wraps the third-party
+ * `G722` module as G722(8000, 64000): 8 kHz mode, one code byte per 8 kHz sample, lower sub-band only).  Stateful sub-band
+ * ADPCM: every call owns IFH_G722_STATE_WORDS int32 of state per direction (device memory, ifh_g722_init), carried from
+ * frame to frame; one thread per call.  eight_k = 1: nsamples at 8 kHz <-> nsamples bytes; eight_k = 0 (the codec's native
+ * form): nsamples (even) at 16 kHz <-> nsamples / 2 bytes through the 24-tap QMF.  pcm is int16 or (pcm_f32 = 1) f32 in
+ * [-1, 1] converted as the reference wrapper does (clamp(x * 32767) truncated; decoded value / 32767).  Strides in elements. */
+#define IFH_G722_STATE_WORDS 128
+int ifh_g722_init(int32_t *state, int ncalls, ifh_stream_t stream);
+int ifh_g722_encode(int32_t *state, const void *pcm, int pcm_f32, int64_t pcm_stride, int nsamples, int eight_k, uint8_t *code,
+                    int64_t code_stride, int ncalls, ifh_stream_t stream);
+int ifh_g722_decode(int32_t *state, const uint8_t *code, int64_t code_stride, int nbytes, int eight_k, void *pcm, int pcm_f32,
+                    int64_t pcm_stride, int ncalls, ifh_stream_t stream);
 /* G711Codec.decode (G711.py:34-42), resample=False: u8[n] -> f32[n] = lut[u]/32767.0f */
 int ifh_g711_decode_u8_f32(const uint8_t *in, float *out, int64_t n, ifh_stream_t stream);
 /* G711Codec.encode (G711.py:25-32): f32[n] -> u8[n] */

@@ -164,6 +164,9 @@ SIGNATURES.update({
     'ifh_add_i32_vec': (_i, [_vp, _vp, _i, _i, _vp]),
     'ifh_repetition_penalty_f32': (_i, [_vp, _i64, _i, _i, _vp, _i64, _vp, _f, _vp]),
     'ifh_sample_topk_f32': (_i, [_vp, _i64, _i, _i, _f, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'ifh_g722_init': (_i, [_vp, _i, _vp]),
+    'ifh_g722_encode': (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _i64, _i, _vp]),
+    'ifh_g722_decode': (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _i64, _i, _vp]),
     'ifh_argmax_pick_f32': (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
     'ifh_tts_stop_update': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp]),
     'ifh_tts_stop_advance': (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp, _i64, _vp, _vp]),

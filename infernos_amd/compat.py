@@ -10,6 +10,7 @@ import types
 MAP = {
     'Core.Codecs.GenCodec': ('infernos_amd.codecs', ['GenCodec']),
     'Core.Codecs.G711': ('infernos_amd.codecs', ['G711Codec']),
+    'Core.Codecs.G722': ('infernos_amd.codecs', ['G722Codec']),
     'Core.AudioChunk': ('infernos_amd.audio', ['AudioChunk', 'VadAudioChunk']),
     'Core.AStreamMarkers': ('infernos_amd.muxer', ['ASMarkerGeneric', 'ASMarkerNewSent', 'ASMarkerSentDoneCB']),
     'Core.OutputMuxer': ('infernos_amd.muxer', ['OutputMuxer', 'OutputMTMuxer']),

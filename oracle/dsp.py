@@ -192,3 +192,28 @@ def mux_encode(tracks, present, ndiv):
             mix = (acc / np.float32(ndiv[c])).astype(np.float32)
         out[c] = g711_encode(mix)
     return out, has
+
+
+# ---- G.722 (g722_oracle.c; parity unpinned: see its header) -----------------------------------------------------
+def g722_new_state():
+    st = np.zeros(128, np.int32)
+    lib().orc_g722_init(_p(st))
+    return st
+
+
+def g722_encode(state, pcm16, eight_k=True):
+    """pcm16 int16 [n] -> uint8 [n] (eight_k) or [n/2]; `state` (g722_new_state) is advanced"""
+    pcm16 = np.ascontiguousarray(pcm16, np.int16)
+    out = np.zeros(pcm16.size if eight_k else (pcm16.size + 1) // 2, np.uint8)
+    lib().orc_g722_encode.restype = ctypes.c_int64
+    n = lib().orc_g722_encode(_p(state), _p(pcm16), ctypes.c_int64(pcm16.size), int(eight_k), _p(out))
+    return out[:n]
+
+
+def g722_decode(state, code, eight_k=True):
+    """uint8 [n] -> int16 [n] (eight_k) or [2n]"""
+    code = np.ascontiguousarray(code, np.uint8)
+    out = np.zeros(code.size if eight_k else 2 * code.size, np.int16)
+    lib().orc_g722_decode.restype = ctypes.c_int64
+    n = lib().orc_g722_decode(_p(state), _p(code), ctypes.c_int64(code.size), int(eight_k), _p(out))
+    return out[:n]

@@ -452,3 +452,65 @@ def test_mux_encode_matches_oracle(dev):
     assert np.array_equal(has.cpu().numpy().astype(bool), has_ref)
     o = out.cpu().numpy()
     assert np.array_equal(o[has_ref], ref[has_ref])
+
+
+# ---- G.722 ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize('eight_k', [True, False])
+def test_g722_batch_matches_oracle_bit_exact(dev, eight_k):
+    """ifh_g722_encode / _decode for 37 calls, three consecutive frames with carried state, int16 and f32 interfaces, against
+    the CPU restatement call by call (integer recursion: bit-exact; the f32 interface is the wrapper's conversion)."""
+    from infernos_amd.codecs import G722Batch
+    N, F = 37, 3
+    S = 160 if eight_k else 320
+    rng = np.random.default_rng(5 + int(eight_k))
+    t = np.arange(F * S)
+    pcm = np.stack([np.clip((0.5 * np.sin(t * (0.02 + 0.003 * c)) + 0.1 * rng.standard_normal(F * S)) * (3000 + 700 * c), -32768, 32767)
+                    for c in range(N)]).astype(np.int16)
+    pcm[5] = 0
+    pcm[6, ::2], pcm[6, 1::2] = 32767, -32768
+    b16, bf = G722Batch(N, dev, eight_k), G722Batch(N, dev, eight_k)
+    enc_st = [odsp.g722_new_state() for _ in range(N)]
+    dec_st = [odsp.g722_new_state() for _ in range(N)]
+    for f in range(F):
+        fr = pcm[:, f * S:(f + 1) * S]
+        code = b16.encode(torch.from_numpy(fr.copy()).to(dev))
+        ref = np.stack([odsp.g722_encode(enc_st[c], fr[c], eight_k) for c in range(N)])
+        assert np.array_equal(code.cpu().numpy(), ref), f
+        # the f32 interface: x -> clamp(x * 32767) truncated, as the reference wrapper prepares its int16
+        xf = (fr.astype(np.float32) / 32767.0)
+        as16 = np.clip(xf * np.float32(32767.0), -32768, 32767).astype(np.int16)
+        codef = bf.encode(torch.from_numpy(xf).to(dev))
+        if f == 0:
+            reff = np.stack([odsp.g722_encode(odsp.g722_new_state(), as16[c], eight_k) for c in range(N)])
+            assert np.array_equal(codef.cpu().numpy(), reff)
+        dec = b16.decode(code, f32=False).cpu().numpy()
+        refd = np.stack([odsp.g722_decode(dec_st[c], ref[c], eight_k) for c in range(N)])
+        assert np.array_equal(dec, refd), f
+    assert np.array_equal(b16.enc_state.cpu().numpy()[:, :114], np.stack(enc_st)[:, :114])
+    d32 = G722Batch(N, dev, eight_k)
+    o32 = d32.decode(torch.from_numpy(np.stack([odsp.g722_encode(odsp.g722_new_state(), pcm[c, :S], eight_k) for c in range(N)])).to(dev))
+    o16 = np.stack([odsp.g722_decode(odsp.g722_new_state(), odsp.g722_encode(odsp.g722_new_state(), pcm[c, :S], eight_k), eight_k) for c in range(N)])
+    assert np.array_equal(o32.cpu().numpy(), o16.astype(np.float32) / np.float32(32767.0))
+
+
+def test_g722_codec_wrapper(dev):
+    """G722Codec as Core/Codecs/G722.py:8-56 uses it: bytes out of encode (state carried across calls), AudioChunk out of
+    decode (optionally resampled), silence()."""
+    from infernos_amd.audio import AudioChunk
+    from infernos_amd.codecs import G722Codec
+    c = G722Codec().to(dev)
+    rng = np.random.default_rng(9)
+    x = (0.3 * np.sin(np.arange(480) * 0.07) + 0.02 * rng.standard_normal(480)).astype(np.float32)
+    st = odsp.g722_new_state()
+    as16 = np.clip(x * np.float32(32767.0), -32768, 32767).astype(np.int16)
+    for f in range(3):
+        b = c.encode(torch.from_numpy(x[f * 160:(f + 1) * 160]))
+        assert isinstance(b, bytes) and b == odsp.g722_encode(st, as16[f * 160:(f + 1) * 160]).tobytes()
+    dst = odsp.g722_new_state()
+    code = odsp.g722_encode(odsp.g722_new_state(), as16)
+    ch = c.decode(code[:160].tobytes())
+    assert isinstance(ch, AudioChunk) and ch.samplerate == 8000 and ch.audio.numel() == 160
+    assert np.array_equal(ch.audio.cpu().numpy(), odsp.g722_decode(dst, code[:160]).astype(np.float32) / np.float32(32767.0))
+    ch2 = c.decode(code[160:320].tobytes(), resample=True, sample_rate=16000)
+    assert ch2.samplerate == 16000 and ch2.audio.numel() == 320
+    assert len(c.silence(160)) == 160 and c.decode(b'').audio.numel() == 0 and c.encode(torch.zeros(0)) == b''

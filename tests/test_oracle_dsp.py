@@ -119,3 +119,59 @@ def test_mux_encode_oracle_matches_reference_mixer(golden_dir):
     assert np.array_equal(enc[0], ref_encode(ref))
     enc, has = dsp.mux_encode(np.stack([a, b])[None], [[False, False]], [2])
     assert not has[0]
+
+
+# ---- G.722 (parity unpinned: the reference wraps the absent third-party `G722` module; what CAN be checked offline are the
+# properties of a correct sub-band ADPCM codec and the wrapper's frame arithmetic) ---------------------------------------------
+def _speechlike(seed, n, sr):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / sr
+    f0 = 110 + 30 * np.sin(2 * np.pi * 1.5 * t)
+    x = sum(np.sin(2 * np.pi * k * np.cumsum(f0) / sr) / k for k in range(1, 12))
+    x = x * (0.5 + 0.5 * np.sin(2 * np.pi * 3 * t) ** 2) + 0.01 * rng.standard_normal(n)
+    return np.clip(x / np.abs(x).max() * 0.6 * 32767, -32768, 32767).astype(np.int16)
+
+
+def _snr(ref, dec, delay):
+    r, d = ref[:len(ref) - delay].astype(np.float64), dec[delay:len(ref)].astype(np.float64)
+    return 10 * np.log10(np.mean(r ** 2) / np.mean((d - r) ** 2))
+
+
+@pytest.mark.parametrize('eight_k', [True, False])
+def test_g722_oracle_round_trip_state_and_structure(eight_k):
+    sr = 8000 if eight_k else 16000
+    pcm = _speechlike(3, sr, sr)
+    enc, dec = dsp.g722_new_state(), dsp.g722_new_state()
+    code = dsp.g722_encode(enc, pcm, eight_k)
+    assert code.size == (pcm.size if eight_k else pcm.size // 2)            # 64 kbit/s either way
+    out = dsp.g722_decode(dec, code, eight_k)
+    assert out.size == pcm.size
+    delay = 0 if eight_k else 22                                             # the two 12-tap QMF halves
+    snr = _snr(pcm, out, delay)
+    assert snr > (30.0 if eight_k else 28.0), snr
+    if eight_k:
+        assert np.all(code >= 0xC0)                                          # upper-band bits parked at 11
+    # frame-by-frame with carried state == one pass (the per-call state is the whole story)
+    enc2, dec2 = dsp.g722_new_state(), dsp.g722_new_state()
+    step = 160 if eight_k else 320
+    parts = [dsp.g722_encode(enc2, pcm[i:i + step], eight_k) for i in range(0, pcm.size, step)]
+    assert np.array_equal(np.concatenate(parts), code) and np.array_equal(enc2, enc)
+    outs = [dsp.g722_decode(dec2, p, eight_k) for p in parts]
+    assert np.array_equal(np.concatenate(outs), out)
+    # silence decodes to (near) silence, full-scale square waves neither overflow nor desynchronise the two ends
+    z = dsp.g722_decode(dsp.g722_new_state(), dsp.g722_encode(dsp.g722_new_state(), np.zeros(800, np.int16), eight_k), eight_k)
+    assert np.abs(z).max() <= 8
+    sq = (np.sign(np.sin(np.arange(4000) * 0.05)) * 32767).astype(np.int16)
+    e3, d3 = dsp.g722_new_state(), dsp.g722_new_state()
+    o3 = dsp.g722_decode(d3, dsp.g722_encode(e3, sq, eight_k), eight_k)
+    assert np.abs(o3.astype(np.int32)).max() <= 32768 and _snr(sq, o3, delay) > 8.0
+    # encoder and decoder predictors stay in lock-step: band-0 predictor words are identical after the same code stream
+    assert np.array_equal(e3[:45], d3[:45])
+
+
+def test_g722_codec_wrapper_frame_arithmetic():
+    from infernos_amd.codecs import G722Codec
+    c = G722Codec()                                                          # no device touched until audio is coded
+    assert (c.srate, c.default_br, c.ptype, c.ename) == (8000, 64000, 9, 'G722') and c.rtpmap() == 'rtpmap:9 G722/8000'
+    assert c.e2d_frames(160) == 160 and c.e2d_frames(160, 16000) == 320 and c.d2e_frames(320, 16000) == 160
+    assert c.d2e_frames(160) == 160
