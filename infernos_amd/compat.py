@@ -11,6 +11,8 @@ MAP = {
     'Core.Codecs.GenCodec': ('infernos_amd.codecs', ['GenCodec']),
     'Core.Codecs.G711': ('infernos_amd.codecs', ['G711Codec']),
     'Core.Codecs.G722': ('infernos_amd.codecs', ['G722Codec']),
+    'Core.T2T.Translator': ('infernos_amd.t2t', ['Translator']),
+    'Core.T2T.NumbersToWords': ('infernos_amd.t2t', ['NumbersToWords']),
     'Core.AudioChunk': ('infernos_amd.audio', ['AudioChunk', 'VadAudioChunk']),
     'Core.AStreamMarkers': ('infernos_amd.muxer', ['ASMarkerGeneric', 'ASMarkerNewSent', 'ASMarkerSentDoneCB']),
     'Core.OutputMuxer': ('infernos_amd.muxer', ['OutputMuxer', 'OutputMTMuxer']),

@@ -5,6 +5,7 @@ Interface of safetorch/InfernTorcher.py:20-66 and the InfernGlobals singleton th
 the lock only serialises host-side state mutation of one engine between the worker thread
 (infer) and dispatch; it is kept because callers use `with InfernGlobals().torcher:`.
 """
+from functools import lru_cache
 import math
 from threading import Lock
 from time import monotonic
@@ -92,9 +93,11 @@ class InfernGlobals:
         return get_resampler(from_sr, to_sr, str(device))
 
     @staticmethod
+    @lru_cache(maxsize=8)
     def get_translator(from_lang: str, to_lang: str, **kwa):
-        """config/InfernGlobals.py:28-31.  The T2T translator (argostranslate) is outside the hot path."""
-        raise NotImplementedError('T2T translation is not part of the MI355X hot path; keep Core.T2T.Translator')
+        """config/InfernGlobals.py:28-31: one cached Translator per (from, to, options)"""
+        from .t2t import Translator
+        return Translator(from_lang, to_lang, **kwa)
 
     @staticmethod
     def stdtss():

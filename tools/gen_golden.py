@@ -429,7 +429,83 @@ def gen_logmel():
     dump_json('logmel_meta.json', meta)
 
 
-SECTIONS = {'g711': gen_g711, 'vad': gen_vad, 'vad_stateful': gen_vad_stateful, 'stt': gen_stt, 'batched': gen_batched, 'muxer': gen_muxer,
+def gen_t2t():
+    """Core/T2T/Translator.py and NumbersToWords.py run in place over scripted stand-ins for the packages they wrap
+    (argostranslate's package index / installed languages, inflect's number_to_words): what is pinned is the reference's own
+    logic -- pair search and pivot order, chaining, the number regex, suffix rules, replacement order, translation cache."""
+    import types
+    import argostranslate.package as apkg
+    import argostranslate.translate as atr
+    out = {'translator': [], 'numbers': []}
+
+    def world(pairs):
+        log = []
+
+        class Pkg:
+            def __init__(self, a, b):
+                self.from_code, self.to_code = a, b
+
+            def download(self):
+                return '%s_%s.argosmodel' % (self.from_code, self.to_code)
+
+        class Lang:
+            def __init__(self, code):
+                self.code = code
+
+            def get_translation(self, to):
+                frm = self.code
+                return types.SimpleNamespace(translate=lambda s, frm=frm, to=to.code: '[%s>%s]%s' % (frm, to, s))
+        apkg.update_package_index = lambda: log.append('update')
+        apkg.get_available_packages = lambda: [Pkg(a, b) for a, b in pairs]
+        apkg.install_from_path = lambda path: log.append('install ' + path)
+        atr.get_installed_languages = lambda: [Lang(c) for c in ('en', 'it', 'de', 'ru', 'ja', 'pt')]
+        return log
+    import importlib
+    import Core.T2T.Translator as T
+    for name, pairs, frm, to, use_filter in (
+            ('direct', [('en', 'ja'), ('ru', 'en')], 'en', 'ja', False),
+            ('pivot through the last candidate', [('ru', 'ja'), ('ja', 'it'), ('ru', 'en'), ('en', 'it')], 'ru', 'it', False),
+            ('pivot, later candidates missing', [('ru', 'en'), ('en', 'it')], 'ru', 'it', True),
+            ('no path', [('en', 'de')], 'ru', 'it', False)):
+        log = world(pairs)
+        importlib.reload(T)
+        rec = {'name': name, 'pairs': pairs, 'from': frm, 'to': to, 'filter': use_filter}
+        flt = (lambda text, from_code, to_code, tr: '<%s-%s>' % (from_code, to_code) + tr(text)) if use_filter else None
+        import contextlib, io
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                t = T.Translator(frm, to, filter=flt)
+            rec['nstages'] = len(t.translators)
+            rec['out'] = t.translate('hello')
+        except StopIteration:
+            rec['raises'] = 'StopIteration'
+        rec['log'] = [l for l in log if l != 'update']
+        out['translator'].append(rec)
+    # NumbersToWords over a scripted number_to_words
+    inflect = types.ModuleType('inflect')
+    inflect.engine = lambda: types.SimpleNamespace(number_to_words=lambda s: 'N(%s)' % s)
+    sys.modules['inflect'] = inflect
+    import config.InfernGlobals as IGm
+    calls = []
+    IGm.InfernGlobals.get_translator = staticmethod(lambda a, b, **k: types.SimpleNamespace(
+        translate=lambda s: (calls.append(s), '{%s:%s}' % (b, s))[1]))
+    import Core.T2T.NumbersToWords as N
+    importlib.reload(N)
+    texts = ['I have 3 cats and 2 dogs.', 'I have 3% cats and 2% dogs.', 'I have 30000 cats and 2999 dogs.',
+             'I have 50% cats and 29.0% dogs.', 'I have 3,090.6 cats and 21,188,128 dogs.%,', 'I have 3% cats and dogs 2%.',
+             'I have 3% cats and dogs 20%, and mice 3.0%.', 'I have 3% cats and dogs since 2024, or 2023.', 'No numbers here!',
+             '7 7 7, and 7!', 'x1 2x 3.', '12,5 then 1.5.']
+    for lang in ('en', 'de'):
+        n2w = N.NumbersToWords(lang)
+        del calls[:]
+        res = [n2w(t) for t in texts]
+        out['numbers'].append({'lang': lang, 'texts': texts, 'out': res, 'translated': list(calls)})
+    out['source'] = 'Core/T2T/Translator.py:19-57, Core/T2T/NumbersToWords.py:7-35 run in place over scripted package stand-ins'
+    json.dump(out, open(os.path.join(GOLD, 't2t.json'), 'w'), indent=0, sort_keys=True)
+    print('wrote t2t.json:', [r.get('out', r.get('raises')) for r in out['translator']])
+
+
+SECTIONS = {'t2t': gen_t2t, 'g711': gen_g711, 'vad': gen_vad, 'vad_stateful': gen_vad_stateful, 'stt': gen_stt, 'batched': gen_batched, 'muxer': gen_muxer,
             'logmel': gen_logmel}
 
 if __name__ == '__main__':
