@@ -9,7 +9,7 @@ the prompt once, then one int64 [B] tensor of tokens per step (pad for rows that
 from functools import partial
 from time import monotonic
 from typing import List, Tuple
-from uuid import UUID, uuid4
+from uuid import uuid4
 
 import torch
 
@@ -17,73 +17,71 @@ from . import _lib
 from .workers import InfernBatchedWorker
 
 
-class LLMRequest():
-    id: UUID
-    text: str
-    textout_cb: callable
-    auto_ctx_add: bool = True
+class LLMRequest:
+    """text for the model + where the answer's pieces go (`textout_cb(result=LLMResult)`); `auto_ctx_add = False` keeps the
+    answer out of the session's context (the attendant adds what was actually spoken itself)"""
+    auto_ctx_add = True
 
-    def __init__(self, text: str, textout_cb: callable):
-        self.text, self.textout_cb = text, textout_cb
+    def __init__(self, text, textout_cb):
         self.id = uuid4()
+        self.text = text
+        self.textout_cb = textout_cb
 
 
-class LLMResult():
-    req_id: UUID
-    text: str
+class LLMResult:
+    """one delivered piece of an answer, tagged with the request it belongs to"""
 
-    def __init__(self, text: str, req_id: UUID):
-        self.text, self.req_id = text, req_id
-
-
-class LLMInferRequest():
-    req: LLMRequest
-    context: Tuple[dict]
-    textout_cb: callable
-
-    def __init__(self, req: LLMRequest, context: List[dict]):
-        self.req, self.context = req, tuple(context)
+    def __init__(self, text, req_id):
+        self.req_id = req_id
+        self.text = text
 
 
-class LLMSessionParams():
-    system_prompt: str
+class LLMInferRequest:
+    """the worker's queue item: the request, a shallow snapshot of the session context (tuple of the same message dicts), and
+    -- set by the session -- `textout_cb`"""
 
-    def __init__(self, system_prompt: str):
+    def __init__(self, req, context):
+        self.context = tuple(context)
+        self.req = req
+
+
+class LLMSessionParams:
+    def __init__(self, system_prompt):
         self.system_prompt = system_prompt
 
 
 class LLMSession():
-    """Per-call chat context (LLMSession.py:34-70): consecutive messages of one role are joined with a space; the
-    request is queued with a snapshot of the context; answers are appended as 'assistant' unless the request opts
-    out (auto_ctx_add)."""
-    id: UUID
-    context: List[dict]
-    debug: bool = False
+    """Per-call chat context (Cluster/LLMSession.py:34-70).  Behaviour, pinned by tests/golden/llm_host.json: a message of the
+    role the context already ends with is appended to that message after a space, anything else opens a new message; a
+    request is queued with a SHALLOW snapshot of the context (the worker sees later additions to the last message); every
+    piece of the answer is added as 'assistant' unless the request opted out (auto_ctx_add), then handed to the caller."""
+    debug = False
 
-    def __init__(self, llm: 'InfernLLMWorker', params: LLMSessionParams):
+    def __init__(self, llm, params):
         self.id = uuid4()
-        self.context = [{"role": "system", "content": params.system_prompt}]
         self.llm = llm
+        self.context = [dict(role='system', content=params.system_prompt)]
 
-    def context_add(self, content: str, role: str = "user"):
-        if self.debug:
-            print(f'{monotonic():4.3f}: LLMSession.context_add: {self.context=}, {content=}')
-        if len(self.context) > 0 and self.context[-1]["role"] == role:
-            self.context[-1]["content"] += f' {content}'
+    def context_add(self, content, role='user'):
+        tail = self.context[-1] if self.context else None
+        if tail is None or tail['role'] != role:
+            self.context.append(dict(role=role, content=content))
         else:
-            self.context.append({"role": role, "content": content})
+            tail['content'] = '%s %s' % (tail['content'], content)
+        if self.debug:
+            print('%4.3f: LLMSession.context_add -> %r' % (monotonic(), self.context))
 
-    def textin(self, req: LLMRequest):
+    def textin(self, req):
         self.context_add(req.text)
-        ireq = LLMInferRequest(req, self.context)
+        work = LLMInferRequest(req, self.context)
+        work.textout_cb = partial(self.textout, req=req)
         if hasattr(req, '_proc_start_cb'):
-            ireq._proc_start_cb = req._proc_start_cb
-        ireq.textout_cb = partial(self.textout, req=req)
-        self.llm.infer(ireq)
+            work._proc_start_cb = req._proc_start_cb
+        self.llm.infer(work)
 
-    def textout(self, req: LLMRequest, result: LLMResult):
+    def textout(self, req, result):
         if req.auto_ctx_add:
-            self.context_add(result.text, "assistant")
+            self.context_add(result.text, 'assistant')
         req.textout_cb(result=result)
 
     def stop(self):
@@ -91,53 +89,54 @@ class LLMSession():
 
 
 class ResultsStreamer:
-    """Sentence-boundary streaming of a batch being generated (InfernLLMWorker.py:15-66).  `put` receives the prompt
-    first (ignored), then the new token of every row per step; the text decoded so far is cut at the last of
-    '. ', '? ', '! ', newline and everything before it delivered (if at least 10 characters); no decode on steps where
-    the token count is a multiple of decode_batch_size; `end` delivers the rest."""
+    """Sentence-boundary streaming of a batch while it is generated (Cluster/InfernLLMWorker.py:15-66; the protocol is
+    transformers' streamer: `put(prompt ids)` once, `put(int64 [B])` per generated token, `end()`).  Behaviour, pinned by
+    tests/golden/llm_host.json: the whole batch is re-decoded after every token except when the token count is a multiple of
+    `decode_batch_size`; of a row's not yet delivered text, the part in front of the LAST occurrence of the FIRST marker of
+    `sync_on` that occurs at all -- minus that marker's final character -- is delivered if it is at least 10 characters
+    long, and delivery resumes behind the marker; `end()` delivers whatever is left."""
     debug = False
     sync_on = ('. ', '? ', '! ', '\n')
     decode_batch_size = 8
 
     def __init__(self, wis: List[LLMInferRequest], upper: 'InfernLLMWorker'):
         self.tokenizer = upper.llm_tokenizer
+        self.batch_decode = partial(upper.llm_tokenizer.batch_decode, skip_special_tokens=True)
         self.wi_cbs = tuple(wi.textout_cb for wi in wis)
         self.newLLMResult = tuple(partial(LLMResult, req_id=wi.req.id) for wi in wis)
-        self.oposs = [0 for _ in range(len(wis))]
+        self.oposs = [0] * len(wis)            # per row: characters already delivered
         self.current_tokens = None
-        self.batch_decode = partial(upper.llm_tokenizer.batch_decode, skip_special_tokens=True)
+
+    def _boundary(self, text: str) -> int:
+        """offset just behind the marker the delivery cuts at, or -1"""
+        for mark in self.sync_on:
+            at = text.rfind(mark)
+            if at >= 0:
+                return at + len(mark)
+        return -1
 
     def put(self, token_ids):
-        if self.current_tokens is None:
+        if self.current_tokens is None:        # the prompt: only the batch size matters
             self.current_tokens = torch.zeros((token_ids.shape[0], 0), dtype=torch.long)
             return
-        if token_ids.dim() == 1:
-            token_ids = token_ids.unsqueeze(1)
-        self.current_tokens = torch.cat([self.current_tokens, token_ids], dim=1)
+        step = token_ids if token_ids.dim() == 2 else token_ids.unsqueeze(1)
+        self.current_tokens = torch.cat([self.current_tokens, step], dim=1)
         if self.current_tokens.shape[1] % self.decode_batch_size == 0:
             return
-        results = self.batch_decode(self.current_tokens)
-        for (ir, r), op, cb, newLR in zip(enumerate(results), self.oposs, self.wi_cbs, self.newLLMResult):
-            new_content = r[op:]
-            if len(new_content) == 0:
+        for row, text in enumerate(self.batch_decode(self.current_tokens)):
+            start = self.oposs[row]
+            fresh = text[start:]
+            cut = self._boundary(fresh) if fresh else -1
+            if cut < 0 or cut - 1 < 10:
                 continue
-            sp = (op + pos + len(c) for c in self.sync_on if (pos := new_content.rfind(c)) >= 0)
-            try:
-                spos = next(sp)
-            except StopIteration:
-                continue
-            r = r[op:spos - 1]
-            if len(r) < 10:
-                continue
-            cb(result=newLR(r))
-            self.oposs[ir] = spos
+            self.wi_cbs[row](result=self.newLLMResult[row](fresh[:cut - 1]))
+            self.oposs[row] = start + cut
 
     def end(self):
-        results = self.batch_decode(self.current_tokens)
-        for r, op, cb, newLR in zip(results, self.oposs, self.wi_cbs, self.newLLMResult):
-            if len(r) == op:
-                continue
-            cb(result=newLR(r[op:]))
+        for row, text in enumerate(self.batch_decode(self.current_tokens)):
+            rest = text[self.oposs[row]:]
+            if rest:
+                self.wi_cbs[row](result=self.newLLMResult[row](rest))
         del self.current_tokens
         del self.wi_cbs
 

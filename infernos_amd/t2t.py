@@ -42,47 +42,39 @@ class Translator():
 
     def __init__(self, from_code: str, to_code: str, filter: Optional[callable] = None, backend=None):
         be = backend if backend is not None else ArgosBackend()
-        to_code_p = [to_code, ]
-        inter_codes = [x for x in self.supported_langs if x not in (from_code, to_code)]
-        success = False
-        while not success:
+        langs = None
+        stages, cur = [], from_code
+        for code in self._plan(be, from_code, to_code):
+            if langs is None:
+                langs = {lang.code: lang for lang in be.installed_languages()}
+            step = langs[cur].get_translation(langs[code]).translate
+            stages.append(step if filter is None else partial(filter, from_code=cur, to_code=code, tr=step))
+            cur = code
+        self.translators = tuple(stages)
+
+    def _plan(self, be, src: str, dst: str):
+        """The target codes of the stages, in order, after installing the language pairs they need: [dst] when the index
+        has src -> dst; otherwise the first pivot, tried from the end of supported_langs, for which both src -> pivot and
+        pivot -> dst install -- and then, as the reference does (Translator.py:38 queues the target, not the pivot), the
+        plan is [dst, dst].  No pair and no pivot: the index's StopIteration propagates."""
+        def install(a, b):
             try:
-                be.load_pair(from_code, to_code)
+                be.load_pair(a, b)
             except StopIteration:
-                pass
-            else:
-                success = True
-                break
-            while len(inter_codes) > 0:
-                inter_code = inter_codes.pop()
-                try:
-                    be.load_pair(from_code, inter_code)
-                    be.load_pair(inter_code, to_code)
-                except StopIteration:
-                    if len(inter_codes) == 0:
-                        raise
-                    continue
-                # NB: the reference inserts to_code (not inter_code) in front, so a pivoted chain asks the installed
-                # languages for from -> to twice (Translator.py:38); kept as is
-                to_code_p.insert(0, to_code)
-                success = True
-                break
-        ilangs = dict((x.code, x) for x in be.installed_languages())
-        from_lang = ilangs[from_code]
-        translators = []
-        for tc in to_code_p:
-            to_lang = ilangs[tc]
-            tr = from_lang.get_translation(to_lang).translate
-            if filter is not None:
-                tr = partial(filter, from_code=from_code, to_code=tc, tr=tr)
-            translators.append(tr)
-            from_lang, from_code = to_lang, tc
-        self.translators = tuple(translators)
+                return False
+            return True
+        if install(src, dst):
+            return [dst]
+        for via in reversed([c for c in self.supported_langs if c not in (src, dst)]):
+            if install(src, via) and install(via, dst):
+                return [dst, dst]
+        raise StopIteration
 
     def translate(self, sourceText):
-        for translator in self.translators:
-            sourceText = translatedText = translator(sourceText)
-        return translatedText
+        text = sourceText
+        for stage in self.translators:
+            text = stage(text)
+        return text
 
 
 _ONES = ('zero one two three four five six seven eight nine ten eleven twelve thirteen fourteen fifteen sixteen seventeen '
@@ -155,22 +147,28 @@ class NumbersToWords:
                 translator = InfernGlobals.get_translator('en', lang).translate
             self.tr, self.cache = translator, {}
 
+    _NUMBER = re.compile(r'\b\d[\d.,]*%?(?=[\s.,!]|$)')           # the reference's pattern (NumbersToWords.py:18)
+
+    def _spell(self, token: str) -> str:
+        """one matched number: '%' reads ' percent', a trailing '.', ',' or '!' is punctuation and stays; other languages
+        get the translated words, remembered per matched string"""
+        if token.endswith('%'):
+            body, tail = token[:-1], ' percent'
+        elif token[-1] in '.,!':
+            body, tail = token[:-1], token[-1]
+        else:
+            body, tail = token, ''
+        words = self.number_to_words(body) + tail
+        if self.tr is None:
+            return words
+        known = self.cache.get(token)
+        if known is None:
+            known = self.cache[token] = self.tr(words)
+        return known
+
     def __call__(self, text):
-        numbers = re.findall(r'\b\d[\d.,]*%?(?=[\s.,!]|$)', text)
-        for number in numbers:
-            if number.endswith('%'):
-                tr_number = number[:-1]
-                suffix = ' percent'
-            elif number[-1] in ('.', ',', '!'):
-                tr_number = number[:-1]
-                suffix = number[-1]
-            else:
-                suffix = ''
-                tr_number = number
-            word = self.number_to_words(tr_number) + suffix
-            if self.tr is not None:
-                if (word_tr := self.cache.get(number, None)) is None:
-                    self.cache[number] = word_tr = self.tr(word)
-                word = word_tr
-            text = text.replace(number, word, 1)
+        # every match replaces the FIRST occurrence of its string in the text as it stands by then (the reference's
+        # str.replace(..., 1) semantics, which the fixture pins)
+        for token in self._NUMBER.findall(text):
+            text = text.replace(token, self._spell(token), 1)
         return text
