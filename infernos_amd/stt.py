@@ -11,64 +11,55 @@ from fractions import Fraction
 from functools import partial
 from threading import Lock
 from time import monotonic
-from typing import List, Optional, Union
-from uuid import UUID, uuid4
+from typing import List, Union
+from uuid import uuid4
 
 from .audio import AudioChunk, VadAudioChunk
 
 
 class STTRequest:
-    lang: str
-    chunk: AudioChunk
-    text_cb: callable
-    mode: str = 'transcribe'
-    timestamps: bool = False
-    stime: float
-    max_ns_prob: float = 0.5
+    """one utterance for the recogniser: audio chunk, language, where the STTResult goes; `mode` 'transcribe' or
+    'translate', `timestamps`, and the no-speech probability above which the caller discards the text"""
+    mode = 'transcribe'
+    timestamps = False
+    max_ns_prob = 0.5
 
-    def __init__(self, chunk: AudioChunk, text_cb: callable, lang: str):
+    def __init__(self, chunk, text_cb, lang):
+        self.chunk = chunk
+        self.lang = lang
+        self.text_cb = text_cb
         self.stime = monotonic()
-        self.lang, self.chunk, self.text_cb = lang, chunk, text_cb
 
 
 class STTSentinel:
-    stime: float
-    text_cb: callable
+    """an in-band marker ('flush', ...): echoed to its callback in order with the results around it"""
 
-    def __init__(self, signal: str, text_cb: callable):
+    def __init__(self, signal, text_cb):
+        self.signal = signal
+        self.text_cb = text_cb
         self.stime = monotonic()
-        self.signal, self.text_cb = signal, text_cb
 
 
 class STTResult:
-    text: str
-    no_speech_prob: float
-    duration: Fraction
-    offsets: Optional[List] = None
-    inf_time: float
+    offsets = None
 
-    def __init__(self, text: str, no_speech_prob: float, req: STTRequest):
-        self.text = text
-        self.no_speech_prob = no_speech_prob
-        self.duration = Fraction(len(req.chunk.audio), req.chunk.samplerate)
+    def __init__(self, text, no_speech_prob, req):
+        self.text, self.no_speech_prob = text, no_speech_prob
+        self.duration = Fraction(len(req.chunk.audio), req.chunk.samplerate)      # exact seconds of the recognised audio
         self.inf_time = monotonic() - req.stime
 
 
 class STTSession:
     debug = False
-    id: UUID
-    lang: str = 'en'
-    context: Optional[List[int]]
-    state_lock: Lock
-    busy: bool = False
-    pending: List[Union[STTRequest, STTSentinel]]
+    lang = 'en'
+    busy = False
 
-    def __init__(self, stt, keep_context: bool):
+    def __init__(self, stt, keep_context):
         self.id = uuid4()
         self.stt = stt
+        self.pending = []                                   # STTRequest / STTSentinel in arrival order
+        self.context = [] if keep_context else None         # token history handed to the worker
         self.state_lock = Lock()
-        self.context = [] if keep_context else None
-        self.pending = []
 
     def stop(self):
         with self.state_lock:
