@@ -31,6 +31,9 @@ QWEN2_CONFIGS = {
     # SiLU-gate epilogue on the weight-streaming GEMM: gate|up >= 8192 columns); checked against the oracle directly
     'qwen2_wide': dict(vocab=1000, hidden=512, ffn=4096, layers=3, heads=4, kv_heads=2, head_dim=128, rope_theta=1.0e6,
                        rms_eps=1e-6, tie=True, max_pos=512),
+    # the reference's default checkpoint (Cluster/InfernLLMWorker.py:69: Qwen/Qwen2.5-14B-Instruct), for shape / capacity probes
+    'qwen2_14b': dict(vocab=152064, hidden=5120, ffn=13824, layers=48, heads=40, kv_heads=8, head_dim=128, rope_theta=1.0e6,
+                      rms_eps=1e-6, tie=False, max_pos=32768),
     'qwen2_1p5b': dict(vocab=151936, hidden=1536, ffn=8960, layers=28, heads=12, kv_heads=2, head_dim=128, rope_theta=1.0e6,
                        rms_eps=1e-6, tie=True, max_pos=32768),
 }

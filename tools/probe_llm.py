@@ -1,5 +1,5 @@
-"""Qwen2.5-1.5B-shaped decode on one GPU (BASELINE configuration 5's LLM): prefill and per-token step time at B rows.
-usage: python tools/probe_llm.py [B] [prompt_len] [new_tokens]"""
+"""Qwen2.5-shaped decode on one GPU (BASELINE configuration 5's LLM): prefill and per-token step time at B rows.
+usage: python tools/probe_llm.py [B] [prompt_len] [new_tokens] [qwen2_1p5b|qwen2_14b]"""
 import os
 import sys
 import time
@@ -15,7 +15,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 192
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 dev = _lib.require_device('cuda:0')
-cfg = QWEN2_CONFIGS['qwen2_1p5b']
+FAM = sys.argv[4] if len(sys.argv) > 4 else 'qwen2_1p5b'
+cfg = QWEN2_CONFIGS[FAM]
 
 
 t0 = time.perf_counter()
@@ -23,7 +24,7 @@ model = Qwen2(qwen2_random_on_device(cfg, dev), cfg, dev, max_tokens=P + N + 8)
 torch.cuda.synchronize()
 print('model built in %.1f s' % (time.perf_counter() - t0))
 g = torch.Generator().manual_seed(1)
-prompts = [torch.randint(10, 150000, (P - (i % 7),), generator=g).tolist() for i in range(B)]
+prompts = [torch.randint(10, cfg['vocab'] - 10, (P - (i % 7),), generator=g).tolist() for i in range(B)]
 for rep in range(2):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -40,7 +41,7 @@ torch.cuda.synchronize()
 t_step = (time.perf_counter() - t0) / N
 params = sum(int(torch.tensor(s).prod()) for s, _ in qwen2_schema(cfg).values())
 wbytes = 2 * params
-print('Qwen2.5-1.5B shape, B=%d, prompt %d: prefill %.1f ms (%.0f tok/s); decode %.3f ms/step = %.0f tok/s; weights %.2f GB -> '
+print(FAM + ' shape, B=%d, prompt %d: prefill %.1f ms (%.0f tok/s); decode %.3f ms/step = %.0f tok/s; weights %.2f GB -> '
       '%.2f TB/s of weight streaming (%.0f %% of 8 TB/s)' % (B, P, t_pre * 1e3, B * P / t_pre, t_step * 1e3, B / t_step, wbytes / 1e9,
                                                             wbytes / t_step / 1e12, 100 * wbytes / t_step / 8e12))
 
