@@ -184,10 +184,14 @@ class SpeechPipeline:
         lens16 = (lens8 * 2).to(dev)
         raw, wmax = fl.logmel.raw(x16, lens=lens16)        # normalisation fused into conv1's layout change
         enc = fl.whisper.encode(raw=(fl.logmel, raw, wmax))
+        # bounded queue depth per lane: the encoder (~60 long kernels) and every 8 decode steps are waited for before more is
+        # queued -- the process's streams share four hardware queues, and whatever a lane has queued stands in front of a
+        # real-time tick whose launches land on the same queue (p99 tick latency 76-136 ms -> 7-36 ms; throughput +3 %)
+        torch.cuda.current_stream(dev).synchronize()
         prompt = self.prompt if nrow == self.n else self.prompt.repeat(nrow // self.n, 1)
         if self.stt_beam > 1:
             toks, _, _, nsp = fl.whisper.generate_beam(enc, prompt, self.n_new, beams=self.stt_beam, eos_id=50257,
-                                                       no_speech_id=50362, check_every=self.n_new + 1)
+                                                       no_speech_id=50362, check_every=8)
         else:
             toks, nsp, _ = fl.whisper.generate(enc, prompt, self.n_new, no_speech_id=50362)
         return toks, nsp, (lens8.float() / 8000.0)
