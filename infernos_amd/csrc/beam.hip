@@ -7,12 +7,13 @@
 //
 // Everything lives on the device and is indexed through the step counter the decode graph advances, so a step
 // (decoder launches + ifh_beam_step + ifh_kv_gather_bf16 per layer) is one hipGraph replay with no host round trip:
-//   k_beam_rowtop  one workgroup per decode row (batch item x beam): log-sum-exp of the row's logits and its 16 best
-//                  (masked) logits, one pass over the row, 16-byte loads.
+//   k_beam_rowtop  one workgroup per decode row (batch item x beam): log-sum-exp of the row's logits and its 16 (sampling:
+//                  32) best masked logits -- thread maxima give a threshold, a second pass lists what reaches it, 16-byte loads.
 //   k_beam_update  one wave per batch item: K-way merge of the rows' lists into the 2K candidates, then the running /
 //                  finished bookkeeping, the permutation of the token matrix columns and the source row of every
 //                  running beam for the KV gather.
 //   k_kv_gather    dst[row] = src[beam_src[row]] for the first cur_len tokens of a self-attention KV cache.
+// The row stage also serves token sampling for the LLM worker (k_rep_penalty, k_sample_pick further down).
 #include "common.h"
 
 namespace ifh {
