@@ -5,14 +5,10 @@
 // STFT (n_fft 400, hop 160, periodic Hann), power, slaney mel filterbank, log10,
 // per-utterance max-8 clamp, (x+4)/4.
 //
-// Kernel 1 (k_logmel_dft): one block = 128 frames of one utterance, 7 waves.  The audio
-// tile (20.7k samples) is staged once in LDS (index-padded so frame-strided reads are
-// conflict-free); the 400-point real DFT is done as an exact-f32 MFMA contraction
-// (v_mfma_f32_32x32x2_f32) against a window-folded cos/sin table, using the even/odd fold
-// e[n]=x[n]+x[400-n], o[n]=x[n]-x[400-n] that halves K to 201.  Wave w owns bins
-// 32w..32w+31 for both cos and sin, so power is formed in registers; it is then parked in
-// LDS (overlaying the audio tile) for the sparse mel projection + log10 and a per-utterance
-// atomic max.  Kernel 2 applies the clamp/scale (needs the completed max).
+// k_logmel_fft computes the raw log-mel rows and the per-window maximum (real 400-point FFT, sparse mel projection);
+// the clamp / scale is a second small kernel (k_logmel_finish) or is folded into the layout change in front of Whisper's
+// conv1 (k_logmel_finish_transpose).  (The two DFT-as-GEMM formulations of round 1 -- exact-f32 MFMA and 3-way bf16 split --
+// were removed: their matrix work alone exceeds the FFT kernel's whole time)
 // Algorithmic bytes per 30 s window: 480000*4 read + 80*3000*4 written = 2.88 MB.
 #include <math.h>
 #include <stdio.h>
@@ -23,441 +19,9 @@
 
 #include "common.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 namespace ifh {
 
 constexpr int kNfft = 400, kHop = 160, kBins = 201, kFrames = 3000, kNsamp = 480000;
-constexpr int kFT = 128;            // frames per block
-constexpr int kTabCols = 448;       // 224 cos bins | 224 sin bins
-constexpr int kTabRows = 202;       // folded n = 0..201 (201 is a zero row)
-constexpr int kTile = (kFT - 1) * kHop + kNfft + 1;      // 20721 samples (+1: index 400 of the last frame)
-constexpr int kTileLds = kTile + kTile / kHop + 2;       // padded index space
-constexpr int kPLds = kBins * kFT;                       // power tile overlay
-constexpr int kLdsFloats = (kTileLds > kPLds) ? kTileLds : kPLds;
-
-__device__ __forceinline__ int pad_idx(int m) { return m + m / kHop; }
-
-__global__ __launch_bounds__(448) void k_logmel_dft(const float *__restrict__ audio, int64_t stride,
-                                                    const int32_t *__restrict__ lens,
-                                                    const float *__restrict__ tab,
-                                                    const int32_t *__restrict__ mel_lo,
-                                                    const int32_t *__restrict__ mel_cnt,
-                                                    const int32_t *__restrict__ mel_off,
-                                                    const float *__restrict__ mel_w, int n_mel,
-                                                    float *__restrict__ raw /* [B][n_mel][3000] */,
-                                                    int *__restrict__ gmax)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int b = blockIdx.y;
-    const int f0 = blockIdx.x * kFT;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..6, bin tile
-    int len = lens ? lens[b] : kNsamp;
-    len = len > kNsamp ? kNsamp : (len < 0 ? 0 : len);
-    const float *x = audio + (int64_t)b * stride;
-    float *rawb = raw + (int64_t)b * n_mel * kFrames;
-    const int a0 = f0 * kHop - kNfft / 2;  // absolute index of tile sample 0 in the unpadded signal
-
-    float lmax = -INFINITY;
-    const int a_last = a0 + kTile - 1;
-    const bool tail_clear = (a_last < kNsamp) || (2 * (kNsamp - 1) - a_last >= len);
-    if (a0 >= len && a0 >= 0 && tail_clear) {
-        // every sample this block would read is zero: power 0 -> log10(clamp 1e-10)
-        const float v0 = log10f(fmaxf(0.0f * (float)len, 1e-10f));
-        for (int idx = tid; idx < n_mel * kFT; idx += 448) {
-            const int m = idx >> 7, f = f0 + (idx & (kFT - 1));
-            if (f < kFrames) rawb[(int64_t)m * kFrames + f] = v0;
-        }
-        if (tid == 0) atomicMax(gmax + b, float_to_ordered(v0));
-        return;
-    }
-
-    // ---- stage the audio tile (reflect at the 30 s boundaries, zero beyond len)
-    for (int m = tid; m < kTile; m += 448) {
-        int a = a0 + m;
-        if (a < 0) a = -a;
-        if (a >= kNsamp) a = 2 * (kNsamp - 1) - a;
-        float v = 0.0f;
-        if (a >= 0 && a < len) v = x[a];
-        lds[pad_idx(m)] = v;
-    }
-    __syncthreads();
-
-    // ---- folded DFT on the f32 matrix pipe
-    const int i = lane & 31, kh = lane >> 5;
-    f32x16 accc[4], accs[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            accc[q][r] = 0.0f;
-            accs[q][r] = 0.0f;
-        }
-    }
-    const float *tc = tab + 32 * w + i;
-    const float *ts = tab + 224 + 32 * w + i;
-    const int fb = 161 * i;  // pad_idx(f*160) for f = i (+ 161*32*q per frame tile)
-    // The table operands come from L2 (362 KB table, shared by every block).  With one block per CU
-    // nothing else hides that latency, so the loop is software-pipelined by hand: the operands of the
-    // next PF steps are in flight (registers) while the current PF steps feed the matrix pipe.
-    constexpr int PF = 8;
-    constexpr int NSTEP = kTabRows / 2;          // 101
-    float pc[PF], ps[PF];
-#pragma unroll
-    for (int u = 0; u < PF; u++) {
-        const int n = 2 * u + kh;
-        pc[u] = tc[n * kTabCols];
-        ps[u] = ts[n * kTabCols];
-    }
-    for (int s0 = 0; s0 < NSTEP; s0 += PF) {
-        float cc[PF], cs[PF];
-#pragma unroll
-        for (int u = 0; u < PF; u++) {
-            cc[u] = pc[u];
-            cs[u] = ps[u];
-        }
-#pragma unroll
-        for (int u = 0; u < PF; u++) {          // prefetch the following group (clamped: row 201 is all zeros)
-            int n = 2 * (s0 + PF + u) + kh;
-            n = n < kTabRows ? n : kTabRows - 1;
-            pc[u] = tc[n * kTabCols];
-            ps[u] = ts[n * kTabCols];
-        }
-#pragma unroll
-        for (int u = 0; u < PF; u++) {
-            const int step = s0 + u;
-            if (step < NSTEP) {
-                const int n = 2 * step + kh;
-                const int n2 = kNfft - n;
-                const int o1 = n + (n >= 160) + (n >= 320);
-                const int o2 = n2 + (n2 >= 160) + (n2 >= 320);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int base = fb + 161 * 32 * q;
-                    const float xa = lds[base + o1];
-                    const float xb = lds[base + o2];
-                    const float e = xa + xb, o = xa - xb;
-                    accc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(cc[u], e, accc[q], 0, 0, 0);
-                    accs[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(cs[u], o, accs[q], 0, 0, 0);
-                }
-            }
-        }
-    }
-    __syncthreads();  // everyone is done with the audio tile; overlay the power tile
-
-    // D layout: col = lane&31 (frame), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (bin in tile)
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int bin = 32 * w + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (bin < kBins) {
-                const float c = accc[q][r], s = accs[q][r];
-                lds[bin * kFT + 32 * q + i] = __fmaf_rn(c, c, s * s);
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- sparse mel projection + log10; (mel, frame) pairs, frame fastest
-    for (int idx = tid; idx < n_mel * kFT; idx += 448) {
-        const int m = idx >> 7, fl = idx & (kFT - 1);
-        const int lo = mel_lo[m], cnt = mel_cnt[m];
-        const float *wv = mel_w + mel_off[m];
-        float acc = 0.0f;
-        for (int c = 0; c < cnt; c++) acc = __fmaf_rn(wv[c], lds[(lo + c) * kFT + fl], acc);
-        const float v = log10f(fmaxf(acc, 1e-10f));
-        const int f = f0 + fl;
-        if (f < kFrames) {
-            rawb[(int64_t)m * kFrames + f] = v;
-            lmax = fmaxf(lmax, v);
-        }
-    }
-    lmax = wave_max(lmax);
-    if (lane == 0 && lmax > -INFINITY) atomicMax(gmax + b, float_to_ordered(lmax));
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// k_logmel_dft2: the same folded DFT on the bf16 matrix pipe with exact 3-way operand splitting.
-// An f32 value v is written v = v0 + v1 + v2 with v0 = bf16(v), v1 = bf16(v - v0), v2 = bf16(v - v0 - v1)
-// (24 mantissa bits in all).  table*audio is then the sum of the six products
-//   t0a0 + t0a1 + t1a0 + t1a1 + t0a2 + t2a0           (dropped terms are <= 2^-24 relative)
-// each an exact bf16 product accumulated in f32 by v_mfma_f32_32x32x16_bf16: f32-grade accuracy at
-// 6/16 of the f32-MFMA cost (2.7x fewer matrix-pipe cycles).  Geometry: block = 128 frames, 4 waves,
-// wave w owns frames 32w..32w+31 and ALL 14 bin tiles (7 cos + 7 sin, 224 accumulator registers), so
-// its audio fragments are formed and split once per k-step; the table slice of a k-step (448 rows x
-// 16 k x 3 splits, 48-byte padded rows: conflict-free ds_read_b128) is staged in LDS for all waves
-// through a register prefetch.
-// ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-constexpr int kK2 = 208;                    // folded n padded to 13 k-steps of 16
-constexpr int kKS2 = kK2 / 16;
-constexpr int kRowB = 48;                   // LDS bytes per table row (32 data + 16 pad)
-constexpr int kTabSliceB = 3 * 448 * kRowB; // 64512
-constexpr int kTab2LdsOff = ((kTileLds * 4 + 15) / 16) * 16;
-constexpr int kLds2Bytes = (kTab2LdsOff + kTabSliceB > kPLds * 4) ? (kTab2LdsOff + kTabSliceB) : (kPLds * 4);
-
-__device__ __forceinline__ void split3(float v, uint16_t &a, uint16_t &b, uint16_t &c)
-{
-    a = f32_to_bf16(v);
-    const float r1 = v - bf16_to_f32(a);
-    b = f32_to_bf16(r1);
-    const float r2 = r1 - bf16_to_f32(b);
-    c = f32_to_bf16(r2);
-}
-
-__global__ __launch_bounds__(256) void k_logmel_dft2(const float *__restrict__ audio, int64_t stride,
-                                                     const int32_t *__restrict__ lens,
-                                                     const uint16_t *__restrict__ tab2 /* [13][3][448][16] bf16 */,
-                                                     const int32_t *__restrict__ mel2 /* packed filters, see create */,
-                                                     int mel2_words, int n_mel,
-                                                     float *__restrict__ raw, int *__restrict__ gmax,
-                                                     unsigned long long *__restrict__ prof)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    const long long tp0 = clock64();
-    unsigned char *ldsb = reinterpret_cast<unsigned char *>(lds);
-    unsigned char *tabl = ldsb + kTab2LdsOff;
-    int32_t *mell = reinterpret_cast<int32_t *>(ldsb + kLds2Bytes);
-    const int b = blockIdx.y;
-    const int f0 = blockIdx.x * kFT;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int w = tid >> 6;
-    int len = lens ? lens[b] : kNsamp;
-    len = len > kNsamp ? kNsamp : (len < 0 ? 0 : len);
-    const float *x = audio + (int64_t)b * stride;
-    float *rawb = raw + (int64_t)b * n_mel * kFrames;
-    const int a0 = f0 * kHop - kNfft / 2;
-    float lmax = -INFINITY;
-    const int a_last = a0 + kTile - 1;
-    const bool tail_clear = (a_last < kNsamp) || (2 * (kNsamp - 1) - a_last >= len);
-    if (len == 0 || (a0 >= len && a0 >= 0 && tail_clear)) {
-        const float v0 = log10f(fmaxf(0.0f * (float)len, 1e-10f));
-        for (int idx = tid; idx < n_mel * kFT; idx += 256) {
-            const int m = idx >> 7, f = f0 + (idx & (kFT - 1));
-            if (f < kFrames) rawb[(int64_t)m * kFrames + f] = v0;
-        }
-        if (tid == 0) atomicMax(gmax + b, float_to_ordered(v0));
-        return;
-    }
-    // ---- stage the audio tile with every load of the thread in flight at once (one wave per SIMD:
-    // nothing else hides the HBM latency).  Interior, 16-byte aligned tiles take the float4 path.
-    const bool interior = a0 >= 0 && a_last < len && ((reinterpret_cast<uintptr_t>(x + a0) & 15) == 0);
-    if (interior) {
-        constexpr int NV4 = kTile / 4;          // 5180 float4 (+1 scalar tail)
-        constexpr int NI = (NV4 + 255) / 256;   // 21
-        const float4 *x4 = reinterpret_cast<const float4 *>(x + a0);
-        float4 v[NI];
-#pragma unroll
-        for (int i = 0; i < NI; i++) {
-            const int q = tid + 256 * i;
-            v[i] = x4[q < NV4 ? q : NV4 - 1];
-        }
-        if (tid == 0) lds[pad_idx(kTile - 1)] = x[a0 + kTile - 1];
-#pragma unroll
-        for (int i = 0; i < NI; i++) {
-            const int q = tid + 256 * i;
-            if (q < NV4) {
-                const int pi = pad_idx(4 * q);   // 4q..4q+3 never straddle a multiple of 160
-                lds[pi] = v[i].x;
-                lds[pi + 1] = v[i].y;
-                lds[pi + 2] = v[i].z;
-                lds[pi + 3] = v[i].w;
-            }
-        }
-    } else {
-        constexpr int NI = (kTile + 255) / 256;  // 81
-        float v[NI];
-#pragma unroll
-        for (int i = 0; i < NI; i++) {
-            int a = a0 + tid + 256 * i;
-            if (a < 0) a = -a;
-            if (a >= kNsamp) a = 2 * (kNsamp - 1) - a;
-            const bool ok = a >= 0 && a < len;
-            const float t_ = x[ok ? a : 0];
-            v[i] = ok ? t_ : 0.0f;
-        }
-#pragma unroll
-        for (int i = 0; i < NI; i++) {
-            const int m = tid + 256 * i;
-            if (m < kTile) lds[pad_idx(m)] = v[i];
-        }
-    }
-    for (int i = tid; i < mel2_words; i += 256) mell[i] = mel2[i];
-    // table slice prefetch registers (named: arrays tend to end up in scratch)
-    constexpr int NV = 2688;                  // 16-byte vectors per slice (3*448*2)
-    uint4 p0, p1, p2, p3, p4, p5, p6, p7, p8, p9, p10;
-    p0 = p1 = p2 = p3 = p4 = p5 = p6 = p7 = p8 = p9 = p10 = make_uint4(0, 0, 0, 0);
-#define LM_PF1(I, REG, KS)                                                                              \
-    {                                                                                                   \
-        const int v = tid + 256 * I;                                                                    \
-        if (v < NV) REG = reinterpret_cast<const uint4 *>(tab2 + (int64_t)(KS) * (NV * 8))[v];          \
-    }
-#define LM_PREFETCH(KS)                                                                                 \
-    LM_PF1(0, p0, KS) LM_PF1(1, p1, KS) LM_PF1(2, p2, KS) LM_PF1(3, p3, KS) LM_PF1(4, p4, KS) LM_PF1(5, p5, KS) \
-    LM_PF1(6, p6, KS) LM_PF1(7, p7, KS) LM_PF1(8, p8, KS) LM_PF1(9, p9, KS) LM_PF1(10, p10, KS)
-#define LM_CM1(I, REG)                                                                                  \
-    {                                                                                                   \
-        const int v = tid + 256 * I;                                                                    \
-        if (v < NV) *reinterpret_cast<uint4 *>(tabl + (v >> 1) * kRowB + (v & 1) * 16) = REG;           \
-    }
-#define LM_COMMIT()                                                                                     \
-    LM_CM1(0, p0) LM_CM1(1, p1) LM_CM1(2, p2) LM_CM1(3, p3) LM_CM1(4, p4) LM_CM1(5, p5) LM_CM1(6, p6)   \
-    LM_CM1(7, p7) LM_CM1(8, p8) LM_CM1(9, p9) LM_CM1(10, p10)
-    LM_PREFETCH(0)
-    __syncthreads();                           // audio tile staged
-    const long long tp1 = clock64();
-
-    const int r = lane & 31, h = lane >> 5;
-    f32x16 acc[14];
-#pragma unroll
-    for (int t = 0; t < 14; t++)
-#pragma unroll
-        for (int q = 0; q < 16; q++) acc[t][q] = 0.0f;
-    const int fbase = 161 * (32 * w + r);      // pad_idx(frame*160)
-    // audio fragments: e = x[n] + x[400-n], o = x[n] - x[400-n], each split 3 ways.  The fragments of
-    // k-step ks+1 are formed between the MFMAs of k-step ks.
-    uint16_t e0[8], e1[8], e2[8], o0[8], o1[8], o2[8];
-#define LM_ELEM(KS, J)                                                                                  \
-    {                                                                                                   \
-        const int n = (KS) * 16 + 8 * h + (J);     /* <= 223; table rows > 200 are zero */             \
-        const int n2 = kNfft - n;                                                                       \
-        const float xa = lds[fbase + n + (n >= 160)];                                                   \
-        const float xb = lds[fbase + n2 + (n2 >= 160) + (n2 >= 320)];                                   \
-        split3(xa + xb, e0[J], e1[J], e2[J]);                                                           \
-        split3(xa - xb, o0[J], o1[J], o2[J]);                                                           \
-    }
-#define LM_PACK(DST, SRC)                                                                               \
-    {                                                                                                   \
-        uint4 t_;                                                                                       \
-        t_.x = (uint32_t)SRC[0] | ((uint32_t)SRC[1] << 16);                                             \
-        t_.y = (uint32_t)SRC[2] | ((uint32_t)SRC[3] << 16);                                             \
-        t_.z = (uint32_t)SRC[4] | ((uint32_t)SRC[5] << 16);                                             \
-        t_.w = (uint32_t)SRC[6] | ((uint32_t)SRC[7] << 16);                                             \
-        DST = __builtin_bit_cast(bf16x8_t, t_);                                                         \
-    }
-    // Fragment registers are ping-ponged (A: even k-steps, B: odd): the set being re-packed was last read by
-    // MFMAs two barriers ago.  Re-packing the set in use right behind its last MFMA gave run-to-run
-    // different results in lanes 16..31/48..63 of the B operand (gfx950 reads the 4-VGPR operand of the
-    // K=16 MFMA over more than one beat; the compiler does not guard that write-after-read).
-    bf16x8_t EA0, EA1, EA2, OA0, OA1, OA2, EB0, EB1, EB2, OB0, OB1, OB2;
-    LM_ELEM(0, 0) LM_ELEM(0, 1) LM_ELEM(0, 2) LM_ELEM(0, 3) LM_ELEM(0, 4) LM_ELEM(0, 5) LM_ELEM(0, 6) LM_ELEM(0, 7)
-    LM_PACK(EA0, e0) LM_PACK(EA1, e1) LM_PACK(EA2, e2) LM_PACK(OA0, o0) LM_PACK(OA1, o1) LM_PACK(OA2, o2)
-#define LM_KSTEP(KS, CE0, CE1, CE2, CO0, CO1, CO2, NE0, NE1, NE2, NO0, NO1, NO2)                        \
-    {                                                                                                   \
-        if ((KS) > 0) __syncthreads(); /* previous slice fully consumed */                              \
-        LM_COMMIT()                                                                                     \
-        __syncthreads();                                                                                \
-        if ((KS) + 1 < kKS2) LM_PREFETCH((KS) + 1)                                                      \
-        _Pragma("unroll") for (int t = 0; t < 14; t++)                                                  \
-        {                                                                                               \
-            const unsigned char *rowp = tabl + (32 * t + r) * kRowB + h * 16;                           \
-            const bf16x8_t T0 = *reinterpret_cast<const bf16x8_t *>(rowp);                              \
-            const bf16x8_t T1 = *reinterpret_cast<const bf16x8_t *>(rowp + 448 * kRowB);                \
-            const bf16x8_t T2 = *reinterpret_cast<const bf16x8_t *>(rowp + 2 * 448 * kRowB);            \
-            const bf16x8_t B0 = t < 7 ? CE0 : CO0, B1 = t < 7 ? CE1 : CO1, B2 = t < 7 ? CE2 : CO2;      \
-            f32x16 a = acc[t];                                                                          \
-            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(T2, B0, a, 0, 0, 0); /* small terms first */    \
-            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(T0, B2, a, 0, 0, 0);                            \
-            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(T1, B1, a, 0, 0, 0);                            \
-            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(T1, B0, a, 0, 0, 0);                            \
-            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(T0, B1, a, 0, 0, 0);                            \
-            a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(T0, B0, a, 0, 0, 0);                            \
-            acc[t] = a;                                                                                 \
-            if (t < 8) LM_ELEM((KS) + 1, t)                                                             \
-        }                                                                                               \
-        LM_PACK(NE0, e0) LM_PACK(NE1, e1) LM_PACK(NE2, e2) LM_PACK(NO0, o0) LM_PACK(NO1, o1) LM_PACK(NO2, o2) \
-    }
-    for (int ks = 0; ks + 1 < kKS2; ks += 2) {
-        LM_KSTEP(ks, EA0, EA1, EA2, OA0, OA1, OA2, EB0, EB1, EB2, OB0, OB1, OB2)
-        LM_KSTEP(ks + 1, EB0, EB1, EB2, OB0, OB1, OB2, EA0, EA1, EA2, OA0, OA1, OA2)
-    }
-    static_assert(kKS2 % 2 == 1, "tail k-step uses the A set");
-    LM_KSTEP(kKS2 - 1, EA0, EA1, EA2, OA0, OA1, OA2, EB0, EB1, EB2, OB0, OB1, OB2)
-#undef LM_KSTEP
-#undef LM_PF1
-#undef LM_PREFETCH
-#undef LM_CM1
-#undef LM_COMMIT
-#undef LM_PACK
-#undef LM_ELEM
-    __syncthreads();  // audio tile and table slice are dead: overlay the power tile
-    const long long tp2 = clock64();
-#pragma unroll
-    for (int t = 0; t < 7; t++) {
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int bin = 32 * t + (q & 3) + 8 * (q >> 2) + 4 * h;
-            if (bin < kBins) {
-                const float c = acc[t][q], sn = acc[7 + t][q];
-                lds[bin * kFT + 32 * w + r] = __fmaf_rn(c, c, sn * sn);
-            }
-        }
-    }
-    __syncthreads();
-    // ---- sparse mel projection: thread = (frame, mel parity), four filters in flight per iteration
-    // (filter weights padded to groups of 4 in LDS; group index past a filter's end reads zero weights)
-    {
-        const int fl = tid & (kFT - 1);
-        const int f = f0 + fl;
-        const float4 *w4 = reinterpret_cast<const float4 *>(mell + 384);
-        const int zero_g = (mel2_words - 384) / 4 - 1;   // the last group is all-zero
-        for (int mb = tid >> 7; mb < n_mel; mb += 8) {
-            int lo[4], c4[4], o4[4];
-            float a[4] = {0.f, 0.f, 0.f, 0.f};
-            int gmaxn = 0;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int m = mb + 2 * u;
-                lo[u] = mell[m];
-                c4[u] = mell[128 + m];
-                o4[u] = mell[256 + m];
-                gmaxn = max(gmaxn, c4[u]);
-            }
-            for (int g = 0; g < gmaxn; g++) {
-                float4 wv[4];
-                float q[4][4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const bool on = g < c4[u];
-                    wv[u] = w4[on ? o4[u] + g : zero_g];
-                    const int k = on ? lo[u] + 4 * g : 0;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) q[u][e] = lds[min(k + e, kBins - 1) * kFT + fl];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    a[u] = __fmaf_rn(wv[u].x, q[u][0], a[u]);
-                    a[u] = __fmaf_rn(wv[u].y, q[u][1], a[u]);
-                    a[u] = __fmaf_rn(wv[u].z, q[u][2], a[u]);
-                    a[u] = __fmaf_rn(wv[u].w, q[u][3], a[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const float v = log10f(fmaxf(a[u], 1e-10f));
-                if (f < kFrames) {
-                    rawb[(int64_t)(mb + 2 * u) * kFrames + f] = v;
-                    lmax = fmaxf(lmax, v);
-                }
-            }
-        }
-    }
-    lmax = wave_max(lmax);
-    if (lane == 0 && lmax > -INFINITY) atomicMax(gmax + b, float_to_ordered(lmax));
-    if (prof && tid == 0) {
-        const long long tp3 = clock64();
-        atomicAdd(prof + 0, (unsigned long long)(tp1 - tp0));
-        atomicAdd(prof + 1, (unsigned long long)(tp2 - tp1));
-        atomicAdd(prof + 2, (unsigned long long)(tp3 - tp2));
-        atomicAdd(prof + 3, 1ull);
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------
 // k_logmel_fft: the power spectrum through a real FFT instead of a DFT-as-GEMM (which cannot reach the HBM roof: its
@@ -872,14 +436,10 @@ using namespace ifh;
 struct ifh_logmel {
     int n_mel;
     std::vector<float> filters;  // [201][n_mel]
-    float *d_tab = nullptr;
-    int32_t *d_mel2 = nullptr;    // packed filters for k_logmel_dft2: lo[128] | groups[128] | first group[128] | weights (x4 padded)
+    int32_t *d_mel2 = nullptr;    // packed filters: lo[128] | groups[128] | first group[128] | weights (x4 padded)
     int mel2_words = 0;
-    float *d_win = nullptr;       // k_logmel_fft: hann window [400], W200^(n2 k1) [8][25], W400^k [101]
+    float *d_win = nullptr;       // hann window [400], W200^(n2 k1) [8][25], W400^k [101]
     f2v *d_tw200 = nullptr, *d_tw400 = nullptr;
-    uint16_t *d_tab2 = nullptr;   // [13][3][448][16] bf16 splits of the folded DFT table (k_logmel_dft2)
-    int32_t *d_lo = nullptr, *d_cnt = nullptr, *d_off = nullptr;
-    float *d_w = nullptr;
 };
 
 extern "C" int ifh_logmel_create(int n_mel, ifh_logmel_t *out)
@@ -936,44 +496,6 @@ extern "C" int ifh_logmel_create(int n_mel, ifh_logmel_t *out)
     }
     for (int k = 0; k < 4; k++) mel2.push_back(0);       // trailing all-zero weight group
     h->mel2_words = (int)mel2.size();
-    // ---- folded DFT table: row n, col c<224: hann[n]*cos(2pi c n/400) (c<=200), col 224+c: sin
-    std::vector<float> tab((size_t)kTabRows * kTabCols, 0.0f);
-    for (int n = 0; n <= 200; n++) {
-        const double win = 0.5 - 0.5 * cos(2.0 * M_PI * (double)n / 400.0);
-        const double fwin = (double)(float)win * ((n == 200) ? 0.5 : 1.0);
-        for (int c = 0; c <= 200; c++) {
-            const int ph = (int)(((long long)c * n) % 400);
-            const double ang = 2.0 * M_PI * (double)ph / 400.0;
-            tab[(size_t)n * kTabCols + c] = (float)(fwin * cos(ang));
-            if (n >= 1 && n <= 199 && c >= 1 && c <= 199) tab[(size_t)n * kTabCols + 224 + c] = (float)(fwin * sin(ang));
-        }
-    }
-    // ---- v2 table: rows = output bins (cos 0..223 | sin 224..447), cols = folded n, three bf16 splits
-    auto bf16_rn = [](float f) -> uint16_t {
-        uint32_t u;
-        memcpy(&u, &f, 4);
-        u += 0x7fffu + ((u >> 16) & 1u);
-        return (uint16_t)(u >> 16);
-    };
-    auto bf16_f = [](uint16_t hbits) -> float {
-        uint32_t u = (uint32_t)hbits << 16;
-        float f;
-        memcpy(&f, &u, 4);
-        return f;
-    };
-    std::vector<uint16_t> tab2((size_t)kKS2 * 3 * 448 * 16, 0);
-    for (int bin = 0; bin < 448; bin++)
-        for (int n = 0; n < kK2; n++) {
-            const float tv = (n < kTabRows) ? tab[(size_t)n * kTabCols + bin] : 0.0f;
-            const uint16_t s0 = bf16_rn(tv);
-            const float r1 = tv - bf16_f(s0);
-            const uint16_t s1 = bf16_rn(r1);
-            const float r2 = r1 - bf16_f(s1);
-            const uint16_t s2 = bf16_rn(r2);
-            const int ks = n / 16, kk = n % 16;
-            const uint16_t sp[3] = {s0, s1, s2};
-            for (int q = 0; q < 3; q++) tab2[(((size_t)ks * 3 + q) * 448 + bin) * 16 + kk] = sp[q];
-        }
     hipError_t e = hipSuccess;
     auto up = [&](void **dst, const void *src, size_t bytes) {
         if (e != hipSuccess) return;
@@ -1004,13 +526,7 @@ extern "C" int ifh_logmel_create(int n_mel, ifh_logmel_t *out)
         up((void **)&h->d_tw200, t200.data(), t200.size() * sizeof(f2v));
         up((void **)&h->d_tw400, t400.data(), t400.size() * sizeof(f2v));
     }
-    up((void **)&h->d_tab, tab.data(), tab.size() * 4);
-    up((void **)&h->d_tab2, tab2.data(), tab2.size() * 2);
     up((void **)&h->d_mel2, mel2.data(), mel2.size() * 4);
-    up((void **)&h->d_lo, lo.data(), lo.size() * 4);
-    up((void **)&h->d_cnt, cnt.data(), cnt.size() * 4);
-    up((void **)&h->d_off, off.data(), off.size() * 4);
-    up((void **)&h->d_w, wts.data(), wts.size() * 4);
     if (e != hipSuccess) {
         ifh_logmel_destroy(h);
         return check_hip(e, "logmel_create");
@@ -1022,16 +538,10 @@ extern "C" int ifh_logmel_create(int n_mel, ifh_logmel_t *out)
 extern "C" int ifh_logmel_destroy(ifh_logmel_t h)
 {
     if (!h) return IFH_OK;
-    if (h->d_tab) (void)hipFree(h->d_tab);
-    if (h->d_tab2) (void)hipFree(h->d_tab2);
     if (h->d_win) (void)hipFree(h->d_win);
     if (h->d_tw200) (void)hipFree(h->d_tw200);
     if (h->d_tw400) (void)hipFree(h->d_tw400);
     if (h->d_mel2) (void)hipFree(h->d_mel2);
-    if (h->d_lo) (void)hipFree(h->d_lo);
-    if (h->d_cnt) (void)hipFree(h->d_cnt);
-    if (h->d_off) (void)hipFree(h->d_off);
-    if (h->d_w) (void)hipFree(h->d_w);
     delete h;
     return IFH_OK;
 }
@@ -1099,54 +609,28 @@ static int logmel_transform(ifh_logmel_t h, const float *audio, int64_t stride, 
 {
     hipError_t e = hipMemsetD32Async((hipDeviceptr_t)gmax, (int)0x80000000, (size_t)nbatch, st);
     if (e != hipSuccess) return check_hip(e, "logmel memset");
-    const size_t ldsb = (size_t)kLdsFloats * sizeof(float);
     static unsigned long long attr_mask = 0;
     int attr_dev = 0;
-    static const bool use_v1 = getenv("IFH_LOGMEL_V1") != nullptr;      // tuning switch: f32-MFMA formulation
-    static const bool use_dft = getenv("IFH_LOGMEL_DFT") != nullptr;    // tuning switch: bf16x3-MFMA DFT instead of the FFT
     if (attr_needed_on_this_device(attr_mask, &attr_dev)) {
-        e = hipFuncSetAttribute((const void *)k_logmel_dft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_logmel_dft2, hipFuncAttributeMaxDynamicSharedMemorySize, kLds2Bytes + 8192);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *)k_logmel_fft, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsFftBytes + 8192);
+        e = hipFuncSetAttribute((const void *)k_logmel_fft, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsFftBytes + 8192);
         if (e != hipSuccess) return check_hip(e, "logmel set lds attr");
         attr_mask |= 1ull << attr_dev;
     }
-    dim3 grid((kFrames + kFT - 1) / kFT, nbatch);
-    if (!use_v1 && !use_dft) {
-        static unsigned long long *d_proff = nullptr;
-        static const bool do_proff = getenv("IFH_LOGMEL_PROF") != nullptr;
-        if (do_proff && !d_proff) (void)hipMalloc((void **)&d_proff, 64);
-        if (do_proff) (void)hipMemsetAsync(d_proff, 0, 64, st);
-        const int ntile = (kFrames + kFB - 1) / kFB;
-        int gx = (2 * 256 + nbatch - 1) / nbatch;            // ~2 resident blocks per CU in all, each walking its share of the tiles
-        gx = gx < 1 ? 1 : (gx > ntile ? ntile : gx);
-        hipLaunchKernelGGL(k_logmel_fft, dim3(gx, nbatch), dim3(256), (size_t)kLdsFftBytes + 816 + (size_t)h->mel2_words * 4, st, audio, stride,
-                           lens, h->d_win, h->d_tw200, h->d_tw400, h->d_mel2, h->mel2_words, h->n_mel, raw, gmax,
-                           do_proff ? d_proff : nullptr);
-        if (do_proff) {
-            unsigned long long hp[5];
-            (void)hipStreamSynchronize(st);
-            (void)hipMemcpy(hp, d_proff, 40, hipMemcpyDeviceToHost);
-            if (hp[4]) fprintf(stderr, "logmel fft prof: blocks=%llu stage=%llu A=%llu B=%llu mel=%llu cycles/block\n", hp[4], hp[0] / hp[4], hp[1] / hp[4], hp[2] / hp[4], hp[3] / hp[4]);
-        }
-    } else if (use_v1)
-        hipLaunchKernelGGL(k_logmel_dft, grid, dim3(448), ldsb, st, audio, stride, lens, h->d_tab, h->d_lo, h->d_cnt,
-                           h->d_off, h->d_w, h->n_mel, raw, gmax);
-    else {
-        static unsigned long long *d_prof = nullptr;
-        static const bool do_prof = getenv("IFH_LOGMEL_PROF") != nullptr;
-        if (do_prof && !d_prof) { (void)hipMalloc((void **)&d_prof, 64); }
-        if (do_prof) (void)hipMemsetAsync(d_prof, 0, 64, st);
-        hipLaunchKernelGGL(k_logmel_dft2, grid, dim3(256), (size_t)kLds2Bytes + (size_t)h->mel2_words * 4, st, audio, stride, lens,
-                           h->d_tab2, h->d_mel2, h->mel2_words, h->n_mel, raw, gmax, do_prof ? d_prof : nullptr);
-        if (do_prof) {
-            unsigned long long hp[4];
-            (void)hipStreamSynchronize(st);
-            (void)hipMemcpy(hp, d_prof, 32, hipMemcpyDeviceToHost);
-            if (hp[3]) fprintf(stderr, "logmel2 prof: blocks=%llu stage=%llu dft=%llu mel=%llu cycles/block\n", hp[3], hp[0] / hp[3], hp[1] / hp[3], hp[2] / hp[3]);
-        }
+    static unsigned long long *d_proff = nullptr;
+    static const bool do_proff = getenv("IFH_LOGMEL_PROF") != nullptr;      // diagnostic: phase clocks of the kernel to stderr
+    if (do_proff && !d_proff) (void)hipMalloc((void **)&d_proff, 64);
+    if (do_proff) (void)hipMemsetAsync(d_proff, 0, 64, st);
+    const int ntile = (kFrames + kFB - 1) / kFB;
+    int gx = (2 * 256 + nbatch - 1) / nbatch;            // ~2 resident blocks per CU in all, each walking its share of the tiles
+    gx = gx < 1 ? 1 : (gx > ntile ? ntile : gx);
+    hipLaunchKernelGGL(k_logmel_fft, dim3(gx, nbatch), dim3(256), (size_t)kLdsFftBytes + 816 + (size_t)h->mel2_words * 4, st, audio, stride,
+                       lens, h->d_win, h->d_tw200, h->d_tw400, h->d_mel2, h->mel2_words, h->n_mel, raw, gmax,
+                       do_proff ? d_proff : nullptr);
+    if (do_proff) {
+        unsigned long long hp[5];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(hp, d_proff, 40, hipMemcpyDeviceToHost);
+        if (hp[4]) fprintf(stderr, "logmel fft prof: blocks=%llu stage=%llu A=%llu B=%llu mel=%llu cycles/block\n", hp[4], hp[0] / hp[4], hp[1] / hp[4], hp[2] / hp[4], hp[3] / hp[4]);
     }
     IFH_LAUNCH_CHECK("logmel_dft");
     return IFH_OK;
