@@ -201,12 +201,17 @@ def time_steps(pipe, frames_for, nsteps, warmup, world, pipelined, egress, dry, 
         dist.barrier()
     if probe is not None:
         probe.start()
+    from infernos_amd import _lib
+    c0 = _lib.CALLS[0]
+    e0 = (pipe.ctts.calls_run, pipe.ctts.rows_run) if pipe.ctts is not None else None
     t0 = time.perf_counter()
     res = pipe.run_steps(frames_for, nsteps, pipelined=pipelined, on_cycle=egress)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    time_steps.launches_per_step = (_lib.CALLS[0] - c0) / max(1, nsteps)
+    time_steps.engine = None if e0 is None else (pipe.ctts.calls_run - e0[0], pipe.ctts.rows_run - e0[1])
     if probe is not None:
         probe.stop()
     tmax = torch.tensor([dt], dtype=torch.float64, device='cpu' if dry else dev)
@@ -262,6 +267,7 @@ def c5_share(dev, args, build, n_sessions=64, prompt_len=192, first_sentence=16,
            'llm_reply_ms': round(float(pa[:, 2].mean()) * 1e3, 1), 'tts_first_chunk_ms': round(float(pa[:, 3].mean()) * 1e3, 1),
            'llm_decode_tokens_per_s': round(n_sessions * (reply_tokens - first_sentence) / float((pa[:, 2] - pa[:, 1]).mean()), 0),
            'turns': turns}
+    pipe.close()
     del pipe, llm, frames_all
     torch.cuda.empty_cache()
     return res
@@ -278,14 +284,17 @@ def main():
     ap.add_argument('--no-extra-configs', action='store_true', help='skip the short C2 / C4-share runs after the main one')
     ap.add_argument('--no-tick-probe', action='store_true', help='do not run the per-tick latency thread inside the timed region')
     ap.add_argument('--breakdown', action='store_true', help='print per-stage wall times to stderr')
-    ap.add_argument('--tts-lanes', type=int, default=4, help='TTS engine instances whose utterance batches may be in flight together')
-    ap.add_argument('--front-lanes', type=int, default=3, help='ingest+STT lanes (cycles k, k+1, k+2 in flight together; 3 since the '
-                    'STT decode is the 5-beam search: 2 -> 3 lanes = +7 %, 4 lanes lose 9 %)')
+    ap.add_argument('--tts-mode', choices=['continuous', 'lanes'], default='continuous',
+                    help='continuous: ONE ragged TTS decode batch over every utterance batch in flight (rows at different decoder '
+                         'positions, joined at infer() boundaries); lanes: one engine clone and launch chain per batch (round 2)')
+    ap.add_argument('--tts-lanes', type=int, default=4, help='utterance batches that may be in flight in the TTS stage together')
+    ap.add_argument('--front-lanes', type=int, default=3, help='ingest+STT lanes (cycles k, k+1, k+2 in flight together)')
     ap.add_argument('--tts-group', type=int, default=1, help='utterance cycles of the SAME calls synthesised as one TTS batch '
                     '(> 1 is an offline-throughput mode: a live call cannot have utterance k+1 before k has been spoken)')
     ap.add_argument('--no-tts-overlap', action='store_true', help='render on the lane stream instead of a second stream per lane')
-    ap.add_argument('--stt-beam', type=int, default=5, help='Whisper decode: 5 = the reference default engine\'s beam search '
-                    '(ctranslate2 defaults, InfernSTTWorker.py:61-75); 1 = greedy (its torch engine)')
+    ap.add_argument('--stt-beam', type=int, default=5, help='Whisper decode: 5 = beam search at the width of the reference default '
+                    'engine (ctranslate2 defaults, InfernSTTWorker.py:61-75; transformers formulation of the search, ctranslate2 '
+                    'parity unpinned); 1 = greedy (its torch engine)')
     ap.add_argument('--c5-only', action='store_true', help='run only the configuration-5 per-GPU share (STT -> LLM -> TTS turn latency) and print it')
     ap.add_argument('--c5-sessions', type=int, default=64)
     ap.add_argument('--c5-llm', default='qwen2_1p5b', help='infernos_amd.weights.QWEN2_CONFIGS entry (random weights of that shape)')
@@ -329,10 +338,11 @@ def main():
     def enc(x):
         return np.frombuffer(codec.encode(torch.from_numpy(x)), dtype=np.uint8).reshape(x.shape)
 
-    def build(cfg, n_local):
+    def build(cfg, n_local, beam=None):
         _, family, _ = CONFIGS[cfg]
         pipe = SpeechPipeline(n_local, dev, whisper_family=family, tts_lanes=args.tts_lanes, tts_overlap=not args.no_tts_overlap,
-                              tts_group=args.tts_group, front_lanes=args.front_lanes, stt_beam=args.stt_beam)
+                              tts_group=args.tts_group, front_lanes=args.front_lanes, stt_beam=args.stt_beam if beam is None else beam,
+                              tts_mode=args.tts_mode)
         n_total = n_local * world
         # every rank builds its own rows for the N=1 path; with N>1 rank 0 holds all rows and scatters
         if world == 1:
@@ -373,20 +383,31 @@ def main():
     dt, res = time_steps(pipe, frames_for, args.steps, args.warmup, world, not args.no_pipeline, egress, dry, dev, probe)
     ms_per_step = dt / args.steps * 1e3
     value = n_total * UTT_SECONDS / (dt / args.steps)
+    launches_per_cycle, engine = time_steps.launches_per_step, time_steps.engine
+    # strictly sequential stage times of one cycle (ingest / STT / TTS one after another on an otherwise idle GPU): their sum
+    # against ms_per_step says what the stage pipelining + continuous batching buy
+    stage_ms = None
+    if rank == 0 and world == 1:
+        pipe.reset_calls()
+        fr = frames_for(0)
+        ts = []
+        for _ in range(2):
+            pipe.reset_calls()
+            torch.cuda.synchronize(); a = time.perf_counter()
+            ch = pipe.ingest(fr); torch.cuda.synchronize(); b = time.perf_counter()
+            pipe.stt(ch); torch.cuda.synchronize(); c = time.perf_counter()
+            pipe.synthesize(); torch.cuda.synchronize(); d = time.perf_counter()
+            ts.append(((b - a) * 1e3, (c - b) * 1e3, (d - c) * 1e3))
+        stage_ms = {'ingest': round(ts[-1][0], 2), 'stt': round(ts[-1][1], 2), 'tts': round(ts[-1][2], 2),
+                    'sum': round(sum(ts[-1]), 2)}
 
     if args.breakdown and rank == 0 and getattr(pipe, 'stage_wall', None):
         sw = pipe.stage_wall
         print('pipelined job wall ms: front %.1f (n=%d)  tts %.1f (n=%d)' % (
             1e3 * sum(sw['front']) / max(1, len(sw['front'])), len(sw['front']),
             1e3 * sum(sw['tts']) / max(1, len(sw['tts'])), len(sw['tts'])), file=sys.stderr)
-    if args.breakdown and rank == 0 and world == 1:
-        pipe.reset_calls()
-        fr = frames_for(0)
-        torch.cuda.synchronize(); a = time.perf_counter()
-        ch = pipe.ingest(fr); torch.cuda.synchronize(); b = time.perf_counter()
-        pipe.stt(ch); torch.cuda.synchronize(); c = time.perf_counter()
-        pipe.synthesize(); torch.cuda.synchronize(); d = time.perf_counter()
-        print('breakdown ms: ingest %.1f stt %.1f tts %.1f' % ((b - a) * 1e3, (c - b) * 1e3, (d - c) * 1e3), file=sys.stderr)
+    if args.breakdown and rank == 0 and stage_ms:
+        print('sequential stage ms: %r' % (stage_ms,), file=sys.stderr)
     out = None
     if rank == 0:
         # ---- stage timings + rooflines (HIP events on the launch stream = torch's current stream)
@@ -398,7 +419,12 @@ def main():
                 fn()
             e1.record(); torch.cuda.synchronize()
             return e0.elapsed_time(e1) / n * 1e-3
-        nchunks = 4 * n_local * max(1, args.tts_group)        # the vocoder launch group of the timed region: 4 chunks per TTS row
+        # the vocoder launch group of the timed region: 4 chunks per TTS row of a render pass -- with the continuous engine the
+        # rows of every utterance batch in flight (mean over the timed engine calls, in whole batches)
+        tts_rows = n_local * max(1, args.tts_group)
+        if engine is not None and engine[0]:
+            tts_rows = max(tts_rows, int(round(engine[1] / engine[0] / tts_rows)) * tts_rows)
+        nchunks = 4 * tts_rows
         voc_in = torch.randn(nchunks, 12, 80, device=dev).to(torch.bfloat16)
         t_voc = ev_time(lambda: pipe.tts.vocoder(voc_in), n=5)
         ach_tf = nchunks * VOCODER_GFLOP_PER_CHUNK / t_voc / 1e3
@@ -430,9 +456,15 @@ def main():
                        'batching': 'across calls only (one utterance per call per batch)' if args.tts_group == 1 else
                                    'OFFLINE mode: %d consecutive utterances of the same calls per TTS batch' % args.tts_group,
                        'stage_pipelining': not args.no_pipeline, 'front_lanes': args.front_lanes, 'tts_lanes': args.tts_lanes,
-                       'tts_rows_per_batch': n_local * args.tts_group,
+                       'tts_rows_per_batch': n_local * args.tts_group, 'tts_mode': args.tts_mode,
+                       'tts_rows_per_decode_step': (round(engine[1] / engine[0], 1) if engine is not None and engine[0] else
+                                                    n_local * args.tts_group),
                        'stt_decode': ('beam search, %d beams (%d decode rows), 32 tokens' % (args.stt_beam, n_local * args.stt_beam))
                                      if args.stt_beam > 1 else 'greedy, 32 tokens'},
+            'launches_per_cycle': round(launches_per_cycle, 1),
+            'launches_note': 'calls into stream-taking C-ABI entry points per utterance cycle inside the timed region, hipGraph replays '
+                             'counted by the launches they hold (infernos_amd/_lib.py:CALLS)',
+            'sequential_stage_ms': stage_ms,
             'stt_audio_seconds_per_call': round(float(res['stt_seconds'].mean()), 3),
             'tts_samples_per_call': int(res['tts_samples'].float().mean()),
             'roofline': {'kernel': 'HiFi-GAN vocoder pass (%d chunks x 12 frames per launch group)' % nchunks,
@@ -451,19 +483,27 @@ def main():
                         'p99_tick_latency_ms': round(float(np.percentile(lat, 99)), 4),
                         'tick_latency_note': '%d ticks of [%d,160] paced at 20 ms INSIDE the timed region (H2D -> ingest_tick -> VAD '
                                              'window+decision on %d of them -> mux_encode of real TTS rows -> D2H, host to host), '
-                                             'while the TTS/STT lanes were running' % (len(lat), n_local, probe.windows)})
+                                             'while the TTS/STT lanes were running; the VAD network is a stand-in (ifh_vad_energy_prob: the '
+                                             'Silero v3.1 TorchScript model of Core/VAD/SileroVAD.py:44 is not available offline), so the '
+                                             'per-window model cost of a real detector is NOT in this figure' % (len(lat), n_local, probe.windows)})
     # ---- the other single-GPU configurations, briefly (N = 1 only: extra keys, not the headline)
     if world == 1 and not args.no_extra_configs and not args.calls_per_gpu:
+        pipe.close()
         del pipe, frames_all, probe
         torch.cuda.empty_cache()
         extra = {}
-        for cfg in [c for c in ('C2', 'C4', 'C3') if c != args.config]:
+        runs = [(c, c, None) for c in ('C2', 'C4', 'C3') if c != args.config]
+        if args.stt_beam > 1:            # SURVEY.md 8(d)'s workload as written (greedy, 32 tokens): keeps rounds comparable
+            runs.append((args.config + '_greedy', args.config, 1))
+        for name, cfg, beam in runs:
             n2 = CONFIGS[cfg][0]
-            p2, fa2, ff2, eg2, _ = build(cfg, n2)
+            p2, fa2, ff2, eg2, _ = build(cfg, n2, beam=beam)
             k2 = max(4, min(args.steps, 12))
             dt2, _ = time_steps(p2, ff2, k2, 2, 1, not args.no_pipeline, eg2, dry, dev)
-            extra[cfg] = {'workload': CONFIGS[cfg][2] % n2, 'value': round(n2 * UTT_SECONDS / (dt2 / k2), 2), 'steps': k2,
-                          'ms_per_step': round(dt2 / k2 * 1e3, 2), 'tts_rows_per_batch': n2 * args.tts_group}
+            extra[name] = {'workload': CONFIGS[cfg][2] % n2, 'value': round(n2 * UTT_SECONDS / (dt2 / k2), 2), 'steps': k2,
+                           'ms_per_step': round(dt2 / k2 * 1e3, 2), 'tts_rows_per_batch': n2 * args.tts_group,
+                           'stt_decode': 'greedy' if (beam or args.stt_beam) == 1 else '%d beams' % (beam or args.stt_beam)}
+            p2.close()
             del p2, fa2
             torch.cuda.empty_cache()
         try:
@@ -471,6 +511,8 @@ def main():
         except Exception as e:                             # the LLM leg is a "next" row: never take the headline line down
             extra['C5_share'] = {'error': repr(e)}
         out['other_configs'] = extra
+    elif rank == 0:
+        pipe.close()
     if rank == 0:
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(CONFIGS[args.config][1], beams=args.stt_beam)

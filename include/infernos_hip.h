@@ -335,6 +335,10 @@ typedef struct ifh_conv_desc {
     float ln_eps;
     int32_t ln_rms;        /* 1: the folded normalisation is an RMSNorm -- aln: out = rsqrt(mean(x^2) + eps) * acc (aln_c1 unused);
                             * stats_out as for LayerNorm (only the sum of squares is consumed) */
+    int32_t dyn_stride;    /* 0: dyn_pos is one scalar for the launch.  1: one value per output row m = b*t_out + t
+                            * (dyn_pos[m]): rows of a ragged decode batch sit at different positions -- each appends its K|V
+                            * at its own cache row and adds its own positional-encoding row (continuous batching of the
+                            * loop at HelloSippyRTPipe.py:195-229 across utterances that joined at different infer() calls) */
 } ifh_conv_desc;
 int ifh_conv_bf16(const ifh_conv_desc *desc, ifh_stream_t stream);
 
@@ -432,7 +436,8 @@ typedef struct ifh_attn_desc {
     int32_t nrel;
 } ifh_attn_desc;
 int ifh_attn_prefill_bf16(const ifh_attn_desc *desc, ifh_stream_t stream);
-/* one query token per (batch, head) against a KV cache.  Number of keys: key_len[b] if given, else
+/* one query token per (batch, head) against a KV cache.  Number of keys: key_len[b] + dyn_add if key_len is given
+ * (per-row device counts: padded encoder lengths, or the rows' own decoder positions in a ragged batch), else
  * dyn_len[0] + dyn_add if dyn_len (device scalar; lets a captured graph be replayed per step), else
  * max_keys (which must bound the key count in every case). */
 int ifh_attn_decode_bf16(const void *q, int64_t q_bs, const void *k, const void *v, int64_t kv_bs, int64_t kv_ts,
@@ -507,7 +512,7 @@ int ifh_add_i32(int32_t *value, int delta, void *zero_buf, int64_t zero_bytes, i
  * do_sample (Qwen2.5-Instruct: repetition_penalty 1.05, temperature 0.7, top_k 20, top_p 0.8), i.e. the reference's
  * InfernLLMWorker.py:113-118 call with no sampling arguments (generation/logits_process.py order). ---- */
 /* logits[r, t] = l < 0 ? l * penalty : l / penalty for every token t in history[r, 0 .. lens[r]) (each token once);
- * history int32 [nrows, hist_ld], at most 8192 tokens per row are considered */
+ * history int32 [nrows, hist_ld], any length; vocab <= 262144 (one presence bit per entry in LDS) */
 int ifh_repetition_penalty_f32(float *logits, int64_t ld, int vocab, int nrows, const int32_t *history, int64_t hist_ld,
                                const int32_t *lens, float penalty, ifh_stream_t stream);
 /* per row: logits / temperature, the top_k (<= 32; 0 = 32) best (ties to the lower token id), top-p on their softmax
@@ -567,6 +572,23 @@ int ifh_tts_stop_update(const float *prob_logits, int64_t *ends_at, int n, int i
 int ifh_tts_stop_advance(const float *prob_logits, int64_t *ends_at, int n, int minlen, int maxlen, float threshold,
                          int ends_inc, int32_t *pos, int logits_ld, void *zero_buf, int64_t zero_bytes,
                          const int32_t *dyn_minmax, ifh_stream_t stream);
+/* ---- the same loop over a RAGGED batch: rows joined at different infer() calls and sit at different decoder
+ * positions (continuous batching; engines/speecht5.py:TTSRaggedState).  pos int32[n] per-row position (= the
+ * reference's idx), active uint8[n] (0: the slot holds no live utterance -- its position and ends_at stay frozen),
+ * minmax int32[n][2] per-row {minlen, maxlen}. */
+/* stop rule (:227-228) per row at idx = pos[b], then pos[b] += 1, for rows with active[b] != 0; clears zero_bytes
+ * at zero_buf (the next step's LayerNorm statistics) */
+int ifh_tts_stop_advance_rows(const float *prob_logits, int64_t *ends_at, int n, float threshold, int ends_inc,
+                              int32_t *pos, const uint8_t *active, const int32_t *minmax, int logits_ld, void *zero_buf,
+                              int64_t zero_bytes, ifh_stream_t stream);
+/* frame 0 of this call's frame buffer = the last frame of the previous call (:217 `spectrum[:, -1:, :]` feeding the
+ * next prenet), or zeros for a row that starts now (pos[b] == 0: `output_sequence = zeros`, :119).  prev, cur bf16
+ * [n][frames][80]; copies prev[b][frames-1] -> cur[b][0] */
+int ifh_tts_carry_rows_bf16(const void *prev, void *cur, const int32_t *pos, int n, int frames, ifh_stream_t stream);
+/* ifh_tts_chunks_bf16 where rows with fresh[b] != 0 take zeros as their carried frames (`pre_frames = zeros[B,4,80]`,
+ * :78) instead of what the slot's previous occupant left; fresh may be NULL */
+int ifh_tts_chunks_rows_bf16(void *pre_frames, const void *post, const float *mean, const float *scale, void *voc_in,
+                             void *amd_mel, const uint8_t *fresh, int nbatch, ifh_stream_t stream);
 /* carry + 4 overlapped 12-frame chunks (:231-235): pre_frames bf16 [B][4][80] (updated), post bf16
  * [B][32][80] -> voc_in bf16 [4B][12][80] normalised by (x-mean)/scale, amd_mel bf16 [4B][12][80] =
  * channels-last form of the chunk re-viewed as [80][12] (HelloSippyRT.py:224) */

@@ -73,7 +73,8 @@ class ConvDesc(ctypes.Structure):
                 ('n_split', ctypes.c_int32), ('out2', _vp), ('out2_bstride', _i64), ('ldc2', ctypes.c_int32),
                 ('ooff2', ctypes.c_int32), ('dyn_ooff2_mul', ctypes.c_int32),
                 ('aln_stats', _vp), ('aln_c1', _vp), ('rln_stats', _vp), ('rln_gamma', _vp), ('rln_beta', _vp),
-                ('stats_out', _vp), ('ln_dim', ctypes.c_int32), ('ln_eps', _f), ('ln_rms', ctypes.c_int32)]
+                ('stats_out', _vp), ('ln_dim', ctypes.c_int32), ('ln_eps', _f), ('ln_rms', ctypes.c_int32),
+                ('dyn_stride', ctypes.c_int32)]
 
 
 class ResblockDesc(ctypes.Structure):
@@ -171,6 +172,9 @@ SIGNATURES.update({
     'ifh_tts_stop_update': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp]),
     'ifh_tts_stop_advance': (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp, _i64, _vp, _vp]),
     'ifh_tts_chunks_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    'ifh_tts_chunks_rows_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    'ifh_tts_stop_advance_rows': (_i, [_vp, _vp, _i, _f, _i, _vp, _vp, _vp, _i, _vp, _i64, _vp]),
+    'ifh_tts_carry_rows_bf16': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'ifh_hifigan_post_bf16': (_i, [_vp, _vp, _f, _vp, _i, _i, _f, _vp]),
     'ifh_amend_final_bf16': (_i, [_vp, _vp, _vp, _i, _vp]),
     'ifh_l2norm_rows_bf16': (_i, [_vp, _i, _i, _vp, _i, _vp]),
@@ -178,6 +182,38 @@ SIGNATURES.update({
 
 _lib = None
 _lock = threading.Lock()
+# Statistic: calls into stream-taking entry points (~ kernel launches issued through the C ABI), including those replayed from
+# captured hipGraphs (CountedGraph); bench.py reports it per utterance cycle.
+CALLS = [0]
+_HOST_ONLY = ('ifh_g711_tables_host',)
+
+
+def _counted(fn):
+    def call(*a):
+        CALLS[0] += 1
+        return fn(*a)
+    call.__name__ = getattr(fn, '__name__', 'ifh')
+    return call
+
+
+class CountedGraph:
+    """hipGraph of the launches `fn` issues on the current stream (thread-local capture), remembering how many C-ABI calls
+    it holds so that replays keep the CALLS statistic meaningful."""
+
+    def __init__(self, fn):
+        import torch
+        torch.cuda.synchronize()
+        self.g = torch.cuda.CUDAGraph()
+        c0 = CALLS[0]
+        with torch.cuda.graph(self.g, capture_error_mode='thread_local'):          # records the launches; nothing executes until replay
+            fn()
+        self.n = CALLS[0] - c0
+        CALLS[0] = c0
+
+    def replay(self):
+        self.g.replay()
+        CALLS[0] += self.n
+
 
 
 class InfernosHipError(RuntimeError):
@@ -203,6 +239,8 @@ def lib():
                     fn = getattr(L, name)
                     fn.restype = res
                     fn.argtypes = args
+                    if args and args[-1] is _vp and name not in _HOST_ONLY:     # stream-taking entry points launch kernels
+                        setattr(L, name, _counted(fn))
                 _lib = L
     return _lib
 

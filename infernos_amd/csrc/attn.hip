@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_decode(const uint16_t *__restr
     const int b = blockIdx.y, h = blockIdx.x;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 7, g = lane >> 3;
-    int klen = key_len ? key_len[b] : (dyn_len ? dyn_len[0] + dyn_add : S);
+    int klen = key_len ? key_len[b] + dyn_add : (dyn_len ? dyn_len[0] + dyn_add : S);
     float qv[8];
     {
         const uint4 t = *reinterpret_cast<const uint4 *>(q + (int64_t)b * q_bs + h * HD + 8 * c);

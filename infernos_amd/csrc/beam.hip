@@ -1,6 +1,7 @@
-// Beam search over the per-token decode step: the search CTranslate2's Whisper.generate runs by default for
-// InfernSTTWorker.infer_and_decode_ct2 (Cluster/InfernSTTWorker.py:61-75; beam_size 5, length_penalty 1).  The
-// bookkeeping is the formulation the parity fixtures pin (include/infernos_hip.h: ifh_beam_desc): 2K candidates per batch
+// Beam search over the per-token decode step, at the width and length penalty CTranslate2's Whisper.generate uses by default
+// for InfernSTTWorker.infer_and_decode_ct2 (Cluster/InfernSTTWorker.py:61-75; beam_size 5, length_penalty 1).  The
+// bookkeeping is transformers' GenerationMixin._beam_search -- NOT CTranslate2's own termination rule, which is absent from
+// the image and unpinned -- the formulation the parity fixtures pin (include/infernos_hip.h: ifh_beam_desc): 2K candidates per batch
 // item per step, the best K that did not just end keep running, candidates ranked inside the first K that end
 // (eos or length) compete with the K finished hypotheses kept so far on sum(log p) / length ** length_penalty, and
 // a batch item stops improving once its best running beam cannot beat its worst finished one.
@@ -243,27 +244,30 @@ __global__ __launch_bounds__(256) void k_beam_rowtop(const float *__restrict__ l
 // ---- sampling (transformers' generate with do_sample: RepetitionPenaltyLogitsProcessor, then TemperatureLogitsWarper,
 // TopKLogitsWarper, TopPLogitsWarper, softmax, one draw; generation/logits_process.py) ----
 constexpr int SAMPLE_SLOTS = 32;       // top_k <= 32
-constexpr int REP_HIST = 8192;
+constexpr int REP_VOCAB_MAX = 262144;   // one presence bit per vocabulary entry in LDS (32 KB)
 
-// logits[row, t] = l < 0 ? l * penalty : l / penalty for every token t of the row's history (each token once however
-// often it occurs: all reads of a row precede its writes)
+// logits[row, t] = l < 0 ? l * penalty : l / penalty for every token t of the row's history, each token once however
+// often it occurs and however long the history is: a presence bitmap over the vocabulary lives in LDS, and the thread
+// whose atomicOr sets a token's bit is the only one that rewrites that logit.
 __global__ __launch_bounds__(256) void k_rep_penalty(float *__restrict__ logits, int64_t ld, int V,
                                                      const int32_t *__restrict__ hist, int64_t hist_ld,
                                                      const int32_t *__restrict__ lens, float penalty)
 {
-    __shared__ float val[REP_HIST];
+    __shared__ uint32_t seen[REP_VOCAB_MAX / 32];
     const int row = blockIdx.x;
     float *x = logits + (int64_t)row * ld;
     const int32_t *h = hist + (int64_t)row * hist_ld;
-    const int n = min(lens[row], REP_HIST);
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int t = h[i];
-        val[i] = (t >= 0 && t < V) ? x[t] : 0.0f;
-    }
+    const int n = lens[row];
+    const int words = (V + 31) / 32;
+    for (int i = threadIdx.x; i < words; i += 256) seen[i] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < n; i += 256) {
         const int t = h[i];
-        if (t >= 0 && t < V) x[t] = val[i] < 0.0f ? val[i] * penalty : val[i] / penalty;
+        if (t < 0 || t >= V) continue;
+        const uint32_t bit = 1u << (t & 31);
+        if (atomicOr(&seen[t >> 5], bit) & bit) continue;       // another occurrence already owns this token
+        const float v = x[t];
+        x[t] = v < 0.0f ? v * penalty : v / penalty;
     }
 }
 
@@ -541,6 +545,7 @@ extern "C" int ifh_repetition_penalty_f32(float *logits, int64_t ld, int vocab, 
     IFH_CHECK_ARG(nrows >= 0);
     if (nrows == 0 || penalty == 1.0f) return IFH_OK;
     IFH_CHECK_ARG(logits && history && lens && vocab > 0 && ld >= vocab && penalty > 0.0f && hist_ld > 0);
+    IFH_CHECK_ARG(vocab <= REP_VOCAB_MAX);
     hipLaunchKernelGGL(k_rep_penalty, dim3(nrows), dim3(256), 0, as_stream(stream), logits, ld, vocab, history, hist_ld, lens,
                        penalty);
     IFH_LAUNCH_CHECK("rep_penalty");

@@ -466,26 +466,21 @@ static int launch_chain(ChainParams &p, hipStream_t st)
     if (HC == 0 && p.T > R) return fail(IFH_EINVAL, "resblock_chain: whole-sequence tile, t too large");
     const int ksteps = 6 * TAPS * (C / 32);
     if (p.nunits != (ksteps + UK - 1) / UK) return fail(IFH_EINVAL, "resblock_chain: weight stream length does not match c/taps");
-    static unsigned long long attr_mask = 0;
+    static DeviceOnce attr_once;
     int attr_dev = 0;
-    if (attr_needed_on_this_device(attr_mask, &attr_dev)) {
+    if (attr_once.needed(&attr_dev)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_resblock_chain<C, TAPS, WGM, WGN, MT, NT, HC, NRING, GX, false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess)
             e = hipFuncSetAttribute((const void *)k_resblock_chain<C, TAPS, WGM, WGN, MT, NT, HC, NRING, GX, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return check_hip(e, "resblock_chain lds attr");
-        attr_mask |= 1ull << attr_dev;
+        attr_once.done(attr_dev);
     }
     p.tiles_per_seq = (p.T + R - 1) / R;
     p.ntiles = p.tiles_per_seq * p.nbatch;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(IFH_EHIP, "resblock_chain: device query");
-        ncu = prop.multiProcessorCount;
-    }
+    const int ncu = device_cu_count();
+    if (ncu <= 0) return fail(IFH_EHIP, "resblock_chain: device query");
     const int grid = p.ntiles < ncu ? p.ntiles : ncu;
     if (p.prof)
         hipLaunchKernelGGL((k_resblock_chain<C, TAPS, WGM, WGN, MT, NT, HC, NRING, GX, true>), dim3(grid), dim3(512), bytes, st, p);
@@ -775,20 +770,15 @@ extern "C" int ifh_conv_ring256_bf16(const ifh_ring256_desc *d, ifh_stream_t str
     p.out_bstride = d->out_bstride;
     constexpr size_t bytes = (size_t)(128 + 50) * 544 + 4 * 16384 + 256 * sizeof(float);
     static_assert(bytes <= 160 * 1024, "ring256 tile");
-    static unsigned long long attr_mask = 0;
+    static DeviceOnce attr_once;
     int attr_dev = 0;
-    if (attr_needed_on_this_device(attr_mask, &attr_dev)) {
+    if (attr_once.needed(&attr_dev)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_conv_ring256, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return check_hip(e, "conv_ring256 lds attr");
-        attr_mask |= 1ull << attr_dev;
+        attr_once.done(attr_dev);
     }
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return fail(IFH_EHIP, "conv_ring256: device query");
-        ncu = prop.multiProcessorCount;
-    }
+    const int ncu = device_cu_count();
+    if (ncu <= 0) return fail(IFH_EHIP, "conv_ring256: device query");
     const int npairs = (d->nbatch + 1) / 2;
     hipLaunchKernelGGL(k_conv_ring256, dim3(npairs < ncu ? npairs : ncu), dim3(512), bytes, as_stream(stream), p);
     IFH_LAUNCH_CHECK("conv_ring256_bf16");

@@ -1,6 +1,8 @@
 // common.h -- shared helpers for the gfx950 kernels of libinfernos_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 #include <string>
 
@@ -26,13 +28,38 @@ int check_hip(hipError_t e, const char *what);
 static inline hipStream_t as_stream(ifh_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // hipFuncSetAttribute acts on the CURRENT device: a process that drives several GPUs (one worker thread per device behind the
-// actors) must set a kernel's dynamic-LDS limit once per device, not once per process.  `mask` is a per-call-site static.
-static inline bool attr_needed_on_this_device(unsigned long long &mask, int *dev_out)
+// actors) must set a kernel's dynamic-LDS limit once per device, not once per process.  One DeviceOnce per call site (a
+// function-local static); worker threads of different devices may pass through it concurrently, hence the atomic mask.  A
+// device whose index cannot be read, or above 63, is never marked: its attribute is simply set again on every call.
+struct DeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    bool needed(int *dev_out)
+    {
+        int dev = -1;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = -1;
+        *dev_out = dev;
+        return dev < 0 || !((mask.load(std::memory_order_acquire) >> dev) & 1ull);
+    }
+    void done(int dev)
+    {
+        if (dev >= 0) mask.fetch_or(1ull << dev, std::memory_order_release);
+    }
+};
+
+// compute units of the CURRENT device (cached per device index)
+static inline int device_cu_count()
 {
+    static std::atomic<int> cache[64];
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 0;
-    *dev_out = dev;
-    return !((mask >> dev) & 1ull);
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64) {
+        const int c = cache[dev].load(std::memory_order_relaxed);
+        if (c > 0) return c;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    if (dev >= 0 && dev < 64) cache[dev].store(prop.multiProcessorCount, std::memory_order_relaxed);
+    return prop.multiProcessorCount;
 }
 
 constexpr int kWave = 64;

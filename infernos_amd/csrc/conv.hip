@@ -219,13 +219,13 @@ static bool launch_direct(const IgemmParams &p, hipStream_t st)
     static_assert(EPB == 1 || BM * (BN + 8) <= BM * XS, "the store16 staging of a group lies inside its own input tile");
     const size_t bytes = ((size_t)EPB * ((R * XS + 7) & ~7) + (size_t)BN * (KW + 8)) * sizeof(uint16_t);
     if (bytes > 160 * 1024) return false;
-    static unsigned long long attr_mask = 0;
+    static DeviceOnce attr_once;
     int attr_dev = 0;
-    if (bytes > 64 * 1024 && attr_needed_on_this_device(attr_mask, &attr_dev)) {
+    if (bytes > 64 * 1024 && attr_once.needed(&attr_dev)) {
         if (hipFuncSetAttribute((const void *)k_conv_direct<CIN, WGM, MT, NT, RESIDENT, KC, EPB>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
             return false;
-        attr_mask |= 1ull << attr_dev;
+        attr_once.done(attr_dev);
     }
     dim3 grid((p.T_out + BM - 1) / BM, (p.nbatch + EPB - 1) / EPB);
     hipLaunchKernelGGL((k_conv_direct<CIN, WGM, MT, NT, RESIDENT, KC, EPB>), grid, dim3(256 * EPB), bytes, st, p);
@@ -235,6 +235,7 @@ static bool launch_direct(const IgemmParams &p, hipStream_t st)
 bool try_launch_conv_direct(const IgemmParams &p_, bool pre, hipStream_t st)
 {
     IgemmParams p = p_;
+    if (p.dyn && p.dyn_stride != 0) return false;          // per-row dynamic offsets: the generic kernels (nn.hip)
     static const bool no16 = getenv("IFH_CONV_NO_STORE16") != nullptr;      // tuning switch
     p.store16 = !no16 && !p.out_f32 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && p.ldc % 8 == 0 &&
                 p.out_bstride % 8 == 0 && ((int64_t)p.ooff * p.ldc) % 8 == 0 && ((int64_t)p.ostride * p.ldc) % 8 == 0 &&

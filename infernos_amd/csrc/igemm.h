@@ -39,7 +39,8 @@ struct IgemmParams {
     void *out2;
     int64_t out2_bstride;
     int ldc2, ooff2, dyn_ooff2_mul;
-    const int32_t *dyn;       // optional device scalar (e.g. decoder position)
+    const int32_t *dyn;       // optional device scalar (e.g. decoder position), or one value per output row (dyn_stride = 1)
+    int dyn_stride;           // value for output row m = dyn[m * dyn_stride]
     int dyn_ooff_mul;         // ooff += dyn[0] * dyn_ooff_mul
     int64_t dyn_resid_mul;    // resid += dyn[0] * dyn_resid_mul (elements)
     // LayerNorm folded around a skinny GEMM (decode steps; see ifh_conv_desc):
@@ -87,6 +88,11 @@ __device__ __forceinline__ uint4 lrelu8(uint4 v, float slope)
 // unrolling those loops and put the accumulator tiles in scratch memory (2x slower kernels).
 // The general form (ragged N, unaligned pointers, ...) lives in separate kernel instantiations
 // (template parameter FAST = false), chosen by the host when p.fast_epi == 0.
+__device__ __forceinline__ int dyn_value(const IgemmParams &p, int m)
+{
+    return p.dyn ? p.dyn[(int64_t)m * p.dyn_stride] : 0;
+}
+
 struct EpiRow {
     int64_t obase, rbase;
     void *outp;

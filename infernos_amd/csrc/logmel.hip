@@ -609,12 +609,12 @@ static int logmel_transform(ifh_logmel_t h, const float *audio, int64_t stride, 
 {
     hipError_t e = hipMemsetD32Async((hipDeviceptr_t)gmax, (int)0x80000000, (size_t)nbatch, st);
     if (e != hipSuccess) return check_hip(e, "logmel memset");
-    static unsigned long long attr_mask = 0;
+    static DeviceOnce attr_once;
     int attr_dev = 0;
-    if (attr_needed_on_this_device(attr_mask, &attr_dev)) {
+    if (attr_once.needed(&attr_dev)) {
         e = hipFuncSetAttribute((const void *)k_logmel_fft, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsFftBytes + 8192);
         if (e != hipSuccess) return check_hip(e, "logmel set lds attr");
-        attr_mask |= 1ull << attr_dev;
+        attr_once.done(attr_dev);
     }
     static unsigned long long *d_proff = nullptr;
     static const bool do_proff = getenv("IFH_LOGMEL_PROF") != nullptr;      // diagnostic: phase clocks of the kernel to stderr

@@ -151,18 +151,51 @@ __global__ __launch_bounds__(256) void k_tts_stop_advance(const float *__restric
     if (threadIdx.x == 0) pos[0] = idx + 1;
 }
 
+// the stop rule over a ragged batch: every row has its own position, lengths and liveness (continuous batching)
+__global__ __launch_bounds__(256) void k_tts_stop_advance_rows(const float *__restrict__ logits, int64_t *__restrict__ ends_at,
+                                                              int n, float thr, int ends_inc, int32_t *__restrict__ pos,
+                                                              const uint8_t *__restrict__ active,
+                                                              const int32_t *__restrict__ minmax, int ld,
+                                                              uint4 *__restrict__ zbuf, int nz16)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    for (int i = tid; i < nz16; i += nt) zbuf[i] = make_uint4(0, 0, 0, 0);      // next step's LN statistics
+    for (int b = tid; b < n; b += nt) {
+        if (!active[b]) continue;
+        const int idx = pos[b], minlen = minmax[2 * b], maxlen = minmax[2 * b + 1];
+        const float p0 = 1.0f / (1.0f + expf(-logits[ld * b])), p1 = 1.0f / (1.0f + expf(-logits[ld * b + 1]));
+        const bool hit = (ends_at[b] < 0) && (minlen <= idx) && ((p0 >= thr) || (p1 >= thr) || (maxlen <= idx));
+        if (hit) ends_at[b] = idx + ends_inc;
+        pos[b] = idx + 1;
+    }
+}
+
+// frame 0 of the current frame buffer <- last frame of the previous one, zeros for rows that start now (pos == 0)
+__global__ __launch_bounds__(256) void k_tts_carry_rows(const uint16_t *__restrict__ prev, uint16_t *__restrict__ cur,
+                                                        const int32_t *__restrict__ pos, int n, int frames)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // one thread per 8 mel bins: 10 per row
+    if (i >= n * 10) return;
+    const int b = i / 10, c = i - b * 10;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (pos[b] != 0) v = *reinterpret_cast<const uint4 *>(prev + ((int64_t)b * frames + frames - 1) * 80 + 8 * c);
+    *reinterpret_cast<uint4 *>(cur + (int64_t)b * frames * 80 + 8 * c) = v;
+}
+
 // HelloSippyRTPipe.py:231-235: S = cat(pre_frames[B,4,80], post[B,32,80]); pre_frames <- S[:, -4:];
 // chunk i = S[:, 8i:8i+12] stacked chunk-major.  Emits
 //   voc_in  [4B][12][80]  = (chunk - mean)/scale            (SpeechT5HifiGan normalize_before)
 //   amd_mel [4B][12][80]  with amd_mel[n][t][c] = chunk_flat[n][c*12 + t]   (the .view at HelloSippyRT.py:224)
 __global__ __launch_bounds__(256) void k_tts_chunks(uint16_t *__restrict__ pre_frames, const uint16_t *__restrict__ post,
                                                     const float *__restrict__ mean, const float *__restrict__ scale,
-                                                    uint16_t *__restrict__ voc_in, uint16_t *__restrict__ amd_mel, int B)
+                                                    uint16_t *__restrict__ voc_in, uint16_t *__restrict__ amd_mel, int B,
+                                                    const uint8_t *__restrict__ fresh)
 {
     __shared__ uint16_t S[36 * 80];
     const int b = blockIdx.x, tid = threadIdx.x;
+    const bool zero_pre = fresh && fresh[b];            // a row that starts with this call: carried frames are zeros
     for (int i = tid; i < 36 * 80; i += 256)
-        S[i] = (i < 320) ? pre_frames[(int64_t)b * 320 + i] : post[(int64_t)b * 2560 + (i - 320)];
+        S[i] = (i < 320) ? (zero_pre ? (uint16_t)0 : pre_frames[(int64_t)b * 320 + i]) : post[(int64_t)b * 2560 + (i - 320)];
     __syncthreads();
     for (int i = tid; i < 320; i += 256) pre_frames[(int64_t)b * 320 + i] = S[32 * 80 + i];
     for (int i = tid; i < 4 * 960; i += 256) {
@@ -320,15 +353,46 @@ extern "C" int ifh_tts_stop_advance(const float *prob_logits, int64_t *ends_at, 
     return IFH_OK;
 }
 
-extern "C" int ifh_tts_chunks_bf16(void *pre_frames, const void *post, const float *mean, const float *scale,
-                                   void *voc_in, void *amd_mel, int nbatch, ifh_stream_t stream)
+extern "C" int ifh_tts_chunks_rows_bf16(void *pre_frames, const void *post, const float *mean, const float *scale,
+                                        void *voc_in, void *amd_mel, const uint8_t *fresh, int nbatch, ifh_stream_t stream)
 {
     IFH_CHECK_ARG(nbatch >= 0);
     if (nbatch == 0) return IFH_OK;
     IFH_CHECK_ARG(pre_frames && post && mean && scale && voc_in && amd_mel);
     hipLaunchKernelGGL(k_tts_chunks, dim3(nbatch), dim3(256), 0, as_stream(stream), (uint16_t *)pre_frames,
-                       (const uint16_t *)post, mean, scale, (uint16_t *)voc_in, (uint16_t *)amd_mel, nbatch);
+                       (const uint16_t *)post, mean, scale, (uint16_t *)voc_in, (uint16_t *)amd_mel, nbatch, fresh);
     IFH_LAUNCH_CHECK("tts_chunks");
+    return IFH_OK;
+}
+
+extern "C" int ifh_tts_chunks_bf16(void *pre_frames, const void *post, const float *mean, const float *scale,
+                                   void *voc_in, void *amd_mel, int nbatch, ifh_stream_t stream)
+{
+    return ifh_tts_chunks_rows_bf16(pre_frames, post, mean, scale, voc_in, amd_mel, nullptr, nbatch, stream);
+}
+
+extern "C" int ifh_tts_stop_advance_rows(const float *prob_logits, int64_t *ends_at, int n, float threshold, int ends_inc,
+                                         int32_t *pos, const uint8_t *active, const int32_t *minmax, int logits_ld,
+                                         void *zero_buf, int64_t zero_bytes, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(n >= 0 && prob_logits && ends_at && pos && active && minmax && logits_ld >= 2);
+    IFH_CHECK_ARG(zero_bytes >= 0 && zero_bytes % 16 == 0 && zero_bytes < (1ll << 30) && (zero_bytes == 0 || zero_buf));
+    IFH_CHECK_ARG((((uintptr_t)zero_buf) & 15) == 0);
+    // a few blocks: the statistics of a 1024-row step are 300 KB to clear
+    hipLaunchKernelGGL(k_tts_stop_advance_rows, dim3(zero_bytes > 65536 ? 8 : 1), dim3(256), 0, as_stream(stream), prob_logits,
+                       ends_at, n, threshold, ends_inc, pos, active, minmax, logits_ld, (uint4 *)zero_buf, (int)(zero_bytes / 16));
+    IFH_LAUNCH_CHECK("tts_stop_advance_rows");
+    return IFH_OK;
+}
+
+extern "C" int ifh_tts_carry_rows_bf16(const void *prev, void *cur, const int32_t *pos, int n, int frames, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(n >= 0);
+    if (n == 0) return IFH_OK;
+    IFH_CHECK_ARG(prev && cur && pos && frames >= 1 && (((uintptr_t)prev) & 15) == 0 && (((uintptr_t)cur) & 15) == 0);
+    hipLaunchKernelGGL(k_tts_carry_rows, dim3((n * 10 + 255) / 256), dim3(256), 0, as_stream(stream), (const uint16_t *)prev,
+                       (uint16_t *)cur, pos, n, frames);
+    IFH_LAUNCH_CHECK("tts_carry_rows");
     return IFH_OK;
 }
 

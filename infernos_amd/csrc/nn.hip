@@ -25,7 +25,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
 {
     static_assert(MT == 1 || MT == 2, "row tiles per block");
     static_assert(NT == 1 || (NT == 2 && MT == 2), "column tiles per block");
-    static_assert(MT * NT <= NW, "wave t stores output tile t (row tile t % MT, column tile t / MT)");
+    // output tile t (row tile t % MT, column tile t / MT) is finished by wave t % NW: TPW tiles per wave.  With NW = 2 and
+    // four tiles (the 32 x 32 block of a big grid) a wave finishes two -- the K split stays 2-way, so the bits of a row do
+    // not depend on how many rows the launch has (a row of a 640-row ragged decode batch == the same row in a 64-row batch)
+    constexpr int TPW = (MT * NT + NW - 1) / NW;
     __shared__ __attribute__((aligned(16))) float red[NW][MT * NT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -51,36 +54,46 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
         const int bb1 = mm1 / p.T_out, tt1 = mm1 - bb1 * p.T_out;
         xrow1 = p.x + (int64_t)bb1 * p.x_bstride + (int64_t)tt1 * p.lda + fg * 8;
     }
-    // the epilogue of output tile t (row tile t % MT, column tile t / MT) belongs to wave t
-    const bool owner = wid < MT * NT;
-    const int m = m0 + 16 * (owner ? wid % MT : 0) + fr;
-    const int nb = n0 + 16 * (owner ? wid / MT : 0);          // first column of this wave's tile
-    const bool xok = owner && m < M;
     // LayerNorm folding (ifh_conv_desc.aln_* / rln_*): row statistics are two 64-bit fixed-point sums per row
     // ([rows][2] int64, scale 2^16) that producers build with integer atomics -- integer addition commutes,
     // so unlike float atomics the result is bit-reproducible.  One 16-byte load per lane, issued before the
     // weight stream and consumed in the epilogue.
-    longlong2 st_a = make_longlong2(0, 0), st_r = make_longlong2(0, 0);
-    if (xok) {
-        if (p.aln_stats) st_a = reinterpret_cast<const longlong2 *>(p.aln_stats)[m];
-        if (p.rln_stats) st_r = reinterpret_cast<const longlong2 *>(p.rln_stats)[m];
-    }
-    // Epilogue operands of the LN mode are requested here as well (wave 0, ahead of the weight stream): the
+    // Epilogue operands of the LN mode are requested here as well (ahead of the weight stream): the
     // decoder step is a chain of ~50 of these launches, each only a few microseconds long, and a second
     // dependent round trip after the K loop is a visible fraction of it.
     const bool ln_mode = p.aln_stats || p.rln_stats || p.stats_out;
-    float4 pc1 = make_float4(0.f, 0.f, 0.f, 0.f), pbias = pc1, pgam = pc1, pbeta = pc1;
-    uint2 presid = make_uint2(0, 0);
-    const int dynv0 = p.dyn ? p.dyn[0] : 0;
-    if (ln_mode && xok && nb + 4 * fg < p.N) {
-        const int n = nb + 4 * fg;
-        if (p.aln_stats && !p.ln_rms) pc1 = *reinterpret_cast<const float4 *>(p.aln_c1 + n);
-        if (p.bias) pbias = *reinterpret_cast<const float4 *>(p.bias + n);
-        if (p.resid) {
-            presid = *reinterpret_cast<const uint2 *>(p.resid + epi_row(p, m, n, dynv0).rbase + n);
-            if (p.rln_stats) {
-                pgam = *reinterpret_cast<const float4 *>(p.rln_gamma + n);
-                pbeta = *reinterpret_cast<const float4 *>(p.rln_beta + n);
+    int em[TPW], enb[TPW], edyn[TPW];
+    bool eown[TPW], exok[TPW];
+    longlong2 st_a[TPW], st_r[TPW];
+    float4 pc1[TPW], pbias[TPW], pgam[TPW], pbeta[TPW];
+    uint2 presid[TPW];
+#pragma unroll
+    for (int e = 0; e < TPW; e++) {
+        const int t = wid + e * NW;
+        eown[e] = t < MT * NT;
+        em[e] = m0 + 16 * (eown[e] ? t % MT : 0) + fr;
+        enb[e] = n0 + 16 * (eown[e] ? t / MT : 0);            // first column of this tile
+        exok[e] = eown[e] && em[e] < M;
+        edyn[e] = dyn_value(p, exok[e] ? em[e] : 0);          // per output row when dyn_stride = 1 (ragged decode positions)
+        st_a[e] = make_longlong2(0, 0);
+        st_r[e] = make_longlong2(0, 0);
+        pc1[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pbias[e] = pc1[e]; pgam[e] = pc1[e]; pbeta[e] = pc1[e];
+        presid[e] = make_uint2(0, 0);
+        if (exok[e]) {
+            if (p.aln_stats) st_a[e] = reinterpret_cast<const longlong2 *>(p.aln_stats)[em[e]];
+            if (p.rln_stats) st_r[e] = reinterpret_cast<const longlong2 *>(p.rln_stats)[em[e]];
+        }
+        if (ln_mode && exok[e] && enb[e] + 4 * fg < p.N) {
+            const int n = enb[e] + 4 * fg;
+            if (p.aln_stats && !p.ln_rms) pc1[e] = *reinterpret_cast<const float4 *>(p.aln_c1 + n);
+            if (p.bias) pbias[e] = *reinterpret_cast<const float4 *>(p.bias + n);
+            if (p.resid) {
+                presid[e] = *reinterpret_cast<const uint2 *>(p.resid + epi_row(p, em[e], n, edyn[e]).rbase + n);
+                if (p.rln_stats) {
+                    pgam[e] = *reinterpret_cast<const float4 *>(p.rln_gamma + n);
+                    pbeta[e] = *reinterpret_cast<const float4 *>(p.rln_beta + n);
+                }
             }
         }
     }
@@ -123,31 +136,37 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
         *reinterpret_cast<f32x4 *>(&red[wid][MT * NT - 1][lane][0]) = acc3;
     }
     const float fx = (1.0f / 65536.0f) / (float)p.ln_dim;
-    const float a_mean = p.ln_rms ? 0.0f : (float)st_a.x * fx, r_mean = (float)st_r.x * fx;
-    const float a_rstd = rsqrtf(fmaxf((float)st_a.y * fx - a_mean * a_mean, 0.0f) + p.ln_eps);
-    const float r_rstd = rsqrtf(fmaxf((float)st_r.y * fx - r_mean * r_mean, 0.0f) + p.ln_eps);
     __syncthreads();
-    if (owner) {
+#pragma unroll
+    for (int e = 0; e < TPW; e++) {
+        if (!eown[e]) continue;
+        const int tile = wid + e * NW;
+        const int m = em[e];
+        const bool xok = exok[e];
+        const int dynv0 = edyn[e];
+        const float a_mean = p.ln_rms ? 0.0f : (float)st_a[e].x * fx, r_mean = (float)st_r[e].x * fx;
+        const float a_rstd = rsqrtf(fmaxf((float)st_a[e].y * fx - a_mean * a_mean, 0.0f) + p.ln_eps);
+        const float r_rstd = rsqrtf(fmaxf((float)st_r[e].y * fx - r_mean * r_mean, 0.0f) + p.ln_eps);
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w][wid][lane][0]);
-        const int n = nb + 4 * fg;
+        for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w][tile][lane][0]);
+        const int n = enb[e] + 4 * fg;
         if (ln_mode) {
             // LayerNorm folded around the GEMM (host guarantees the vector epilogue conditions, N % 16 == 0)
             float v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
             const bool ok = xok && n < p.N;
             if (ok) {
-                const EpiRow e = epi_row(p, m, n, dynv0);
+                const EpiRow er = epi_row(p, m, n, dynv0);
                 if (p.aln_stats) {
                     const float mean = a_mean, rstd = a_rstd;
-                    const float4 c1 = pc1;
+                    const float4 c1 = pc1[e];
                     v0 = rstd * (v0 - mean * c1.x);
                     v1 = rstd * (v1 - mean * c1.y);
                     v2 = rstd * (v2 - mean * c1.z);
                     v3 = rstd * (v3 - mean * c1.w);
                 }
                 if (p.bias) {
-                    const float4 bv = pbias;
+                    const float4 bv = pbias[e];
                     v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
                 }
                 if (p.act != ACT_NONE) {
@@ -157,13 +176,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
                     v3 = apply_act(v3, p.act, p.act_slope);
                 }
                 if (p.resid) {
-                    const uint2 rv = presid;
+                    const uint2 rv = presid[e];
                     float r0 = __uint_as_float(rv.x << 16), r1 = __uint_as_float(rv.x & 0xffff0000u);
                     float r2 = __uint_as_float(rv.y << 16), r3 = __uint_as_float(rv.y & 0xffff0000u);
                     if (p.rln_stats) {
                         const float mean = r_mean, rstd = r_rstd;
-                        const float4 g = pgam;
-                        const float4 bt = pbeta;
+                        const float4 g = pgam[e];
+                        const float4 bt = pbeta[e];
                         r0 = (r0 - mean) * rstd * g.x + bt.x;
                         r1 = (r1 - mean) * rstd * g.y + bt.y;
                         r2 = (r2 - mean) * rstd * g.z + bt.z;
@@ -173,12 +192,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
                 }
                 v0 *= p.out_scale; v1 *= p.out_scale; v2 *= p.out_scale; v3 *= p.out_scale;
                 if (p.out_f32) {
-                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(e.outp) + e.obase + n) = make_float4(v0, v1, v2, v3);
+                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(er.outp) + er.obase + n) = make_float4(v0, v1, v2, v3);
                 } else {
                     uint2 pk;
                     pk.x = f32x2_to_bf16x2(v0, v1);
                     pk.y = f32x2_to_bf16x2(v2, v3);
-                    *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(e.outp) + e.obase + n) = pk;
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(er.outp) + er.obase + n) = pk;
                     v0 = __uint_as_float(pk.x << 16); v1 = __uint_as_float(pk.x & 0xffff0000u);   // what consumers will read
                     v2 = __uint_as_float(pk.y << 16); v3 = __uint_as_float(pk.y & 0xffff0000u);
                 }
@@ -195,11 +214,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
                 }
             }
         } else if (xok && n < p.N) {
-            const int dynv = p.dyn ? p.dyn[0] : 0;
             if (p.fast_epi)
-                igemm_store4<true>(p, m, n, s, dynv);
+                igemm_store4<true>(p, m, n, s, dynv0);
             else
-                igemm_store4<false>(p, m, n, s, dynv);
+                igemm_store4<false>(p, m, n, s, dynv0);
         }
     }
 }
@@ -277,7 +295,6 @@ __global__ __launch_bounds__(256) void k_gemm_m64(const IgemmParams p)
 #pragma unroll
         for (int r = 0; r < MT; r++) *reinterpret_cast<f32x4 *>(&red[wid][t * MT + r][lane][0]) = acc[t][r];
     __syncthreads();
-    const int dynv = p.dyn ? p.dyn[0] : 0;
     // wave w finishes tiles w, w + 4, ...: column tile = tile / MT, row tile = tile % MT
 #pragma unroll
     for (int i = 0; i < NTB; i++) {
@@ -287,6 +304,7 @@ __global__ __launch_bounds__(256) void k_gemm_m64(const IgemmParams p)
         for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w][tile][lane][0]);
         const int m = 16 * (tile % MT) + fr, n = n0 + 16 * (tile / MT) + 4 * fg;
         if (m < M && n < p.N) {
+            const int dynv = dyn_value(p, m);
             if (p.aln_stats) {
                 // normalisation of the A rows folded in (ifh_conv_desc.aln_*): the producer left (sum, sum of squares)
                 const longlong2 st = reinterpret_cast<const longlong2 *>(p.aln_stats)[m];
@@ -445,11 +463,11 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
 #undef IFH_LOAD_TILES
 #undef IFH_STORE_TILES
     // ---- epilogue: lane holds D[n = 4*fg + r][m = fr] of each 16x16 tile
-    const int dynv = p.dyn ? p.dyn[0] : 0;
 #pragma unroll
     for (int j = 0; j < MT; j++) {
         const int m = m0 + wm * WM + j * 16 + fr;
         if (m >= M) continue;
+        const int dynv = dyn_value(p, m);
 #pragma unroll
         for (int i = 0; i < NT; i++) {
             const int n = n0 + wn * WN + i * 16 + 4 * fg;
@@ -647,6 +665,8 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         IFH_CHECK_ARG(!d->rln_stats || (d->rln_gamma && d->rln_beta && d->resid));
     }
     p.dyn = d->dyn_pos;
+    p.dyn_stride = d->dyn_stride;
+    IFH_CHECK_ARG(d->dyn_stride == 0 || d->dyn_stride == 1);
     p.dyn_ooff_mul = d->dyn_ooff_mul;
     p.dyn_resid_mul = d->dyn_resid_mul;
     const bool pre = d->pre_slope != 1.0f;
@@ -694,7 +714,9 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
             if (p.K >= 2048) {
                 if (nt2 & 1) hipLaunchKernelGGL((k_gemm_skinny<4, 6, 2, 2>), grid3, dim3(256), 0, st, p);
                 else hipLaunchKernelGGL((k_gemm_skinny<4, 12, 2>), grid2, dim3(256), 0, st, p);
-            } else if (big && (nt2 & 2))
+            } else if (big && (nt2 & 2))     // 32 x 32 block, K still split 2-way (the bits do not depend on the row count)
+                hipLaunchKernelGGL((k_gemm_skinny<2, 6, 2, 2>), grid3, dim3(128), 0, st, p);
+            else if (big && (nt2 & 4))       // (tuning: the 4-way split of round 2 -- a different summation order)
                 hipLaunchKernelGGL((k_gemm_skinny<4, 6, 2, 2>), grid3, dim3(256), 0, st, p);
             else if (u6 && big)
                 hipLaunchKernelGGL((k_gemm_skinny<2, 6, 2>), grid2, dim3(128), 0, st, p);

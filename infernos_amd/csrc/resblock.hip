@@ -364,13 +364,13 @@ static int launch_pair(PairParams &p, hipStream_t st)
     if (RESIDENT && BN * (K / 8) > 6 * 256) return fail(IFH_EINVAL, "resblock_pair: at most 11 taps at c = 32");
     const size_t bytes = ((size_t)((EPB * R1 * XS + 7) & ~7) + (size_t)BN * (KW + 8) + (RES_LDS ? (size_t)EPB * BME * XS : 0)) * sizeof(uint16_t);
     if (bytes > 160 * 1024) return fail(IFH_EINVAL, "resblock_pair: tile does not fit in LDS (taps*dil too large)");
-    static unsigned long long attr_mask = 0;
+    static DeviceOnce attr_once;
     int attr_dev = 0;
-    if (attr_needed_on_this_device(attr_mask, &attr_dev)) {
+    if (attr_once.needed(&attr_dev)) {
         hipError_t e = hipFuncSetAttribute((const void *)k_resblock_pair<CIN, WGM, MT1, NT, RESIDENT, KC, EPB, RES_LDS, NWV, MINW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return check_hip(e, "resblock_pair lds attr");
-        attr_mask |= 1ull << attr_dev;
+        attr_once.done(attr_dev);
     }
     const int nblk = (p.T + BME - 1) / BME;
     p.rows_per_block = (p.T + nblk - 1) / nblk;

@@ -24,8 +24,17 @@ class Sampler:
     repetition_penalty 1.05, temperature 0.7, top_k 20, top_p 0.8): ifh_repetition_penalty_f32 over the row's prompt and
     generated tokens, then ifh_sample_topk_f32 with one uniform number per row from a seeded device generator."""
 
+    MAX_CANDIDATES = 32          # ifh_sample_topk_f32 keeps the 32 best logits of a row
+
     def __init__(self, temperature=0.7, top_k=20, top_p=0.8, repetition_penalty=1.05, seed=0):
-        assert 0 <= top_k <= 32, 'ifh_sample_topk_f32 keeps at most 32 candidates'
+        # top_k = 0 is transformers' "top-k disabled": the draw is then top-p over the 32 best candidates, which equals
+        # the unrestricted nucleus whenever top_p < 1 leaves at most 32 tokens in it; a wider request cannot be served
+        if not 0 <= top_k <= self.MAX_CANDIDATES:
+            raise ValueError('Sampler: top_k=%r is outside 0..%d (ifh_sample_topk_f32 keeps the %d best candidates of a row); '
+                             'lower the checkpoint\'s generation_config.top_k' % (top_k, self.MAX_CANDIDATES, self.MAX_CANDIDATES))
+        if top_k == 0 and top_p >= 1.0:
+            raise ValueError('Sampler: top_k=0 with top_p=1 asks for a draw over the whole vocabulary; the device sampler '
+                             'keeps %d candidates per row -- set top_k or top_p' % self.MAX_CANDIDATES)
         self.temperature, self.top_k, self.top_p, self.repetition_penalty = temperature, top_k, top_p, repetition_penalty
         self.seed, self.gen = seed, None
 
@@ -220,11 +229,7 @@ class Qwen2:
             return self._step_launches(st, B, argmax)
         key = 'graph%d' % int(argmax)
         if st.get(key) is None:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                self._step_launches(st, B, argmax)
-            st[key] = g
+            st[key] = _lib.CountedGraph(lambda: self._step_launches(st, B, argmax))
         st[key].replay()
 
     def generate(self, prompts, max_new_tokens, eos_ids=(), pad_id=0, on_tokens=None, sampler=None, use_graphs=True,

@@ -363,10 +363,7 @@ def decoder_steps(model: 'SpeechT5', st: TTSBatchState, masks: torch.Tensor, nst
         else:
             g = st.graphs.get((s, threshold, par, step_fn is _decoder_step_folded))
             if g is None:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode='thread_local'):          # records the launches; nothing executes until replay
-                    step_fn(model, st, s, threshold, par)
+                g = _lib.CountedGraph(lambda: step_fn(model, st, s, threshold, par))
                 st.graphs[(s, threshold, par, step_fn is _decoder_step_folded)] = g
             g.replay()
         st.idx += 1
@@ -374,9 +371,9 @@ def decoder_steps(model: 'SpeechT5', st: TTSBatchState, masks: torch.Tensor, nst
         st.eager_calls += 1
 
 
-def postnet(model: SpeechT5, st: TTSBatchState, par: int):
-    """speech_decoder_postnet.postnet on the 32 new frames (:230) -> st.post[par] bf16 [B,32,80]"""
-    B = st.B
+def postnet(model: SpeechT5, st, par: int, B: int = None):
+    """speech_decoder_postnet.postnet on the 32 new frames (:230) -> st.post[par] bf16 [B,32,80] (first B rows of a ragged state)"""
+    B = st.B if B is None else B
     spec = st.spec[par]
     src, off, cin = spec, 80, 80
     for i, (w, shift) in enumerate(model.postnet):
@@ -388,3 +385,130 @@ def postnet(model: SpeechT5, st: TTSBatchState, par: int):
                  resid=(spec if last else None), resid_off=(80 if last else 0), resid_ld=80, resid_bstride=33 * 80)
         src, off, cin = out, 0, cout
     return st.post[par]
+
+
+# ---- continuous (ragged-position) batching of the decode loop ------------------------------------------------------
+class TTSRaggedState:
+    """Device tables of ONE running decode batch whose rows joined at different infer() calls and therefore sit at
+    different decoder positions.  The reference freezes a batch at process_batch entry and loops it to the end
+    (Cluster/InfernTTSWorker.py:83-92), so the GPU sees as many small launch chains as there are batches in flight;
+    here every in-flight utterance is a row slot of one step whose position-dependent quantities -- KV append row,
+    self-attention key count, positional-encoding row, stop-rule index and lengths -- are per-row device vectors
+    (`pos`, `minmax`, `enc_len`), so one captured launch sequence per in-call step serves all of them.  Rows join at an
+    infer() boundary (`pos` = 0: zero carry frame, zero pre-frames via `fresh`) and leave when their utterance ends;
+    a slot without a live utterance (`active` = 0) is still computed -- as an ended row is in the reference
+    (HelloSippyRTPipe.py:254-255 "still occupies its batch slot") -- with its position frozen.
+    Arithmetic per row is that of TTSBatchState's LayerNorm-folded step: same kernels, same K order."""
+
+    def __init__(self, model: 'SpeechT5', max_rows: int, max_text: int):
+        dev = model.device
+        R = -(-max_rows // 16) * 16
+        T = -(-max_text // TTSBatchState.T_BUCKET) * TTSBatchState.T_BUCKET
+        assert R <= 1024, 'the LayerNorm-folded decode GEMMs take at most 1024 rows per launch'
+        self.model, self.R, self.T = model, R, T
+        self.smax = min(model.max_steps, int(T * 20.0 / 2) + 48)
+        z = lambda *s, dt=BF16: torch.zeros(s, dtype=dt, device=dev)
+        self.pos = z(R, dt=torch.int32)
+        self.active = z(R, dt=torch.uint8)
+        self.minmax = z(R, 2, dt=torch.int32)
+        self.enc_len = z(R, dt=torch.int32)
+        self.ends_at = torch.full((R,), -1, dtype=torch.int64, device=dev)
+        self.fresh = [z(R, dt=torch.uint8) for _ in range(2)]        # per frame-buffer parity: rows whose first call this is
+        self.cross = [z(R * T, KVP) for _ in model.dec_layers]
+        self.self_kv = [z(R, self.smax, KVP) for _ in model.dec_layers]
+        self.spec = [z(R, 33, 80) for _ in range(2)]
+        self.cat = z(R, D + 512)
+        self.pre_frames = z(R, 4, 80)
+        self.post = [z(R, 32, 80), z(R, 32, 80)]
+        self.masks = z(16, 2, 256, dt=torch.uint8)
+        self.DP, self.FP = D + ROW_PAD, FF + ROW_PAD
+        self.h1, self.h2 = z(R, 256), z(R, 256)
+        self.x0, self.q, self.att, self.t1, self.t2, self.t3 = (z(R, self.DP) for _ in range(6))
+        self.ff = z(R, self.FP)
+        self.plog16 = z(R, 16, dt=torch.float32)
+        self.stat_rows = max(64, R)
+        self.stats = z(3 * len(model.dec_layers), self.stat_rows, 2, dt=torch.int64)
+        self.pn = [z(R, 32, 256), z(R, 32, 256)]
+        self.graphs, self.eager = {}, {}
+        self.ncalls = 0
+
+
+def _decoder_step_ragged(model: 'SpeechT5', st: TTSRaggedState, s: int, threshold: float, par: int, n: int):
+    """_decoder_step_folded over the first n row slots of a ragged state: identical launches, but whatever depended on
+    the batch's one position reads the row's own (`dyn_stride=1`, per-row key counts, per-row stop rule)."""
+    dev = model.device
+    T = st.T
+    masks, spec, stats = st.masks, st.spec[par], st.stats
+    DP, FP = st.DP, st.FP
+    SO = st.stat_rows * 2
+    ops.linear(spec, *model.p0, st.h1, rows=n, k=80, n=256, x_off=2 * s * 80, lda=33 * 80, act=ACT_RELU,
+               colmask=masks, colmask_off=(s * 2) * 256)
+    ops.linear(st.h1, *model.p1, st.h2, rows=n, k=256, n=256, act=ACT_RELU, colmask=masks, colmask_off=(s * 2 + 1) * 256)
+    ops.linear(st.h2, *model.pf, st.cat, rows=n, k=256, n=D, ldc=D + 512, resid=model.pe_dec, resid_ld=0, resid_bstride=0,
+               dyn_pos=st.pos, dyn_stride=1, dyn_resid_mul=D)
+    ops.linear(st.cat, *model.ps, st.x0, rows=n, k=D + 512, n=D, act=ACT_RELU, ldc=DP)
+    nl = len(model.dec_layers)
+    ld = dict(lda=DP, ldc=DP, resid_ld=DP)
+    for li, (L, F) in enumerate(zip(model.dec_layers, model.dec_fold)):
+        kv = st.self_kv[li]
+        s1, s2, s3, s3p = (3 * li) * SO, (3 * li + 1) * SO, (3 * li + 2) * SO, (3 * li - 1) * SO
+        kvargs = dict(nbatch=n, t_in=1, t_out=1, cin=D, n=3 * D, lda=DP, ldc=DP, out_bstride=DP, dyn_pos=st.pos, dyn_stride=1,
+                      n_split=D, out2=kv, out2_bstride=st.smax * KVP, ldc2=KVP, dyn_ooff2_mul=1)
+        if li == 0:
+            ops.conv(st.x0, L['wqkv'], L['bqkv'], st.q, **kvargs)
+        else:
+            w, c2, c1 = F['qkv']
+            ops.conv(st.t3, w, c2, st.q, aln=(stats, s3p, c1), ln_dim=D, **kvargs)
+        ops.attn_decode(st.q, kv, kv, st.att, nbatch=n, nheads=H, max_keys=st.smax, q_bs=DP, kv_bs=st.smax * KVP,
+                        kv_ts=KVP, o_bs=DP, v_off=D, key_len=st.pos, dyn_add=1)
+        if li == 0:
+            ops.linear(st.att, L['wo'], L['bo'], st.t1, rows=n, k=D, n=D, resid=st.x0, stats_out=stats, stats_off=s1, ln_dim=D, **ld)
+        else:
+            ops.linear(st.att, L['wo'], L['bo'], st.t1, rows=n, k=D, n=D, resid=st.t3, rln=(stats, s3p) + F['ln_prev'],
+                       stats_out=stats, stats_off=s1, ln_dim=D, **ld)
+        w, c2, c1 = F['cq']
+        ops.linear(st.t1, w, c2, st.q, rows=n, k=D, n=D, aln=(stats, s1, c1), ln_dim=D, lda=DP, ldc=DP)
+        ck = st.cross[li]
+        ops.attn_decode(st.q, ck, ck, st.att, nbatch=n, nheads=H, max_keys=T, q_bs=DP, kv_bs=T * KVP, kv_ts=KVP,
+                        o_bs=DP, v_off=D, key_len=st.enc_len)
+        ops.linear(st.att, L['cwo'], L['cbo'], st.t2, rows=n, k=D, n=D, resid=st.t1, rln=(stats, s1) + F['ln1'],
+                   stats_out=stats, stats_off=s2, ln_dim=D, **ld)
+        w, c2, c1 = F['ff1']
+        ops.linear(st.t2, w, c2, st.ff, rows=n, k=D, n=FF, act=ACT_GELU, aln=(stats, s2, c1), ln_dim=D, lda=DP, ldc=FP)
+        ops.linear(st.ff, L['w2'], L['b2'], st.t3, rows=n, k=FF, n=D, resid=st.t2, rln=(stats, s2) + F['ln2'],
+                   stats_out=stats, stats_off=s3, ln_dim=D, lda=FP, ldc=DP, resid_ld=DP)
+    sl = (3 * nl - 1) * SO
+    w, c2, c1 = model.feat_fold
+    ops.linear(st.t3, w, c2, spec, rows=n, k=D, n=160, out_off=(2 * s + 1) * 80, ldc=33 * 80, aln=(stats, sl, c1), ln_dim=D, lda=DP)
+    w, c2, c1 = model.prob_fold
+    ops.linear(st.t3, w, c2, st.plog16, rows=n, k=D, n=16, aln=(stats, sl, c1), ln_dim=D, lda=DP)
+    _lib.check(_lib.lib().ifh_tts_stop_advance_rows(ops._addr(st.plog16), ops._addr(st.ends_at), n, threshold, 2, ops._addr(st.pos),
+                                                    ops._addr(st.active), ops._addr(st.minmax), 16, ops._addr(st.stats),
+                                                    st.stats.numel() * 8, _lib.stream_ptr(dev)), 'ifh_tts_stop_advance_rows')
+
+
+def ragged_decoder_steps(model: 'SpeechT5', st: TTSRaggedState, masks: torch.Tensor, n: int, nsteps=16, threshold=0.5,
+                         use_graphs=None):
+    """One infer() call's decoder steps (HelloSippyRTPipe.py:195-229) for the first n row slots of a ragged state.
+    The same [nsteps,2,256] dropout keep-masks serve every row of the step, as the reference shares one mask across
+    its batch (modeling_speecht5.py:671-674).  One hipGraph per (in-call step, frame-buffer parity, n)."""
+    assert nsteps <= 16 and n <= st.R and n % 16 == 0
+    use_graphs = model.use_graphs if use_graphs is None else use_graphs
+    par = st.ncalls & 1
+    st.masks[:nsteps].copy_(masks)
+    _lib.check(_lib.lib().ifh_tts_carry_rows_bf16(ops._addr(st.spec[1 - par]), ops._addr(st.spec[par]), ops._addr(st.pos), n, 33,
+                                                  _lib.stream_ptr(model.device)), 'ifh_tts_carry_rows_bf16')
+    use_graphs = use_graphs and st.eager.get(n, 0) >= 1            # the first call at a row count runs eagerly (loads kernels)
+    for s in range(nsteps):
+        if not use_graphs:
+            _decoder_step_ragged(model, st, s, threshold, par, n)
+        else:
+            key = (s, threshold, par, n)
+            g = st.graphs.get(key)
+            if g is None:
+                g = st.graphs[key] = _lib.CountedGraph(lambda: _decoder_step_ragged(model, st, s, threshold, par, n))
+            g.replay()
+    if not use_graphs:
+        st.eager[n] = st.eager.get(n, 0) + 1
+    st.ncalls += 1
+    return par

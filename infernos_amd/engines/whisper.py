@@ -278,11 +278,7 @@ class Whisper:
             return step_fn(bufs, Bn, argmax)
         g = bufs['graphs'].get(argmax)
         if g is None:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                step_fn(bufs, Bn, argmax)
-            bufs['graphs'][argmax] = g
+            g = bufs['graphs'][argmax] = _lib.CountedGraph(lambda: step_fn(bufs, Bn, argmax))
         g.replay()
         return bufs['logits']
 
@@ -361,8 +357,9 @@ class Whisper:
     def generate_beam(self, enc: torch.Tensor, prompts: torch.Tensor, n_new: int, beams: int = 5, eos_id: int = 50257,
                       length_penalty: float = 1.0, suppress=None, begin_suppress=None, no_speech_id=None, check_every=8,
                       use_graphs=True):
-        """Beam search (the decode ctranslate2's Whisper.generate runs by default, Cluster/InfernSTTWorker.py:61-75:
-        beam_size 5, length_penalty 1, return_no_speech_prob) over the same per-token step `generate` uses, on
+        """Beam search at the width ctranslate2's Whisper.generate defaults to (Cluster/InfernSTTWorker.py:61-75: beam_size 5,
+        length_penalty 1, return_no_speech_prob), in transformers' formulation (GenerationMixin._beam_search: pinned by
+        tests/golden/whisper_beam.npz; ctranslate2's own termination rule is unpinned), over the same per-token step `generate` uses, on
         B * beams decode rows that share each utterance's cross-attention K/V.  Search bookkeeping, token-matrix
         permutation and the per-step self-attention KV gather all run on the device (ifh_beam_step,
         ifh_kv_gather_bf16) inside the replayed hipGraph; the host only polls `alive` every `check_every` tokens.

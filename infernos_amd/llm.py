@@ -184,6 +184,13 @@ class InfernLLMWorker(InfernBatchedWorker):
                 gc = hf.generation_config
                 generation_config = dict(do_sample=bool(gc.do_sample), temperature=gc.temperature or 1.0, top_k=gc.top_k or 0,
                                          top_p=gc.top_p or 1.0, repetition_penalty=gc.repetition_penalty or 1.0)
+                if generation_config['do_sample'] and generation_config['top_k'] > 32:
+                    # transformers' default top_k (50) on a checkpoint that does not set it: the device sampler keeps the 32
+                    # best candidates of a row -- clamp, loudly, rather than die in the sampler's constructor
+                    import warnings
+                    warnings.warn('InfernLLMWorker: generation_config.top_k=%d clamped to 32 (the device sampler keeps the 32 best '
+                                  'candidates per row)' % generation_config['top_k'])
+                    generation_config['top_k'] = 32
                 if eos_token_ids is None and gc.eos_token_id is not None:
                     eos_token_ids = gc.eos_token_id
             del hf

@@ -82,7 +82,7 @@ class BatchedVAD:
 class SpeechPipeline:
     def __init__(self, ncalls: int, device=None, whisper_family='whisper_tiny', seed=0, n_text=64, n_infer=10,
                  n_new_tokens=32, tts_output_sr=8000, weights=None, tts_lanes=2, tts_overlap=True, tts_group=1,
-                 front_lanes=1, stt_beam=1):
+                 front_lanes=1, stt_beam=1, tts_mode='lanes'):
         from .engines.whisper import Whisper
         from .features import WhisperLogMel
         from .tts import HelloSippyRTPipe
@@ -108,6 +108,18 @@ class SpeechPipeline:
             self.tts = HelloSippyRTPipe(dev, weights=tw, processor=_NoProcessor(), speaker_embeddings=[],
                                         output_sr=tts_output_sr)
             self.tts_lanes = [self.tts] + [self.tts.clone_for_lane() for _ in range(max(1, tts_lanes) - 1)]
+        # tts_mode 'continuous': ONE ragged decode batch over every utterance batch in flight (tts.ContinuousTTS) instead
+        # of one engine clone + launch chain per lane; tts_lanes then bounds the utterance batches in flight
+        assert tts_mode in ('lanes', 'continuous')
+        self.tts_mode = tts_mode
+        self.ctts = None
+        if tts_mode == 'continuous':
+            from .tts import ContinuousTTS
+            bucket = -(-ncalls * self.tts_group // 16) * 16
+            # (+1 batch of head-room: a finished batch frees its rows one engine call after its last audio was queued)
+            self.ctts = ContinuousTTS(self.tts, max_rows=min(1024, bucket * (max(1, tts_lanes) + 1)), max_text=n_text,
+                                      row_bucket=bucket).start()
+            self.tts_lanes = [self.tts] * max(1, tts_lanes)
         self.slots = torch.arange(ncalls, dtype=torch.int32, device=dev)
         self.prompt = torch.tensor([[50258, 50259, 50359, 50363]] * ncalls, dtype=torch.int32)
         g = torch.Generator().manual_seed(2000 + seed)
@@ -210,6 +222,14 @@ class SpeechPipeline:
         if group > 1:                                  # the utterances of `group` consecutive cycles as ONE batch (rows g*n + call)
             ids, spk = ids.repeat(group, 1), spk.repeat(group, 1)
         nb = ids.size(0)
+        if self.ctts is not None:
+            # continuous batching: the batch joins the engine's running decode batch at its next infer() boundary
+            grp = self.ctts.submit(ids, torch.full((nb,), ids.size(1), dtype=torch.int32), spk, max_calls=self.n_infer,
+                                   want_ulaw=True).result()
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(grp.done_event)
+            grp.ulaw.record_stream(cur)
+            return grp.ulaw, grp.valid, grp.spans
         state = _make_state(pp, ids, spk)
         st = state.dev
         rr = pp.model_sr // pp.output_sr
@@ -304,6 +324,12 @@ class SpeechPipeline:
                         for _ in range(3):
                             self.front_group([frames] * g, fl)
                 fl.stream.synchronize()
+        if self.ctts is not None:
+            b = self.ctts.row_bucket
+            self.ctts.warm([b * k for k in range(1, self.ctts.st.R // b + 1)])
+            self.synthesize()
+            torch.cuda.synchronize(self.device)
+            return
         for lane in range(len(self.tts_lanes)):
             for g in sorted({self.tts_group, 1} | set(range(1, self.tts_group))):     # a trailing group may be smaller
                 for _ in range(3):
@@ -400,6 +426,16 @@ class SpeechPipeline:
         out = schedule_cycles(nsteps, G, L, fetch, lambda gi, frs: self._pool.submit(job, gi, frs), submit_tts, retire)
         sys.setswitchinterval(swi)
         return out
+
+    def close(self):
+        """stop the continuous TTS engine thread (its state holds the KV caches of every row slot)"""
+        if self.ctts is not None:
+            self.ctts.stop()
+            self.ctts = None
+        for name in ('_pool', '_tts_pool'):
+            if hasattr(self, name):
+                getattr(self, name).shutdown(wait=True)
+                delattr(self, name)
 
     def step(self, frames: torch.Tensor):
         chunks = self.ingest(frames)

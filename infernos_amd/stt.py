@@ -144,9 +144,12 @@ class InfernSTTWorker(InfernBatchedWorker):
     state dict; default: download `model_name`), `tokenizer` (needs convert_tokens_to_ids / decode;
     default: WhisperTokenizer.from_pretrained), `max_new_tokens`.
 
-    beam_size selects the reference's decode: 5 (default) is what its default engine runs --
-    ctranslate2.models.Whisper.generate(features, prompts, return_no_speech_prob=True) with that library's defaults
-    (beam_size 5, length_penalty 1; InfernSTTWorker.py:61-75): every request is decoded, no_speech_prob is reported;
+    beam_size selects the decode: 5 (default) is the beam width and length penalty the reference's default engine runs with --
+    ctranslate2.models.Whisper.generate(features, prompts, return_no_speech_prob=True), that library's defaults
+    (beam_size 5, length_penalty 1; InfernSTTWorker.py:61-75).  The SEARCH itself is transformers' formulation
+    (GenerationMixin._beam_search: the K best finished hypotheses are kept and replaced, a row stops when its best running
+    beam cannot beat its worst finished one), which is what the fixtures pin; ctranslate2's own termination rule (it is not
+    in the image) may pick different tokens -- parity with it is UNPINNED.  Every request is decoded, no_speech_prob is reported;
     1 is its torch engine (infer_and_decode_torch, :77-107): greedy, and nothing is generated when every request of
     the batch is above its max_ns_prob (:91-92).  suppress_tokens / begin_suppress_tokens: token ids masked at every /
     at the first generated position (the model's generation config; ctranslate2 applies them by default)."""

@@ -14,11 +14,12 @@ from time import monotonic
 from typing import Dict, List, Optional, Tuple, Union
 from uuid import UUID, uuid4
 
+import numpy as np
 import torch
 
 from . import _lib, ops
 from .audio import AudioChunk, get_resampler
-from .engines.speecht5 import SpeechT5, TTSBatchState, decoder_steps, postnet
+from .engines.speecht5 import SpeechT5, TTSBatchState, TTSRaggedState, decoder_steps, postnet, ragged_decoder_steps
 from .engines.vocoder import Amendment, HifiGan
 from .muxer import ASMarkerGeneric, ASMarkerNewSent, ASMarkerSentDoneCB
 from .torcher import InfernGlobals
@@ -171,11 +172,7 @@ class HelloSippyRTPipe:
         else:
             g = st.render_graphs.get(par)
             if g is None:
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode='thread_local'):
-                    self._render(st, par)
-                st.render_graphs[par] = g
+                g = st.render_graphs[par] = _lib.CountedGraph(lambda: self._render(st, par))
             g.replay()
         return st.render_out[par]
 
@@ -234,6 +231,308 @@ class HelloSippyRTPipe:
 
     def get_voice(self, s_index: int):
         return self.speaker_embeddings[s_index]
+
+
+class TTSGroup:
+    """Utterances that joined the running batch of a ContinuousTTS together (one `submit`): their row slots, progress in
+    decoder steps and output.  `done` is set once the last audio of the group has been produced; `done_event` (a HIP
+    event on the render stream) orders consumers of `ulaw` on other streams."""
+
+    def __init__(self, n, t_true, max_calls, dispatch, want_ulaw):
+        import threading
+        self.n, self.t_true, self.max_calls = n, t_true, max_calls
+        self.dispatch = list(dispatch) if dispatch is not None else None
+        self.want_ulaw = want_ulaw
+        self.slots = None
+        self.idx = self.calls = 0
+        self.ulaw = self.valid = None
+        self.spans = []
+        self.done, self.done_event, self.error = threading.Event(), None, None
+
+    def result(self, timeout=None):
+        if not self.done.wait(timeout):
+            raise TimeoutError('TTS group still running')
+        if self.error is not None:
+            raise self.error
+        return self
+
+
+class ContinuousTTS:
+    """Continuous batching of HelloSippyRTPipe.infer (HelloSippyRTPipe.py:191-259) over ONE ragged decode batch
+    (engines/speecht5.py:TTSRaggedState).  The reference's worker freezes a batch and loops it to the end
+    (Cluster/InfernTTSWorker.py:83-92: "no continuous batching => tail waste"); here utterances join the
+    running batch at the next infer() boundary and leave when they end, so however many utterance batches are in flight
+    the GPU sees one launch chain of ~56 kernels per decoder step over all their rows instead of one chain per batch.
+    Per row the arithmetic, the dispatch offsets (`unbatch_and_dispatch`, :242-259) and the end-of-utterance rule are
+    the reference's.
+
+    submit() may be called from any thread (the text encoder and the cross-attention K|V projection of the new
+    utterances run on the CALLER's current stream); step() -- one infer() call over every live row: 16 decoder steps on the
+    engine stream, postnet + HiFi-GAN + amendment (+ resample, mu-law) on a second stream overlapped with the next call's
+    steps -- runs on the engine thread (start()/stop(), or driven by hand)."""
+
+    def __init__(self, pp: 'HelloSippyRTPipe', max_rows=1024, max_text=64, row_bucket=128):
+        import threading
+        self.pp, self.device = pp, pp.device
+        dev = pp.device
+        self.row_bucket = row_bucket
+        with torch.cuda.device(dev):
+            self.st = TTSRaggedState(pp.model, max_rows, max_text)
+            self.main = torch.cuda.Stream(device=dev)
+            self.side = torch.cuda.Stream(device=dev)
+        R = self.st.R
+        self.free = list(range(R))                       # row slots, lowest first
+        self.pending, self.live = [], []
+        self.cv = threading.Condition()
+        self.ren_done = [None, None]
+        self.h_active = torch.zeros(R, dtype=torch.uint8).pin_memory()
+        self.h_fresh = [torch.zeros(R, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.render_bufs = {}
+        self.thread, self.halt = None, False
+        self.calls_run = self.rows_run = 0               # statistics: engine calls, sum of row slots they covered
+
+    # ---- any thread -----------------------------------------------------------------------------------------------
+    def submit(self, input_ids, lens, speakers, max_calls=None, dispatch=None, want_ulaw=False) -> TTSGroup:
+        """input_ids int [g,T] right-padded, lens int [g], speakers float [g,512].  max_calls bounds the infer() calls
+        the group takes part in (None: until every row has ended)."""
+        from .engines.speecht5 import D, KVP
+        pp, st, dev = self.pp, self.st, self.device
+        g, t_true = input_ids.shape
+        T = -(-t_true // 16) * 16
+        if T > st.T or g > st.R:
+            raise ValueError('ContinuousTTS: %d rows x %d tokens exceed the state (%d rows x %d tokens)' % (g, t_true, st.R, st.T))
+        grp = TTSGroup(g, t_true, max_calls, dispatch, want_ulaw)
+        with torch.cuda.device(dev):
+            ids = torch.nn.functional.pad(input_ids, (0, T - t_true)) if T != t_true else input_ids
+            enc = pp.model.encode(ids, lens)                                            # [g, T, 768] on the caller's stream
+            kvs = []
+            for L in pp.model.dec_layers:
+                kv = torch.empty((g, T, KVP), dtype=torch.bfloat16, device=dev)
+                ops.linear(enc, L['cwkv'], L['cbkv'], kv, rows=g * T, k=D, n=2 * D, ldc=KVP)
+                kvs.append(kv)
+            spk = speakers.to(dev, torch.bfloat16).contiguous().view(g, 512)
+            spn = torch.empty((g, 512), dtype=torch.bfloat16, device=dev)
+            _lib.check(_lib.lib().ifh_l2norm_rows_bf16(ops._addr(spk), 512, g, ops._addr(spn), 512, _lib.stream_ptr(dev)),
+                       'ifh_l2norm_rows_bf16')
+            grp._admit = dict(T=T, kvs=kvs, spn=spn, lens=lens.to(dev, torch.int32), ready=torch.cuda.Event())
+            for t in kvs + [spn, grp._admit['lens']]:
+                t.record_stream(self.main)                   # consumed on the engine stream
+            grp._admit['ready'].record(torch.cuda.current_stream(dev))
+        with self.cv:
+            self.pending.append(grp)
+            self.cv.notify_all()
+        return grp
+
+    # ---- engine thread --------------------------------------------------------------------------------------------
+    def _admit(self):
+        st, dev = self.st, self.device
+        took = []
+        with self.cv:
+            while self.pending and len(self.free) >= self.pending[0].n:
+                grp = self.pending.pop(0)
+                self.free.sort()
+                grp.slots, self.free = self.free[:grp.n], self.free[grp.n:]
+                took.append(grp)
+        if not took:
+            return
+        R, T = st.R, st.T
+        for grp in took:
+            a = grp._admit
+            self.main.wait_event(a['ready'])
+            sl = torch.tensor(grp.slots, dtype=torch.int64).to(dev, non_blocking=True)
+            for kv, cross in zip(a['kvs'], st.cross):
+                cross.view(R, T, -1)[:, :a['T']].index_copy_(0, sl, kv)
+            st.cat[:, 768:].index_copy_(0, sl, a['spn'])
+            st.enc_len.index_copy_(0, sl, a['lens'])
+            mm = torch.tensor([[0, int(grp.t_true * 20.0 / 2)]] * grp.n, dtype=torch.int32).to(dev, non_blocking=True)
+            st.minmax.index_copy_(0, sl, mm)
+            st.pos.index_fill_(0, sl, 0)
+            st.ends_at.index_fill_(0, sl, -1)
+            sl.record_stream(self.side)
+            grp._slots_dev, grp._fresh = sl, True
+            del grp._admit
+            self.live.append(grp)
+
+    def _bucket(self):
+        hi = max(max(grp.slots) for grp in self.live) + 1
+        return min(self.st.R, -(-hi // self.row_bucket) * self.row_bucket)
+
+    def step(self) -> bool:
+        """One infer() call over every live row.  Returns False when nothing is live or pending."""
+        pp, st, dev = self.pp, self.st, self.device
+        with torch.cuda.device(dev), torch.cuda.stream(self.main):
+            self._admit()
+            if not self.live:
+                return False
+            n = self._bucket()
+            par = st.ncalls & 1
+            if self.ren_done[par] is not None:
+                self.main.wait_event(self.ren_done[par])         # the renderer of call c-2 has released this parity's buffers
+            self.h_active.zero_()
+            self.h_fresh[par].zero_()
+            for grp in self.live:
+                self.h_active[grp.slots] = 1
+                if grp._fresh:
+                    self.h_fresh[par][grp.slots] = 1
+                    grp._fresh = False
+            st.active.copy_(self.h_active, non_blocking=True)
+            st.fresh[par].copy_(self.h_fresh[par], non_blocking=True)
+            masks = pp.mask_source(16).to(dev).contiguous()
+            ragged_decoder_steps(pp.model, st, masks, n, nsteps=16, threshold=pp.threshold)
+            dec_done = torch.cuda.Event()
+            dec_done.record(self.main)
+            rr = pp.model_sr // pp.output_sr
+            A, stepsize = 8192 // rr, 512 // rr
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(dec_done)
+                audio = self._render(par, n)                                    # bf16 [n, 8192] @ model_sr
+                if pp.resampler is not None:
+                    audio = pp.resampler(audio.float())
+                ul = None
+                if any(grp.want_ulaw for grp in self.live):
+                    pcm = audio if audio.dtype == torch.float32 else audio.float()
+                    ul = torch.empty((n, A), dtype=torch.uint8, device=dev)
+                    _lib.check(_lib.lib().ifh_g711_encode_f32_u8(_lib.ptr(pcm), _lib.ptr(ul), pcm.numel(), _lib.stream_ptr(dev)),
+                               'ifh_g711_encode_f32_u8')
+                for grp in self.live:
+                    if grp.want_ulaw:
+                        if grp.ulaw is None:
+                            grp.ulaw = torch.empty((grp.n, (grp.max_calls or 64) * A), dtype=torch.uint8, device=dev)
+                            grp.valid = torch.zeros(grp.n, dtype=torch.int64)
+                        c = grp.calls
+                        if (c + 1) * A > grp.ulaw.size(1):
+                            grp.ulaw = torch.cat([grp.ulaw, torch.empty_like(grp.ulaw)], 1)
+                        grp.ulaw[:, c * A:(c + 1) * A] = ul.index_select(0, grp._slots_dev)
+                host_audio = None
+                if any(grp.dispatch is not None for grp in self.live):
+                    host_audio = (audio if audio.dtype == torch.bfloat16 else audio.to(torch.bfloat16))
+                    host_audio = host_audio.to('cpu', non_blocking=False)          # as unbatch_and_dispatch: one D2H of the batch
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                self.ren_done[par] = ev
+            ends_all = st.ends_at[:n].cpu().numpy()              # waits for this call's decoder steps (the reference's .item())
+        self.calls_run += 1
+        self.rows_run += n
+        finished = []
+        for grp in self.live:
+            grp.idx += 16
+            grp.calls += 1
+            idx, end_idx = grp.idx, grp.idx - 1
+            e = ends_all[grp.slots]
+            s_off = max(0, A - (idx - 1) * stepsize)                        # starts_at = post_nframes // 2 = 1 for every row
+            e_off = np.where(e >= 0, np.minimum(A, A - (idx - e) * stepsize), A)
+            if grp.want_ulaw:
+                grp.valid += torch.from_numpy(np.maximum(0, e_off - s_off))
+                grp.spans.append(list(zip([s_off] * grp.n, np.maximum(s_off, e_off).tolist())))
+            if grp.dispatch is not None:
+                for i, d in enumerate(grp.dispatch):
+                    if d is None:
+                        continue
+                    so, eo = s_off, int(e_off[i])
+                    assert so <= eo
+                    if so != eo:
+                        d(host_audio[grp.slots[i]][so:eo].clone())
+                    if 0 <= e[i] <= end_idx:
+                        d(None)
+                        grp.dispatch[i] = None
+            ended = bool(np.all((e >= 0) & (e <= end_idx)))
+            out_of_cache = grp.idx + 16 > st.smax
+            if ended or (grp.max_calls is not None and grp.calls >= grp.max_calls) or out_of_cache:
+                finished.append(grp)
+        for grp in finished:
+            self.live.remove(grp)
+            with self.cv:
+                self.free.extend(grp.slots)
+            grp.done_event = self.ren_done[par]
+            if grp.ulaw is not None:
+                grp.ulaw = grp.ulaw[:, :grp.calls * A]
+            grp.done.set()
+        return True
+
+    def _render(self, par, n):
+        """postnet -> carry + 4 overlapped chunks -> HiFi-GAN -> AmendmentNetwork1 over the first n row slots; one
+        hipGraph per (parity, n) over buffers that live with this engine."""
+        pp, st, dev = self.pp, self.st, self.device
+        b = self.render_bufs.get(n)
+        if b is None:
+            b = self.render_bufs[n] = dict(
+                voc_in=torch.empty((4 * n, 12, 80), dtype=torch.bfloat16, device=dev),
+                amd_mel=torch.empty((4 * n, 12, 80), dtype=torch.bfloat16, device=dev),
+                out=[torch.empty((n, 8192), dtype=torch.bfloat16, device=dev) for _ in range(2)],
+                graphs={}, eager=0, voc_cache={}, amd_cache={})
+
+        def run():
+            post = postnet(pp.model, st, par, B=n)
+            _lib.check(_lib.lib().ifh_tts_chunks_rows_bf16(ops._addr(st.pre_frames), ops._addr(post), ops._addr(pp.vocoder.mean),
+                                                           ops._addr(pp.vocoder.scale), ops._addr(b['voc_in']), ops._addr(b['amd_mel']),
+                                                           ops._addr(st.fresh[par]), n, _lib.stream_ptr(dev)), 'ifh_tts_chunks_rows_bf16')
+            audio = pp.vocoder(b['voc_in'], cache=b['voc_cache'])
+            pp.chunker(b['amd_mel'], audio, b['out'][par], n, cache=b['amd_cache'])
+        if not pp.model.use_graphs or b['eager'] < 2:
+            run()
+            b['eager'] += 1
+        else:
+            g = b['graphs'].get(par)
+            if g is None:
+                g = b['graphs'][par] = _lib.CountedGraph(run)
+            g.replay()
+        return b['out'][par]
+
+    def warm(self, rows):
+        """Untimed preparation for the row counts `rows` (multiples of row_bucket): with no live utterance (every slot
+        inactive, positions frozen) run the decoder steps and the renderer often enough to load the kernels, size the
+        buffers and capture the hipGraphs of both frame-buffer parities -- so that no capture happens while other threads
+        are launching.  Only with the engine idle."""
+        pp, st, dev = self.pp, self.st, self.device
+        assert not self.live and not self.pending
+        with torch.cuda.device(dev), torch.cuda.stream(self.main):
+            st.active.zero_()
+            for n in sorted(set(min(st.R, -(-r // self.row_bucket) * self.row_bucket) for r in rows)):
+                for _ in range(4 + (st.ncalls & 1)):
+                    masks = torch.zeros((16, 2, 256), dtype=torch.uint8, device=dev)
+                    par = ragged_decoder_steps(pp.model, st, masks, n, nsteps=16, threshold=pp.threshold)
+                    self._render(par, n)
+                    self.main.synchronize()
+            if st.ncalls & 1:                                       # leave the parity where a fresh engine starts
+                st.ncalls += 1
+            st.fresh[0].zero_()
+            st.fresh[1].zero_()
+            self.main.synchronize()
+
+    # ---- background engine thread -----------------------------------------------------------------------------------
+    def start(self):
+        import threading
+        assert self.thread is None
+        self.halt = False
+
+        def loop():
+            torch.cuda.set_device(self.device)
+            while True:
+                with self.cv:
+                    while not self.halt and not self.pending and not self.live:
+                        self.cv.wait()
+                    if self.halt and not self.pending and not self.live:
+                        return
+                try:
+                    self.step()
+                except BaseException as e:                  # fail every waiting group loudly, then re-raise
+                    with self.cv:
+                        for grp in self.live + self.pending:
+                            grp.error = e
+                            grp.done.set()
+                        self.live, self.pending = [], []
+                    raise
+        self.thread = threading.Thread(target=loop, daemon=True, name='ContinuousTTS')
+        self.thread.start()
+        return self
+
+    def stop(self):
+        with self.cv:
+            self.halt = True
+            self.cv.notify_all()
+        if self.thread is not None:
+            self.thread.join()
+            self.thread = None
 
 
 def load_pretrained_weights(model_name):

@@ -296,6 +296,69 @@ def test_whisper_generate_beam_matches_transformers_fixture(dev, golden_dir):
     assert torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1]) and torch.allclose(a[2], b_[2])
 
 
+def test_whisper_base_beam_at_bench_batch_128(dev, golden_dir):
+    """The decode bench.py times: Whisper-BASE, 128 utterances x 5 beams = 640 decode rows (LayerNorm-folded skinny
+    GEMMs at 640 rows, small-grid k_igemm for layer 0's q|k|v, the beams' shared cross-attention, device search step and
+    KV gather), 32 new tokens.  Utterances 0-3 are the fixture's (transformers generate(num_beams=5) on the seeded
+    base weights, tools/gen_golden_nn.py:gen_whisper_beam; `oracle.nn.whisper_beam` equals it exactly); the other 124
+    rows carry other audio.  Per sampled utterance: the hypothesis is the fixture's, or -- where bf16 logit error
+    reorders near-tied beams -- scores within the logit error of the fixture's best under the fp32 oracle; and the score the
+    device reports is the teacher-forced fp32 score of what it returned.  Also: the batch-position invariance of the 640-row
+    step (utterances 64.. repeat 0..) and graph replay == eager."""
+    from infernos_amd.engines.whisper import Whisper
+    from infernos_amd.features import WhisperLogMel
+    from infernos_amd.synth import synth_utterance
+    from infernos_amd.audio import get_resampler
+    from infernos_amd.weights import synth_state_dict
+    g = np.load(os.path.join(golden_dir, 'whisper_beam.npz'))
+    meta = json.load(open(os.path.join(golden_dir, 'whisper_beam_meta.json')))
+    mb = meta['base']
+    sd = synth_state_dict('whisper_base', mb['weights_seed'])
+    model = Whisper(sd, dev)
+    B, K, V = 128, 5, 51865
+    seeds = mb['audio_seeds'] + [1100 + i for i in range(64 - len(mb['audio_seeds']))]
+    seeds = seeds + seeds                                       # utterance 64 + j == utterance j
+    rs = get_resampler(8000, 16000, str(dev))
+    x8 = torch.from_numpy(np.stack([synth_utterance(s_, 10.0) for s_ in seeds])).to(dev)
+    mel = WhisperLogMel(80, dev)(rs(x8))
+    enc = model.encode(mel)
+    melc = mel[:4].float().cpu()
+    prompt = torch.tensor([meta['prompt']] * B, dtype=torch.int32)
+    exact = total = 0
+    for ci, c in enumerate(mb['cases']):
+        sup = torch.zeros(V)
+        sup[50257:] = float('-inf')
+        sup[c['eos']] = 0.0
+        runs = []
+        for use_graphs in (False, True, True):                  # eager, capture, replay
+            runs.append(model.generate_beam(enc, prompt, c['n_new'], beams=K, eos_id=c['eos'], length_penalty=c['lp'],
+                                            suppress=sup, no_speech_id=50362, check_every=8, use_graphs=use_graphs))
+        for a, b_ in zip(runs[0][:3], runs[2][:3]):
+            assert torch.equal(a, b_), 'graph replay differs from the eager search'
+        toks, lens, scores, nsp = (t.cpu() for t in runs[2])
+        assert torch.equal(toks[:64], toks[64:]) and torch.equal(lens[:64], lens[64:]) and torch.equal(scores[:64], scores[64:])
+        assert torch.equal(nsp[:64], nsp[64:])
+        glen = g['base_len%d' % ci]
+        for b in range(4):
+            mine = toks[b, :lens[b]].tolist()
+            ref = g['base_seq%d' % ci][b, :glen[b]].tolist()
+            n = max(1, len(mine))
+            norm = n ** c['lp']
+            tol = 0.12 * n / norm                               # bf16 logits: <= ~0.12 absolute on one token's log-prob
+            with torch.no_grad():
+                ts = _teacher_score(sd, melc[b:b + 1], meta['prompt'], mine, mb['nheads'], sup, None) / norm
+            assert abs(ts - float(scores[b])) < tol, (ci, b, ts, float(scores[b]), tol)
+            total += 1
+            if mine == ref:
+                exact += 1
+                assert abs(float(scores[b]) - float(g['base_score%d' % ci][b])) < tol
+            else:
+                rn = max(1, len(ref))
+                assert ts > float(g['base_score%d' % ci][b]) - 0.12 * max(n / norm, rn / rn ** c['lp']), (ci, b, mine, ref, ts)
+    print('base beam at 640 rows: %d / %d sampled hypotheses identical to the transformers fixture' % (exact, total))
+    assert exact >= total // 2
+
+
 def test_whisper_generate_beam_one_beam_is_greedy(dev):
     """beams=1 walks the greedy path: same tokens as generate() up to the first eos."""
     from infernos_amd.engines.whisper import Whisper

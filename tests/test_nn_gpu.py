@@ -108,11 +108,12 @@ def test_conv_kernel_matches_torch(dev, case):
 
 # ---- decode-step GEMMs at the row counts the bench runs (65..256 rows: the two-row-tile k_gemm_skinny variants) ----------
 def _skinny_variant(M, K, N):
-    """which instantiation csrc/nn.hip selects (ifh_conv_bf16, M <= 256, one tap): (K-split waves, row tiles, column tiles)"""
+    """which instantiation csrc/nn.hip selects (ifh_conv_bf16, one tap): (K-split waves, row tiles, column tiles).  The K split
+    depends on K alone (2-way below 2048, 4-way from there), so a row's bits do not depend on the launch's row count."""
     if M <= 64:
         return (4, 1, 1) if K >= 2048 else (2, 1, 1)
     big = ((N + 15) // 16) * ((M + 31) // 32) > 1024
-    return (4, 2, 2) if (K >= 2048 or big) else (2, 2, 1)
+    return (4, 2, 2) if K >= 2048 else ((2, 2, 2) if big else (2, 2, 1))
 
 
 @pytest.mark.parametrize('M', [65, 128, 192, 256])
@@ -182,6 +183,167 @@ def test_skinny_gemm_variants_match_torch(dev, M, KN):
         yf = y.float().cpu().double()
         st2 = stats[1, :M].cpu().double() / 65536.0
         assert (st2[:, 0] - yf.sum(1)).abs().max() < 1e-2 and (st2[:, 1] - (yf ** 2).sum(1)).abs().max() < 5e-2
+
+
+# ---- the GEMMs of the decode path bench.py times: 5-beam Whisper-base = 640 rows (csrc/nn.hip:676-725) ---------------
+def _ln_chain_case(dev, M, D, g):
+    """One decoder layer's LayerNorm-folded chain at M rows, width D (ffn 4D), through ifh_conv_bf16 exactly as
+    engines/whisper.py:decoder_step_folded / engines/speecht5.py:_decoder_step_folded issue it; every launch against
+    fp32 torch `layer_norm -> linear` on the rounded inputs it actually read."""
+    from infernos_amd import ops
+    FFN = 4 * D
+    rows_pad = -(-M // 16) * 16
+    stats = torch.zeros((3, max(64, rows_pad), 2), dtype=torch.int64, device=dev)
+    SO = stats.size(1) * 2
+    rnd = lambda *s, sc=1.0: bfr(torch.randn(*s, generator=g) * sc)
+    att, x0 = rnd(M, D), rnd(M, D)
+    wo, bo = rnd(D, D, sc=D ** -0.5), torch.randn(D, generator=g) * 0.1
+    g1, b1 = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    errs = {}
+    # producer (out_proj shape): t1 = att @ wo^T + bo + x0, row statistics of the ROUNDED rows into stats[0]
+    t1 = torch.empty(M, D, dtype=BF, device=dev)
+    ops.linear(att.to(dev, BF), wo.to(dev, BF), bo.to(dev), t1, rows=M, k=D, n=D, resid=x0.to(dev, BF), stats_out=stats,
+               stats_off=0, ln_dim=D)
+    errs['producer'] = rel_l2(t1.float().cpu(), att @ wo.t() + bo + x0)
+    t1f = t1.float().cpu()
+    st = stats[0, :M].cpu().double() / 65536.0
+    assert (st[:, 0] - t1f.double().sum(1)).abs().max() < 1e-2 and (st[:, 1] - (t1f.double() ** 2).sum(1)).abs().max() < 5e-2
+    ln1 = F.layer_norm(t1f, (D,), g1, b1, 1e-5)
+    # aln consumers: N = D (cross q), 3D (q|k|v, second output region = K|V cache rows), 4D + GELU (fc1)
+    for name, N, actf, actc in (('q', D, lambda v: v, 0), ('qkv', 3 * D, lambda v: v, 0), ('ff1', FFN, F.gelu, 2)):
+        w, b = rnd(N, D, sc=D ** -0.5), torch.randn(N, generator=g) * 0.1
+        wf, c2, c1 = ops.w_linear_ln(w, b, g1, b1, dev)
+        ref = actf(ln1 @ w.t() + b)
+        if name == 'qkv':
+            y, kv = torch.empty(M, D, dtype=BF, device=dev), torch.zeros(M, 4, 2 * D, dtype=BF, device=dev)
+            pos = torch.tensor([2], dtype=torch.int32, device=dev)
+            ops.conv(t1, wf, c2, y, nbatch=M, t_in=1, t_out=1, cin=D, n=3 * D, ldc=D, out_bstride=D, dyn_pos=pos, n_split=D,
+                     out2=kv, out2_bstride=4 * 2 * D, ldc2=2 * D, dyn_ooff2_mul=1, aln=(stats, 0, c1), ln_dim=D)
+            got = torch.cat([y.float().cpu(), kv[:, 2].float().cpu()], 1)
+            assert not bool(kv[:, [0, 1, 3]].any()), 'K|V rows written outside the dynamic position'
+        else:
+            y = torch.empty(M, N, dtype=BF, device=dev)
+            ops.linear(t1, wf, c2, y, rows=M, k=D, n=N, act=actc, aln=(stats, 0, c1), ln_dim=D)
+            got = y.float().cpu()
+            if name == 'ff1':
+                ffd, ff = y, got
+        errs['aln_' + name] = rel_l2(got, ref)
+    # deep-K producer with a LayerNorm'd residual (fc2 shape, SpeechT5 post-LN form) and, plain residual, the Whisper form
+    w2, b2 = rnd(D, FFN, sc=FFN ** -0.5), torch.randn(D, generator=g) * 0.1
+    y = torch.empty(M, D, dtype=BF, device=dev)
+    ops.linear(ffd, w2.to(dev, BF), b2.to(dev), y, rows=M, k=FFN, n=D, resid=t1, rln=(stats, 0, g1.to(dev), b1.to(dev)),
+               stats_out=stats, stats_off=SO, ln_dim=D)
+    errs['rln_ff2'] = rel_l2(y.float().cpu(), ff @ w2.t() + b2 + ln1)
+    yf = y.float().cpu().double()
+    st2 = stats[1, :M].cpu().double() / 65536.0
+    assert (st2[:, 0] - yf.sum(1)).abs().max() < 1e-2 and (st2[:, 1] - (yf ** 2).sum(1)).abs().max() < 5e-2
+    y2 = torch.empty(M, D, dtype=BF, device=dev)
+    ops.linear(ffd, w2.to(dev, BF), b2.to(dev), y2, rows=M, k=FFN, n=D, resid=t1, stats_out=stats, stats_off=2 * SO, ln_dim=D)
+    errs['ff2'] = rel_l2(y2.float().cpu(), ff @ w2.t() + b2 + t1f)
+    # bits: the M-row launch against the same rows in 64-row pieces (the one-tile kernels) where both split K alike
+    pieces = torch.empty(M, D, dtype=BF, device=dev)
+    stp = torch.zeros_like(stats)
+    for r0 in range(0, M, 64):
+        r1 = min(M, r0 + 64)
+        ops.linear(ffd[r0:r1], w2.to(dev, BF), b2.to(dev), pieces[r0:r1], rows=r1 - r0, k=FFN, n=D, resid=t1[r0:r1],
+                   stats_out=stp, stats_off=r0 * 2, ln_dim=D)
+    if _skinny_variant(M, FFN, D)[0] == _skinny_variant(64, FFN, D)[0]:
+        assert torch.equal(y2.view(torch.int16), pieces.view(torch.int16)), ('bits', M, D)
+        assert torch.equal(stats[2, :M], stp[0, :M]), 'row statistics differ between the M-row launch and its 64-row pieces'
+    else:
+        assert rel_l2(y2.float().cpu(), pieces.float().cpu()) < 2e-3
+    return errs
+
+
+@pytest.mark.parametrize('M', [320, 640, 1024])
+@pytest.mark.parametrize('D', [384, 512, 768])
+def test_skinny_gemm_ln_folded_at_beam_rows(dev, M, D):
+    """The LayerNorm-folded k_gemm_skinny branch above 256 rows ("up to 1024", csrc/nn.hip:676-702): what the 5-beam
+    decode of bench.py runs at 128 utterances x 5 = 640 rows (Whisper-base, D = 512), plus tiny (384) and the SpeechT5
+    width (768), at 320 / 640 / 1024 rows."""
+    g = torch.Generator().manual_seed(M * 7 + D)
+    errs = _ln_chain_case(dev, M, D, g)
+    print('M=%d D=%d' % (M, D), {k: '%.2e' % v for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v < (8e-3 if k.startswith('aln') else 5e-3), (M, D, k, v)
+
+
+@pytest.mark.parametrize('N', [512, 1536, 2048])
+def test_small_grid_igemm_at_640_rows(dev, N):
+    """The un-folded GEMMs of the 640-row decode step (layer 0's q|k|v behind an explicit LayerNorm, and every GEMM when
+    IFH_FOLD_LN=0) take k_igemm's small-grid tile selection (csrc/nn.hip:715-725: 64 x 32 / 128 x 64 tiles so that a
+    640 x N layer still yields a workgroup per CU): against fp32 torch, and bit-identical to the same rows run in
+    64-row pieces (<= 64 rows: k_gemm_skinny<2,12,1> -- a different kernel with a different K order, so only close) and to
+    a 4096-row launch of the same rows repeated (the 128 x 128 tile: same k order per output element, same bits)."""
+    from infernos_amd import ops
+    M, K = 640, 512
+    g = torch.Generator().manual_seed(N)
+    x = bfr(torch.randn(M, K, generator=g))
+    w = bfr(torch.randn(N, K, generator=g) / K ** 0.5)
+    b = torch.randn(N, generator=g) * 0.1
+    act, actc = (F.gelu, 2) if N == 2048 else ((lambda v: v), 0)
+    xd, wd, bd = x.to(dev, BF), w.to(dev, BF), b.to(dev)
+    ref = act(x @ w.t() + b)
+    if N == 1536:           # the q|k|v launch: q -> scratch, K|V -> cache rows at the device-held position
+        y, kv = torch.empty(M, 512, dtype=BF, device=dev), torch.zeros(M, 3, 1024, dtype=BF, device=dev)
+        pos = torch.tensor([1], dtype=torch.int32, device=dev)
+        ops.conv(xd, wd, bd, y, nbatch=M, t_in=1, t_out=1, cin=K, n=N, ldc=512, out_bstride=512, dyn_pos=pos, n_split=512,
+                 out2=kv, out2_bstride=3 * 1024, ldc2=1024, dyn_ooff2_mul=1)
+        out = torch.cat([y, kv[:, 1]], 1)
+        assert not bool(kv[:, [0, 2]].any())
+    else:
+        out = torch.empty(M, N, dtype=BF, device=dev)
+        ops.linear(xd, wd, bd, out, rows=M, k=K, n=N, act=actc)
+    e = rel_l2(out.float().cpu(), ref)
+    assert e < 5e-3, (N, e)
+    big = torch.empty(4096, N, dtype=BF, device=dev)
+    ops.linear(xd.repeat(7, 1)[:4096].contiguous(), wd, bd, big, rows=4096, k=K, n=N, act=actc)
+    assert torch.equal(big[:M].view(torch.int16), out.contiguous().view(torch.int16)), 'tile selection changed the bits'
+    pieces = torch.empty(M, N, dtype=BF, device=dev)
+    for r0 in range(0, M, 64):
+        ops.linear(xd[r0:r0 + 64], wd, bd, pieces[r0:r0 + 64], rows=64, k=K, n=N, act=actc)
+    assert rel_l2(pieces.float().cpu(), out.float().cpu()) < 2e-3
+
+
+@pytest.mark.parametrize('shape', ['gate_up', 'head'])
+def test_gemm_m64_at_qwen2_1p5b_shapes(dev, shape):
+    """k_gemm_m64<4,2> is selected only from 1024 column tiles up (csrc/nn.hip:672): the two layers of Qwen2.5-1.5B
+    (BASELINE configuration 5) that reach it, at 64 rows -- gate|up 17920 x 1536 with the folded RMSNorm scale and the
+    SiLU(gate)*up epilogue, and the 151936-row vocabulary head with the folded final norm -- against fp32 torch."""
+    from infernos_amd import ops
+    M, K = 64, 1536
+    g = torch.Generator().manual_seed(11 if shape == 'head' else 12)
+    x = bfr(torch.randn(M, K, generator=g))
+    gam = 1 + 0.2 * torch.randn(K, generator=g)
+    stats = torch.zeros((1, 64, 2), dtype=torch.int64, device=dev)
+    xs = x.double()
+    stats[0, :, 0] = torch.round(xs.sum(1) * 65536).long().to(dev)
+    stats[0, :, 1] = torch.round((xs ** 2).sum(1) * 65536).long().to(dev)
+    xn = x * torch.rsqrt((x ** 2).mean(1, keepdim=True) + 1e-6)              # RMSNorm without gamma (folded into W)
+    if shape == 'gate_up':
+        FFN = 8960
+        wg = torch.randn(FFN, K, generator=g) / K ** 0.5
+        wu = torch.randn(FFN, K, generator=g) / K ** 0.5
+        wi = torch.stack([wg, wu], 1).reshape(2 * FFN, K)                     # (gate, up)-interleaved rows
+        wf = (wi * gam[None, :]).to(BF)
+        out = torch.empty(M, FFN, dtype=BF, device=dev)
+        ops.linear(x.to(dev, BF), wf.to(dev), None, out, rows=M, k=K, n=2 * FFN, ldc=FFN, act=ops.ACT_SILU_GLU,
+                   aln=(stats, 0, None), ln_dim=K, ln_eps=1e-6, ln_rms=True)
+        wff = wf.float()
+        ref = F.silu(xn @ wff[0::2].t()) * (xn @ wff[1::2].t())
+        e = rel_l2(out.float().cpu(), ref)
+        assert e < 6e-3, e
+    else:
+        V = 151936
+        w = torch.randn(V, K, generator=g) / K ** 0.5
+        wf = (w * gam[None, :]).to(BF)
+        out = torch.empty(M, V, dtype=torch.float32, device=dev)
+        ops.linear(x.to(dev, BF), wf.to(dev), None, out, rows=M, k=K, n=V, aln=(stats, 0, None), ln_dim=K, ln_eps=1e-6,
+                   ln_rms=True)
+        ref = xn @ wf.float().t()
+        e = rel_l2(out.cpu(), ref)
+        assert e < 1e-3, e
+        assert torch.equal(out.cpu().argmax(1), ref.argmax(1)) or float((ref.topk(2).values[:, 0] - ref.topk(2).values[:, 1]).min()) < 1e-2
 
 
 def test_conv_transpose_phases_match_torch(dev):
@@ -645,16 +807,20 @@ def test_whisper_matches_oracle_and_reference_fixture(dev, golden_dir):
     x8 = torch.from_numpy(np.stack([synth_utterance(s, 10.0) for s in meta['audio_seeds']])).to(dev)
     mel = WhisperLogMel(80, dev)(rs(x8))
     enc = model.encode(mel)
+    # bars: 1.5 x the error the reference's own HF engine makes when it merely runs in bf16 (tools/gen_golden_nn.py:
+    # gen_whisper_tf, same weights and utterances): encoder output, and the logits after the whole prompt (position 3)
+    tf = json.load(open(os.path.join(golden_dir, 'whisper_tf_meta.json')))['whisper_tiny']
+    bar_enc, bar_log = 1.5 * tf['enc_bf16_vs_fp32_rel_l2'], 1.5 * tf['bf16_vs_fp32_rel_l2'][len(meta['prompt']) - 1]
     e_enc = rel_l2(enc.float().cpu()[:, ::25, :32], torch.from_numpy(g['enc_slice']))
-    assert e_enc < 3e-2, e_enc
+    assert e_enc < bar_enc, (e_enc, bar_enc)
     prompt = torch.tensor([meta['prompt']] * 2, dtype=torch.int32)
     toks, nsp, first = model.generate(enc, prompt, 8, no_speech_id=meta['no_speech_id'], keep_logits=True)
     ref_first = torch.from_numpy(g['first_logits_slice'])
     e_log = rel_l2(first.cpu()[:, ::97], ref_first)
-    assert e_log < 5e-2, e_log
+    assert e_log < bar_log, (e_log, bar_log)
     with torch.no_grad():
         o_toks, o_first, o_l0, o_enc = onn.whisper_greedy(sd, mel.float().cpu(), prompt.long(), 8, 6)
-    assert rel_l2(enc.float().cpu(), o_enc) < 3e-2
+    assert rel_l2(enc.float().cpu(), o_enc) < bar_enc
     # greedy tokens: must agree wherever the oracle's top-1 margin exceeds the logit error
     agree = (toks.cpu() == o_toks.int())
     print('whisper: enc rel_l2 %.3e logits rel_l2 %.3e token agreement %s' % (e_enc, e_log, agree.tolist()))
@@ -668,9 +834,10 @@ def test_whisper_matches_oracle_and_reference_fixture(dev, golden_dir):
     np.testing.assert_allclose(nsp.cpu().numpy(), meta['no_speech_prob'], rtol=0.5)
 
 
-def test_whisper_base_config3_matches_oracle(dev):
+def test_whisper_base_config3_matches_oracle(dev, golden_dir):
     """BASELINE config 3 dims (Whisper-base: d=512, 6+6 layers, 8 heads, ffn 2048): encoder and the first
-    greedy tokens against the fp32 oracle on seeded weights (no reference fixture exists for base)."""
+    greedy tokens against the fp32 oracle on seeded weights; bars = 1.5 x the HF engine's own bf16-vs-fp32 error on
+    these weights (tests/golden/whisper_tf_meta.json)."""
     from infernos_amd.engines.whisper import Whisper
     from infernos_amd.features import WhisperLogMel
     from infernos_amd.synth import synth_utterance
@@ -686,8 +853,10 @@ def test_whisper_base_config3_matches_oracle(dev):
     toks, nsp, first = model.generate(enc, prompt, 4, no_speech_id=50362, keep_logits=True)
     with torch.no_grad():
         o_toks, o_first, o_l0, o_enc = onn.whisper_greedy(sd, mel.float().cpu(), prompt.long(), 4, 8)
-    assert rel_l2(enc.float().cpu(), o_enc) < 3e-2
-    assert rel_l2(first.cpu(), o_first) < 5e-2
+    tf = json.load(open(os.path.join(golden_dir, 'whisper_tf_meta.json')))['whisper_base']
+    e_enc, e_log = rel_l2(enc.float().cpu(), o_enc), rel_l2(first.cpu(), o_first)
+    assert e_enc < 1.5 * tf['enc_bf16_vs_fp32_rel_l2'], (e_enc, tf['enc_bf16_vs_fp32_rel_l2'])
+    assert e_log < 1.5 * tf['bf16_vs_fp32_rel_l2'][3], (e_log, tf['bf16_vs_fp32_rel_l2'][3])
     top2 = o_first.topk(2).values
     for b in range(2):
         if float(top2[b, 0] - top2[b, 1]) > 0.05:
@@ -745,4 +914,4 @@ def test_whisper_teacher_forced_logits_every_step(dev, golden_dir, family, Bn):
             assert e < bar[t], (family, 'oracle', rows[r], t, e, bar[t])
     print('%s B=%d: encoder rel_l2 %.3e; worst teacher-forced logit error = %.2f x the bar (1.5 x HF-bf16 error %.1e..%.1e)'
           % (family, Bn, e_enc, worst, min(meta['bf16_vs_fp32_rel_l2']), max(meta['bf16_vs_fp32_rel_l2'])))
-    assert e_enc < 1.5e-2
+    assert e_enc < 1.5 * meta['enc_bf16_vs_fp32_rel_l2'], (e_enc, meta['enc_bf16_vs_fp32_rel_l2'])

@@ -258,9 +258,11 @@ def gen_whisper_tf():
         auds = [dsp.resample(synth_utterance(a, 10.0), 8000, 16000) for a in aseeds]
         mel = torch.from_numpy(fe(auds, sampling_rate=16000, return_tensors='np').input_features)
         with torch.no_grad():
-            l32 = model(input_features=mel, decoder_input_ids=toks).logits                # [2, 36, V]
+            fo32 = model(input_features=mel, decoder_input_ids=toks)
+            l32, enc32 = fo32.logits, fo32.encoder_last_hidden_state                      # [2, 36, V], [2, 1500, d]
             mb = model.to(torch.bfloat16)
-            l16 = mb(input_features=mel.to(torch.bfloat16), decoder_input_ids=toks).logits.float()
+            fo16 = mb(input_features=mel.to(torch.bfloat16), decoder_input_ids=toks)
+            l16, enc16 = fo16.logits.float(), fo16.encoder_last_hidden_state.float()
             model.to(torch.float32)
             # the oracle (oracle/nn.py) on the same inputs: pins it for teacher-forced steps as well
             enc = onn.whisper_encoder(sd, mel, nh)
@@ -273,7 +275,9 @@ def gen_whisper_tf():
         print(fam, 'oracle vs HF fp32 (max over positions) %.2e ; HF bf16 vs fp32 per position: min %.2e max %.2e' % (eo, min(e16), max(e16)))
         assert eo < 1e-4
         meta[fam] = {'weights_seed': seed, 'audio_seeds': aseeds, 'tokens': toks.tolist(), 'nheads': nh,
-                     'bf16_vs_fp32_rel_l2': e16, 'oracle_vs_hf_fp32_rel_l2_max': eo, 'vocab': vocab}
+                     'bf16_vs_fp32_rel_l2': e16, 'oracle_vs_hf_fp32_rel_l2_max': eo, 'vocab': vocab,
+                     # the same engine's encoder output, bf16 run against fp32 run: the bar for the device encoder
+                     'enc_bf16_vs_fp32_rel_l2': rel(enc16, enc32), 'oracle_enc_vs_hf_fp32_rel_l2': rel(enc, enc32)}
         if fam == 'whisper_tiny':
             arrays['tiny_logits_fp32_slice'] = l32[:, :, ::97].numpy()
             arrays['tiny_logits_bf16_slice'] = l16[:, :, ::97].numpy()
@@ -350,11 +354,53 @@ def gen_whisper_beam():
         arrays['len%d' % ci] = np.asarray(lens, np.int32)
         arrays['score%d' % ci] = out.sequences_scores.numpy()
         meta.append(c)
+    # ---- Whisper-BASE (BASELINE config 3), the search bench.py times: 5 beams, 32 new tokens, length_penalty 1; four
+    # utterances; a second case ends early on an eos taken from the first case's output
+    base_cfg = dict(d_model=512, encoder_layers=6, decoder_layers=6, encoder_attention_heads=8, decoder_attention_heads=8,
+                    encoder_ffn_dim=2048, decoder_ffn_dim=2048)
+    sdb = synth_state_dict('whisper_base', 1)
+    mb = WhisperForConditionalGeneration(WhisperConfig(**base_cfg))
+    mb.load_state_dict(sdb, strict=True)
+    mb.eval()
+    bseeds = [1000, 1001, 1002, 1003]
+    bauds = [dsp.resample(synth_utterance(a, 10.0), 8000, 16000) for a in bseeds]
+    bmel = torch.from_numpy(fe(bauds, sampling_rate=16000, return_tensors='np').input_features)
+    bprompt = torch.tensor([PROMPT] * len(bseeds))
+    bcases = [dict(beams=5, eos=50257, n_new=32, lp=1.0, begin=[])]
+    bmeta = []
+    ci = 0
+    while ci < len(bcases):
+        c = bcases[ci]
+        sup_ids = [i for i in range(50257, V) if i != c['eos']]
+        with torch.no_grad():
+            out = GenerationMixin.generate(mb, input_features=bmel, decoder_input_ids=bprompt, num_beams=c['beams'],
+                                           do_sample=False, max_new_tokens=c['n_new'], eos_token_id=c['eos'],
+                                           pad_token_id=50256, length_penalty=c['lp'], early_stopping=False,
+                                           return_dict_in_generate=True, output_scores=True, suppress_tokens=sup_ids,
+                                           begin_suppress_tokens=None, forced_decoder_ids=None)
+        seq = out.sequences[:, len(PROMPT):]
+        lens = [r.index(c['eos']) + 1 if c['eos'] in r else len(r) for r in seq.tolist()]
+        sup = torch.zeros(V)
+        sup[sup_ids] = float('-inf')
+        o_seq, o_sc, _ = onn.whisper_beam(sdb, bmel, bprompt, c['n_new'], 8, c['beams'], c['eos'], c['lp'], suppress=sup)
+        same = all(o_seq[b] == seq[b, :lens[b]].tolist() for b in range(len(bseeds)))
+        print('base beam case', ci, c, 'lens', lens, 'tokens equal', same, 'score diff',
+              float((o_sc - out.sequences_scores).abs().max()))
+        assert same
+        arrays['base_seq%d' % ci] = seq.numpy().astype(np.int32)
+        arrays['base_len%d' % ci] = np.asarray(lens, np.int32)
+        arrays['base_score%d' % ci] = out.sequences_scores.numpy()
+        bmeta.append(c)
+        if ci == 0:
+            bcases.append(dict(beams=5, eos=int(seq[0, 10]), n_new=32, lp=1.0, begin=[]))
+        ci += 1
     np.savez_compressed(os.path.join(GOLD, 'whisper_beam.npz'), **arrays)
     json.dump({'source': 'transformers 5.15.0 GenerationMixin.generate(num_beams=K, do_sample=False, early_stopping=False) '
                          'on WhisperForConditionalGeneration(WhisperConfig()) holding synth_state_dict(whisper_tiny, 0); '
-                         'ids >= 50257 other than eos suppressed (suppress_tokens), `begin` = begin_suppress_tokens',
-               'prompt': PROMPT, 'audio_seeds': [1000, 1001], 'cases': meta},
+                         'ids >= 50257 other than eos suppressed (suppress_tokens), `begin` = begin_suppress_tokens; '
+                         '`base_*`: the same on synth_state_dict(whisper_base, 1) (d 512, 6+6 layers, 8 heads)',
+               'prompt': PROMPT, 'audio_seeds': [1000, 1001], 'cases': meta,
+               'base': {'weights_seed': 1, 'audio_seeds': bseeds, 'nheads': 8, 'cases': bmeta}},
               open(os.path.join(GOLD, 'whisper_beam_meta.json'), 'w'), indent=1, sort_keys=True)
     print('wrote whisper_beam.npz')
 
