@@ -339,6 +339,10 @@ typedef struct ifh_conv_desc {
                             * (dyn_pos[m]): rows of a ragged decode batch sit at different positions -- each appends its K|V
                             * at its own cache row and adds its own positional-encoding row (continuous batching of the
                             * loop at HelloSippyRTPipe.py:195-229 across utterances that joined at different infer() calls) */
+    int32_t decode_step;   /* 1: the launch belongs to a latency-bound decode step of up to 1024 rows: it takes the weight-streaming
+                            * kernel whose K split depends on K alone (the one every launch of <= 256 rows takes), so that a row's
+                            * bits do not depend on how many rows share the step -- a row of a 640-row ragged batch equals the
+                            * same row decoded in a batch of 8 */
 } ifh_conv_desc;
 int ifh_conv_bf16(const ifh_conv_desc *desc, ifh_stream_t stream);
 

@@ -204,6 +204,86 @@ __device__ __forceinline__ void igemm_store4(const IgemmParams &p, int m, int n,
         igemm_store4_general(p, m, n, acc[0], acc[1], acc[2], acc[3], dynv);
 }
 
+// ---- LayerNorm-folded epilogue of the decode-step GEMMs (ifh_conv_desc.aln_* / rln_* / stats_out), shared by the
+// weight-streaming kernel (k_gemm_skinny) and the LDS-tiled one (k_gemm_dec) so that both produce the same bits from the same
+// accumulated 4-vector.  `s` = D[n .. n+3][m]; operands were fetched by the caller ahead of its K loop.
+struct LnRow {
+    float a_mean, a_rstd, r_mean, r_rstd;
+};
+
+__device__ __forceinline__ LnRow ln_row(const IgemmParams &p, longlong2 st_a, longlong2 st_r)
+{
+    const float fx = (1.0f / 65536.0f) / (float)p.ln_dim;
+    LnRow r;
+    r.a_mean = p.ln_rms ? 0.0f : (float)st_a.x * fx;
+    r.r_mean = (float)st_r.x * fx;
+    r.a_rstd = rsqrtf(fmaxf((float)st_a.y * fx - r.a_mean * r.a_mean, 0.0f) + p.ln_eps);
+    r.r_rstd = rsqrtf(fmaxf((float)st_r.y * fx - r.r_mean * r.r_mean, 0.0f) + p.ln_eps);
+    return r;
+}
+
+// xok: row m is a real row; lanes fg = 0..3 of a 16-lane group hold columns n = nb + 4*fg of the same row (all 64 lanes of the
+// wave must call this: the row statistics are reduced across them by shuffles)
+__device__ __forceinline__ void ln_epi4(const IgemmParams &p, int m, int n, bool xok, f32x4 s, int dynv, const LnRow &lr,
+                                        float4 c1, float4 bias, float4 gam, float4 beta, uint2 resid, int fg)
+{
+    float v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
+    const bool ok = xok && n < p.N;
+    if (ok) {
+        const EpiRow er = epi_row(p, m, n, dynv);
+        if (p.aln_stats) {
+            const float mean = lr.a_mean, rstd = lr.a_rstd;
+            v0 = rstd * (v0 - mean * c1.x);
+            v1 = rstd * (v1 - mean * c1.y);
+            v2 = rstd * (v2 - mean * c1.z);
+            v3 = rstd * (v3 - mean * c1.w);
+        }
+        if (p.bias) {
+            v0 += bias.x; v1 += bias.y; v2 += bias.z; v3 += bias.w;
+        }
+        if (p.act != ACT_NONE) {
+            v0 = apply_act(v0, p.act, p.act_slope);
+            v1 = apply_act(v1, p.act, p.act_slope);
+            v2 = apply_act(v2, p.act, p.act_slope);
+            v3 = apply_act(v3, p.act, p.act_slope);
+        }
+        if (p.resid) {
+            float r0 = __uint_as_float(resid.x << 16), r1 = __uint_as_float(resid.x & 0xffff0000u);
+            float r2 = __uint_as_float(resid.y << 16), r3 = __uint_as_float(resid.y & 0xffff0000u);
+            if (p.rln_stats) {
+                const float mean = lr.r_mean, rstd = lr.r_rstd;
+                r0 = (r0 - mean) * rstd * gam.x + beta.x;
+                r1 = (r1 - mean) * rstd * gam.y + beta.y;
+                r2 = (r2 - mean) * rstd * gam.z + beta.z;
+                r3 = (r3 - mean) * rstd * gam.w + beta.w;
+            }
+            v0 += r0; v1 += r1; v2 += r2; v3 += r3;
+        }
+        v0 *= p.out_scale; v1 *= p.out_scale; v2 *= p.out_scale; v3 *= p.out_scale;
+        if (p.out_f32) {
+            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(er.outp) + er.obase + n) = make_float4(v0, v1, v2, v3);
+        } else {
+            uint2 pk;
+            pk.x = f32x2_to_bf16x2(v0, v1);
+            pk.y = f32x2_to_bf16x2(v2, v3);
+            *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(er.outp) + er.obase + n) = pk;
+            v0 = __uint_as_float(pk.x << 16); v1 = __uint_as_float(pk.x & 0xffff0000u);   // what consumers will read
+            v2 = __uint_as_float(pk.y << 16); v3 = __uint_as_float(pk.y & 0xffff0000u);
+        }
+    }
+    if (p.stats_out) {
+        float s1 = ok ? (v0 + v1) + (v2 + v3) : 0.0f;
+        float s2 = ok ? (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3) : 0.0f;
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);      // the 4 lanes fg = 0..3 share row m
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if (fg == 0 && xok) {
+            unsigned long long *so = reinterpret_cast<unsigned long long *>(p.stats_out) + 2 * m;
+            atomicAdd(so, (unsigned long long)__double2ll_rn((double)s1 * 65536.0));
+            atomicAdd(so + 1, (unsigned long long)__double2ll_rn((double)s2 * 65536.0));
+        }
+    }
+}
+
 // conv.hip: LDS-resident-input convolution for the stride-1 residual-block shapes.
 // Returns true if it took the launch.
 bool try_launch_conv_direct(const IgemmParams &p, bool pre, hipStream_t st);

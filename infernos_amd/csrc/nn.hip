@@ -135,89 +135,188 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
         *reinterpret_cast<f32x4 *>(&red[wid][MT * (NT - 1)][lane][0]) = acc2;
         *reinterpret_cast<f32x4 *>(&red[wid][MT * NT - 1][lane][0]) = acc3;
     }
-    const float fx = (1.0f / 65536.0f) / (float)p.ln_dim;
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < TPW; e++) {
         if (!eown[e]) continue;
         const int tile = wid + e * NW;
-        const int m = em[e];
-        const bool xok = exok[e];
-        const int dynv0 = edyn[e];
-        const float a_mean = p.ln_rms ? 0.0f : (float)st_a[e].x * fx, r_mean = (float)st_r[e].x * fx;
-        const float a_rstd = rsqrtf(fmaxf((float)st_a[e].y * fx - a_mean * a_mean, 0.0f) + p.ln_eps);
-        const float r_rstd = rsqrtf(fmaxf((float)st_r[e].y * fx - r_mean * r_mean, 0.0f) + p.ln_eps);
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w][tile][lane][0]);
         const int n = enb[e] + 4 * fg;
         if (ln_mode) {
             // LayerNorm folded around the GEMM (host guarantees the vector epilogue conditions, N % 16 == 0)
-            float v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
-            const bool ok = xok && n < p.N;
-            if (ok) {
-                const EpiRow er = epi_row(p, m, n, dynv0);
-                if (p.aln_stats) {
-                    const float mean = a_mean, rstd = a_rstd;
-                    const float4 c1 = pc1[e];
-                    v0 = rstd * (v0 - mean * c1.x);
-                    v1 = rstd * (v1 - mean * c1.y);
-                    v2 = rstd * (v2 - mean * c1.z);
-                    v3 = rstd * (v3 - mean * c1.w);
-                }
-                if (p.bias) {
-                    const float4 bv = pbias[e];
-                    v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
-                }
-                if (p.act != ACT_NONE) {
-                    v0 = apply_act(v0, p.act, p.act_slope);
-                    v1 = apply_act(v1, p.act, p.act_slope);
-                    v2 = apply_act(v2, p.act, p.act_slope);
-                    v3 = apply_act(v3, p.act, p.act_slope);
-                }
-                if (p.resid) {
-                    const uint2 rv = presid[e];
-                    float r0 = __uint_as_float(rv.x << 16), r1 = __uint_as_float(rv.x & 0xffff0000u);
-                    float r2 = __uint_as_float(rv.y << 16), r3 = __uint_as_float(rv.y & 0xffff0000u);
-                    if (p.rln_stats) {
-                        const float mean = r_mean, rstd = r_rstd;
-                        const float4 g = pgam[e];
-                        const float4 bt = pbeta[e];
-                        r0 = (r0 - mean) * rstd * g.x + bt.x;
-                        r1 = (r1 - mean) * rstd * g.y + bt.y;
-                        r2 = (r2 - mean) * rstd * g.z + bt.z;
-                        r3 = (r3 - mean) * rstd * g.w + bt.w;
-                    }
-                    v0 += r0; v1 += r1; v2 += r2; v3 += r3;
-                }
-                v0 *= p.out_scale; v1 *= p.out_scale; v2 *= p.out_scale; v3 *= p.out_scale;
-                if (p.out_f32) {
-                    *reinterpret_cast<float4 *>(reinterpret_cast<float *>(er.outp) + er.obase + n) = make_float4(v0, v1, v2, v3);
-                } else {
-                    uint2 pk;
-                    pk.x = f32x2_to_bf16x2(v0, v1);
-                    pk.y = f32x2_to_bf16x2(v2, v3);
-                    *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(er.outp) + er.obase + n) = pk;
-                    v0 = __uint_as_float(pk.x << 16); v1 = __uint_as_float(pk.x & 0xffff0000u);   // what consumers will read
-                    v2 = __uint_as_float(pk.y << 16); v3 = __uint_as_float(pk.y & 0xffff0000u);
-                }
-            }
-            if (p.stats_out) {
-                float s1 = ok ? (v0 + v1) + (v2 + v3) : 0.0f;
-                float s2 = ok ? (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3) : 0.0f;
-                s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);      // the 4 lanes fg = 0..3 share row m
-                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-                if (fg == 0 && xok) {
-                    unsigned long long *so = reinterpret_cast<unsigned long long *>(p.stats_out) + 2 * m;
-                    atomicAdd(so, (unsigned long long)__double2ll_rn((double)s1 * 65536.0));
-                    atomicAdd(so + 1, (unsigned long long)__double2ll_rn((double)s2 * 65536.0));
-                }
-            }
-        } else if (xok && n < p.N) {
+            ln_epi4(p, em[e], n, exok[e], s, edyn[e], ln_row(p, st_a[e], st_r[e]), pc1[e], pbias[e], pgam[e], pbeta[e], presid[e], fg);
+        } else if (exok[e] && n < p.N) {
             if (p.fast_epi)
-                igemm_store4<true>(p, m, n, s, dynv0);
+                igemm_store4<true>(p, em[e], n, s, edyn[e]);
             else
-                igemm_store4<false>(p, m, n, s, dynv0);
+                igemm_store4<false>(p, em[e], n, s, edyn[e]);
+        }
+    }
+}
+
+// ---- LDS-tiled GEMM for decode steps of a few hundred rows (continuous batching: 192..1024 rows per step, the 640 rows of a
+// 5-beam search).  k_gemm_skinny re-streams the weights for every 32 rows from L2 -- 16 FLOP per L2 byte, fine while the step is
+// launch-bound at <= 128 rows, 20-40 us per launch at 512.  Here a 64 x BN output tile stages its operands through LDS, but a
+// decode-step GEMM is a LATENCY problem (K = 512..3072: a handful of microseconds of work), so the staging is built around
+// memory round trips, not around MFMA rate: K is walked in chunks of KC = 256 (8 k-steps of 32), all 16-byte loads of a
+// chunk are in flight at once (into registers, one chunk ahead of the one being multiplied), and a chunk costs two barriers.
+// K = 768 is three round trips instead of the 24 of a 32-wide double-buffered loop (the first version of this kernel: 23 us per
+// launch whatever the row count).  The ARITHMETIC is the streaming kernel's: K is accumulated in `ksplit` chains over the same
+// contiguous k ranges the streaming kernel's waves take (2 below K = 2048, 4 from there), the chains are added in wave order,
+// and the epilogue is the shared ln_epi4 / igemm_store4 -- so a row's bits are the same whichever kernel the row count selects
+// (tests/test_nn_gpu.py::test_gemm_dec_is_bit_identical_to_skinny).  taps == 1, K % 32 == 0, N % 16 == 0 in the LN modes.
+template <int BN>
+__global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const int ksplit)
+{
+    constexpr int BM = 64, KC = 256, LDK = KC + 8;        // row stride 528 B: the 16 rows of a fragment read fall on 16 distinct 16-byte slots
+    constexpr int WGM = 2, WGN = 2;
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int MT = WM / 16, NT = WN / 16;
+    constexpr int AV = BM * (KC / 8) / 256, BV = BN * (KC / 8) / 256;      // 16-byte vectors per thread per chunk
+    static_assert(BN == 32 || BN == 64, "column tile");
+    __shared__ __attribute__((aligned(16))) uint16_t As[BM * LDK];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid % WGM, wn = wid / WGM;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int M = p.nbatch * p.T_out;
+    // thread -> (row, 16-byte column) of the operand chunks: 32 consecutive threads read one row's 512 contiguous bytes
+    const int lrow = tid >> 5, lcol = (tid & 31) * 8;
+    const uint16_t *arow[AV], *brow[BV];
+    bool aval[AV], bval[BV];
+#pragma unroll
+    for (int i = 0; i < AV; i++) {
+        const int m = m0 + lrow + 8 * i;
+        aval[i] = m < M;
+        const int mm = aval[i] ? m : 0;
+        const int b = mm / p.T_out, t = mm - b * p.T_out;
+        arow[i] = p.x + (int64_t)b * p.x_bstride + (int64_t)t * p.lda + lcol;
+    }
+#pragma unroll
+    for (int i = 0; i < BV; i++) {
+        const int n = n0 + lrow + 8 * i;
+        bval[i] = n < p.N;
+        brow[i] = p.w + (int64_t)(bval[i] ? n : 0) * p.K + lcol;
+    }
+    uint4 ra[AV], rb[BV];
+#define IFH_DEC_LOAD(K0)                                                                                       \
+    {                                                                                                          \
+        const bool kin_ = (K0) + lcol < p.K;                                                                   \
+        _Pragma("unroll") for (int i = 0; i < AV; i++)                                                         \
+            ra[i] = (aval[i] && kin_) ? *reinterpret_cast<const uint4 *>(arow[i] + (K0)) : make_uint4(0, 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < BV; i++)                                                         \
+            rb[i] = (bval[i] && kin_) ? *reinterpret_cast<const uint4 *>(brow[i] + (K0)) : make_uint4(0, 0, 0, 0); \
+    }
+#define IFH_DEC_STORE()                                                                                        \
+    {                                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < AV; i++)                                                         \
+            *reinterpret_cast<uint4 *>(&As[(lrow + 8 * i) * LDK + lcol]) = ra[i];                              \
+        _Pragma("unroll") for (int i = 0; i < BV; i++)                                                         \
+            *reinterpret_cast<uint4 *>(&Bs[(lrow + 8 * i) * LDK + lcol]) = rb[i];                              \
+    }
+    IFH_DEC_LOAD(0);
+    // epilogue operands, requested behind the first chunk (as the streaming kernel requests them ahead of its K loop)
+    const bool ln_mode = p.aln_stats || p.rln_stats || p.stats_out;
+    int em[MT], edyn[MT];
+    bool exok[MT];
+    longlong2 st_a[MT], st_r[MT];
+#pragma unroll
+    for (int j = 0; j < MT; j++) {
+        em[j] = m0 + wm * WM + j * 16 + fr;
+        exok[j] = em[j] < M;
+        edyn[j] = dyn_value(p, exok[j] ? em[j] : 0);
+        st_a[j] = make_longlong2(0, 0);
+        st_r[j] = make_longlong2(0, 0);
+        if (exok[j]) {
+            if (p.aln_stats) st_a[j] = reinterpret_cast<const longlong2 *>(p.aln_stats)[em[j]];
+            if (p.rln_stats) st_r[j] = reinterpret_cast<const longlong2 *>(p.rln_stats)[em[j]];
+        }
+    }
+    float4 pc1[NT], pbias[NT], pgam[NT], pbeta[NT];
+    uint2 presid[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; i++) {
+        const int n = n0 + wn * WN + i * 16 + 4 * fg;
+        pc1[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pbias[i] = pc1[i]; pgam[i] = pc1[i]; pbeta[i] = pc1[i];
+        if (ln_mode && n < p.N) {
+            if (p.aln_stats && !p.ln_rms) pc1[i] = *reinterpret_cast<const float4 *>(p.aln_c1 + n);
+            if (p.bias) pbias[i] = *reinterpret_cast<const float4 *>(p.bias + n);
+            if (p.resid && p.rln_stats) {
+                pgam[i] = *reinterpret_cast<const float4 *>(p.rln_gamma + n);
+                pbeta[i] = *reinterpret_cast<const float4 *>(p.rln_beta + n);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MT; j++) {
+            presid[i][j] = make_uint2(0, 0);
+            if (ln_mode && p.resid && exok[j] && n < p.N)
+                presid[i][j] = *reinterpret_cast<const uint2 *>(p.resid + epi_row(p, em[j], n, edyn[j]).rbase + n);
+        }
+    }
+    f32x4 acc[NT][MT], sum[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < MT; j++) {
+            acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            sum[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    const int nk = p.K / 32;
+    const int per = (nk + ksplit - 1) / ksplit;      // k-steps per accumulation chain (= per wave of the streaming kernel)
+    int next_flush = per;
+    const int nchunk = (p.K + KC - 1) / KC;
+    for (int c = 0; c < nchunk; c++) {
+        IFH_DEC_STORE();
+        __syncthreads();
+        if (c + 1 < nchunk) IFH_DEC_LOAD((c + 1) * KC);         // the next chunk's round trip overlaps this chunk's MFMAs
+        const int ks1 = min(KC / 32, nk - c * (KC / 32));
+        for (int ks = 0; ks < ks1; ks++) {
+            bf16x8_t fa[NT], fb[MT];
+#pragma unroll
+            for (int i = 0; i < NT; i++)
+                fa[i] = *reinterpret_cast<const bf16x8_t *>(&Bs[(wn * WN + i * 16 + fr) * LDK + ks * 32 + fg * 8]);
+#pragma unroll
+            for (int j = 0; j < MT; j++)
+                fb[j] = *reinterpret_cast<const bf16x8_t *>(&As[(wm * WM + j * 16 + fr) * LDK + ks * 32 + fg * 8]);
+#pragma unroll
+            for (int i = 0; i < NT; i++)
+#pragma unroll
+                for (int j = 0; j < MT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            const int kt1 = c * (KC / 32) + ks + 1;
+            if (kt1 == next_flush || kt1 == nk) {               // end of a chain: add it to the running sum, in chain order
+#pragma unroll
+                for (int i = 0; i < NT; i++)
+#pragma unroll
+                    for (int j = 0; j < MT; j++) {
+                        sum[i][j] += acc[i][j];
+                        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                next_flush += per;
+            }
+        }
+        __syncthreads();
+    }
+#undef IFH_DEC_LOAD
+#undef IFH_DEC_STORE
+#pragma unroll
+    for (int j = 0; j < MT; j++) {
+        const LnRow lr = ln_row(p, st_a[j], st_r[j]);
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            const int n = n0 + wn * WN + i * 16 + 4 * fg;
+            if (ln_mode) {
+                ln_epi4(p, em[j], n, exok[j], sum[i][j], edyn[j], lr, pc1[i], pbias[i], pgam[i], pbeta[i], presid[i][j], fg);
+            } else if (exok[j] && n < p.N) {
+                if (p.fast_epi)
+                    igemm_store4<true>(p, em[j], n, sum[i][j], edyn[j]);
+                else
+                    igemm_store4<false>(p, em[j], n, sum[i][j], edyn[j]);
+            }
         }
     }
 }
@@ -693,7 +792,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
             hipLaunchKernelGGL((k_gemm_m64<4, 2>), dim3((ct + 3) / 4), dim3(256), 0, st, p);
         else
             hipLaunchKernelGGL((k_gemm_m64<2, 3>), dim3((ct + 1) / 2), dim3(256), 0, st, p);
-    } else if ((M <= 256 || (ln_fold && M <= 1024)) && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre) {
+    } else if ((M <= 256 || ((ln_fold || d->decode_step) && M <= 1024)) && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre) {
         // (LayerNorm-folded launches exist only in this kernel: up to 1024 rows -- the 640 decode rows of a 5-beam search)
         const dim3 grid((d->n + 15) / 16, (unsigned)((M + 15) / 16));
         // waves per block = K split: 2 (12 k-steps each at K = 768) / 4 for deep K.  With several decode loops in
@@ -701,7 +800,18 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         // launch takes the same time either way.  Above 64 rows a block takes two row tiles per weight fragment
         // (same K split, hence the same bits): the step time grows by the L2 re-reads of W per 16-row tile.
         static const bool one_tile = getenv("IFH_SKINNY_MT1") != nullptr;              // tuning switch
-        if (M > 64 && !one_tile) {
+        // From a few hundred rows up the step is no longer launch-bound and the streaming kernel's L2 traffic (all of W per 32
+        // rows) is what a launch costs: the LDS-tiled kernel with the same accumulation chains takes over (same bits).
+        static const int dec_rows = getenv("IFH_GEMM_DEC_ROWS") ? atoi(getenv("IFH_GEMM_DEC_ROWS")) : 192;   // tuning switch
+        if (M >= dec_rows && p.K % 32 == 0 && p.K >= 64 && (!ln_fold || d->n % 16 == 0)) {
+            const int ksplit = p.K >= 2048 ? 4 : 2;
+            // 64 x 64 tiles; 64 x 32 where that is what it takes to give every CU a workgroup
+            const int64_t t64 = ((M + 63) / 64) * ((d->n + 63) / 64);
+            if (t64 >= 200)
+                hipLaunchKernelGGL((k_gemm_dec<64>), dim3((M + 63) / 64, (d->n + 63) / 64), dim3(256), 0, st, p, ksplit);
+            else
+                hipLaunchKernelGGL((k_gemm_dec<32>), dim3((M + 63) / 64, (d->n + 31) / 32), dim3(256), 0, st, p, ksplit);
+        } else if (M > 64 && !one_tile) {
             const dim3 grid2((d->n + 15) / 16, (unsigned)((M + 31) / 32));
             // Grids beyond what the chip holds at once (qkv, ff1 at 192-256 rows: 1152-1536 blocks against 4 x 256
             // co-resident at 200 registers) take the half-depth load batch: 128 registers, twice the blocks per CU --

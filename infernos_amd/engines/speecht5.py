@@ -441,19 +441,21 @@ def _decoder_step_ragged(model: 'SpeechT5', st: TTSRaggedState, s: int, threshol
     masks, spec, stats = st.masks, st.spec[par], st.stats
     DP, FP = st.DP, st.FP
     SO = st.stat_rows * 2
+    # (decode_step: the un-folded launches take the K-split streaming kernel at every row count, like the folded ones)
     ops.linear(spec, *model.p0, st.h1, rows=n, k=80, n=256, x_off=2 * s * 80, lda=33 * 80, act=ACT_RELU,
-               colmask=masks, colmask_off=(s * 2) * 256)
-    ops.linear(st.h1, *model.p1, st.h2, rows=n, k=256, n=256, act=ACT_RELU, colmask=masks, colmask_off=(s * 2 + 1) * 256)
+               colmask=masks, colmask_off=(s * 2) * 256, decode_step=True)
+    ops.linear(st.h1, *model.p1, st.h2, rows=n, k=256, n=256, act=ACT_RELU, colmask=masks, colmask_off=(s * 2 + 1) * 256,
+               decode_step=True)
     ops.linear(st.h2, *model.pf, st.cat, rows=n, k=256, n=D, ldc=D + 512, resid=model.pe_dec, resid_ld=0, resid_bstride=0,
-               dyn_pos=st.pos, dyn_stride=1, dyn_resid_mul=D)
-    ops.linear(st.cat, *model.ps, st.x0, rows=n, k=D + 512, n=D, act=ACT_RELU, ldc=DP)
+               dyn_pos=st.pos, dyn_stride=1, dyn_resid_mul=D, decode_step=True)
+    ops.linear(st.cat, *model.ps, st.x0, rows=n, k=D + 512, n=D, act=ACT_RELU, ldc=DP, decode_step=True)
     nl = len(model.dec_layers)
     ld = dict(lda=DP, ldc=DP, resid_ld=DP)
     for li, (L, F) in enumerate(zip(model.dec_layers, model.dec_fold)):
         kv = st.self_kv[li]
         s1, s2, s3, s3p = (3 * li) * SO, (3 * li + 1) * SO, (3 * li + 2) * SO, (3 * li - 1) * SO
         kvargs = dict(nbatch=n, t_in=1, t_out=1, cin=D, n=3 * D, lda=DP, ldc=DP, out_bstride=DP, dyn_pos=st.pos, dyn_stride=1,
-                      n_split=D, out2=kv, out2_bstride=st.smax * KVP, ldc2=KVP, dyn_ooff2_mul=1)
+                      n_split=D, out2=kv, out2_bstride=st.smax * KVP, ldc2=KVP, dyn_ooff2_mul=1, decode_step=True)
         if li == 0:
             ops.conv(st.x0, L['wqkv'], L['bqkv'], st.q, **kvargs)
         else:

@@ -7,6 +7,7 @@ postnet, carry+chunking, HiFi-GAN, AmendmentNetwork1, optional 16k->8k resample)
 kernels; `unbatch_and_dispatch()` reproduces the reference's offset arithmetic and hands each
 live session a 1-D CPU tensor, then None at the end of the utterance.
 """
+import os
 import uuid
 import weakref
 from functools import partial
@@ -278,7 +279,11 @@ class ContinuousTTS:
         self.row_bucket = row_bucket
         with torch.cuda.device(dev):
             self.st = TTSRaggedState(pp.model, max_rows, max_text)
-            self.main = torch.cuda.Stream(device=dev)
+            # the decode chain is one latency-bound sequence of small dependent launches for ALL in-flight rows: on an ordinary
+            # queue each of them waits for CU slots behind whatever long throughput kernels other stages have resident (the
+            # Whisper encoder's GEMMs), serially; a high-priority queue lets them through (tuning switch IFH_TTS_PRIO)
+            prio = int(os.environ.get('IFH_TTS_PRIO', '-1'))
+            self.main = torch.cuda.Stream(device=dev, priority=prio)
             self.side = torch.cuda.Stream(device=dev)
         R = self.st.R
         self.free = list(range(R))                       # row slots, lowest first

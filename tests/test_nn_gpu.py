@@ -268,6 +268,98 @@ def test_skinny_gemm_ln_folded_at_beam_rows(dev, M, D):
         assert v < (8e-3 if k.startswith('aln') else 5e-3), (M, D, k, v)
 
 
+@pytest.mark.parametrize('M', [192, 257, 512, 1000])
+def test_gemm_dec_is_bit_identical_to_skinny(dev, M):
+    """From 192 rows up the decode-step launches take the LDS-tiled k_gemm_dec instead of the weight-streaming k_gemm_skinny
+    (csrc/nn.hip).  It keeps the streaming kernel's accumulation chains and epilogue, so every launch form of the SpeechT5 /
+    Whisper decode step must give, bit for bit, what the same rows give in pieces of <= 64 rows (which always take the
+    streaming kernel): plain + dropout column mask (prenet), per-row positional-encoding residual (dyn_stride = 1), the
+    q|k|v launch with K|V appended at per-row cache positions, LayerNorm-folded consumer / producer forms, ragged N (160, 16),
+    deep K (3072, 4 chains), f32 output."""
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(M)
+    D, FFN = 768, 3072
+    rnd = lambda *s_, sc=1.0: bfr(torch.randn(*s_, generator=g) * sc).to(dev, BF)
+    pos = torch.randint(0, 40, (M,), generator=g, dtype=torch.int32).to(dev)
+
+    def both(fn, outs):
+        """fn(r0, r1, dst...) launches rows [r0, r1); run once over all rows, once in 64-row pieces; compare every output"""
+        full = [o.clone() for o in outs]
+        fn(0, M, *full)
+        pcs = [o.clone() for o in outs]
+        for r0 in range(0, M, 64):
+            fn(r0, min(M, r0 + 64), *pcs)
+        torch.cuda.synchronize()
+        for a, b in zip(full, pcs):
+            va, vb = (a.view(torch.int16), b.view(torch.int16)) if a.dtype == BF else (a, b)
+            assert torch.equal(va, vb), (M, fn.__name__, int((va != vb).sum()))
+    # prenet layer 1: K = 256, ReLU, dropout column mask
+    x, w, b = rnd(M, 256), rnd(256, 256, sc=1 / 16), (torch.randn(256, generator=g) * 0.1).to(dev)
+    mask = torch.randint(0, 2, (256,), generator=g, dtype=torch.uint8).to(dev)
+
+    def prenet(r0, r1, out):
+        ops.linear(x[r0:r1], w, b, out[r0:r1], rows=r1 - r0, k=256, n=256, act=1, colmask=mask, decode_step=True)
+    both(prenet, [torch.zeros(M, 256, dtype=BF, device=dev)])
+    # prenet final: + positional-encoding row of the row's own position, written into a wider row (ldc)
+    pe, wf_ = rnd(64, D), rnd(D, 256, sc=1 / 16)
+    bf_ = (torch.randn(D, generator=g) * 0.1).to(dev)
+
+    def pe_resid(r0, r1, out):
+        ops.linear(x[r0:r1], wf_, bf_, out[r0:r1], rows=r1 - r0, k=256, n=D, ldc=D + 512, resid=pe, resid_ld=0, resid_bstride=0,
+                   dyn_pos=pos[r0:r1], dyn_stride=1, dyn_resid_mul=D, decode_step=True)
+    both(pe_resid, [torch.zeros(M, D + 512, dtype=BF, device=dev)])
+    # speaker projection: K = 1280
+    xc, wc = rnd(M, D + 512), rnd(D, D + 512, sc=1 / 36)
+
+    def spk(r0, r1, out):
+        ops.linear(xc[r0:r1], wc, bf_, out[r0:r1], rows=r1 - r0, k=D + 512, n=D, act=1, ldc=D + 8, decode_step=True)
+    both(spk, [torch.zeros(M, D + 8, dtype=BF, device=dev)])
+    # LayerNorm-folded chain: producer with statistics, q|k|v consumer appending K|V at per-row positions, fc1, fc2 (rln), heads
+    stats = torch.zeros((3, 1024, 2), dtype=torch.int64, device=dev)
+    SO = 1024 * 2
+    att, x0, wo = rnd(M, D + 8), rnd(M, D + 8), rnd(D, D, sc=1 / 28)
+    g1, b1 = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+
+    def producer(r0, r1, out, st):
+        ops.linear(att[r0:r1], wo, bf_, out[r0:r1], rows=r1 - r0, k=D, n=D, resid=x0[r0:r1], stats_out=st, stats_off=r0 * 2, ln_dim=D,
+                   lda=D + 8, ldc=D + 8, resid_ld=D + 8, decode_step=True)
+    t1 = torch.zeros(M, D + 8, dtype=BF, device=dev)
+    both(producer, [t1, torch.zeros((1, 1024, 2), dtype=torch.int64, device=dev)])
+    producer(0, M, t1, stats)
+    wq, cq2, cq1 = ops.w_linear_ln(torch.randn(3 * D, D, generator=g) / 28, torch.randn(3 * D, generator=g) * 0.1, g1, b1, dev)
+
+    def qkv(r0, r1, q, kv):
+        ops.conv(t1[r0:r1], wq, cq2, q[r0:r1], nbatch=r1 - r0, t_in=1, t_out=1, cin=D, n=3 * D, lda=D + 8, ldc=D + 8, out_bstride=D + 8,
+                 dyn_pos=pos[r0:r1], dyn_stride=1, n_split=D, out2=kv[r0:r1], out2_bstride=40 * 2 * D, ldc2=2 * D, dyn_ooff2_mul=1,
+                 aln=(stats, r0 * 2, cq1), ln_dim=D, decode_step=True)
+    both(qkv, [torch.zeros(M, D + 8, dtype=BF, device=dev), torch.zeros(M, 40, 2 * D, dtype=BF, device=dev)])
+    w1, c12, c11 = ops.w_linear_ln(torch.randn(FFN, D, generator=g) / 28, torch.randn(FFN, generator=g) * 0.1, g1, b1, dev)
+    ffb = torch.zeros(M, FFN + 8, dtype=BF, device=dev)
+
+    def fc1(r0, r1, out):
+        ops.linear(t1[r0:r1], w1, c12, out[r0:r1], rows=r1 - r0, k=D, n=FFN, act=2, aln=(stats, r0 * 2, c11), ln_dim=D, lda=D + 8,
+                   ldc=FFN + 8, decode_step=True)
+    both(fc1, [ffb])
+    fc1(0, M, ffb)
+    w2 = rnd(D, FFN, sc=1 / 55)
+
+    def fc2(r0, r1, out, st):
+        ops.linear(ffb[r0:r1], w2, bf_, out[r0:r1], rows=r1 - r0, k=FFN, n=D, resid=t1[r0:r1], rln=(stats, r0 * 2, g1.to(dev), b1.to(dev)),
+                   stats_out=st, stats_off=r0 * 2, ln_dim=D, lda=FFN + 8, ldc=D + 8, resid_ld=D + 8, decode_step=True)
+    both(fc2, [torch.zeros(M, D + 8, dtype=BF, device=dev), torch.zeros((1, 1024, 2), dtype=torch.int64, device=dev)])
+    for N_, f32 in ((160, False), (16, True)):              # feat_out (2 mel frames into a strided frame buffer), stop logits
+        wh, ch2, ch1 = ops.w_linear_ln(torch.randn(N_, D, generator=g) / 28, torch.randn(N_, generator=g) * 0.1, g1, b1, dev)
+
+        def head(r0, r1, out):
+            if f32:
+                ops.linear(t1[r0:r1], wh, ch2, out[r0:r1], rows=r1 - r0, k=D, n=N_, aln=(stats, r0 * 2, ch1), ln_dim=D, lda=D + 8,
+                           decode_step=True)
+            else:
+                ops.linear(t1[r0:r1], wh, ch2, out[r0:r1], rows=r1 - r0, k=D, n=N_, out_off=5 * 80, ldc=33 * 80,
+                           aln=(stats, r0 * 2, ch1), ln_dim=D, lda=D + 8, decode_step=True)
+        both(head, [torch.zeros(M, 16, dtype=torch.float32, device=dev) if f32 else torch.zeros(M, 33 * 80, dtype=BF, device=dev)])
+
+
 @pytest.mark.parametrize('N', [512, 1536, 2048])
 def test_small_grid_igemm_at_640_rows(dev, N):
     """The un-folded GEMMs of the 640-row decode step (layer 0's q|k|v behind an explicit LayerNorm, and every GEMM when

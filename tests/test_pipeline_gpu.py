@@ -141,7 +141,8 @@ def test_continuous_tts_schedule_matches_sequential_lane_schedule(built_lib, lan
             assert torch.equal(tk, ref[k % 2][1]), k
             assert torch.equal(ns, ref[k % 2][2]), k
             assert torch.equal(ul, ref[k % 2][0]), k
-        assert pipe.ctts.rows_run > pipe.ctts.calls_run * pipe.ctts.row_bucket or lanes == 1, 'no two batches ever shared a step'
+        if fronts > 1:          # (one front lane feeds the engine one batch at a time)
+            assert pipe.ctts.rows_run > pipe.ctts.calls_run * pipe.ctts.row_bucket, 'no two batches ever shared a step'
     finally:
         pipe.ctts.stop()
 

@@ -1,0 +1,56 @@
+"""GPU occupancy from a rocprofv3 kernel trace: union of busy intervals, sum of kernel durations (> union = overlap), and the
+top kernels by time inside [t0 + skip, t1].  python tools/trace_busy.py <kernel_trace.csv> [skip_fraction]"""
+import csv, sys, collections
+f = sys.argv[1]
+skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+rows = []
+cols = None
+for r in csv.DictReader(open(f)):
+    if cols is None:
+        cols = list(r.keys())
+    name = r['Kernel_Name']
+    short = 'MARK spin_kernel' if 'spin_kernel' in name else name.split('(')[0][:70]
+    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), short, r.get('Queue_Id', '?')))
+rows.sort()
+marks = [r for r in rows if r[2].startswith('MARK')]
+if len(marks) >= 2:             # bench.py with IFH_TRACE_MARK=1: the timed region lies between the first and the last marker pair
+    lo, t1 = marks[-2][1], marks[-1][0]
+    if len(marks) >= 4:         # (a warm-up pass was bracketed too: take the widest gap)
+        gaps = [(marks[i + 1][0] - marks[i][1], i) for i in range(len(marks) - 1)]
+        i = max(gaps)[1]
+        lo, t1 = marks[i][1], marks[i + 1][0]
+    rows = [r for r in rows if r[0] >= lo and r[1] <= t1]
+else:
+    t0, t1 = rows[0][0], max(r[1] for r in rows)
+    lo = t0 + (t1 - t0) * skip
+    rows = [r for r in rows if r[0] >= lo]
+wall = (t1 - lo) * 1e-6
+busy, cur_s, cur_e = 0, None, None
+for s, e, _, _ in rows:
+    if cur_e is None or s > cur_e:
+        if cur_e is not None:
+            busy += cur_e - cur_s
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+tot = sum(e - s for s, e, _, _ in rows)
+print('window %.1f ms: GPU busy (union) %.1f ms = %.1f %%; sum of kernel durations %.1f ms (x%.2f of busy); %d launches = %.0f / s'
+      % (wall, busy * 1e-6, 100 * busy * 1e-6 / wall, tot * 1e-6, tot / busy, len(rows), len(rows) / wall * 1e3))
+ev = sorted([(s_, 1) for s_, e_, _, _ in rows] + [(e_, -1) for s_, e_, _, _ in rows])
+lvl, last, hist = 0, ev[0][0], collections.Counter()
+for t, d in ev:
+    hist[min(lvl, 4)] += t - last
+    last, lvl = t, lvl + d
+tt = sum(hist.values())
+print('kernels resident: ' + '  '.join('%s: %.1f %%' % (('%d' % k) if k < 4 else '4+', 100 * hist[k] / tt) for k in sorted(hist)))
+by = collections.defaultdict(lambda: [0, 0])
+qs = collections.Counter()
+for s, e, k, q in rows:
+    qs[q] += e - s
+    by[k][0] += e - s
+    by[k][1] += 1
+for k, (d, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:28]:
+    print('%6.1f ms %5.1f %% %7d x %7.1f us  %s' % (d * 1e-6, 100 * d / tot, n, d / n * 1e-3, k))
+print('columns:', cols)
+print('busy per queue (ms):', {q: round(v * 1e-6, 1) for q, v in qs.most_common()})
