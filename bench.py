@@ -294,7 +294,7 @@ def main():
     ap.add_argument('--tts-mode', choices=['continuous', 'lanes'], default='continuous',
                     help='continuous: ONE ragged TTS decode batch over every utterance batch in flight (rows at different decoder '
                          'positions, joined at infer() boundaries); lanes: one engine clone and launch chain per batch (round 2)')
-    ap.add_argument('--tts-lanes', type=int, default=4, help='utterance batches that may be in flight in the TTS stage together')
+    ap.add_argument('--tts-lanes', type=int, default=3, help='utterance batches that may be in flight in the TTS stage together')
     ap.add_argument('--front-lanes', type=int, default=3, help='ingest+STT lanes (cycles k, k+1, k+2 in flight together)')
     ap.add_argument('--tts-group', type=int, default=1, help='utterance cycles of the SAME calls synthesised as one TTS batch '
                     '(> 1 is an offline-throughput mode: a live call cannot have utterance k+1 before k has been spoken)')
@@ -468,6 +468,7 @@ def main():
                                                     n_local * args.tts_group),
                        'stt_decode': ('beam search, %d beams (%d decode rows), 32 tokens' % (args.stt_beam, n_local * args.stt_beam))
                                      if args.stt_beam > 1 else 'greedy, 32 tokens'},
+            'rccl_version': (list(torch.cuda.nccl.version()) if world > 1 and not dry else None),
             'launches_per_cycle': round(launches_per_cycle, 1),
             'launches_note': 'calls into stream-taking C-ABI entry points per utterance cycle inside the timed region, hipGraph replays '
                              'counted by the launches they hold (infernos_amd/_lib.py:CALLS)',

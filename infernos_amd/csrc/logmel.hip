@@ -105,7 +105,7 @@ __device__ __forceinline__ void power_pair(f2v zk, f2v zm, f2v tw, float &pk, fl
     pm = __fmaf_rn(qx, qx, qy * qy);
 }
 
-__global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ audio, int64_t stride,
+__global__ __launch_bounds__(256, 2) void k_logmel_fft(const float *__restrict__ audio, int64_t stride,
                                                     const int32_t *__restrict__ lens, const float *__restrict__ win,
                                                     const f2v *__restrict__ tw200 /* [8][25] */,
                                                     const f2v *__restrict__ tw400 /* [101] */,
@@ -159,6 +159,15 @@ __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ au
     const bool tail_clear = (a_last < kNsamp) || (2 * (kNsamp - 1) - a_last >= len);                   \
     const bool zero_tile = len == 0 || (a0 >= len && a0 >= 0 && tail_clear);                           \
     const bool interior = a0 >= 0 && a_last < len && ((reinterpret_cast<uintptr_t>(x + a0) & 15) == 0);
+    // per-thread constants of phase A, loaded once per block (a thread keeps its n2 = tid & 7 over all tiles): the 25 window
+    // pairs w[2n], w[2n+1] of its samples n = 8 n1 + n2.  As per-tile global loads they were 25 L1 round trips per thread per
+    // tile in front of the transform.  (The 25 output twiddles W200^(n2 k1) as well would take the kernel past 256 registers.)
+    f2v wreg[25];
+    {
+        const int sub_ = tid & 7;
+#pragma unroll
+        for (int i = 0; i < 25; i++) wreg[i] = *reinterpret_cast<const f2v *>(&win[2 * (8 * i + sub_)]);
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     tq0 = clock64();
     LF_TILE_GEOM(tile)
@@ -204,12 +213,13 @@ __global__ __launch_bounds__(256) void k_logmel_fft(const float *__restrict__ au
     // ---- phase A: DFT-25 over n1 of z[8 n1 + sub], n = 8 n1 + sub, samples 2n, 2n+1 of frame f
     {
         f2v v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11, v12, v13, v14, v15, v16, v17, v18, v19, v20, v21, v22, v23, v24;
+        // sample pair n = 8 n1 + n2 of frame f sits at 176 f + 2 n + 16 ((2 n) / 160); 2 n = 16 n1 + 2 n2 with 2 n2 <= 14 never
+        // carries into the next multiple of 160, so the padding term is the compile-time 16 (n1 / 10): one base + literals
+        const float *abase = aud + 176 * f + 2 * sub;
 #define LF_LOAD(V, N1)                                                                               \
     {                                                                                                \
-        const int n = 8 * (N1) + sub;                                                                \
-        const f2v xs = *reinterpret_cast<const f2v *>(&aud[176 * f + 2 * n + 16 * ((2 * n) / kHop)]); \
-        const f2v wv = *reinterpret_cast<const f2v *>(&win[2 * n]);                            \
-        V = mk2(xs.x * wv.x, xs.y * wv.y);                                                   \
+        const f2v xs = *reinterpret_cast<const f2v *>(abase + (16 * (N1) + 16 * ((N1) / 10)));       \
+        V = xs * wreg[N1];                                                                           \
     }
         LF_LOAD(v0, 0) LF_LOAD(v1, 1) LF_LOAD(v2, 2) LF_LOAD(v3, 3) LF_LOAD(v4, 4) LF_LOAD(v5, 5) LF_LOAD(v6, 6)
         LF_LOAD(v7, 7) LF_LOAD(v8, 8) LF_LOAD(v9, 9) LF_LOAD(v10, 10) LF_LOAD(v11, 11) LF_LOAD(v12, 12) LF_LOAD(v13, 13)

@@ -802,7 +802,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         static const bool one_tile = getenv("IFH_SKINNY_MT1") != nullptr;              // tuning switch
         // From a few hundred rows up the step is no longer launch-bound and the streaming kernel's L2 traffic (all of W per 32
         // rows) is what a launch costs: the LDS-tiled kernel with the same accumulation chains takes over (same bits).
-        static const int dec_rows = getenv("IFH_GEMM_DEC_ROWS") ? atoi(getenv("IFH_GEMM_DEC_ROWS")) : 192;   // tuning switch
+        static const int dec_rows = getenv("IFH_GEMM_DEC_ROWS") ? atoi(getenv("IFH_GEMM_DEC_ROWS")) : 128;   // tuning switch
         if (M >= dec_rows && p.K % 32 == 0 && p.K >= 64 && (!ln_fold || d->n % 16 == 0)) {
             const int ksplit = p.K >= 2048 ? 4 : 2;
             // 64 x 64 tiles; 64 x 32 where that is what it takes to give every CU a workgroup

@@ -72,12 +72,14 @@ def shard_bounds(n_total: int, world: int) -> List[range]:
     return out
 
 
-def scatter_frames(frames_all: Optional[torch.Tensor], n_total: int, t: int, device, src: int = 0, group=None) -> torch.Tensor:
-    """frames_all u8 [T, n_total, 160] on rank `src` (None elsewhere) -> this rank's [T, n_local, 160]."""
+def scatter_frames(frames_all: Optional[torch.Tensor], n_total: int, t: int, device, src: int = 0, group=None,
+                   always_collective: bool = False) -> torch.Tensor:
+    """frames_all u8 [T, n_total, 160] on rank `src` (None elsewhere) -> this rank's [T, n_local, 160].
+    always_collective: issue the collective even in a world of one (lets the RCCL call path run on a single-GPU box)."""
     rank, world = dist.get_rank(), dist.get_world_size()
     bounds = shard_bounds(n_total, world)
     mine = torch.empty((t, len(bounds[rank]), 160), dtype=torch.uint8, device=device)
-    if world == 1:
+    if world == 1 and not always_collective:
         mine.copy_(frames_all)
         return mine
     if _stage(group) and torch.device(device).type != 'cpu':
@@ -105,10 +107,10 @@ def scatter_frames(frames_all: Optional[torch.Tensor], n_total: int, t: int, dev
     return mine
 
 
-def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0, group=None) -> Optional[torch.Tensor]:
+def gather_rows(local: torch.Tensor, n_total: int, dst: int = 0, group=None, always_collective: bool = False) -> Optional[torch.Tensor]:
     """local [n_local, W] -> [n_total, W] on rank dst (None elsewhere)."""
     rank, world = dist.get_rank(), dist.get_world_size()
-    if world == 1:
+    if world == 1 and not always_collective:
         return local
     if _stage(group) and local.device.type != 'cpu':
         full = gather_rows(local.cpu(), n_total, dst=dst, group=group)

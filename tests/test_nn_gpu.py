@@ -268,9 +268,9 @@ def test_skinny_gemm_ln_folded_at_beam_rows(dev, M, D):
         assert v < (8e-3 if k.startswith('aln') else 5e-3), (M, D, k, v)
 
 
-@pytest.mark.parametrize('M', [192, 257, 512, 1000])
+@pytest.mark.parametrize('M', [128, 192, 257, 512, 1000])
 def test_gemm_dec_is_bit_identical_to_skinny(dev, M):
-    """From 192 rows up the decode-step launches take the LDS-tiled k_gemm_dec instead of the weight-streaming k_gemm_skinny
+    """From 128 rows up the decode-step launches take the LDS-tiled k_gemm_dec instead of the weight-streaming k_gemm_skinny
     (csrc/nn.hip).  It keeps the streaming kernel's accumulation chains and epilogue, so every launch form of the SpeechT5 /
     Whisper decode step must give, bit for bit, what the same rows give in pieces of <= 64 rows (which always take the
     streaming kernel): plain + dropout column mask (prenet), per-row positional-encoding residual (dyn_stride = 1), the

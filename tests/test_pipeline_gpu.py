@@ -388,3 +388,38 @@ def test_bench_config5_share_leg(built_lib):
     parts = d['stt_ms'] + d['llm_first_sentence_ms'] + d['tts_first_chunk_ms']
     assert abs(parts - d['p50_turn_latency_ms']) < 0.35 * d['p50_turn_latency_ms']
     assert d['llm_reply_ms'] > d['llm_first_sentence_ms'] and d['llm_decode_tokens_per_s'] > 0
+
+
+def test_rccl_scatter_gather_on_device_tensors_world_1(built_lib):
+    """The `nccl` (= RCCL) branch of shard.scatter_frames / gather_rows on DEVICE tensors, both communicators of the pipelined
+    schedule, in a world of one rank -- what a single-GPU box can show of the multi-GPU path: the RCCL call signatures execute
+    and return the right rows.  (Scaling over xGMI remains unmeasured: no multi-GPU box is reachable from this build.)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    code = """
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from infernos_amd.shard import scatter_frames, gather_rows
+torch.cuda.set_device(0)
+dev = torch.device('cuda', 0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+g_in, g_out = dist.new_group(), dist.new_group()
+frames = torch.randint(0, 256, (50, 7, 160), dtype=torch.uint8, device=dev)
+for k in range(3):
+    mine = scatter_frames(frames, 7, 50, dev, group=g_in, always_collective=True)
+    assert mine.is_cuda and torch.equal(mine, frames)
+    rows = torch.randint(0, 256, (7, 4096), dtype=torch.uint8, device=dev)
+    full = gather_rows(rows, 7, group=g_out, always_collective=True)
+    assert full.is_cuda and torch.equal(full, rows)
+torch.cuda.synchronize()
+print('rccl', torch.cuda.nccl.version(), 'backend', dist.get_backend(g_in))
+dist.destroy_process_group()
+""" % root
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, '-c', code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'rccl' in r.stdout and 'nccl' in r.stdout, r.stdout
