@@ -343,6 +343,9 @@ typedef struct ifh_conv_desc {
                             * kernel whose K split depends on K alone (the one every launch of <= 256 rows takes), so that a row's
                             * bits do not depend on how many rows share the step -- a row of a 640-row ragged batch equals the
                             * same row decoded in a batch of 8 */
+    int32_t convt_cout;    /* > 0: w is a ConvTranspose1d(k=8, stride=4, padding=2) in its fused one-launch form -- 3 taps, n =
+                            * 4*convt_cout columns, column block r = output phase r, whose unused tap (tap 2 for r < 2, tap 0 for
+                            * r >= 2) is all zeros: the kernel then skips those products (same bits, a third less matrix work) */
 } ifh_conv_desc;
 int ifh_conv_bf16(const ifh_conv_desc *desc, ifh_stream_t stream);
 

@@ -74,7 +74,7 @@ class ConvDesc(ctypes.Structure):
                 ('ooff2', ctypes.c_int32), ('dyn_ooff2_mul', ctypes.c_int32),
                 ('aln_stats', _vp), ('aln_c1', _vp), ('rln_stats', _vp), ('rln_gamma', _vp), ('rln_beta', _vp),
                 ('stats_out', _vp), ('ln_dim', ctypes.c_int32), ('ln_eps', _f), ('ln_rms', ctypes.c_int32),
-                ('dyn_stride', ctypes.c_int32), ('decode_step', ctypes.c_int32)]
+                ('dyn_stride', ctypes.c_int32), ('decode_step', ctypes.c_int32), ('convt_cout', ctypes.c_int32)]
 
 
 class ResblockDesc(ctypes.Structure):

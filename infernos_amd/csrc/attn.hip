@@ -39,7 +39,9 @@ __device__ __forceinline__ uint32_t pack2(float a, float b)
 __global__ __launch_bounds__(256) void k_attn_prefill(const AttnParams p)
 {
     __shared__ __attribute__((aligned(16))) uint16_t Ks[KT * KLD];
-    __shared__ __attribute__((aligned(16))) uint16_t Vt[HD * KLD];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[KT * KLD];      // V row-major like K: the PV operand is read TRANSPOSED by
+                                                                        // ds_read_b64_tr_b16 (round 3; the V^T image of rounds 1-2 cost
+                                                                        // sixteen 2-byte LDS stores per thread and tile)
     const int b = blockIdx.z, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -87,14 +89,7 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const AttnParams p)
         const int vv = tid + 256 * I;                                                                                \
         const int key = vv >> 3, dv = (vv & 7) * 8;                                                                  \
         *reinterpret_cast<uint4 *>(&Ks[key * KLD + dv]) = KKV;                                                       \
-        Vt[(dv + 0) * KLD + key] = (uint16_t)(VXV.x & 0xffffu);                                                      \
-        Vt[(dv + 1) * KLD + key] = (uint16_t)(VXV.x >> 16);                                                          \
-        Vt[(dv + 2) * KLD + key] = (uint16_t)(VXV.y & 0xffffu);                                                      \
-        Vt[(dv + 3) * KLD + key] = (uint16_t)(VXV.y >> 16);                                                          \
-        Vt[(dv + 4) * KLD + key] = (uint16_t)(VXV.z & 0xffffu);                                                      \
-        Vt[(dv + 5) * KLD + key] = (uint16_t)(VXV.z >> 16);                                                          \
-        Vt[(dv + 6) * KLD + key] = (uint16_t)(VXV.w & 0xffffu);                                                      \
-        Vt[(dv + 7) * KLD + key] = (uint16_t)(VXV.w >> 16);                                                          \
+        *reinterpret_cast<uint4 *>(&Vs[key * KLD + dv]) = VXV;                                                       \
     }
     if (ntile > 0) AT_LOAD(0)
     for (int kt = 0; kt < ntile; kt++) {
@@ -116,34 +111,44 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const AttnParams p)
                 s[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ds], s[c], 0, 0, 0);
             }
         }
-        // bias, mask, running max
+        // bias, mask, running max.  The kernel is VALU-issue-bound (16 scores per lane against 16 MFMAs per tile), so a tile that
+        // needs neither the relative-position bias nor the key-length mask -- every tile but the last of a Whisper window --
+        // takes the short form: one max per score here, one fma + one exp2 below.
         float mloc = -1e30f;
+        if (rb || kbase + KT > klen) {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+            for (int c = 0; c < 4; c++) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int kidx = kbase + c * 16 + 4 * fg + r;
-                float val = s[c][r];
-                if (rb) {
-                    int rel = qi - kidx;
-                    rel = rel < -half ? -half : (rel > half - 1 ? half - 1 : rel);
-                    val += rb[rel + half];
+                for (int r = 0; r < 4; r++) {
+                    const int kidx = kbase + c * 16 + 4 * fg + r;
+                    float val = s[c][r];
+                    if (rb) {
+                        int rel = qi - kidx;
+                        rel = rel < -half ? -half : (rel > half - 1 ? half - 1 : rel);
+                        val += rb[rel + half];
+                    }
+                    val = (kidx < klen) ? val : -1e30f;
+                    s[c][r] = val;
+                    mloc = fmaxf(mloc, val);
                 }
-                val = (kidx < klen) ? val : -1e30f;
-                s[c][r] = val;
-                mloc = fmaxf(mloc, val);
             }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) mloc = fmaxf(fmaxf(mloc, fmaxf(s[c][0], s[c][1])), fmaxf(s[c][2], s[c][3]));
         }
         mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float mnew = fmaxf(mrun, mloc);
-        const float alpha = __expf(mrun - mnew);
+        // exp(x - m) = exp2(x * log2e - m * log2e): one fma + the hardware's native exp2 per score
+        constexpr float kLog2e = 1.4426950408889634f;
+        const float mscaled = mnew * kLog2e;
+        const float alpha = __builtin_amdgcn_exp2f(mrun * kLog2e - mscaled);
         float lsum = 0.0f;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float pv = __expf(s[c][r] - mnew);
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[c][r], kLog2e, -mscaled));
                 s[c][r] = pv;
                 lsum += pv;
             }
@@ -159,7 +164,10 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const AttnParams p)
             o[i][2] *= alpha;
             o[i][3] *= alpha;
         }
-        // O^T += V^T . P^T ; k-step ks covers keys 32*ks..32*ks+31, element j <-> key 16*(j>>2) + 4*fg + (j&3)
+        // O^T += V^T . P^T ; k-step ks covers keys 32*ks..32*ks+31, element j <-> key 16*(j>>2) + 4*fg + (j&3).
+        // A operand V^T[d = 16 dt + fr][those 8 keys] from the row-major V image: ds_read_b64_tr_b16 hands lane i of a 16-lane
+        // group column i of a 4-row x 16-column block (lane 4q + p of the group supplies the address of row q, columns 4p..4p+3):
+        // rows = keys 32 ks + 4 fg + (0..3) (+16 for the second half), columns = d 16 dt .. 16 dt + 15.  Every lane is active here.
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
             uint4 pb;
@@ -168,16 +176,26 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const AttnParams p)
             pb.z = pack2(s[2 * ks + 1][0], s[2 * ks + 1][1]);
             pb.w = pack2(s[2 * ks + 1][2], s[2 * ks + 1][3]);
             const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pb);
+            const uint32_t vaddr = (uint32_t)(uintptr_t)(&Vs[(ks * 32 + 4 * fg + (fr >> 2)) * KLD + 4 * (fr & 3)]);
+            uint2 lo[4], hi[4];
 #pragma unroll
             for (int dt = 0; dt < 4; dt++) {
-                const uint16_t *vr = &Vt[(dt * 16 + fr) * KLD + ks * 32 + 4 * fg];
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[dt]) : "v"(vaddr), "n"(dt * 32) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[dt]) : "v"(vaddr), "n"(dt * 32 + 16 * KLD * 2) : "memory");
+            }
+            // (the wait names the eight results as in/out operands: the MFMAs below depend on IT, not only on the read statements,
+            // so the scheduler cannot hoist them above the wait)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
                 uint4 va;
-                const uint2 lo = *reinterpret_cast<const uint2 *>(vr);
-                const uint2 hi = *reinterpret_cast<const uint2 *>(vr + 16);
-                va.x = lo.x;
-                va.y = lo.y;
-                va.z = hi.x;
-                va.w = hi.y;
+                va.x = lo[dt].x;
+                va.y = lo[dt].y;
+                va.z = hi[dt].x;
+                va.w = hi[dt].y;
                 o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, va), pf, o[dt], 0, 0, 0);
             }
         }

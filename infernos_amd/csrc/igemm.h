@@ -52,6 +52,8 @@ struct IgemmParams {
     int ln_dim;               // LayerNorm width
     float ln_eps;
     int ln_rms;               // RMSNorm instead of LayerNorm in the folded modes (mean term dropped)
+    int zt_cout;              // > 0: fused ConvTranspose1d(k8,s4,p2) form (3 taps, 4*zt_cout columns): columns of phases 0-1 have an
+                              // all-zero tap 2, of phases 2-3 an all-zero tap 0 -- a column tile inside one half skips those k-steps
 };
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_TANH = 3, ACT_LRELU = 4, ACT_SIGMOID = 5, ACT_SILU_GLU = 6 };
@@ -66,6 +68,33 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope)
     case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
     default: return v;
     }
+}
+
+// GELU (exact erf form) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the stored
+// result): one reciprocal, one exp2 and a 5-term polynomial instead of the library erff's branchy ~35 instructions.  The
+// large-GEMM epilogue applies it to 64 outputs per thread; with erff the activation cost as much as the K = 512 loop it follows.
+__device__ __forceinline__ float gelu_fast(float v)
+{
+    const float z = fabsf(v) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
+    float pl = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    pl = __builtin_fmaf(t, pl, 1.421413741f);
+    pl = __builtin_fmaf(t, pl, -0.284496736f);
+    pl = __builtin_fmaf(t, pl, 0.254829592f);
+    pl *= t;
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erfabs = __builtin_fmaf(-pl, e, 1.0f);
+    return 0.5f * v * (1.0f + copysignf(erfabs, v));
+}
+
+// activation chosen at compile time (ACTC >= 0) or by the runtime switch (ACTC < 0)
+template <int ACTC>
+__device__ __forceinline__ float apply_act_c(float v, int act, float slope)
+{
+    if (ACTC == ACT_NONE) return v;
+    if (ACTC == ACT_GELU) return gelu_fast(v);
+    if (ACTC == ACT_RELU) return fmaxf(v, 0.0f);
+    return apply_act(v, act, slope);
 }
 
 __device__ __forceinline__ uint4 lrelu8(uint4 v, float slope)
@@ -115,7 +144,7 @@ __device__ __forceinline__ EpiRow epi_row(const IgemmParams &p, int m, int n, in
 // STORE = false: bf16 outputs only; the rounded 4-vector is returned instead of written (the caller
 // transposes it through LDS into full-row stores).
 // HAVE_B: same for the bias 4-vector (bpre; ignored when p.bias is null)
-template <bool HAVE_R = false, bool STORE = true, bool HAVE_B = false>
+template <bool HAVE_R = false, bool STORE = true, bool HAVE_B = false, int ACTC = -1>
 __device__ __forceinline__ uint2 igemm_store4_fast(const IgemmParams &p, int m, int n, f32x4 acc, int dynv,
                                                    uint2 rpre = make_uint2(0, 0),
                                                    float4 bpre = make_float4(0.f, 0.f, 0.f, 0.f))
@@ -126,11 +155,11 @@ __device__ __forceinline__ uint2 igemm_store4_fast(const IgemmParams &p, int m, 
         const float4 bv = HAVE_B ? bpre : *reinterpret_cast<const float4 *>(p.bias + n);
         v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
     }
-    if (p.act != ACT_NONE) {
-        v0 = apply_act(v0, p.act, p.act_slope);
-        v1 = apply_act(v1, p.act, p.act_slope);
-        v2 = apply_act(v2, p.act, p.act_slope);
-        v3 = apply_act(v3, p.act, p.act_slope);
+    if (ACTC >= 0 ? ACTC != ACT_NONE : p.act != ACT_NONE) {
+        v0 = apply_act_c<ACTC>(v0, p.act, p.act_slope);
+        v1 = apply_act_c<ACTC>(v1, p.act, p.act_slope);
+        v2 = apply_act_c<ACTC>(v2, p.act, p.act_slope);
+        v3 = apply_act_c<ACTC>(v3, p.act, p.act_slope);
     }
     if (p.colmask) {
         const uint32_t mk = *reinterpret_cast<const uint32_t *>(p.colmask + n);

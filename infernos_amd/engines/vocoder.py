@@ -95,7 +95,7 @@ class HifiGan:
             u = B['u%d' % i]
             if self.fused_up:          # the 4 output phases as one 3-tap conv with 4*Cout channels: x read once, rows written whole
                 wf, bf = self.upf[i]
-                ops.conv(prev, wf, bf, u, nbatch=n, t_in=t, t_out=t, cin=c, n=2 * c, taps=3, pad=1, pre_slope=0.1)
+                ops.conv(prev, wf, bf, u, nbatch=n, t_in=t, t_out=t, cin=c, n=2 * c, taps=3, pad=1, pre_slope=0.1, convt_cout=c // 2)
             else:
                 phases, ub = self.up[i]
                 for r, (w, pad) in enumerate(phases):
@@ -186,7 +186,8 @@ class Amendment:
         for i, co in enumerate((128, 64)):
             wf, bf = self.upf[i]
             u = B['u%d' % i]
-            ops.conv(prev, wf, bf, u, nbatch=n, t_in=t, t_out=t, cin=c, n=4 * co, taps=3, pad=1, pre_slope=0.01)
+            ops.conv(prev, wf, bf, u, nbatch=n, t_in=t, t_out=t, cin=c, n=4 * co, taps=3, pad=1, pre_slope=0.01,
+                     convt_cout=(co if c % 32 == 0 else 0))
             prev, t, c = u, t * 4, co
         ops.conv(prev, self.r1_w, self.r1_b, B['h'], nbatch=n, t_in=192, t_out=192, cin=64, n=64, taps=3, pad=1, pre_slope=0.01)
         ops.conv(B['h'], self.r2_w, self.r2_b, B['r'], nbatch=n, t_in=192, t_out=192, cin=64, n=64, taps=3, dil=3, pad=3,

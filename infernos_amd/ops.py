@@ -22,7 +22,7 @@ def _addr(t, off=0):
 def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=1, pad=0,
          x_off=0, lda=None, x_bstride=None, act=ACT_NONE, act_slope=0.0, pre_slope=1.0, colmask=None, colmask_off=0,
          resid=None, resid_off=0, resid_ld=None, resid_bstride=None, scale=1.0, accumulate=False,
-         out_off=0, ldc=None, out_bstride=None, ostride=1, ooff=0, dyn_pos=None, dyn_ooff_mul=0, dyn_resid_mul=0, dyn_stride=0, decode_step=False,
+         out_off=0, ldc=None, out_bstride=None, ostride=1, ooff=0, dyn_pos=None, dyn_ooff_mul=0, dyn_resid_mul=0, dyn_stride=0, decode_step=False, convt_cout=0,
          n_split=0, out2=None, out2_bstride=0, ldc2=0, ooff2=0, dyn_ooff2_mul=0,
          aln=None, rln=None, stats_out=None, stats_off=0, ln_dim=0, ln_eps=1e-5, ln_rms=False):
     # aln = (stats, stats_off, c1); rln = (stats, stats_off, gamma, beta)
@@ -44,7 +44,7 @@ def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=
     d.out_bstride = (t_out * ostride * ldc if out_bstride is None else out_bstride)
     d.ldc, d.ostride, d.ooff = ldc, ostride, ooff
     d.dyn_pos, d.dyn_ooff_mul, d.dyn_resid_mul, d.dyn_stride = _addr(dyn_pos), dyn_ooff_mul, dyn_resid_mul, dyn_stride
-    d.decode_step = int(decode_step)
+    d.decode_step, d.convt_cout = int(decode_step), convt_cout
     d.n_split, d.out2, d.out2_bstride, d.ldc2, d.ooff2, d.dyn_ooff2_mul = n_split, _addr(out2), out2_bstride, ldc2, ooff2, dyn_ooff2_mul
     if aln is not None:
         d.aln_stats, d.aln_c1 = _addr(aln[0], aln[1]), _addr(aln[2])
