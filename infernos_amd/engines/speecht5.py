@@ -490,7 +490,7 @@ def _decoder_step_ragged(model: 'SpeechT5', st: TTSRaggedState, s: int, threshol
 
 
 def ragged_decoder_steps(model: 'SpeechT5', st: TTSRaggedState, masks: torch.Tensor, n: int, nsteps=16, threshold=0.5,
-                         use_graphs=None):
+                         use_graphs=None, sync_every=0):
     """One infer() call's decoder steps (HelloSippyRTPipe.py:195-229) for the first n row slots of a ragged state.
     The same [nsteps,2,256] dropout keep-masks serve every row of the step, as the reference shares one mask across
     its batch (modeling_speecht5.py:671-674).  One hipGraph per (in-call step, frame-buffer parity, n)."""
@@ -510,6 +510,10 @@ def ragged_decoder_steps(model: 'SpeechT5', st: TTSRaggedState, masks: torch.Ten
             if g is None:
                 g = st.graphs[key] = _lib.CountedGraph(lambda: _decoder_step_ragged(model, st, s, threshold, par, n))
             g.replay()
+            # bounded queue depth: whatever this stream has queued stands in front of a real-time tick whose launches land on the
+            # same hardware queue (16 steps = ~900 kernels); waiting every few steps keeps that to a handful of milliseconds
+            if sync_every and (s + 1) % sync_every == 0 and s + 1 < nsteps:
+                torch.cuda.current_stream(model.device).synchronize()
     if not use_graphs:
         st.eager[n] = st.eager.get(n, 0) + 1
     st.ncalls += 1

@@ -277,6 +277,7 @@ class ContinuousTTS:
         self.pp, self.device = pp, pp.device
         dev = pp.device
         self.row_bucket = row_bucket
+        self.sync_every = int(os.environ.get('IFH_TTS_SYNC_EVERY', '0'))         # decoder steps queued at a time (0: all 16)
         with torch.cuda.device(dev):
             self.st = TTSRaggedState(pp.model, max_rows, max_text)
             # the decode chain is one latency-bound sequence of small dependent launches for ALL in-flight rows: on an ordinary
@@ -383,7 +384,7 @@ class ContinuousTTS:
             st.active.copy_(self.h_active, non_blocking=True)
             st.fresh[par].copy_(self.h_fresh[par], non_blocking=True)
             masks = pp.mask_source(16).to(dev).contiguous()
-            ragged_decoder_steps(pp.model, st, masks, n, nsteps=16, threshold=pp.threshold)
+            ragged_decoder_steps(pp.model, st, masks, n, nsteps=16, threshold=pp.threshold, sync_every=self.sync_every)
             dec_done = torch.cuda.Event()
             dec_done.record(self.main)
             rr = pp.model_sr // pp.output_sr

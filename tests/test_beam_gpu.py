@@ -213,6 +213,17 @@ def test_attn_decode_shared_equals_repeated_cache(dev, keys):
     assert torch.equal(out_s, out_r)
 
 
+def _token_logprob_tol(golden_dir, family='whisper_tiny'):
+    """Tolerance on ONE token's log-prob for a bf16 engine, derived from the fixture instead of chosen: 1.5 x the 99th percentile
+    of |logit_bf16 - logit_fp32| that the reference's own HF engine shows on these weights when it merely runs in bf16
+    (tests/golden/whisper_tf.npz, tiny: 0.21 -> 0.32; base has no stored slice: scaled by its larger rel-L2 error)."""
+    g = np.load(os.path.join(golden_dir, 'whisper_tf.npz'))
+    meta = json.load(open(os.path.join(golden_dir, 'whisper_tf_meta.json')))
+    p99 = float(np.percentile(np.abs(g['tiny_logits_bf16_slice'] - g['tiny_logits_fp32_slice']), 99))
+    scale = max(meta[family]['bf16_vs_fp32_rel_l2']) / max(meta['whisper_tiny']['bf16_vs_fp32_rel_l2'])
+    return 1.5 * p99 * max(1.0, scale)
+
+
 def _teacher_score(sd, mel, prompt_row, new_tokens, nheads, sup, bsup):
     """sum log p of `new_tokens` under the fp32 oracle (masks as the search applies them)"""
     enc = onn.whisper_encoder(sd, mel, nheads)
@@ -254,6 +265,7 @@ def test_whisper_generate_beam_matches_transformers_fixture(dev, golden_dir):
     prompt = torch.tensor([meta['prompt']] * 2, dtype=torch.int32)
     V = 51865
     exact = 0
+    tok_tol = _token_logprob_tol(golden_dir)
     for ci, c in enumerate(meta['cases']):
         sup = torch.zeros(V)
         sup[50257:] = float('-inf')
@@ -271,9 +283,8 @@ def test_whisper_generate_beam_matches_transformers_fixture(dev, golden_dir):
             mine = toks[b, :lens[b]].tolist()
             ref = g['seq%d' % ci][b, :glen[b]].tolist()
             n, norm = max(1, len(mine)), max(1, len(mine)) ** c['lp']
-            # bf16 logits (|logit| ~ 20-30 with the tied embedding head; the teacher-forced test holds them to 1e-2
-            # relative): up to ~0.12 absolute on one token's log-prob = logit - lse
-            tol = 0.12 * n / norm
+            # bf16 logits (|logit| up to ~40 with the tied embedding head): per-token log-prob tolerance from the fixture
+            tol = tok_tol * n / norm
             with torch.no_grad():
                 ts = _teacher_score(sd, melc[b:b + 1], meta['prompt'], mine, 6, sup, bs) / norm
             assert abs(ts - float(scores[b])) < tol, (ci, b, ts, float(scores[b]), tol)
@@ -282,7 +293,7 @@ def test_whisper_generate_beam_matches_transformers_fixture(dev, golden_dir):
                 assert abs(float(scores[b]) - float(g['score%d' % ci][b])) < tol
             else:
                 rn = max(1, len(ref))
-                assert ts > float(g['score%d' % ci][b]) - 0.12 * max(n / norm, rn / rn ** c['lp']), (ci, b, mine, ref, ts)
+                assert ts > float(g['score%d' % ci][b]) - tok_tol * max(n / norm, rn / rn ** c['lp']), (ci, b, mine, ref, ts)
         assert nsp is not None and nsp.shape == (2,)
     print('beam: %d / %d hypotheses identical to the fixture' % (exact, 2 * len(meta['cases'])))
     assert exact >= len(meta['cases'])          # at least half identical; the rest are near-tied reorderings
@@ -325,6 +336,7 @@ def test_whisper_base_beam_at_bench_batch_128(dev, golden_dir):
     melc = mel[:4].float().cpu()
     prompt = torch.tensor([meta['prompt']] * B, dtype=torch.int32)
     exact = total = 0
+    tok_tol = _token_logprob_tol(golden_dir, 'whisper_base')
     for ci, c in enumerate(mb['cases']):
         sup = torch.zeros(V)
         sup[50257:] = float('-inf')
@@ -344,7 +356,7 @@ def test_whisper_base_beam_at_bench_batch_128(dev, golden_dir):
             ref = g['base_seq%d' % ci][b, :glen[b]].tolist()
             n = max(1, len(mine))
             norm = n ** c['lp']
-            tol = 0.12 * n / norm                               # bf16 logits: <= ~0.12 absolute on one token's log-prob
+            tol = tok_tol * n / norm                            # per-token log-prob tolerance derived from the fixture
             with torch.no_grad():
                 ts = _teacher_score(sd, melc[b:b + 1], meta['prompt'], mine, mb['nheads'], sup, None) / norm
             assert abs(ts - float(scores[b])) < tol, (ci, b, ts, float(scores[b]), tol)
@@ -354,7 +366,7 @@ def test_whisper_base_beam_at_bench_batch_128(dev, golden_dir):
                 assert abs(float(scores[b]) - float(g['base_score%d' % ci][b])) < tol
             else:
                 rn = max(1, len(ref))
-                assert ts > float(g['base_score%d' % ci][b]) - 0.12 * max(n / norm, rn / rn ** c['lp']), (ci, b, mine, ref, ts)
+                assert ts > float(g['base_score%d' % ci][b]) - tok_tol * max(n / norm, rn / rn ** c['lp']), (ci, b, mine, ref, ts)
     print('base beam at 640 rows: %d / %d sampled hypotheses identical to the transformers fixture' % (exact, total))
     assert exact >= total // 2
 

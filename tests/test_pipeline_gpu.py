@@ -322,7 +322,9 @@ def test_baseline_config_full_cycle(built_lib, name, N, family, nheads, stt_beam
                     lg = onn.whisper_decoder(sd_w, full[:, :-1], 0, o_enc, nheads, caches)[0]
                     lp = torch.log_softmax(lg[3:].float(), -1)
                     ts = float(sum(lp[j, t] for j, t in enumerate(mine))) / len(mine)
-                    assert ts > float(o_scores[0]) - 0.12 - 0.3 / len(mine), (name, i, mine, o_seqs[0], ts, float(o_scores[0]))
+                    # per-token log-prob tolerance of a bf16 engine: 1.5 x the 99th percentile of the HF engine's own bf16-vs-fp32
+                    # logit difference (tests/golden/whisper_tf.npz: 0.21 -> 0.32), plus the stale start-pad samples' share
+                    assert ts > float(o_scores[0]) - 0.32 - 0.3 / len(mine), (name, i, mine, o_seqs[0], ts, float(o_scores[0]))
         else:
             with torch.no_grad():
                 o_toks, o_first, _, _ = onn.whisper_greedy(sd_w, mel, pipe.prompt[:1].long(), 2, nheads)
