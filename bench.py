@@ -3,7 +3,7 @@
 
 Default workload = BASELINE.json configs[2] ("C3", the largest single-GPU configuration): 128 concurrent synthetic
 calls per GPU, each a 10 s G.711 mu-law utterance in 20 ms / 160 B frames, carried through
-    ingest (decode + 8k->16k + VAD windows) -> Whisper-BASE STT (log-mel, encoder, 32 greedy tokens) -> T2T stub
+    ingest (decode + 8k->16k + VAD windows) -> Whisper-BASE STT (log-mel, encoder, 32 tokens; 5-beam search by default, --stt-beam 1 = greedy) -> T2T stub
     -> SpeechT5 + HiFi-GAN + Amendment TTS (10 infer() calls = 5.12 s of speech at T_text = 64) -> 16k->8k -> mu-law,
 bf16 models with seeded random weights (no checkpoints offline), synthetic audio.
 `--config C2` = 64 calls + Whisper-tiny (configs[1]); `--config C4` = the per-GPU share of configs[3]: 256 calls +
@@ -15,10 +15,13 @@ when the timed region starts.  With N > 1 GPUs calls are sharded (weak scaling);
 gathers the encoded output over RCCL inside the timed region.
 
 Batches are formed ACROSS CALLS ONLY (one utterance per call per batch: --tts-group 1); consecutive cycles are
-stage-pipelined the way a serving loop is: --front-lanes ingest+STT lanes run ahead of --tts-lanes synthesis lanes, so
-up to that many utterance batches are in flight on independent launch chains (the path is bound by the dispatch rate of
-small dependent kernels).  Every cycle's whole work -- and the fill and drain of this pipeline -- is inside
-the timed K steps; outputs are byte-identical to the sequential schedule (tests/test_pipeline_gpu.py).
+stage-pipelined the way a serving loop is: --front-lanes ingest+STT lanes (5-beam Whisper decode) run ahead of the TTS
+stage, which (--tts-mode continuous, the default) is ONE ragged decode batch: every utterance batch in flight (at most
+--tts-lanes) is a set of row slots of the same decoder step, each row at its own decoder position; batches join at an
+infer() boundary and leave when their utterances end (infernos_amd/tts.py:ContinuousTTS).  --tts-mode lanes is round
+2's schedule (one engine clone and launch chain per batch).  Every cycle's whole work -- and the fill and drain of this
+pipeline -- is inside the timed K steps; outputs are byte-identical to the sequential per-batch schedule
+(tests/test_pipeline_gpu.py, tests/test_continuous_tts_gpu.py).
 
 p50/p99 tick latency is measured INSIDE the timed region, under that load: a tick thread hands one [N,160] mu-law
 frame matrix (pinned host memory) to the boundary every 20 ms and waits for that tick's ingest outputs (H2D ->
@@ -477,13 +480,13 @@ def main():
             'tts_samples_per_call': int(res['tts_samples'].float().mean()),
             'roofline': {'kernel': 'HiFi-GAN vocoder pass (%d chunks x 12 frames per launch group)' % nchunks,
                          'bound': 'mfma', 'achieved': round(ach_tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': pmc('r02_vocoder_pmc.json', nchunks),
-                         'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r02_vocoder_pmc.json (scaled by chunks if the pass sizes differ)',
+                         'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': pmc('r03_vocoder_pmc.json', nchunks),
+                         'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r03_vocoder_pmc.json (1280-chunk pass; scaled by chunks if the pass sizes differ)',
                          'seconds_per_vocoder_pass': t_voc},
             'roofline_logmel': {'kernel': 'k_logmel_fft (%d x 30 s windows -> raw log-mel [80,3000] f32 + window maximum)' % n_local, 'bound': 'hbm',
                                 'achieved': round(ach_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                'frac': round(ach_gbs / PEAK_HBM_GBS, 4), 'traffic': pmc('r02_logmel_pmc.json', n_local),
-                                'traffic_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r02_logmel_pmc.json',
+                                'frac': round(ach_gbs / PEAK_HBM_GBS, 4), 'traffic': pmc('r03_logmel_pmc.json', n_local),
+                                'traffic_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r03_logmel_pmc.json',
                                 'seconds': t_mel},
         }
         if lat is not None:
@@ -503,21 +506,32 @@ def main():
         runs = [(c, c, None) for c in ('C2', 'C4', 'C3') if c != args.config]
         if args.stt_beam > 1:            # SURVEY.md 8(d)'s workload as written (greedy, 32 tokens): keeps rounds comparable
             runs.append((args.config + '_greedy', args.config, 1))
+        k2 = max(4, min(args.steps, 12))
+        # every extra configuration in a fresh child process (started, not exec'ed: this process keeps the GPU): a pipeline built
+        # in a process that has already run another one measured 15-30 % slower than the same pipeline alone
+        import subprocess
+        common = [sys.executable, os.path.abspath(__file__), '--no-extra-configs', '--no-cpu-baseline', '--no-tick-probe',
+                  '--tts-mode', args.tts_mode, '--tts-lanes', str(args.tts_lanes), '--front-lanes', str(args.front_lanes),
+                  '--tts-group', str(args.tts_group)]
+
+        def child(argv):
+            r = subprocess.run(common + argv, capture_output=True, text=True, timeout=1200)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            if r.returncode != 0 or not lines:
+                return {'error': (r.stderr or r.stdout)[-400:]}
+            return json.loads(lines[-1])
         for name, cfg, beam in runs:
             n2 = CONFIGS[cfg][0]
-            p2, fa2, ff2, eg2, _ = build(cfg, n2, beam=beam)
-            k2 = max(4, min(args.steps, 12))
-            dt2, _ = time_steps(p2, ff2, k2, 2, 1, not args.no_pipeline, eg2, dry, dev)
-            extra[name] = {'workload': CONFIGS[cfg][2] % n2, 'value': round(n2 * UTT_SECONDS / (dt2 / k2), 2), 'steps': k2,
-                           'ms_per_step': round(dt2 / k2 * 1e3, 2), 'tts_rows_per_batch': n2 * args.tts_group,
+            d2 = child(['--config', cfg, '--steps', str(k2), '--warmup', '2', '--stt-beam', str(beam or args.stt_beam)])
+            if 'error' in d2:
+                extra[name] = d2
+                continue
+            extra[name] = {'workload': CONFIGS[cfg][2] % n2, 'value': d2['value'], 'steps': k2, 'ms_per_step': d2['ms_per_step'],
+                           'tts_rows_per_batch': n2 * args.tts_group,
+                           'tts_rows_per_decode_step': d2['config'].get('tts_rows_per_decode_step'),
                            'stt_decode': 'greedy' if (beam or args.stt_beam) == 1 else '%d beams' % (beam or args.stt_beam)}
-            p2.close()
-            del p2, fa2
-            torch.cuda.empty_cache()
-        try:
-            extra['C5_share'] = c5_share(dev, args, build)
-        except Exception as e:                             # the LLM leg is a "next" row: never take the headline line down
-            extra['C5_share'] = {'error': repr(e)}
+        d5 = child(['--c5-only', '--steps', '5', '--stt-beam', str(args.stt_beam)])
+        extra['C5_share'] = d5.get('C5_share', d5)
         out['other_configs'] = extra
     elif rank == 0:
         pipe.close()

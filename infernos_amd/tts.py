@@ -606,12 +606,63 @@ class InfernTTSWorker(InfernBatchedWorker):
     tts_engine: HelloSippyRTPipe
     output_sr: int
 
-    def __init__(self, lang, output_sr, device=None, **engine_kwa):
+    def __init__(self, lang, output_sr, device=None, continuous=False, max_rows=256, max_text=128, **engine_kwa):
+        """continuous=True: requests join ONE running decode batch at the next infer() boundary instead of waiting for the frozen
+        batch in front of them to loop to its end (ContinuousTTS; max_rows row slots, texts of up to max_text tokens -- a longer
+        text takes the frozen-batch path).  Every request receives the same audio either way."""
         super().__init__()
         kwa = dict(lang2model[lang])
         kwa.update(engine_kwa)
         self.tts_engine = HelloSippyRTPipe(_lib.require_device(device), output_sr=output_sr, **kwa)
         self.output_sr = output_sr
+        self.continuous, self._cont_shape = bool(continuous), (max_rows, max_text)
+
+    def run(self):
+        if not self.continuous:
+            return super().run()
+        from queue import Empty
+        from .workers import RTPWrkTRun
+        self.thread_started()
+        torch.cuda.set_device(self.tts_engine.device)
+        eng = ContinuousTTS(self.tts_engine, max_rows=self._cont_shape[0], max_text=self._cont_shape[1], row_bucket=16)
+        while self.get_state() == RTPWrkTRun:
+            wis, stop = [], False
+            while len(wis) < self.max_batch_size:           # block for work only while nothing is being synthesised
+                try:
+                    wi = self.inf_queue.get(block=not (wis or eng.live or eng.pending))
+                except Empty:
+                    break
+                if wi is None:
+                    stop = True
+                    break
+                wis.append(wi)
+            if wis:
+                for wi in wis:
+                    cb = getattr(wi, '_proc_start_cb', None)
+                    if cb is not None:
+                        cb()
+                states = [HelloSippyPipeState(self.tts_engine, r) for r in wis]
+                fits = [st for st in states if st.inputs.size(1) <= eng.st.T]
+                rest = [(st, r) for st, r in zip(states, wis) if st.inputs.size(1) > eng.st.T]
+                if fits:
+                    T = max(st.inputs.size(1) for st in fits)
+                    ids = torch.zeros((len(fits), T), dtype=torch.int32)
+                    lens = torch.zeros(len(fits), dtype=torch.int32)
+                    for i, st in enumerate(fits):
+                        n = st.inputs.size(1)
+                        ids[i, :n] = st.inputs[0].to(torch.int32)
+                        lens[i] = n
+                    spk = torch.cat([st.speaker_embeddings.reshape(1, 512).float() for st in fits])
+                    # one utterance = one group: its maxlen follows its own text length, as in a batch of one
+                    for i, st in enumerate(fits):
+                        eng.submit(ids[i:i + 1, :int(lens[i])], lens[i:i + 1], spk[i:i + 1], dispatch=[st.dispatch])
+                if rest:
+                    self.process_batch([r for _, r in rest])
+            if stop:
+                while eng.step():
+                    pass
+                break
+            eng.step()
 
     def process_batch(self, wis: List[HelloSippyPlayRequest]):
         new_states = [HelloSippyPipeState(self.tts_engine, r) for r in wis]

@@ -123,6 +123,59 @@ def test_tts_worker_through_sessions(built_lib):
         w.stop()
 
 
+def test_tts_worker_continuous_mode_gives_every_session_its_own_batch_audio(built_lib):
+    """InfernTTSWorker(continuous=True): requests join the running decode batch at the next infer() boundary (tts.ContinuousTTS)
+    instead of queueing behind a frozen batch (Cluster/InfernTTSWorker.py:83-92).  Three sessions speak overlapping utterances of
+    different lengths; each receives, chunk for chunk and byte for byte, what the frozen-batch worker sends when the same request
+    is synthesised alone, and the end-of-sentence marker after it."""
+    from infernos_amd import _lib
+    from infernos_amd.audio import AudioChunk
+    from infernos_amd.muxer import ASMarkerNewSent
+    from infernos_amd.tts import InfernTTSWorker, TTSRequest, TTSSession
+    from infernos_amd.weights import synth_state_dict
+    dev = _lib.require_device('cuda:0')
+    W = {'speecht5_tts': synth_state_dict('speecht5_tts', 0, stop_bias=-20.0), 'hifigan': synth_state_dict('hifigan', 0),
+         'amendment': synth_state_dict('amendment', 0)}
+    g = torch.Generator().manual_seed(1)
+    voices = [torch.randn(1, 512, generator=g) for _ in range(4)]
+    fixed = torch.randint(0, 2, (16, 2, 256), dtype=torch.uint8, generator=torch.Generator().manual_seed(5)).to(dev)
+    texts = ['5 17 33', '44 45 46 47 48 49', '9 8 7 6']             # 3, 6 and 4 tokens: 3, 5 and 4 infer() calls (maxlen arm)
+
+    def run(continuous):
+        w = InfernTTSWorker('en', 8000, dev, weights=W, processor=IdsProcessor(), speaker_embeddings=voices, continuous=continuous)
+        w.tts_engine.mask_source = lambda n: fixed
+        w.start()
+        out = [[] for _ in texts]
+        try:
+            evs = [threading.Event() for _ in texts]
+
+            def so(i):
+                def f(chunk):
+                    out[i].append(chunk)
+                    if isinstance(chunk, ASMarkerNewSent):
+                        evs[i].set()
+                return f
+            sess = [TTSSession(w, None) for _ in texts]
+            for i, s_ in enumerate(sess):
+                s_.start(so(i))
+            for i, s_ in enumerate(sess):
+                s_.say(TTSRequest(texts[i], speaker_id=i))
+                if not continuous:
+                    assert evs[i].wait(180)          # one frozen batch of one at a time
+            assert all(e.wait(180) for e in evs)
+        finally:
+            w.stop()
+        return out
+    ref, got = run(False), run(True)
+    for i in range(len(texts)):
+        a = [c.audio for c in ref[i] if isinstance(c, AudioChunk)]
+        b = [c.audio for c in got[i] if isinstance(c, AudioChunk)]
+        assert len(a) == len(b) and len(a) >= 3, (i, len(a), len(b))
+        for x, y in zip(a, b):
+            assert torch.equal(x.view(torch.int16), y.view(torch.int16)), i
+        assert isinstance(got[i][-1], ASMarkerNewSent) and sum(isinstance(c, ASMarkerNewSent) for c in got[i]) == 1
+
+
 def test_stt_worker_out_of_memory_retries_one_by_one(built_lib):
     """The reference's recovery at Cluster/InfernSTTWorker.py:66-72: a batch that runs out of device memory is retried
     request by request after the allocator's cache has been dropped; results and their order are those of the batch."""
