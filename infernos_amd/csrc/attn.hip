@@ -541,7 +541,11 @@ static int attn_decode_launch(const void *q, int64_t q_bs, const void *k, const 
     IFH_CHECK_ARG(q_bs % 8 == 0 && kv_bs % 8 == 0 && kv_ts % 8 == 0 && o_bs % 8 == 0 && nbatch < 65536);
     IFH_CHECK_ARG(kv_group == 1 || !key_len);       // per-row key counts belong to query rows, not to shared cache rows
     dim3 grid(nheads, nbatch);
-    if (max_keys > 256)      // long caches: 4 waves per (batch, head) (measured faster from ~160 keys up)
+    // 4 waves per (batch, head) for long caches (measured faster from ~160 keys up) -- and for EVERY growing cache (a decode
+    // loop's self-attention: dyn_len, or per-row positions key_len + dyn_add): the waves' partial softmaxes are merged in a
+    // different order than one wave's, so the choice must not depend on the cache CAPACITY, which differs between a frozen batch
+    // (sized by its text length) and the continuous batch (sized for the longest text it admits) holding the same row
+    if (max_keys > 256 || dyn_len || (key_len && dyn_add))
         hipLaunchKernelGGL(k_attn_decode<4>, grid, dim3(256), 0, as_stream(stream), (const uint16_t *)q, q_bs,
                            (const uint16_t *)k, (const uint16_t *)v, kv_bs, kv_ts, (uint16_t *)out, o_bs, key_len, max_keys,
                            dyn_len, dyn_add, kv_group);

@@ -276,6 +276,7 @@ class ContinuousTTS:
         import threading
         self.pp, self.device = pp, pp.device
         dev = pp.device
+        assert max_text <= 256, 'cross-attention over > 256 keys takes the 4-wave kernel: such texts go through the frozen-batch path'
         self.row_bucket = row_bucket
         self.sync_every = int(os.environ.get('IFH_TTS_SYNC_EVERY', '0'))         # decoder steps queued at a time (0: all 16)
         with torch.cuda.device(dev):
@@ -606,7 +607,7 @@ class InfernTTSWorker(InfernBatchedWorker):
     tts_engine: HelloSippyRTPipe
     output_sr: int
 
-    def __init__(self, lang, output_sr, device=None, continuous=False, max_rows=256, max_text=128, **engine_kwa):
+    def __init__(self, lang, output_sr, device=None, continuous=False, max_rows=256, max_text=128, **engine_kwa):   # max_text <= 256
         """continuous=True: requests join ONE running decode batch at the next infer() boundary instead of waiting for the frozen
         batch in front of them to loop to its end (ContinuousTTS; max_rows row slots, texts of up to max_text tokens -- a longer
         text takes the frozen-batch path).  Every request receives the same audio either way."""

@@ -139,7 +139,7 @@ def test_tts_worker_continuous_mode_gives_every_session_its_own_batch_audio(buil
     g = torch.Generator().manual_seed(1)
     voices = [torch.randn(1, 512, generator=g) for _ in range(4)]
     fixed = torch.randint(0, 2, (16, 2, 256), dtype=torch.uint8, generator=torch.Generator().manual_seed(5)).to(dev)
-    texts = ['5 17 33', '44 45 46 47 48 49', '9 8 7 6']             # 3, 6 and 4 tokens: 3, 5 and 4 infer() calls (maxlen arm)
+    texts = ['5 17 33', '44 45 46 47 48 49', '9 8 7 6']             # 3, 6 and 4 tokens: utterances of different lengths (maxlen arm of the stop rule)
 
     def run(continuous):
         w = InfernTTSWorker('en', 8000, dev, weights=W, processor=IdsProcessor(), speaker_embeddings=voices, continuous=continuous)
@@ -170,7 +170,7 @@ def test_tts_worker_continuous_mode_gives_every_session_its_own_batch_audio(buil
     for i in range(len(texts)):
         a = [c.audio for c in ref[i] if isinstance(c, AudioChunk)]
         b = [c.audio for c in got[i] if isinstance(c, AudioChunk)]
-        assert len(a) == len(b) and len(a) >= 3, (i, len(a), len(b))
+        assert len(a) == len(b) and len(a) >= 2, (i, len(a), len(b))
         for x, y in zip(a, b):
             assert torch.equal(x.view(torch.int16), y.view(torch.int16)), i
         assert isinstance(got[i][-1], ASMarkerNewSent) and sum(isinstance(c, ASMarkerNewSent) for c in got[i]) == 1
