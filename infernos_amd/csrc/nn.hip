@@ -434,14 +434,20 @@ __global__ __launch_bounds__(256) void k_gemm_m64(const IgemmParams p)
     }
 }
 
-template <int BM, int BN, int WGM, bool PRE, bool FAST>
-__global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
+#ifndef IFH_IGEMM_MINB
+#define IFH_IGEMM_MINB 3
+#endif
+template <int BM, int BN, int WGM, bool PRE, bool FAST, int NWV = 4>
+// (three 4-wave workgroups per CU: left alone the compiler takes 116 VGPRs + 64 AGPRs = two per CU, and at K = 512 the k-loop is a
+// chain of 16 load -> barrier round trips whose latency only other resident workgroups cover)
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_igemm(const IgemmParams p)
 {
-    constexpr int WGN = 4 / WGM;
+    constexpr int NTH = 64 * NWV;              // threads: 4 waves, or 8 for the 256 x 128 tile
+    constexpr int WGN = NWV / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MT = WM / 16, NT = WN / 16;
     constexpr int LD = 40;  // 32 + 8 pad (80-byte rows)
-    constexpr int AV = BM * 4 / 256, BV = (BN * 4 + 255) / 256;
+    constexpr int AV = BM * 4 / NTH, BV = (BN * 4 + NTH - 1) / NTH;
     __shared__ __attribute__((aligned(16))) uint16_t As2[2][BM * LD];      // double-buffered K tiles: one barrier per k-step
     __shared__ __attribute__((aligned(16))) uint16_t Bs2[2][BN * LD];
 
@@ -470,7 +476,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
     bool avalid[AV];
 #pragma unroll
     for (int i = 0; i < AV; i++) {
-        const int v = tid + 256 * i;
+        const int v = tid + NTH * i;
         const int m = m0 + (v >> 2);
         avalid[i] = m < M;
         const int mm = avalid[i] ? m : 0;
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < AV; i++)                                                   \
         {                                                                                                \
-            const int v = tid + 256 * i;                                                                 \
+            const int v = tid + NTH * i;                                                                 \
             const int k = k0_ + (v & 3) * 8;                                                             \
             int tap, ci;                                                                                 \
             if (uniform_tap) {                                                                           \
@@ -515,7 +521,7 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < BV; i++)                                                   \
         {                                                                                                \
-            const int v = tid + 256 * i;                                                                 \
+            const int v = tid + NTH * i;                                                                 \
             const int n = n0 + (v >> 2);                                                                 \
             const int k = k0_ + (v & 3) * 8;                                                             \
             uint4 val = make_uint4(0, 0, 0, 0);                                                          \
@@ -530,12 +536,12 @@ __global__ __launch_bounds__(256) void k_igemm(const IgemmParams p)
         uint16_t *As_ = As2[BUF], *Bs_ = Bs2[BUF];                                                       \
         _Pragma("unroll") for (int i = 0; i < AV; i++)                                                   \
         {                                                                                                \
-            const int v = tid + 256 * i;                                                                 \
+            const int v = tid + NTH * i;                                                                 \
             *reinterpret_cast<uint4 *>(&As_[(v >> 2) * LD + (v & 3) * 8]) = PRE ? lrelu8(ra[i], p.pre_slope) : ra[i]; \
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < BV; i++)                                                   \
         {                                                                                                \
-            const int v = tid + 256 * i;                                                                 \
+            const int v = tid + NTH * i;                                                                 \
             if (v < BN * 4) *reinterpret_cast<uint4 *>(&Bs_[(v >> 2) * LD + (v & 3) * 8]) = rb[i];       \
         }                                                                                                \
     }
@@ -702,7 +708,7 @@ __global__ __launch_bounds__(256) void k_transpose(const void *__restrict__ in, 
     }
 }
 
-template <int BM, int BN, int WGM>
+template <int BM, int BN, int WGM, int NWV = 4>
 static void launch_igemm(const IgemmParams &p, bool pre, hipStream_t st)
 {
     const int M = p.nbatch * p.T_out;
@@ -710,14 +716,14 @@ static void launch_igemm(const IgemmParams &p, bool pre, hipStream_t st)
     dim3 grid((unsigned)(((tiles + 7) / 8) * 8));          // 1-D, a multiple of 8: see the tile map at the top of k_igemm
     if (p.fast_epi) {
         if (pre)
-            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, true, true>), grid, dim3(256), 0, st, p);
+            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, true, true, NWV>), grid, dim3(64 * NWV), 0, st, p);
         else
-            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, true>), grid, dim3(256), 0, st, p);
+            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, true, NWV>), grid, dim3(64 * NWV), 0, st, p);
     } else {
         if (pre)
-            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, true, false>), grid, dim3(256), 0, st, p);
+            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, true, false, NWV>), grid, dim3(64 * NWV), 0, st, p);
         else
-            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, false>), grid, dim3(256), 0, st, p);
+            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, false, NWV>), grid, dim3(64 * NWV), 0, st, p);
     }
 }
 
@@ -890,7 +896,12 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         // 128 x 128 at n = 512) leaves most of the 256 CUs idle: take the tile that yields at least one workgroup per CU.
         // The k order per output element does not depend on the tile: same bits.
         const int64_t mt = (M + 127) / 128;
-        if (mt * ((d->n + 127) / 128) >= 256)
+        // thousands of row tiles (encoders, prefill): the 256 x 128 tile of eight waves moves a quarter fewer operand bytes per
+        // FLOP through L2 -> CU, which is what these GEMMs wait for at K = 512..2048 (same k order per element: same bits)
+        static const int big_rows = getenv("IFH_IGEMM_256_ROWS") ? atoi(getenv("IFH_IGEMM_256_ROWS")) : 0x7fffffff;   // tuning switch: measured SLOWER (encoder 30.0 vs 28.2 ms), off
+        if (M >= big_rows && (mt / 2) * ((d->n + 127) / 128) >= 512)
+            launch_igemm<256, 128, 4, 8>(p, pre, st);
+        else if (mt * ((d->n + 127) / 128) >= 256)
             launch_igemm<128, 128, 2>(p, pre, st);
         else if (mt * ((d->n + 63) / 64) >= 256 || M > 4096)
             launch_igemm<128, 64, 2>(p, pre, st);
