@@ -36,6 +36,10 @@ QWEN2_CONFIGS = {
                       rms_eps=1e-6, tie=False, max_pos=32768),
     'qwen2_1p5b': dict(vocab=151936, hidden=1536, ffn=8960, layers=28, heads=12, kv_heads=2, head_dim=128, rope_theta=1.0e6,
                        rms_eps=1e-6, tie=True, max_pos=32768),
+    # Qwen2.5-1.5B's layer and vocabulary dimensions with 2 of its 28 layers: every kernel selection of BASELINE configuration 5's
+    # LLM (k_gemm_m64<4,2> on gate|up 17 920 x 1 536 and on the 151 936-row tied head) at a size the fp32 oracle finishes in seconds
+    'qwen2_1p5b_2l': dict(vocab=151936, hidden=1536, ffn=8960, layers=2, heads=12, kv_heads=2, head_dim=128, rope_theta=1.0e6,
+                          rms_eps=1e-6, tie=True, max_pos=32768),
 }
 
 
