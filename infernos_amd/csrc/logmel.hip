@@ -234,7 +234,27 @@ __global__ __launch_bounds__(256, 2) void k_logmel_fft(const float *__restrict__
         FFT5(v0, v5, v10, v15, v20) FFT5(v1, v6, v11, v16, v21) FFT5(v2, v7, v12, v17, v22)
         FFT5(v3, v8, v13, v18, v23) FFT5(v4, v9, v14, v19, v24)
         // twiddle inner[b][c] by W25^(b c) (b, c >= 1)
-#define LF_TW(V, B, C) V = cmul(V, c_fft.w25[B][C]);
+// W25^(b c) as literals (round 3): as __constant__ loads the 16 twiddles sat in 32 SGPRs for the whole kernel and pushed the
+// compiler into 70+ SGPR spills (v_writelane / v_readlane + hazard nops in every tile)
+#define LF_W25(B, C) ( \
+    (B) == 1 && (C) == 1 ? mk2(9.685831611e-01f, -2.486898872e-01f) : \
+    (B) == 1 && (C) == 2 ? mk2(8.763066800e-01f, -4.817536741e-01f) : \
+    (B) == 1 && (C) == 3 ? mk2(7.289686274e-01f, -6.845471059e-01f) : \
+    (B) == 1 && (C) == 4 ? mk2(5.358267950e-01f, -8.443279255e-01f) : \
+    (B) == 2 && (C) == 1 ? mk2(8.763066800e-01f, -4.817536741e-01f) : \
+    (B) == 2 && (C) == 2 ? mk2(5.358267950e-01f, -8.443279255e-01f) : \
+    (B) == 2 && (C) == 3 ? mk2(6.279051953e-02f, -9.980267284e-01f) : \
+    (B) == 2 && (C) == 4 ? mk2(-4.257792916e-01f, -9.048270525e-01f) : \
+    (B) == 3 && (C) == 1 ? mk2(7.289686274e-01f, -6.845471059e-01f) : \
+    (B) == 3 && (C) == 2 ? mk2(6.279051953e-02f, -9.980267284e-01f) : \
+    (B) == 3 && (C) == 3 ? mk2(-6.374239897e-01f, -7.705132428e-01f) : \
+    (B) == 3 && (C) == 4 ? mk2(-9.921147013e-01f, -1.253332336e-01f) : \
+    (B) == 4 && (C) == 1 ? mk2(5.358267950e-01f, -8.443279255e-01f) : \
+    (B) == 4 && (C) == 2 ? mk2(-4.257792916e-01f, -9.048270525e-01f) : \
+    (B) == 4 && (C) == 3 ? mk2(-9.921147013e-01f, -1.253332336e-01f) : \
+    (B) == 4 && (C) == 4 ? mk2(-6.374239897e-01f, 7.705132428e-01f) : \
+    mk2(1.0f, 0.0f))
+#define LF_TW(V, B, C) V = cmul(V, LF_W25(B, C));
         LF_TW(v6, 1, 1) LF_TW(v7, 2, 1) LF_TW(v8, 3, 1) LF_TW(v9, 4, 1)
         LF_TW(v11, 1, 2) LF_TW(v12, 2, 2) LF_TW(v13, 3, 2) LF_TW(v14, 4, 2)
         LF_TW(v16, 1, 3) LF_TW(v17, 2, 3) LF_TW(v18, 3, 3) LF_TW(v19, 4, 3)
