@@ -514,9 +514,13 @@ struct Ring256Params {
     int64_t out_bstride;
 };
 
+// NCH chunks per workgroup: 2 (MT = 8 row tiles, 25-row gaps: any convolution of the level) or -- round 3 -- 3 (MT = 10, 8-row
+// gaps) for the 14 of the level's 18 convolutions whose reach (taps - 1) / 2 * dil is at most 8: 144 of 160 MFMA rows are real
+// instead of 96 of 128, and every weight unit streamed from L2 serves three chunks instead of two.
+template <int MT, int NCH, int GX>
 __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
 {
-    constexpr int C = 256, NT = 2, MT = 8, NR = NT + MT, NRING = 4, GX = 25;
+    constexpr int C = 256, NT = 2, NR = NT + MT, NRING = 4;
     constexpr int SB = (C + 16) * 2;                   // 544-byte rows: stride = 2 (mod 4) sixteen-byte slots
     constexpr int RT = MT * 16;                        // 128 rows computed
     constexpr int XROWS = RT + 2 * GX;
@@ -564,7 +568,9 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
     {                                                                                                                     \
         if ((Q) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(FA[0]) : "v"(nxt_a));                                     \
         else if ((Q) == MT + 1) asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(FA[1]) : "v"(nxt_a));               \
-        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FB[(Q) - 1]) : "v"(nxt_b), "n"(((Q) - 1) * 16 * SB));    \
+        else if ((Q) - 1 < 7) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FB[(Q) - 1]) : "v"(nxt_b), "n"(((Q) - 1) * 16 * SB)); \
+        /* row tiles 7.. (MT = 10): a second base, the 16-bit offset field ends at 65 535 */                                \
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FB[(Q) - 1]) : "v"(nxt_b + 7 * 16 * SB), "n"(((Q) - 8) * 16 * SB)); \
     }
     // entering a unit (= a k-step here): this wave's two pieces of the NEXT unit have landed (all DMAs but the youngest
     // unit's two), everybody's have after the barrier; the slot of the previous unit is refilled three units ahead, behind
@@ -604,20 +610,38 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
         }
     };
 
-    const int npairs = (p.nbatch + 1) / 2;
-    for (int tile = blockIdx.x; tile < npairs; tile += gridDim.x) {
-        const int b0 = tile * 2;
-        const int nb = min(2, p.nbatch - b0);
-        // x image: rows of chunk e at GX + e * pitch + t, LeakyReLU applied once here, 16 bytes per thread per step
-        for (int v = tid; v < nb * T * (C / 8); v += 512) {
-            const int rowi = v / (C / 8), c8 = v - rowi * (C / 8);
-            const int e = rowi / T, t = rowi - e * T;
-            const uint4 xv = *reinterpret_cast<const uint4 *>(p.x + (int64_t)(b0 + e) * p.x_bstride + (int64_t)t * C + c8 * 8);
-            *reinterpret_cast<uint4 *>(lds + (GX + e * pitch + t) * SB + c8 * 16) = p.pre_slope != 1.0f ? lrelu8(xv, p.pre_slope) : xv;
+    const int ngroups = (p.nbatch + NCH - 1) / NCH;
+    for (int tile = blockIdx.x; tile < ngroups; tile += gridDim.x) {
+        const int b0 = tile * NCH;
+        const int nb = min(NCH, p.nbatch - b0);
+        // x image: rows of chunk e at GX + e * pitch + t, LeakyReLU applied once here, 16 bytes per thread per step.  All of a
+        // thread's loads (T <= 48: at most 3 per chunk) are issued before the first LDS write: as a load -> write loop this
+        // was one HBM round trip per step with nothing else running on the CU (round 3: 6-9 round trips per tile)
+        {
+            constexpr int XU = NCH * 3;
+            const int total = nb * T * (C / 8);
+            int tid_ = tid;                            // opaque per tile: the tile-invariant address arithmetic is not hoisted (it was
+            asm volatile("" : "+v"(tid_));             // spilled to scratch next to the accumulators)
+            uint4 xv[XU];
+            int xdst[XU];
+#pragma unroll
+            for (int u = 0; u < XU; u++) {
+                const int v = tid_ + u * 512;
+                const int rowi = v / (C / 8), c8 = v - rowi * (C / 8);
+                const int e = rowi / T, t = rowi - e * T;
+                xdst[u] = (GX + e * pitch + t) * SB + c8 * 16;
+                if (v < total) xv[u] = *reinterpret_cast<const uint4 *>(p.x + (int64_t)(b0 + e) * p.x_bstride + (int64_t)t * C + c8 * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < XU; u++)
+                if (tid_ + u * 512 < total) *reinterpret_cast<uint4 *>(lds + xdst[u]) = p.pre_slope != 1.0f ? lrelu8(xv[u], p.pre_slope) : xv[u];
         }
-        if (nb == 1)                                   // a lone last chunk: the second chunk's rows of the previous tile are stale
-            for (int v = tid; v < T * (C / 8); v += 512)
-                *reinterpret_cast<uint4 *>(lds + (GX + pitch + v / (C / 8)) * SB + (v % (C / 8)) * 16) = make_uint4(0, 0, 0, 0);
+        if (nb < NCH)                                  // a short last group: the missing chunks' rows of the previous tile are stale
+            for (int v = tid; v < (NCH - nb) * T * (C / 8); v += 512) {
+                const int rowi = v / (C / 8);
+                const int e = nb + rowi / T, t = rowi - (rowi / T) * T;
+                *reinterpret_cast<uint4 *>(lds + (GX + e * pitch + t) * SB + (v % (C / 8)) * 16) = make_uint4(0, 0, 0, 0);
+            }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -646,33 +670,55 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
         for (int i = 0; i < NT; i++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[i]) : "v"(bias_b), "n"(i * 64));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
+        // the residual / previous-out loads of four row tiles at a time go out before their first use (as one branch per
+        // row tile they were MT dependent round trips; all MT at once would not fit the registers next to acc)
+        constexpr int EG = 4;
+        int fr_ = fr, cw_ = wid * NT * 16 + 4 * fg;
+        asm volatile("" : "+v"(fr_), "+v"(cw_));
 #pragma unroll
-        for (int j = 0; j < MT; j++) {
-            const int q = j * 16 + fr;
-            const int e = q >= pitch ? 1 : 0, t = q - e * pitch;
-            if (t < T && e < nb) {
+        for (int j0 = 0; j0 < MT; j0 += EG) {
+            uint2 rres[EG][NT], rout[EG][NT];
 #pragma unroll
-                for (int i = 0; i < NT; i++) {
-                    const int64_t off = (int64_t)t * C + (wid * NT + i) * 16 + 4 * fg;
-                    const f32x4 a = acc[i][j];
-                    float v0 = a[0] + bv[i][0], v1 = a[1] + bv[i][1], v2 = a[2] + bv[i][2], v3 = a[3] + bv[i][3];
-                    if (p.resid) {
-                        const uint2 rv = *reinterpret_cast<const uint2 *>(p.resid + (int64_t)(b0 + e) * p.resid_bstride + off);
-                        v0 += __uint_as_float(rv.x << 16);
-                        v1 += __uint_as_float(rv.x & 0xffff0000u);
-                        v2 += __uint_as_float(rv.y << 16);
-                        v3 += __uint_as_float(rv.y & 0xffff0000u);
+            for (int jj = 0; jj < EG && j0 + jj < MT; jj++) {
+                const int q = (j0 + jj) * 16 + fr_;
+                const int e = q / pitch, t = q - e * pitch;
+                if (t < T && e < nb) {
+                    const int64_t off = (int64_t)t * C + cw_;
+#pragma unroll
+                    for (int i = 0; i < NT; i++) {
+                        if (p.resid) rres[jj][i] = *reinterpret_cast<const uint2 *>(p.resid + (int64_t)(b0 + e) * p.resid_bstride + off + i * 16);
+                        if (p.accumulate) rout[jj][i] = *reinterpret_cast<const uint2 *>(p.out + (int64_t)(b0 + e) * p.out_bstride + off + i * 16);
                     }
-                    v0 *= p.out_scale; v1 *= p.out_scale; v2 *= p.out_scale; v3 *= p.out_scale;
-                    uint16_t *dst = p.out + (int64_t)(b0 + e) * p.out_bstride + off;
-                    if (p.accumulate) {
-                        const uint2 q2 = *reinterpret_cast<const uint2 *>(dst);
-                        v0 += __uint_as_float(q2.x << 16);
-                        v1 += __uint_as_float(q2.x & 0xffff0000u);
-                        v2 += __uint_as_float(q2.y << 16);
-                        v3 += __uint_as_float(q2.y & 0xffff0000u);
+                }
+            }
+#pragma unroll
+            for (int jj = 0; jj < EG && j0 + jj < MT; jj++) {
+                const int j = j0 + jj;
+                const int q = j * 16 + fr_;
+                const int e = q / pitch, t = q - e * pitch;
+                if (t < T && e < nb) {
+                    uint16_t *dst = p.out + (int64_t)(b0 + e) * p.out_bstride + (int64_t)t * C + cw_;
+#pragma unroll
+                    for (int i = 0; i < NT; i++) {
+                        const f32x4 a = acc[i][j];
+                        float v0 = a[0] + bv[i][0], v1 = a[1] + bv[i][1], v2 = a[2] + bv[i][2], v3 = a[3] + bv[i][3];
+                        if (p.resid) {
+                            const uint2 rv = rres[jj][i];
+                            v0 += __uint_as_float(rv.x << 16);
+                            v1 += __uint_as_float(rv.x & 0xffff0000u);
+                            v2 += __uint_as_float(rv.y << 16);
+                            v3 += __uint_as_float(rv.y & 0xffff0000u);
+                        }
+                        v0 *= p.out_scale; v1 *= p.out_scale; v2 *= p.out_scale; v3 *= p.out_scale;
+                        if (p.accumulate) {
+                            const uint2 q2 = rout[jj][i];
+                            v0 += __uint_as_float(q2.x << 16);
+                            v1 += __uint_as_float(q2.x & 0xffff0000u);
+                            v2 += __uint_as_float(q2.y << 16);
+                            v3 += __uint_as_float(q2.y & 0xffff0000u);
+                        }
+                        *reinterpret_cast<uint2 *>(dst + i * 16) = make_uint2(f32x2_to_bf16x2(v0, v1), f32x2_to_bf16x2(v2, v3));
                     }
-                    *reinterpret_cast<uint2 *>(dst) = make_uint2(f32x2_to_bf16x2(v0, v1), f32x2_to_bf16x2(v2, v3));
                 }
             }
         }
@@ -768,19 +814,36 @@ extern "C" int ifh_conv_ring256_bf16(const ifh_ring256_desc *d, ifh_stream_t str
     p.accumulate = d->accumulate;
     p.out = (uint16_t *)d->out;
     p.out_bstride = d->out_bstride;
-    constexpr size_t bytes = (size_t)(128 + 50) * 544 + 4 * 16384 + 256 * sizeof(float);
-    static_assert(bytes <= 160 * 1024, "ring256 tile");
-    static DeviceOnce attr_once;
-    int attr_dev = 0;
-    if (attr_once.needed(&attr_dev)) {
-        hipError_t e = hipFuncSetAttribute((const void *)k_conv_ring256, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return check_hip(e, "conv_ring256 lds attr");
-        attr_once.done(attr_dev);
-    }
     const int ncu = device_cu_count();
     if (ncu <= 0) return fail(IFH_EHIP, "conv_ring256: device query");
-    const int npairs = (d->nbatch + 1) / 2;
-    hipLaunchKernelGGL(k_conv_ring256, dim3(npairs < ncu ? npairs : ncu), dim3(512), bytes, as_stream(stream), p);
+    const int reach = (d->taps - 1) / 2 * d->dil;
+    static const bool no3 = getenv("IFH_RING256_NO3") != nullptr;            // tuning switch
+    if (reach <= 8 && !no3 && d->nbatch >= 3 * ncu) {
+        constexpr size_t bytes = (size_t)(160 + 16) * 544 + 4 * 16384 + 256 * sizeof(float);
+        static_assert(bytes <= 160 * 1024, "ring256 tile");
+        static_assert(3 * 48 + 2 * 8 <= 160, "three chunks and their gaps fit the row tiles");
+        static DeviceOnce attr_once;
+        int attr_dev = 0;
+        if (attr_once.needed(&attr_dev)) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_conv_ring256<10, 3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return check_hip(e, "conv_ring256 lds attr");
+            attr_once.done(attr_dev);
+        }
+        const int ng = (d->nbatch + 2) / 3;
+        hipLaunchKernelGGL((k_conv_ring256<10, 3, 8>), dim3(ng < ncu ? ng : ncu), dim3(512), bytes, as_stream(stream), p);
+    } else {
+        constexpr size_t bytes = (size_t)(128 + 50) * 544 + 4 * 16384 + 256 * sizeof(float);
+        static_assert(bytes <= 160 * 1024, "ring256 tile");
+        static DeviceOnce attr_once;
+        int attr_dev = 0;
+        if (attr_once.needed(&attr_dev)) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_conv_ring256<8, 2, 25>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return check_hip(e, "conv_ring256 lds attr");
+            attr_once.done(attr_dev);
+        }
+        const int npairs = (d->nbatch + 1) / 2;
+        hipLaunchKernelGGL((k_conv_ring256<8, 2, 25>), dim3(npairs < ncu ? npairs : ncu), dim3(512), bytes, as_stream(stream), p);
+    }
     IFH_LAUNCH_CHECK("conv_ring256_bf16");
     return IFH_OK;
 }

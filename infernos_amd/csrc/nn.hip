@@ -434,10 +434,19 @@ __global__ __launch_bounds__(256) void k_gemm_m64(const IgemmParams p)
     }
 }
 
+// 16 bytes as a native vector: a uint4 (a struct) copied global -> array -> LDS stays two memcpys through a stack slot that the
+// compiler does not promote (seen as scratch stores behind an s_waitcnt right after the loads)
+__device__ __forceinline__ uint4 ld_u32x4(const uint16_t *ptr)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = *reinterpret_cast<const u32x4 *>(ptr);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 #ifndef IFH_IGEMM_MINB
 #define IFH_IGEMM_MINB 3
 #endif
-template <int BM, int BN, int WGM, bool PRE, bool FAST, int NWV = 4>
+template <int BM, int BN, int WGM, bool PRE, bool FAST, int NWV = 4, int KT = 32, bool PLAIN = false>
 // (three 4-wave workgroups per CU: left alone the compiler takes 116 VGPRs + 64 AGPRs = two per CU, and at K = 512 the k-loop is a
 // chain of 16 load -> barrier round trips whose latency only other resident workgroups cover)
 __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_igemm(const IgemmParams p)
@@ -446,10 +455,15 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_ige
     constexpr int WGN = NWV / WGM;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MT = WM / 16, NT = WN / 16;
-    constexpr int LD = 40;  // 32 + 8 pad (80-byte rows)
-    constexpr int AV = BM * 4 / NTH, BV = (BN * 4 + NTH - 1) / NTH;
-    __shared__ __attribute__((aligned(16))) uint16_t As2[2][BM * LD];      // double-buffered K tiles: one barrier per k-step
-    __shared__ __attribute__((aligned(16))) uint16_t Bs2[2][BN * LD];
+    // KT = 32: 64-byte row pieces, double-buffered K tiles, one barrier per k-step.  KT = 64 (round 3): a row piece is a whole
+    // 128-byte line -- with 64-byte pieces every line of A and W is requested from L2 twice, a k-step apart, and the vector L1 does
+    // not keep it (3 x 16 KB of tiles per CU pass in between): TCP -> TCC read requests per launch were 2 x bytes / 128 at the
+    // Whisper-base encoder shapes, 43 % of the L2s' request rate -- one LDS buffer (two barriers per 64 of K, the same per K).
+    constexpr int KV = KT / 8, NBUF = KT == 32 ? 2 : 1;
+    constexpr int LD = KT + 8;  // 8 pad (80- / 144-byte rows)
+    constexpr int AV = BM * KV / NTH, BV = (BN * KV + NTH - 1) / NTH;
+    __shared__ __attribute__((aligned(16))) uint16_t As2[NBUF][BM * LD];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs2[NBUF][BN * LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid % WGM, wn = wid / WGM;
@@ -468,7 +482,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_ige
         n0 = (t % ntn) * BN;
     }
     const int M = p.nbatch * p.T_out;
-    const bool uniform_tap = (p.Cin & 31) == 0;
+    const bool uniform_tap = (p.Cin % KT) == 0;
 
     // per-thread activation-row descriptors (fixed over the K loop)
     const uint16_t *arow[AV];
@@ -477,12 +491,32 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_ige
 #pragma unroll
     for (int i = 0; i < AV; i++) {
         const int v = tid + NTH * i;
-        const int m = m0 + (v >> 2);
+        const int m = m0 + v / KV;
         avalid[i] = m < M;
         const int mm = avalid[i] ? m : 0;
         const int b = mm / p.T_out, t = mm - b * p.T_out;
         arow[i] = p.x + (int64_t)b * p.x_bstride;
         abase_t[i] = t * p.stride - p.pad;
+    }
+    // PLAIN (round 3): a matrix product (one tap, stride 1, no padding, K a multiple of KT).  The general tile load below is ~230
+    // instructions per k-step around 16 MFMAs -- tap / channel arithmetic, four range tests and an exec branch per 16-byte load,
+    // kernel arguments re-read from memory -- and with three waves per SIMD the issue slots, not memory, bound the k-loop (the
+    // Whisper-base encoder GEMMs ran at 0.4-0.5 PFLOP/s with 92 % L2 hits).  Here a thread's loads are pointer + k: rows and
+    // columns beyond the edge are clamped to the last valid one (loaded, multiplied, never stored), so nothing is predicated.
+    const uint16_t *aptr[AV], *wptr[BV];
+    if (PLAIN) {
+#pragma unroll
+        for (int i = 0; i < AV; i++) {
+            const int v = tid + NTH * i;
+            const int mm = min(m0 + v / KV, M - 1);
+            const int b = mm / p.T_out, t = mm - b * p.T_out;
+            aptr[i] = p.x + (int64_t)b * p.x_bstride + (int64_t)t * p.lda + (v % KV) * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < BV; i++) {
+            const int v = min(tid + NTH * i, BN * KV - 1);
+            wptr[i] = p.w + (int64_t)min(n0 + v / KV, p.N - 1) * p.K + (v % KV) * 8;
+        }
     }
     f32x4 acc[NT][MT];
 #pragma unroll
@@ -494,7 +528,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_ige
     // scratch memory by hipcc (272 B/lane of spills in the 128x128 tile, ~2x slower).
     uint4 ra[AV], rb[BV];
 #define IFH_LOAD_TILES(K0)                                                                               \
-    {                                                                                                    \
+    if (PLAIN) {                                                                                         \
+        const int k0_ = (K0);                                                                            \
+        _Pragma("unroll") for (int i = 0; i < AV; i++) ra[i] = ld_u32x4(aptr[i] + k0_);                  \
+        _Pragma("unroll") for (int i = 0; i < BV; i++) rb[i] = ld_u32x4(wptr[i] + k0_);                  \
+    } else {                                                                                             \
         const int k0_ = (K0);                                                                            \
         int tap_u = 0, ci_u = 0;                                                                         \
         if (uniform_tap) {                                                                               \
@@ -504,11 +542,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_ige
         _Pragma("unroll") for (int i = 0; i < AV; i++)                                                   \
         {                                                                                                \
             const int v = tid + NTH * i;                                                                 \
-            const int k = k0_ + (v & 3) * 8;                                                             \
+            const int k = k0_ + (v % KV) * 8;                                                            \
             int tap, ci;                                                                                 \
             if (uniform_tap) {                                                                           \
                 tap = tap_u;                                                                             \
-                ci = ci_u + (v & 3) * 8;                                                                 \
+                ci = ci_u + (v % KV) * 8;                                                                \
             } else {                                                                                     \
                 tap = k / p.Cin;                                                                         \
                 ci = k - tap * p.Cin;                                                                    \
@@ -522,10 +560,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_ige
         _Pragma("unroll") for (int i = 0; i < BV; i++)                                                   \
         {                                                                                                \
             const int v = tid + NTH * i;                                                                 \
-            const int n = n0 + (v >> 2);                                                                 \
-            const int k = k0_ + (v & 3) * 8;                                                             \
+            const int n = n0 + v / KV;                                                                   \
+            const int k = k0_ + (v % KV) * 8;                                                            \
             uint4 val = make_uint4(0, 0, 0, 0);                                                          \
-            if (v < BN * 4 && n < p.N && k < kend) val = *reinterpret_cast<const uint4 *>(p.w + (int64_t)n * p.K + k); \
+            if (v < BN * KV && n < p.N && k < kend) val = *reinterpret_cast<const uint4 *>(p.w + (int64_t)n * p.K + k); \
             rb[i] = val;                                                                                 \
         }                                                                                                \
     }
@@ -537,12 +575,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_ige
         _Pragma("unroll") for (int i = 0; i < AV; i++)                                                   \
         {                                                                                                \
             const int v = tid + NTH * i;                                                                 \
-            *reinterpret_cast<uint4 *>(&As_[(v >> 2) * LD + (v & 3) * 8]) = PRE ? lrelu8(ra[i], p.pre_slope) : ra[i]; \
+            *reinterpret_cast<uint4 *>(&As_[(v / KV) * LD + (v % KV) * 8]) = PRE ? lrelu8(ra[i], p.pre_slope) : ra[i]; \
         }                                                                                                \
         _Pragma("unroll") for (int i = 0; i < BV; i++)                                                   \
         {                                                                                                \
             const int v = tid + NTH * i;                                                                 \
-            if (v < BN * 4) *reinterpret_cast<uint4 *>(&Bs_[(v >> 2) * LD + (v & 3) * 8]) = rb[i];       \
+            if ((BN * KV) % NTH == 0 || v < BN * KV) *reinterpret_cast<uint4 *>(&Bs_[(v / KV) * LD + (v % KV) * 8]) = rb[i]; \
         }                                                                                                \
     }
 
@@ -554,8 +592,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_ige
         if (r_hi < 2) kend = 2 * p.Cin;
         else if (r_lo >= 2) kbeg = p.Cin;
     }
-    const int nk = (kend - kbeg + 31) / 32;
-    IFH_LOAD_TILES(kbeg);
+    const int nk = (kend - kbeg + KT - 1) / KT;
+    IFH_LOAD_TILES(kbeg)
     const int fr = lane & 15, fg = lane >> 4;
     // bias 4-vectors of this lane's column groups, requested ahead of the K loop (vector epilogue only)
     float4 bpre[NT];
@@ -567,23 +605,32 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_ige
     IFH_STORE_TILES(0);
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
-        const uint16_t *As = As2[kt & 1], *Bs = Bs2[kt & 1];
-        if (kt + 1 < nk) IFH_LOAD_TILES(kbeg + (kt + 1) * 32);
-        bf16x8_t fa[NT], fb[MT];
+        const uint16_t *As = As2[NBUF == 2 ? (kt & 1) : 0], *Bs = Bs2[NBUF == 2 ? (kt & 1) : 0];
+        if (kt + 1 < nk) IFH_LOAD_TILES(kbeg + (kt + 1) * KT)
 #pragma unroll
-        for (int i = 0; i < NT; i++)
-            fa[i] = *reinterpret_cast<const bf16x8_t *>(&Bs[(wn * WN + i * 16 + fr) * LD + fg * 8]);
+        for (int ks = 0; ks < KT / 32; ks++) {
+            bf16x8_t fa[NT], fb[MT];
 #pragma unroll
-        for (int j = 0; j < MT; j++)
-            fb[j] = *reinterpret_cast<const bf16x8_t *>(&As[(wm * WM + j * 16 + fr) * LD + fg * 8]);
-#pragma unroll
-        for (int i = 0; i < NT; i++)
+            for (int i = 0; i < NT; i++)
+                fa[i] = *reinterpret_cast<const bf16x8_t *>(&Bs[(wn * WN + i * 16 + fr) * LD + ks * 32 + fg * 8]);
 #pragma unroll
             for (int j = 0; j < MT; j++)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-        // the other buffer was last read one iteration ago and every wave has passed the barrier since
-        if (kt + 1 < nk) IFH_STORE_TILES((kt + 1) & 1);
-        __syncthreads();
+                fb[j] = *reinterpret_cast<const bf16x8_t *>(&As[(wm * WM + j * 16 + fr) * LD + ks * 32 + fg * 8]);
+#pragma unroll
+            for (int i = 0; i < NT; i++)
+#pragma unroll
+                for (int j = 0; j < MT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (NBUF == 2) {
+            // the other buffer was last read one iteration ago and every wave has passed the barrier since
+            if (kt + 1 < nk) IFH_STORE_TILES((kt + 1) & 1);
+            __syncthreads();
+        } else if (kt + 1 < nk) {
+            __syncthreads();                           // every wave has read this tile's fragments
+            IFH_STORE_TILES(0);
+            __syncthreads();
+        }
     }
 
 #undef IFH_LOAD_TILES
@@ -708,22 +755,25 @@ __global__ __launch_bounds__(256) void k_transpose(const void *__restrict__ in, 
     }
 }
 
-template <int BM, int BN, int WGM, int NWV = 4>
+template <int BM, int BN, int WGM, int NWV = 4, int KT = 32>
 static void launch_igemm(const IgemmParams &p, bool pre, hipStream_t st)
 {
     const int M = p.nbatch * p.T_out;
     const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid((unsigned)(((tiles + 7) / 8) * 8));          // 1-D, a multiple of 8: see the tile map at the top of k_igemm
-    if (p.fast_epi) {
+    static const bool no_plain = getenv("IFH_IGEMM_NO_PLAIN") != nullptr;     // tuning switch
+    if (p.fast_epi && !pre && p.taps == 1 && p.stride == 1 && p.pad == 0 && p.K % KT == 0 && p.T_out <= p.T_in && !p.zt_cout && !no_plain)
+        hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, true, NWV, KT, true>), grid, dim3(64 * NWV), 0, st, p);
+    else if (p.fast_epi) {
         if (pre)
-            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, true, true, NWV>), grid, dim3(64 * NWV), 0, st, p);
+            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, true, true, NWV, KT>), grid, dim3(64 * NWV), 0, st, p);
         else
-            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, true, NWV>), grid, dim3(64 * NWV), 0, st, p);
+            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, true, NWV, KT>), grid, dim3(64 * NWV), 0, st, p);
     } else {
         if (pre)
-            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, true, false, NWV>), grid, dim3(64 * NWV), 0, st, p);
+            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, true, false, NWV, KT>), grid, dim3(64 * NWV), 0, st, p);
         else
-            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, false, NWV>), grid, dim3(64 * NWV), 0, st, p);
+            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, false, NWV, KT>), grid, dim3(64 * NWV), 0, st, p);
     }
 }
 
@@ -901,8 +951,14 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         static const int big_rows = getenv("IFH_IGEMM_256_ROWS") ? atoi(getenv("IFH_IGEMM_256_ROWS")) : 0x7fffffff;   // tuning switch: measured SLOWER (encoder 30.0 vs 28.2 ms), off
         if (M >= big_rows && (mt / 2) * ((d->n + 127) / 128) >= 512)
             launch_igemm<256, 128, 4, 8>(p, pre, st);
-        else if (mt * ((d->n + 127) / 128) >= 256)
-            launch_igemm<128, 128, 2>(p, pre, st);
+        else if (mt * ((d->n + 127) / 128) >= 256) {
+            // three or more tiles per workgroup slot: 128-byte row pieces (KT = 64), +9-12 % at the Whisper-base encoder shapes
+            static const int kt64_rows = getenv("IFH_IGEMM_KT64_ROWS") ? atoi(getenv("IFH_IGEMM_KT64_ROWS")) : 0;
+            if (M >= kt64_rows && p.Cin % 64 == 0 && mt * ((d->n + 127) / 128) >= 3 * 768)
+                launch_igemm<128, 128, 2, 4, 64>(p, pre, st);
+            else
+                launch_igemm<128, 128, 2>(p, pre, st);
+        }
         else if (mt * ((d->n + 63) / 64) >= 256 || M > 4096)
             launch_igemm<128, 64, 2>(p, pre, st);
         else

@@ -93,6 +93,7 @@ class SpeechPipeline:
         self.tts_group = max(1, tts_group)  # utterance cycles synthesised as one TTS batch (rows = group * ncalls)
         self.block_ingest = os.environ.get('IFH_TICK_INGEST') is None
         self.stt_beam = int(stt_beam)      # 1: greedy (the reference's torch engine); 5: its default engine's beam search
+        self.stt_dec_prio = os.environ.get('IFH_STT_DEC_PRIO', '0') != '0'
         with torch.cuda.device(dev):
             self.calls = CallTable(ncalls, dev)
             self.vad = BatchedVAD(ncalls, dev)
@@ -199,13 +200,26 @@ class SpeechPipeline:
         # bounded queue depth per lane: the encoder (~60 long kernels) and every 8 decode steps are waited for before more is
         # queued -- the process's streams share four hardware queues, and whatever a lane has queued stands in front of a
         # real-time tick whose launches land on the same queue (p99 tick latency 76-136 ms -> 7-36 ms; throughput +3 %)
-        torch.cuda.current_stream(dev).synchronize()
+        cur = torch.cuda.current_stream(dev)
+        cur.synchronize()
         prompt = self.prompt if nrow == self.n else self.prompt.repeat(nrow // self.n, 1)
-        if self.stt_beam > 1:
-            toks, _, _, nsp = fl.whisper.generate_beam(enc, prompt, self.n_new, beams=self.stt_beam, eos_id=50257,
-                                                       no_speech_id=50362, check_every=8)
-        else:
-            toks, nsp, _ = fl.whisper.generate(enc, prompt, self.n_new, no_speech_id=50362)
+        # the token loop is a latency-bound chain of small launches like the TTS decode: on a high-priority queue its kernels do
+        # not wait for CU slots behind the other lanes' encoder GEMMs (tuning switch IFH_STT_DEC_PRIO; the encoder stays where it is)
+        dec = getattr(fl, 'dec_stream', None) if self.stt_dec_prio else None
+        with torch.cuda.stream(dec if dec is not None else cur):
+            if dec is not None:
+                enc.record_stream(dec)
+            if self.stt_beam > 1:
+                toks, _, _, nsp = fl.whisper.generate_beam(enc, prompt, self.n_new, beams=self.stt_beam, eos_id=50257,
+                                                           no_speech_id=50362, check_every=8)
+            else:
+                toks, nsp, _ = fl.whisper.generate(enc, prompt, self.n_new, no_speech_id=50362)
+            if dec is not None:
+                ev = torch.cuda.Event()
+                ev.record(dec)
+                cur.wait_event(ev)
+                for t in (toks, nsp):
+                    t.record_stream(cur)
         return toks, nsp, (lens8.float() / 8000.0)
 
     # ---- stage 3 -----------------------------------------------------------------------------
@@ -480,6 +494,7 @@ class _FrontLane:
         self.lock = threading.Lock()                       # one cycle at a time per lane
         with torch.cuda.device(dev):
             self.stream = torch.cuda.Stream(device=dev)
+            self.dec_stream = torch.cuda.Stream(device=dev, priority=-1)
             if first:
                 self.calls, self.vad, self.whisper, self.logmel = pipe.calls, pipe.vad, pipe.whisper, pipe.logmel
                 self.pcm8k, self.pcm16k = pipe.pcm8k, pipe.pcm16k

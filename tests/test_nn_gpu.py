@@ -558,6 +558,9 @@ def test_resblock_chain_is_bit_identical_to_three_pairs(dev, case):
     dict(B=4, T=48, k=3, d=1), dict(B=5, T=48, k=7, d=3, resid=True), dict(B=7, T=48, k=11, d=5, resid=True, scale=1 / 3, acc=True),
     dict(B=1, T=48, k=11, d=1), dict(B=3, T=37, k=7, d=5, resid=True), dict(B=600, T=48, k=11, d=3, resid=True),
     dict(B=2, T=48, k=3, d=5, pre=1.0),
+    # >= 3 chunks per CU and a reach <= 8: three chunks per workgroup (MT = 10), incl. a short last group and short sequences
+    dict(B=770, T=48, k=3, d=1, resid=True), dict(B=769, T=48, k=7, d=1, resid=True, scale=1 / 3, acc=True),
+    dict(B=800, T=48, k=11, d=1), dict(B=771, T=48, k=3, d=5, resid=True), dict(B=768, T=37, k=3, d=3, resid=True),
 ])
 def test_conv_ring256_is_bit_identical_to_conv(dev, case):
     """ifh_conv_ring256_bf16 (two chunks per workgroup around a shared zero gap, weights through the DMA fragment ring,
