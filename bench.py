@@ -210,7 +210,7 @@ def time_steps(pipe, frames_for, nsteps, warmup, world, pipelined, egress, dry, 
         torch.cuda._sleep(1000)
         torch.cuda.synchronize()
     c0 = _lib.CALLS[0]
-    e0 = (pipe.ctts.calls_run, pipe.ctts.rows_run) if pipe.ctts is not None else None
+    e0 = (sum(e.calls_run for e in pipe.ctts_all), sum(e.rows_run for e in pipe.ctts_all)) if pipe.ctts is not None else None
     t0 = time.perf_counter()
     res = pipe.run_steps(frames_for, nsteps, pipelined=pipelined, on_cycle=egress)
     torch.cuda.synchronize()
@@ -221,7 +221,7 @@ def time_steps(pipe, frames_for, nsteps, warmup, world, pipelined, egress, dry, 
         torch.cuda._sleep(1000)
         torch.cuda.synchronize()
     time_steps.launches_per_step = (_lib.CALLS[0] - c0) / max(1, nsteps)
-    time_steps.engine = None if e0 is None else (pipe.ctts.calls_run - e0[0], pipe.ctts.rows_run - e0[1])
+    time_steps.engine = None if e0 is None else (sum(e.calls_run for e in pipe.ctts_all) - e0[0], sum(e.rows_run for e in pipe.ctts_all) - e0[1])
     if probe is not None:
         probe.stop()
     tmax = torch.tensor([dt], dtype=torch.float64, device='cpu' if dry else dev)

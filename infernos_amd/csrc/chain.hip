@@ -614,27 +614,14 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
     for (int tile = blockIdx.x; tile < ngroups; tile += gridDim.x) {
         const int b0 = tile * NCH;
         const int nb = min(NCH, p.nbatch - b0);
-        // x image: rows of chunk e at GX + e * pitch + t, LeakyReLU applied once here, 16 bytes per thread per step.  All of a
-        // thread's loads (T <= 48: at most 3 per chunk) are issued before the first LDS write: as a load -> write loop this
-        // was one HBM round trip per step with nothing else running on the CU (round 3: 6-9 round trips per tile)
-        {
-            constexpr int XU = NCH * 3;
-            const int total = nb * T * (C / 8);
-            int tid_ = tid;                            // opaque per tile: the tile-invariant address arithmetic is not hoisted (it was
-            asm volatile("" : "+v"(tid_));             // spilled to scratch next to the accumulators)
-            uint4 xv[XU];
-            int xdst[XU];
-#pragma unroll
-            for (int u = 0; u < XU; u++) {
-                const int v = tid_ + u * 512;
-                const int rowi = v / (C / 8), c8 = v - rowi * (C / 8);
-                const int e = rowi / T, t = rowi - e * T;
-                xdst[u] = (GX + e * pitch + t) * SB + c8 * 16;
-                if (v < total) xv[u] = *reinterpret_cast<const uint4 *>(p.x + (int64_t)(b0 + e) * p.x_bstride + (int64_t)t * C + c8 * 8);
-            }
-#pragma unroll
-            for (int u = 0; u < XU; u++)
-                if (tid_ + u * 512 < total) *reinterpret_cast<uint4 *>(lds + xdst[u]) = p.pre_slope != 1.0f ? lrelu8(xv[u], p.pre_slope) : xv[u];
+        // x image: rows of chunk e at GX + e * pitch + t, LeakyReLU applied once here, 16 bytes per thread per step.  (Issuing all of
+        // a thread's loads ahead of the first LDS write, and the epilogue's residual loads four row tiles at a time, was measured in
+        // round 3: nothing at two chunks, 8-15 % slower at three, where the extra live registers went to scratch.)
+        for (int v = tid; v < nb * T * (C / 8); v += 512) {
+            const int rowi = v / (C / 8), c8 = v - rowi * (C / 8);
+            const int e = rowi / T, t = rowi - e * T;
+            const uint4 xv = *reinterpret_cast<const uint4 *>(p.x + (int64_t)(b0 + e) * p.x_bstride + (int64_t)t * C + c8 * 8);
+            *reinterpret_cast<uint4 *>(lds + (GX + e * pitch + t) * SB + c8 * 16) = p.pre_slope != 1.0f ? lrelu8(xv, p.pre_slope) : xv;
         }
         if (nb < NCH)                                  // a short last group: the missing chunks' rows of the previous tile are stale
             for (int v = tid; v < (NCH - nb) * T * (C / 8); v += 512) {
@@ -670,55 +657,33 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
         for (int i = 0; i < NT; i++) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[i]) : "v"(bias_b), "n"(i * 64));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        // the residual / previous-out loads of four row tiles at a time go out before their first use (as one branch per
-        // row tile they were MT dependent round trips; all MT at once would not fit the registers next to acc)
-        constexpr int EG = 4;
-        int fr_ = fr, cw_ = wid * NT * 16 + 4 * fg;
-        asm volatile("" : "+v"(fr_), "+v"(cw_));
 #pragma unroll
-        for (int j0 = 0; j0 < MT; j0 += EG) {
-            uint2 rres[EG][NT], rout[EG][NT];
+        for (int j = 0; j < MT; j++) {
+            const int q = j * 16 + fr;
+            const int e = q / pitch, t = q - e * pitch;
+            if (t < T && e < nb) {
 #pragma unroll
-            for (int jj = 0; jj < EG && j0 + jj < MT; jj++) {
-                const int q = (j0 + jj) * 16 + fr_;
-                const int e = q / pitch, t = q - e * pitch;
-                if (t < T && e < nb) {
-                    const int64_t off = (int64_t)t * C + cw_;
-#pragma unroll
-                    for (int i = 0; i < NT; i++) {
-                        if (p.resid) rres[jj][i] = *reinterpret_cast<const uint2 *>(p.resid + (int64_t)(b0 + e) * p.resid_bstride + off + i * 16);
-                        if (p.accumulate) rout[jj][i] = *reinterpret_cast<const uint2 *>(p.out + (int64_t)(b0 + e) * p.out_bstride + off + i * 16);
+                for (int i = 0; i < NT; i++) {
+                    const int64_t off = (int64_t)t * C + (wid * NT + i) * 16 + 4 * fg;
+                    const f32x4 a = acc[i][j];
+                    float v0 = a[0] + bv[i][0], v1 = a[1] + bv[i][1], v2 = a[2] + bv[i][2], v3 = a[3] + bv[i][3];
+                    if (p.resid) {
+                        const uint2 rv = *reinterpret_cast<const uint2 *>(p.resid + (int64_t)(b0 + e) * p.resid_bstride + off);
+                        v0 += __uint_as_float(rv.x << 16);
+                        v1 += __uint_as_float(rv.x & 0xffff0000u);
+                        v2 += __uint_as_float(rv.y << 16);
+                        v3 += __uint_as_float(rv.y & 0xffff0000u);
                     }
-                }
-            }
-#pragma unroll
-            for (int jj = 0; jj < EG && j0 + jj < MT; jj++) {
-                const int j = j0 + jj;
-                const int q = j * 16 + fr_;
-                const int e = q / pitch, t = q - e * pitch;
-                if (t < T && e < nb) {
-                    uint16_t *dst = p.out + (int64_t)(b0 + e) * p.out_bstride + (int64_t)t * C + cw_;
-#pragma unroll
-                    for (int i = 0; i < NT; i++) {
-                        const f32x4 a = acc[i][j];
-                        float v0 = a[0] + bv[i][0], v1 = a[1] + bv[i][1], v2 = a[2] + bv[i][2], v3 = a[3] + bv[i][3];
-                        if (p.resid) {
-                            const uint2 rv = rres[jj][i];
-                            v0 += __uint_as_float(rv.x << 16);
-                            v1 += __uint_as_float(rv.x & 0xffff0000u);
-                            v2 += __uint_as_float(rv.y << 16);
-                            v3 += __uint_as_float(rv.y & 0xffff0000u);
-                        }
-                        v0 *= p.out_scale; v1 *= p.out_scale; v2 *= p.out_scale; v3 *= p.out_scale;
-                        if (p.accumulate) {
-                            const uint2 q2 = rout[jj][i];
-                            v0 += __uint_as_float(q2.x << 16);
-                            v1 += __uint_as_float(q2.x & 0xffff0000u);
-                            v2 += __uint_as_float(q2.y << 16);
-                            v3 += __uint_as_float(q2.y & 0xffff0000u);
-                        }
-                        *reinterpret_cast<uint2 *>(dst + i * 16) = make_uint2(f32x2_to_bf16x2(v0, v1), f32x2_to_bf16x2(v2, v3));
+                    v0 *= p.out_scale; v1 *= p.out_scale; v2 *= p.out_scale; v3 *= p.out_scale;
+                    uint16_t *dst = p.out + (int64_t)(b0 + e) * p.out_bstride + off;
+                    if (p.accumulate) {
+                        const uint2 q2 = *reinterpret_cast<const uint2 *>(dst);
+                        v0 += __uint_as_float(q2.x << 16);
+                        v1 += __uint_as_float(q2.x & 0xffff0000u);
+                        v2 += __uint_as_float(q2.y << 16);
+                        v3 += __uint_as_float(q2.y & 0xffff0000u);
                     }
+                    *reinterpret_cast<uint2 *>(dst) = make_uint2(f32x2_to_bf16x2(v0, v1), f32x2_to_bf16x2(v2, v3));
                 }
             }
         }

@@ -606,7 +606,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_ige
     __syncthreads();
     for (int kt = 0; kt < nk; kt++) {
         const uint16_t *As = As2[NBUF == 2 ? (kt & 1) : 0], *Bs = Bs2[NBUF == 2 ? (kt & 1) : 0];
-        if (kt + 1 < nk) IFH_LOAD_TILES(kbeg + (kt + 1) * KT)
+        if (kt + 1 < nk) {
+            IFH_LOAD_TILES(kbeg + (kt + 1) * KT)
+        }
 #pragma unroll
         for (int ks = 0; ks < KT / 32; ks++) {
             bf16x8_t fa[NT], fb[MT];

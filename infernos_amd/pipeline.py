@@ -118,8 +118,16 @@ class SpeechPipeline:
             from .tts import ContinuousTTS
             bucket = -(-ncalls * self.tts_group // 16) * 16
             # (+1 batch of head-room: a finished batch frees its rows one engine call after its last audio was queued)
-            self.ctts = ContinuousTTS(self.tts, max_rows=min(1024, bucket * (max(1, tts_lanes) + 1)), max_text=n_text,
-                                      row_bucket=bucket).start()
+            # IFH_TTS_ENGINES (tuning switch, default 1): that many ragged batches, each with its own state, graphs, streams and
+            # thread; utterance cycle c joins engine c % n.  Rows are independent, so the audio does not depend on the engine.
+            ne = max(1, int(os.environ.get('IFH_TTS_ENGINES', '1')))
+            per_engine = -(-(max(1, tts_lanes) + 1) // ne) + (1 if ne > 1 else 0)
+            self.ctts_all = [ContinuousTTS(self.tts if e == 0 else self.tts.clone_for_lane(),
+                                           max_rows=min(1024, bucket * per_engine), max_text=n_text, row_bucket=bucket).start()
+                             for e in range(ne)]
+            self.ctts = self.ctts_all[0]
+            import itertools
+            self._tts_rr = itertools.count()
             self.tts_lanes = [self.tts] * max(1, tts_lanes)
         self.slots = torch.arange(ncalls, dtype=torch.int32, device=dev)
         self.prompt = torch.tensor([[50258, 50259, 50359, 50363]] * ncalls, dtype=torch.int32)
@@ -238,8 +246,9 @@ class SpeechPipeline:
         nb = ids.size(0)
         if self.ctts is not None:
             # continuous batching: the batch joins the engine's running decode batch at its next infer() boundary
-            grp = self.ctts.submit(ids, torch.full((nb,), ids.size(1), dtype=torch.int32), spk, max_calls=self.n_infer,
-                                   want_ulaw=True).result()
+            eng = self.ctts_all[next(self._tts_rr) % len(self.ctts_all)]       # round-robin over the engines (one: always it)
+            grp = eng.submit(ids, torch.full((nb,), ids.size(1), dtype=torch.int32), spk, max_calls=self.n_infer,
+                             want_ulaw=True).result()
             cur = torch.cuda.current_stream(dev)
             cur.wait_event(grp.done_event)
             grp.ulaw.record_stream(cur)
@@ -339,9 +348,10 @@ class SpeechPipeline:
                             self.front_group([frames] * g, fl)
                 fl.stream.synchronize()
         if self.ctts is not None:
-            b = self.ctts.row_bucket
-            self.ctts.warm([b * k for k in range(1, self.ctts.st.R // b + 1)])
-            self.synthesize()
+            for e, eng in enumerate(self.ctts_all):
+                b = eng.row_bucket
+                eng.warm([b * k for k in range(1, eng.st.R // b + 1)])
+                self.synthesize(lane=e)
             torch.cuda.synchronize(self.device)
             return
         for lane in range(len(self.tts_lanes)):
@@ -444,8 +454,9 @@ class SpeechPipeline:
     def close(self):
         """stop the continuous TTS engine thread (its state holds the KV caches of every row slot)"""
         if self.ctts is not None:
-            self.ctts.stop()
-            self.ctts = None
+            for eng in self.ctts_all:
+                eng.stop()
+            self.ctts, self.ctts_all = None, []
         for name in ('_pool', '_tts_pool'):
             if hasattr(self, name):
                 getattr(self, name).shutdown(wait=True)
