@@ -609,6 +609,18 @@ int ifh_amend_final_bf16(const void *post, const void *audio, void *out, int nba
 /* rows / max(||row||, 1e-12) (F.normalize) written with leading dimension ld_out */
 int ifh_l2norm_rows_bf16(const void *x, int dim, int nrows, void *out, int ld_out, ifh_stream_t stream);
 
+/* ---- spatial partition of the GPU between stages (round 3) ----
+ * The serving loop (SpeechPipeline.run_steps; no counterpart in the reference, whose stages are separate processes on separate
+ * GPUs or time-slice one) runs throughput kernels that fill every CU and its LDS (Whisper encoder GEMMs, HiFi-GAN) beside chains
+ * of small dependent decode-step launches; while a chip-filling kernel is resident a chain's next launch finds no CU slot and the
+ * chain stalls for the kernel's whole duration.  A stream created here runs its kernels on CUs [first_cu, first_cu + n_cus) only
+ * (hipExtStreamCreateWithCUMask), so the throughput stages can be kept off a few CUs that then always have room for the chains. */
+int ifh_stream_create_cu_range(int first_cu, int n_cus, ifh_stream_t *stream_out);
+int ifh_stream_destroy(ifh_stream_t stream);
+/* persistent kernels (one workgroup per CU: ifh_resblock_chain_bf16, ifh_conv_ring256_bf16) size their grids to n CUs instead of
+ * the device's count; 0 restores the device's count.  Process-wide. */
+int ifh_set_cu_budget(int n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -178,6 +178,9 @@ SIGNATURES.update({
     'ifh_hifigan_post_bf16': (_i, [_vp, _vp, _f, _vp, _i, _i, _f, _vp]),
     'ifh_amend_final_bf16': (_i, [_vp, _vp, _vp, _i, _vp]),
     'ifh_l2norm_rows_bf16': (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    'ifh_stream_create_cu_range': (_i, [_i, _i, ctypes.POINTER(ctypes.c_void_p)]),
+    'ifh_stream_destroy': (_i, [_vp]),
+    'ifh_set_cu_budget': (_i, [_i]),
 })
 
 _lib = None
@@ -263,6 +266,33 @@ def require_device(device=None):
     if d.type != 'cuda':
         raise InfernosHipError('infernos_amd: device %r is not a HIP GPU; the speech path has no CPU fallback' % (device,))
     return d
+
+
+_CU_STREAMS = []            # (handle, ExternalStream): CU-range streams live as long as the process
+
+
+def cu_range_stream(device, first_cu, n_cus):
+    """torch stream whose kernels run on CUs [first_cu, first_cu + n_cus) only (ifh_stream_create_cu_range)."""
+    import torch
+    h = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        check(lib().ifh_stream_create_cu_range(int(first_cu), int(n_cus), ctypes.byref(h)), 'ifh_stream_create_cu_range')
+    s = torch.cuda.ExternalStream(h.value, device=device)
+    _CU_STREAMS.append((h, s))
+    return s
+
+
+def throughput_stream(device, priority=0):
+    """Stream for a stage of chip-filling kernels.  IFH_BIG_CUS=n (tuning switch, default off) keeps those stages on the first n
+    CUs, so that the decode chains (ordinary streams) always find room on the others; the persistent kernels then size their grids
+    to n (ifh_set_cu_budget)."""
+    import os
+    import torch
+    n = int(os.environ.get('IFH_BIG_CUS', '0'))
+    if n <= 0:
+        return torch.cuda.Stream(device=device, priority=priority)
+    check(lib().ifh_set_cu_budget(n), 'ifh_set_cu_budget')
+    return cu_range_stream(device, 0, n)
 
 
 def stream_ptr(device=None):

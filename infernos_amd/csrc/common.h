@@ -46,8 +46,17 @@ struct DeviceOnce {
     }
 };
 
-// compute units of the CURRENT device (cached per device index)
+// ifh_set_cu_budget (misc.hip): CUs the persistent kernels may count on (0 = all of the device's)
+extern std::atomic<int> g_cu_budget;
+
+// compute units of the CURRENT device (cached per device index), capped by the CU budget
+static inline int device_cu_count_physical();
 static inline int device_cu_count()
+{
+    const int n = device_cu_count_physical(), b = g_cu_budget.load(std::memory_order_relaxed);
+    return (b > 0 && b < n) ? b : n;
+}
+static inline int device_cu_count_physical()
 {
     static std::atomic<int> cache[64];
     int dev = 0;

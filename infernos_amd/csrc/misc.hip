@@ -429,3 +429,39 @@ extern "C" int ifh_l2norm_rows_bf16(const void *x, int dim, int nrows, void *out
     IFH_LAUNCH_CHECK("l2norm_rows");
     return IFH_OK;
 }
+
+// ---- spatial partition: CU-range streams and the persistent kernels' CU budget (infernos_hip.h) ----
+namespace ifh {
+std::atomic<int> g_cu_budget{0};
+}
+
+extern "C" int ifh_stream_create_cu_range(int first_cu, int n_cus, ifh_stream_t *stream_out)
+{
+    IFH_CHECK_ARG(stream_out);
+    const int ncu = device_cu_count_physical();
+    if (ncu <= 0) return fail(IFH_EHIP, "stream_create_cu_range: device query");
+    IFH_CHECK_ARG(first_cu >= 0 && n_cus > 0 && first_cu + n_cus <= ncu);
+    uint32_t mask[32] = {0};
+    IFH_CHECK_ARG(ncu <= 32 * 32);
+    for (int c = first_cu; c < first_cu + n_cus; c++) mask[c >> 5] |= 1u << (c & 31);
+    hipStream_t st = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)((ncu + 31) / 32), mask);
+    if (e != hipSuccess) return check_hip(e, "hipExtStreamCreateWithCUMask");
+    *stream_out = (ifh_stream_t)st;
+    return IFH_OK;
+}
+
+extern "C" int ifh_stream_destroy(ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(stream);
+    hipError_t e = hipStreamDestroy(as_stream(stream));
+    if (e != hipSuccess) return check_hip(e, "hipStreamDestroy");
+    return IFH_OK;
+}
+
+extern "C" int ifh_set_cu_budget(int n)
+{
+    IFH_CHECK_ARG(n >= 0);
+    g_cu_budget.store(n, std::memory_order_relaxed);
+    return IFH_OK;
+}

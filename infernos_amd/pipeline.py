@@ -504,7 +504,7 @@ class _FrontLane:
         dev = pipe.device
         self.lock = threading.Lock()                       # one cycle at a time per lane
         with torch.cuda.device(dev):
-            self.stream = torch.cuda.Stream(device=dev)
+            self.stream = _lib.throughput_stream(dev)        # log-mel, encoder, cross K|V, prompt prefill
             self.dec_stream = torch.cuda.Stream(device=dev, priority=-1)
             if first:
                 self.calls, self.vad, self.whisper, self.logmel = pipe.calls, pipe.vad, pipe.whisper, pipe.logmel

@@ -286,7 +286,7 @@ class ContinuousTTS:
             # Whisper encoder's GEMMs), serially; a high-priority queue lets them through (tuning switch IFH_TTS_PRIO)
             prio = int(os.environ.get('IFH_TTS_PRIO', '-1'))
             self.main = torch.cuda.Stream(device=dev, priority=prio)
-            self.side = torch.cuda.Stream(device=dev)
+            self.side = _lib.throughput_stream(dev)          # postnet + HiFi-GAN + amendment passes
         R = self.st.R
         self.free = list(range(R))                       # row slots, lowest first
         self.pending, self.live = [], []

@@ -10,6 +10,7 @@ import json
 import os
 
 import numpy as np
+import ctypes
 import pytest
 import torch
 import torch.nn.functional as F
@@ -358,6 +359,62 @@ def test_gemm_dec_is_bit_identical_to_skinny(dev, M):
                 ops.linear(t1[r0:r1], wh, ch2, out[r0:r1], rows=r1 - r0, k=D, n=N_, out_off=5 * 80, ldc=33 * 80,
                            aln=(stats, r0 * 2, ch1), ln_dim=D, lda=D + 8, decode_step=True)
         both(head, [torch.zeros(M, 16, dtype=torch.float32, device=dev) if f32 else torch.zeros(M, 33 * 80, dtype=BF, device=dev)])
+
+
+@pytest.mark.parametrize('M,N,K,act,resid', [(36864, 1024, 512, 2, False), (36800, 1000, 512, 0, True), (4099, 520, 384, 1, False),
+                                             (16384, 2304, 2048, 0, True)])
+def test_igemm_plain_tile_loads_match_torch(dev, M, N, K, act, resid):
+    """k_igemm's matrix-product form (csrc/nn.hip, PLAIN: pointer + k tile loads, edge rows / columns clamped instead of
+    predicated) in both K-tile widths: >= 2304 tiles of 128 x 128 take 128-byte row pieces (KT = 64, one LDS buffer), fewer the
+    double-buffered 64-byte pieces.  Against fp32 torch, with ragged M and N (edge tiles), GELU / ReLU / residual epilogues; and
+    the first 128 rows bit-identical to a 4096-row launch of them (the other K-tile width: same k order per output element)."""
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = bfr(torch.randn(M, K, generator=g))
+    w = bfr(torch.randn(N, K, generator=g) / K ** 0.5)
+    b = torch.randn(N, generator=g) * 0.1
+    r = bfr(torch.randn(M, N, generator=g)) if resid else None
+    xd, wd, bd = x.to(dev, BF), w.to(dev, BF), b.to(dev)
+    rd = r.to(dev, BF) if resid else None
+    out = torch.empty(M, N, dtype=BF, device=dev)
+    ops.linear(xd, wd, bd, out, rows=M, k=K, n=N, act=act, resid=rd)
+    ref = x @ w.t() + b
+    ref = F.gelu(ref) if act == 2 else (F.relu(ref) if act == 1 else ref)
+    if resid:
+        ref = ref + r
+    e = rel_l2(out.float().cpu(), ref)
+    assert e < 4e-3, (M, N, K, e)
+    if N % 4 == 0:
+        rows = torch.randperm(M, generator=g)[:4096].sort().values
+        small = torch.empty(4096, N, dtype=BF, device=dev)
+        ops.linear(xd[rows.to(dev)].contiguous(), wd, bd, small, rows=4096, k=K, n=N, act=act,
+                   resid=rd[rows.to(dev)].contiguous() if resid else None)
+        assert torch.equal(small.view(torch.int16), out[rows.to(dev)].contiguous().view(torch.int16)), 'K-tile width changed the bits'
+
+
+def test_cu_range_stream_runs_kernels(dev):
+    """ifh_stream_create_cu_range (include/infernos_hip.h): a stream confined to a CU range computes what an ordinary one does,
+    and the persistent kernels follow ifh_set_cu_budget (a chain launch sized to 64 CUs on a 64-CU stream: same bits)."""
+    from infernos_amd import ops, _lib
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1000, 256, generator=g).to(dev, BF)
+    w = (torch.randn(512, 256, generator=g) / 16).to(dev, BF)
+    b = torch.zeros(512, device=dev)
+    ref = torch.empty(1000, 512, dtype=BF, device=dev)
+    ops.linear(x, w, b, ref, rows=1000, k=256, n=512)
+    torch.cuda.synchronize()
+    s = _lib.cu_range_stream(dev, 8, 64)
+    out = torch.empty_like(ref)
+    try:
+        _lib.check(_lib.lib().ifh_set_cu_budget(64), 'ifh_set_cu_budget')
+        with torch.cuda.stream(s):
+            ops.linear(x, w, b, out, rows=1000, k=256, n=512)
+        s.synchronize()
+    finally:
+        _lib.check(_lib.lib().ifh_set_cu_budget(0), 'ifh_set_cu_budget')
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    h = ctypes.c_void_p()
+    assert _lib.lib().ifh_stream_create_cu_range(250, 64, ctypes.byref(h)) != 0        # beyond the device's CUs: refused
 
 
 @pytest.mark.parametrize('N', [512, 1536, 2048])
