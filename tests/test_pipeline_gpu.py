@@ -133,6 +133,12 @@ def test_continuous_tts_schedule_matches_sequential_lane_schedule(built_lib, lan
     try:
         pipe.prime(frames[0])
         got = []
+        if fronts > 1:
+            # 5 calls make an engine call shorter than an STT cycle, so batches would only meet by chance: hold every engine call
+            # back a little so that the three front lanes' batches pile up and share decode steps (which is what is under test)
+            import time
+            step0 = pipe.ctts.step
+            pipe.ctts.step = lambda *a, **kw: (time.sleep(0.03), step0(*a, **kw))[1]
         pipe.run_steps(lambda k: frames[k % 2], 9, pipelined=True,
                        on_cycle=lambda r: got.append((r['ulaw'].clone(), r['tokens'].clone(), r['tts_samples'].clone())))
         torch.cuda.synchronize()
