@@ -58,18 +58,6 @@ struct IgemmParams {
 
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2, ACT_TANH = 3, ACT_LRELU = 4, ACT_SIGMOID = 5, ACT_SILU_GLU = 6 };
 
-__device__ __forceinline__ float apply_act(float v, int act, float slope)
-{
-    switch (act) {
-    case ACT_RELU: return fmaxf(v, 0.0f);
-    case ACT_GELU: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    case ACT_TANH: return tanhf(v);
-    case ACT_LRELU: return v > 0.0f ? v : v * slope;
-    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-    default: return v;
-    }
-}
-
 // GELU (exact erf form) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the stored
 // result): one reciprocal, one exp2 and a 5-term polynomial instead of the library erff's branchy ~35 instructions.  The
 // large-GEMM epilogue applies it to 64 outputs per thread; with erff the activation cost as much as the K = 512 loop it follows.
@@ -85,6 +73,18 @@ __device__ __forceinline__ float gelu_fast(float v)
     const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
     const float erfabs = __builtin_fmaf(-pl, e, 1.0f);
     return 0.5f * v * (1.0f + copysignf(erfabs, v));
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope)
+{
+    switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.0f);
+    case ACT_GELU: return gelu_fast(v);        // (one GELU everywhere: the decode kernels' epilogues spent 3.5 us of a 16 us fc1 launch in erff)
+    case ACT_TANH: return tanhf(v);
+    case ACT_LRELU: return v > 0.0f ? v : v * slope;
+    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+    }
 }
 
 // activation chosen at compile time (ACTC >= 0) or by the runtime switch (ACTC < 0)
@@ -129,7 +129,7 @@ struct EpiRow {
 
 __device__ __forceinline__ EpiRow epi_row(const IgemmParams &p, int m, int n, int dynv)
 {
-    const int b = m / p.T_out, t = m - b * p.T_out;
+    const int b = p.T_out == 1 ? m : m / p.T_out, t = m - b * p.T_out;      // (decode steps: one row per batch entry, no division)
     const bool second = p.n_split > 0 && n >= p.n_split;      // n_split % 16 == 0: a 4-group never straddles
     const int64_t orow = second ? ((int64_t)t * p.ostride + p.ooff2 + (int64_t)dynv * p.dyn_ooff2_mul)
                                 : ((int64_t)t * p.ostride + p.ooff + (int64_t)dynv * p.dyn_ooff_mul);

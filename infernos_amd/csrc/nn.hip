@@ -167,9 +167,32 @@ __global__ __launch_bounds__(NW * 64) void k_gemm_skinny(const IgemmParams p)
 // contiguous k ranges the streaming kernel's waves take (2 below K = 2048, 4 from there), the chains are added in wave order,
 // and the epilogue is the shared ln_epi4 / igemm_store4 -- so a row's bits are the same whichever kernel the row count selects
 // (tests/test_nn_gpu.py::test_gemm_dec_is_bit_identical_to_skinny).  taps == 1, K % 32 == 0, N % 16 == 0 in the LN modes.
+// 16 bytes as a native vector: a uint4 (a struct) copied global -> array -> LDS stays two memcpys through a stack slot that the
+// compiler does not promote (seen as scratch stores behind an s_waitcnt right after the loads)
+__device__ __forceinline__ uint4 ld_u32x4(const uint16_t *ptr)
+{
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = *reinterpret_cast<const u32x4 *>(ptr);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+#ifdef IFH_DEC_PROF
+__device__ unsigned long long g_dec_prof[8];
+#define DEC_STAMP(I)                                                                   \
+    {                                                                                  \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                  \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(&g_dec_prof[I], now_ - tprev_); \
+        tprev_ = now_;                                                                 \
+    }
+#else
+#define DEC_STAMP(I) {}
+#endif
 template <int BN>
 __global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const int ksplit)
 {
+#ifdef IFH_DEC_PROF
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int BM = 64, KC = 256, LDK = KC + 8;        // row stride 528 B: the 16 rows of a fragment read fall on 16 distinct 16-byte slots
     constexpr int WGM = 2, WGN = 2;
     constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -187,28 +210,36 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const 
     const int lrow = tid >> 5, lcol = (tid & 31) * 8;
     const uint16_t *arow[AV], *brow[BV];
     bool aval[AV], bval[BV];
+    // rows / columns beyond the edge are clamped to the last valid one (loaded, multiplied, never stored) and, when K is a whole
+    // number of chunks (every hot shape: 256, 512, 768, 1280, 2048, 3072), nothing is predicated: as one exec branch + range test
+    // + 64-bit address per 16-byte load the first chunk took 2 000 shader clocks (1 us) to ISSUE (tools/probe_dec_phases.py)
+    const bool t1 = p.T_out == 1;
 #pragma unroll
     for (int i = 0; i < AV; i++) {
         const int m = m0 + lrow + 8 * i;
         aval[i] = m < M;
-        const int mm = aval[i] ? m : 0;
-        const int b = mm / p.T_out, t = mm - b * p.T_out;
+        const int mm = aval[i] ? m : M - 1;
+        const int b = t1 ? mm : mm / p.T_out, t = mm - b * p.T_out;
         arow[i] = p.x + (int64_t)b * p.x_bstride + (int64_t)t * p.lda + lcol;
     }
 #pragma unroll
     for (int i = 0; i < BV; i++) {
         const int n = n0 + lrow + 8 * i;
         bval[i] = n < p.N;
-        brow[i] = p.w + (int64_t)(bval[i] ? n : 0) * p.K + lcol;
+        brow[i] = p.w + (int64_t)(bval[i] ? n : p.N - 1) * p.K + lcol;
     }
+    const bool whole = p.K % KC == 0;
     uint4 ra[AV], rb[BV];
 #define IFH_DEC_LOAD(K0)                                                                                       \
-    {                                                                                                          \
+    if (whole) {                                                                                               \
+        _Pragma("unroll") for (int i = 0; i < AV; i++) ra[i] = ld_u32x4(arow[i] + (K0));                       \
+        _Pragma("unroll") for (int i = 0; i < BV; i++) rb[i] = ld_u32x4(brow[i] + (K0));                       \
+    } else {                                                                                                   \
         const bool kin_ = (K0) + lcol < p.K;                                                                   \
         _Pragma("unroll") for (int i = 0; i < AV; i++)                                                         \
-            ra[i] = (aval[i] && kin_) ? *reinterpret_cast<const uint4 *>(arow[i] + (K0)) : make_uint4(0, 0, 0, 0); \
+            ra[i] = kin_ ? ld_u32x4(arow[i] + (K0)) : make_uint4(0, 0, 0, 0);                                  \
         _Pragma("unroll") for (int i = 0; i < BV; i++)                                                         \
-            rb[i] = (bval[i] && kin_) ? *reinterpret_cast<const uint4 *>(brow[i] + (K0)) : make_uint4(0, 0, 0, 0); \
+            rb[i] = kin_ ? ld_u32x4(brow[i] + (K0)) : make_uint4(0, 0, 0, 0);                                  \
     }
 #define IFH_DEC_STORE()                                                                                        \
     {                                                                                                          \
@@ -217,7 +248,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const 
         _Pragma("unroll") for (int i = 0; i < BV; i++)                                                         \
             *reinterpret_cast<uint4 *>(&Bs[(lrow + 8 * i) * LDK + lcol]) = rb[i];                              \
     }
-    IFH_DEC_LOAD(0);
+    DEC_STAMP(0)
+    IFH_DEC_LOAD(0)
+    DEC_STAMP(1)
     // epilogue operands, requested behind the first chunk (as the streaming kernel requests them ahead of its K loop)
     const bool ln_mode = p.aln_stats || p.rln_stats || p.stats_out;
     int em[MT], edyn[MT];
@@ -269,10 +302,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const 
     const int per = (nk + ksplit - 1) / ksplit;      // k-steps per accumulation chain (= per wave of the streaming kernel)
     int next_flush = per;
     const int nchunk = (p.K + KC - 1) / KC;
+    DEC_STAMP(2)
     for (int c = 0; c < nchunk; c++) {
         IFH_DEC_STORE();
         __syncthreads();
-        if (c + 1 < nchunk) IFH_DEC_LOAD((c + 1) * KC);         // the next chunk's round trip overlaps this chunk's MFMAs
+        if (c == 0) {
+            DEC_STAMP(3)
+        }
+        if (c + 1 < nchunk) {                                   // the next chunk's round trip overlaps this chunk's MFMAs
+            IFH_DEC_LOAD((c + 1) * KC)
+        }
         const int ks1 = min(KC / 32, nk - c * (KC / 32));
         for (int ks = 0; ks < ks1; ks++) {
             bf16x8_t fa[NT], fb[MT];
@@ -301,6 +340,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const 
         }
         __syncthreads();
     }
+    DEC_STAMP(4)
 #undef IFH_DEC_LOAD
 #undef IFH_DEC_STORE
 #pragma unroll
@@ -319,6 +359,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const 
             }
         }
     }
+    DEC_STAMP(5)
+#ifdef IFH_DEC_PROF
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(&g_dec_prof[7], 1ull);
+#endif
 }
 
 // ---- weight-streaming GEMM for decode steps of LLM-sized layers (M <= 64 rows, N x K in the tens of MB) ----
@@ -432,15 +476,6 @@ __global__ __launch_bounds__(256) void k_gemm_m64(const IgemmParams p)
                 igemm_store4<false>(p, m, n, s, dynv);
         }
     }
-}
-
-// 16 bytes as a native vector: a uint4 (a struct) copied global -> array -> LDS stays two memcpys through a stack slot that the
-// compiler does not promote (seen as scratch stores behind an s_waitcnt right after the loads)
-__device__ __forceinline__ uint4 ld_u32x4(const uint16_t *ptr)
-{
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = *reinterpret_cast<const u32x4 *>(ptr);
-    return make_uint4(v.x, v.y, v.z, v.w);
 }
 
 #ifndef IFH_IGEMM_MINB
@@ -996,3 +1031,15 @@ extern "C" int ifh_transpose_to_bf16(const void *in, int in_f32, void *out, int 
     IFH_LAUNCH_CHECK("transpose");
     return IFH_OK;
 }
+
+#ifdef IFH_DEC_PROF
+extern "C" int ifh_debug_dec_prof(unsigned long long *out8, int reset)
+{
+    if (out8) hipMemcpyFromSymbol(out8, HIP_SYMBOL(ifh::g_dec_prof), 64);
+    if (reset) {
+        unsigned long long z[8] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(ifh::g_dec_prof), z, 64);
+    }
+    return 0;
+}
+#endif
