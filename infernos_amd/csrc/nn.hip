@@ -187,18 +187,21 @@ __device__ unsigned long long g_dec_prof[8];
 #else
 #define DEC_STAMP(I) {}
 #endif
-template <int BN>
+// BM = 32 (round 3): a launch of fewer workgroups than CUs is one workgroup per CU whose four waves move in lock-step through
+// issue / wait / LDS store / fragment reads (profiles/NOTES.md): half the rows per workgroup = twice the workgroups, each phase 2/3
+// as long.
+template <int BN, int BM = 64>
 __global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const int ksplit)
 {
 #ifdef IFH_DEC_PROF
     unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
 #endif
-    constexpr int BM = 64, KC = 256, LDK = KC + 8;        // row stride 528 B: the 16 rows of a fragment read fall on 16 distinct 16-byte slots
+    constexpr int KC = 256, LDK = KC + 8;        // row stride 528 B: the 16 rows of a fragment read fall on 16 distinct 16-byte slots
     constexpr int WGM = 2, WGN = 2;
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int MT = WM / 16, NT = WN / 16;
     constexpr int AV = BM * (KC / 8) / 256, BV = BN * (KC / 8) / 256;      // 16-byte vectors per thread per chunk
-    static_assert(BN == 32 || BN == 64, "column tile");
+    static_assert((BN == 32 || BN == 64) && (BM == 64 || BM == 32), "tile");
     __shared__ __attribute__((aligned(16))) uint16_t As[BM * LDK];
     __shared__ __attribute__((aligned(16))) uint16_t Bs[BN * LDK];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -941,8 +944,11 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
             const int ksplit = p.K >= 2048 ? 4 : 2;
             // 64 x 64 tiles; 64 x 32 where that is what it takes to give every CU a workgroup
             const int64_t t64 = ((M + 63) / 64) * ((d->n + 63) / 64);
+            static const int64_t bm32_max = getenv("IFH_GEMM_DEC_BM32") ? atoll(getenv("IFH_GEMM_DEC_BM32")) : 150;   // tuning switch: 32-row tiles up to this many 64 x 32 workgroups
             if (t64 >= 200)
                 hipLaunchKernelGGL((k_gemm_dec<64>), dim3((M + 63) / 64, (d->n + 63) / 64), dim3(256), 0, st, p, ksplit);
+            else if (((M + 63) / 64) * ((d->n + 31) / 32) <= bm32_max)
+                hipLaunchKernelGGL((k_gemm_dec<32, 32>), dim3((M + 31) / 32, (d->n + 31) / 32), dim3(256), 0, st, p, ksplit);
             else
                 hipLaunchKernelGGL((k_gemm_dec<32>), dim3((M + 63) / 64, (d->n + 31) / 32), dim3(256), 0, st, p, ksplit);
         } else if (M > 64 && !one_tile) {
