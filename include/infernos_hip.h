@@ -424,7 +424,7 @@ typedef struct ifh_ring256_desc {
 } ifh_ring256_desc;
 int ifh_conv_ring256_bf16(const ifh_ring256_desc *desc, ifh_stream_t stream);
 
-/* y = LayerNorm(x (+ resid)) * gamma + beta; rows of `dim` bf16, dim <= 1024, dim % 4 == 0 */
+/* y = LayerNorm(x (+ resid)) * gamma + beta; rows of `dim` bf16, dim <= 2048, dim % 4 == 0 */
 int ifh_layernorm_bf16(const void *x, const void *resid, const float *gamma, const float *beta, void *out,
                        int rows, int dim, float eps, ifh_stream_t stream);
 /* in [nbatch][rows][cols] (f32 if in_f32 else bf16) -> out bf16 [nbatch][cols][rows] */

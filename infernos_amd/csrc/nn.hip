@@ -707,7 +707,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_ige
 #undef IFH_IGEMM_EPI
 }
 
-// ---- LayerNorm: one wave per row, optional residual add first; D <= 1024, D % 4 == 0
+// ---- LayerNorm: one wave per row, optional residual add first; D <= 256 * NCH (NCH = 4: 1024; 8: 2048 -- Whisper large-v3's 1280), D % 4 == 0
+template <int NCH>
 __global__ __launch_bounds__(256) void k_layernorm(const uint16_t *__restrict__ x, const uint16_t *__restrict__ resid,
                                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                                    uint16_t *__restrict__ out, int rows, int D, float eps)
@@ -717,10 +718,10 @@ __global__ __launch_bounds__(256) void k_layernorm(const uint16_t *__restrict__ 
     if (row >= rows) return;
     const uint16_t *xr = x + (int64_t)row * D;
     const uint16_t *rr = resid ? resid + (int64_t)row * D : nullptr;
-    float v[4][4];
+    float v[NCH][4];
     float s = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NCH; i++) {
         const int e = lane * 4 + 256 * i;
         if (e < D) {
             const uint2 a = *reinterpret_cast<const uint2 *>(xr + e);
@@ -743,7 +744,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const uint16_t *__restrict__ 
     const float mean = wave_sum(s) / (float)D;
     float q = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NCH; i++) {
         const int e = lane * 4 + 256 * i;
         if (e < D) {
 #pragma unroll
@@ -756,7 +757,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const uint16_t *__restrict__ 
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
     uint16_t *orow = out + (int64_t)row * D;
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < NCH; i++) {
         const int e = lane * 4 + 256 * i;
         if (e < D) {
             const float4 g = *reinterpret_cast<const float4 *>(gamma + e);
@@ -1016,8 +1017,12 @@ extern "C" int ifh_layernorm_bf16(const void *x, const void *resid, const float 
 {
     IFH_CHECK_ARG(rows >= 0);
     if (rows == 0) return IFH_OK;
-    IFH_CHECK_ARG(x && gamma && beta && out && dim > 0 && dim <= 1024 && dim % 4 == 0);
-    hipLaunchKernelGGL(k_layernorm, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), (const uint16_t *)x,
+    IFH_CHECK_ARG(x && gamma && beta && out && dim > 0 && dim <= 2048 && dim % 4 == 0);
+    if (dim <= 1024)
+        hipLaunchKernelGGL(k_layernorm<4>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), (const uint16_t *)x,
+                       (const uint16_t *)resid, gamma, beta, (uint16_t *)out, rows, dim, eps);
+    else
+        hipLaunchKernelGGL(k_layernorm<8>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), (const uint16_t *)x,
                        (const uint16_t *)resid, gamma, beta, (uint16_t *)out, rows, dim, eps);
     IFH_LAUNCH_CHECK("layernorm");
     return IFH_OK;

@@ -63,6 +63,31 @@ def qwen2_schema(cfg):
     return sc
 
 
+# Whisper shapes beyond the two families of the schema file, derived from whisper_base's entries (same tensor names; d, ffn, mel bins,
+# vocabulary and layer counts substituted).  whisper_large_v3_2l = the layer shapes of openai/whisper-large-v3 -- the default model of
+# Cluster/InfernSTTWorker.py:25 -- with two encoder and two decoder layers instead of 32 + 32, for parity tests at its widths.
+WHISPER_CONFIGS = {'whisper_large_v3_2l': dict(d=1280, ffn=5120, n_mels=128, vocab=51866, enc_layers=2, dec_layers=2)}
+
+
+def whisper_schema(cfg):
+    base = load_schema()['whisper_base']
+    sub = {512: cfg['d'], 2048: cfg['ffn'], 80: cfg['n_mels'], 51865: cfg['vocab']}
+    sc = {}
+    for name, (shape, dtype) in base.items():
+        shape = [sub.get(v, v) for v in shape]
+        if '.layers.' in name:
+            pre, rest = name.split('.layers.')
+            idx, tail = rest.split('.', 1)
+            if idx != '0':
+                continue
+            n = cfg['enc_layers'] if pre.endswith('encoder') else cfg['dec_layers']
+            for li in range(n):
+                sc['%s.layers.%d.%s' % (pre, li, tail)] = (shape, dtype)
+        else:
+            sc[name] = (shape, dtype)
+    return sc
+
+
 def load_schema():
     with open(SCHEMA_FILE) as f:
         return json.load(f)
@@ -119,7 +144,8 @@ def synth_state_dict(family: str, seed: int = 0, stop_bias=None):
     """Seeded random HF-format state dict (CPU, float32) for one model family.
     stop_bias: value for speech_decoder_postnet.prob_out.bias (e.g. -20 disables the stop
     head)."""
-    schema = qwen2_schema(QWEN2_CONFIGS[family]) if family in QWEN2_CONFIGS else load_schema()[family]
+    schema = (qwen2_schema(QWEN2_CONFIGS[family]) if family in QWEN2_CONFIGS else
+              whisper_schema(WHISPER_CONFIGS[family]) if family in WHISPER_CONFIGS else load_schema()[family])
     sd = {}
     for name in sorted(schema):
         shape, dtype = schema[name]
