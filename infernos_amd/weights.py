@@ -66,7 +66,9 @@ def qwen2_schema(cfg):
 # Whisper shapes beyond the two families of the schema file, derived from whisper_base's entries (same tensor names; d, ffn, mel bins,
 # vocabulary and layer counts substituted).  whisper_large_v3_2l = the layer shapes of openai/whisper-large-v3 -- the default model of
 # Cluster/InfernSTTWorker.py:25 -- with two encoder and two decoder layers instead of 32 + 32, for parity tests at its widths.
-WHISPER_CONFIGS = {'whisper_large_v3_2l': dict(d=1280, ffn=5120, n_mels=128, vocab=51866, enc_layers=2, dec_layers=2)}
+# whisper_tiny_en = openai/whisper-tiny.en, the model BASELINE configuration 1 names (English-only vocabulary of 51 864).
+WHISPER_CONFIGS = {'whisper_large_v3_2l': dict(d=1280, ffn=5120, n_mels=128, vocab=51866, enc_layers=2, dec_layers=2),
+                   'whisper_tiny_en': dict(d=384, ffn=1536, n_mels=80, vocab=51864, enc_layers=4, dec_layers=4)}
 
 
 def whisper_schema(cfg):

@@ -1056,6 +1056,37 @@ def test_whisper_engine_at_large_v3_layer_shapes_matches_oracle(dev, golden_dir)
     assert btoks.shape[0] == 3 and bool(torch.isfinite(bsc).all())
 
 
+def test_whisper_tiny_en_single_call_matches_oracle(dev, golden_dir):
+    """BASELINE configuration 1 as written: openai/whisper-tiny.en (vocabulary 51 864, not the multilingual 51 865 the other tests
+    use), ONE call (the un-batched shapes: one decode row greedy, five with the beam search), prompt <|startoftranscript|>
+    <|notimestamps|> of the English-only models; encoder, first logits and tokens against the fp32 oracle at the bars of the
+    multilingual tiny fixture."""
+    from infernos_amd.engines.whisper import Whisper
+    from infernos_amd.features import WhisperLogMel
+    from infernos_amd.synth import synth_utterance
+    from infernos_amd.audio import get_resampler
+    from infernos_amd.weights import synth_state_dict
+    sd = synth_state_dict('whisper_tiny_en', 1)
+    model = Whisper(sd, dev)
+    assert (model.d, model.h, model.vocab, len(model.dec_layers)) == (384, 6, 51864, 4)
+    x8 = torch.from_numpy(np.stack([synth_utterance(1400, 10.0)])).to(dev)
+    mel = WhisperLogMel(80, dev)(get_resampler(8000, 16000, str(dev))(x8))
+    enc = model.encode(mel)
+    prompt = torch.tensor([[50257, 50362]], dtype=torch.int32)
+    toks, nsp, first = model.generate(enc, prompt, 6, no_speech_id=50361, keep_logits=True)
+    with torch.no_grad():
+        o_toks, o_first, o_l0, o_enc = onn.whisper_greedy(sd, mel.float().cpu(), prompt.long(), 6, 6)
+    tf = json.load(open(os.path.join(golden_dir, 'whisper_tf_meta.json')))['whisper_tiny']
+    e_enc, e_log = rel_l2(enc.float().cpu(), o_enc), rel_l2(first.cpu(), o_first)
+    assert e_enc < 1.5 * tf['enc_bf16_vs_fp32_rel_l2'], (e_enc, tf['enc_bf16_vs_fp32_rel_l2'])
+    assert e_log < 1.5 * max(tf['bf16_vs_fp32_rel_l2'][:4]), (e_log, tf['bf16_vs_fp32_rel_l2'][:4])
+    top2 = o_first.topk(2).values
+    if float(top2[0, 0] - top2[0, 1]) > 0.05:
+        assert int(toks[0, 0]) == int(o_toks[0, 0])
+    btoks, bsc, _, _ = model.generate_beam(enc, prompt, 6, beams=5, eos_id=50256, no_speech_id=50361)
+    assert btoks.shape[0] == 1 and bool(torch.isfinite(bsc).all())
+
+
 @pytest.mark.parametrize('family,Bn', [('whisper_tiny', 64), ('whisper_base', 128)])
 def test_whisper_teacher_forced_logits_every_step(dev, golden_dir, family, Bn):
     """Every decode position, not only the first: the per-token step (KV append, positions, LN folding, hipGraph replay)
