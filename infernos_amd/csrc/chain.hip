@@ -520,7 +520,11 @@ struct Ring256Params {
 template <int MT, int NCH, int GX>
 __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
 {
-    constexpr int C = 256, NT = 2, NR = NT + MT, NRING = 4;
+    // 8 waves = 2 row groups x 4 channel groups: a wave owns MTW = MT / 2 row tiles x NT = 4 channel tiles (64 channels).  (Rounds 2 and
+    // early 3: 1 x 8, every wave all MT row tiles x 2 channel tiles = 10-12 fragment reads per 16-20 MFMAs, 160 B of LDS reads per
+    // clock at full MFMA rate; now 8-9 reads, 128-144 B/clock.  Same k order per output element: same bits.)
+    constexpr int C = 256, NT = 4, MTW = MT / 2, NR = NT + MTW, NRING = 4;
+    static_assert(MT % 2 == 0, "two row groups");
     constexpr int SB = (C + 16) * 2;                   // 544-byte rows: stride = 2 (mod 4) sixteen-byte slots
     constexpr int RT = MT * 16;                        // 128 rows computed
     constexpr int XROWS = RT + 2 * GX;
@@ -529,6 +533,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
     constexpr int BIAS_OFF = RING_OFF + NRING * UNIT;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid & 1, wn = wid >> 1;
     const int fr = lane & 15, fg = lane >> 4;
     const int T = p.T, pitch = T + GX;                 // chunk b starts `pitch` rows after chunk a
     const int H = (p.taps - 1) / 2, KS = p.taps * 8;
@@ -551,11 +556,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    const int ab = RING_OFF + wid * NT * 1024 + lane * 16;               // wave w owns output channels 32w .. 32w+31
-    const int xb = (GX + fr) * SB + fg * 16;
-    const int cw = (wid * NT * 16 + 4 * fg) * 2;
-    const int bias_b = BIAS_OFF + (wid * NT * 16 + 4 * fg) * 4;
-    f32x4 acc[NT][MT];
+    const int ab = RING_OFF + wn * NT * 1024 + lane * 16;                // channel group wn owns output channels 64 wn .. 64 wn + 63
+    const int xb = (GX + wm * MTW * 16 + fr) * SB + fg * 16;             // row group wm owns row tiles wm MTW .. wm MTW + MTW - 1
+    const int bias_b = BIAS_OFF + (wn * NT * 16 + 4 * fg) * 4;
+    f32x4 acc[NT][MTW];
     int nxt_a = 0, nxt_b = 0;
     // addresses of k-step s (= weight unit s): no synchronisation, so it can sit behind MFMAs
     auto advance = [&](int s) {
@@ -566,11 +570,10 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
     };
 #define RING_READ(Q, FA, FB)                                                                                              \
     {                                                                                                                     \
+        /* read order = the order the MFMAs want them: A0, B0 .. B(MTW-1), A1, A2, A3 */                                  \
         if ((Q) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(FA[0]) : "v"(nxt_a));                                     \
-        else if ((Q) == MT + 1) asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(FA[1]) : "v"(nxt_a));               \
-        else if ((Q) - 1 < 7) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FB[(Q) - 1]) : "v"(nxt_b), "n"(((Q) - 1) * 16 * SB)); \
-        /* row tiles 7.. (MT = 10): a second base, the 16-bit offset field ends at 65 535 */                                \
-        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FB[(Q) - 1]) : "v"(nxt_b + 7 * 16 * SB), "n"(((Q) - 8) * 16 * SB)); \
+        else if ((Q) <= MTW) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FB[(Q) - 1]) : "v"(nxt_b), "n"(((Q) - 1) * 16 * SB)); \
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(FA[(Q) - MTW]) : "v"(nxt_a), "n"(((Q) - MTW) * 1024));    \
     }
     // entering a unit (= a k-step here): this wave's two pieces of the NEXT unit have landed (all DMAs but the youngest
     // unit's two), everybody's have after the barrier; the slot of the previous unit is refilled three units ahead, behind
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
         __builtin_amdgcn_s_barrier();                           \
     }
-    auto kstep = [&](const bf16x8_t (&ca)[NT], const bf16x8_t (&cb)[MT], bf16x8_t (&na)[NT], bf16x8_t (&nb)[MT], auto has_next,
+    auto kstep = [&](const bf16x8_t (&ca)[NT], const bf16x8_t (&cb)[MTW], bf16x8_t (&na)[NT], bf16x8_t (&nb)[MTW], auto has_next,
                      int s_after) {
         constexpr bool NEXT = decltype(has_next)::value;
         if (NEXT) RING_ENTER()
@@ -590,20 +593,24 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int k = 0; k < NT * MT; k++) {
+        for (int k = 0; k < NT * MTW; k++) {
             if (NEXT) {
-                if (k <= MT) wait_lgkm(NR - 2 - (k < MT ? k : MT) + rd_before(k, NR, NT * MT));
-                if (rd_at(k, NR, NT * MT) >= 0) RING_READ(rd_at(k, NR, NT * MT), na, nb)
+                // MFMA k needs fragment k + 1 (B_k) while it walks the first channel tile, fragment MTW + i (A_i) when it enters
+                // channel tile i; the reads were issued in that order, so NR - 1 - (that index) of this k-step's may still be out,
+                // plus those of the next k-step issued so far
+                if (k < MTW) wait_lgkm(NR - 2 - k + rd_before(k, NR, NT * MTW));
+                else if (k % MTW == 0) wait_lgkm(NR - 1 - (MTW + k / MTW) + rd_before(k, NR, NT * MTW));
+                if (rd_at(k, NR, NT * MTW) >= 0) RING_READ(rd_at(k, NR, NT * MTW), na, nb)
                 __builtin_amdgcn_sched_barrier(0);
             }
-            const int i = k / MT, j = k - i * MT;
+            const int i = k / MTW, j = k - i * MTW;
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ca[i], cb[j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if (k == 1 && NEXT) {
                 RING_DMA()
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (k == NT * MT - 1 && s_after >= 0) {
+            if (k == NT * MTW - 1 && s_after >= 0) {
                 advance(s_after);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -634,8 +641,8 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
 #pragma unroll
         for (int i = 0; i < NT; i++)
 #pragma unroll
-            for (int j = 0; j < MT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bf16x8_t fa0[NT], fb0[MT], fa1[NT], fb1[MT];
+            for (int j = 0; j < MTW; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8_t fa0[NT], fb0[MTW], fa1[NT], fb1[MTW];
         advance(0);
         RING_ENTER()
         RING_DMA()
@@ -658,13 +665,13 @@ __global__ __launch_bounds__(512, 2) void k_conv_ring256(const Ring256Params p)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < MT; j++) {
-            const int q = j * 16 + fr;
+        for (int j = 0; j < MTW; j++) {
+            const int q = (wm * MTW + j) * 16 + fr;
             const int e = q / pitch, t = q - e * pitch;
             if (t < T && e < nb) {
 #pragma unroll
                 for (int i = 0; i < NT; i++) {
-                    const int64_t off = (int64_t)t * C + (wid * NT + i) * 16 + 4 * fg;
+                    const int64_t off = (int64_t)t * C + (wn * NT + i) * 16 + 4 * fg;
                     const f32x4 a = acc[i][j];
                     float v0 = a[0] + bv[i][0], v1 = a[1] + bv[i][1], v2 = a[2] + bv[i][2], v3 = a[3] + bv[i][3];
                     if (p.resid) {
