@@ -484,7 +484,7 @@ __global__ __launch_bounds__(256) void k_gemm_m64(const IgemmParams p)
 #ifndef IFH_IGEMM_MINB
 #define IFH_IGEMM_MINB 3
 #endif
-template <int BM, int BN, int WGM, bool PRE, bool FAST, int NWV = 4, int KT = 32, bool PLAIN = false>
+template <int BM, int BN, int WGM, bool PRE, bool FAST, int NWV = 4, int KT = 32, bool PLAIN = false, bool ALN = false>
 // (three 4-wave workgroups per CU: left alone the compiler takes 116 VGPRs + 64 AGPRs = two per CU, and at K = 512 the k-loop is a
 // chain of 16 load -> barrier round trips whose latency only other resident workgroups cover)
 __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_igemm(const IgemmParams p)
@@ -685,10 +685,24 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_ige
         const int m = m0 + wm * WM + j * 16 + fr;                                                                    \
         if (m >= M) continue;                                                                                        \
         const int dynv = dyn_value(p, m);                                                                            \
+        float a_mean = 0.0f, a_rstd = 1.0f;                                                                          \
+        if (ALN) {      /* LayerNorm of the A rows folded in (ifh_conv_desc.aln_*): ln_row's arithmetic */           \
+            const LnRow lr = ln_row(p, reinterpret_cast<const longlong2 *>(p.aln_stats)[m], make_longlong2(0, 0));   \
+            a_mean = lr.a_mean;                                                                                      \
+            a_rstd = lr.a_rstd;                                                                                      \
+        }                                                                                                            \
         _Pragma("unroll") for (int i = 0; i < NT; i++)                                                               \
         {                                                                                                            \
             const int n = n0 + wn * WN + i * 16 + 4 * fg;                                                            \
             if (n >= p.N) continue;                                                                                  \
+            if (ALN) {                                                                                               \
+                float4 c1 = make_float4(0.f, 0.f, 0.f, 0.f);                                                         \
+                if (!p.ln_rms) c1 = *reinterpret_cast<const float4 *>(p.aln_c1 + n);                                 \
+                acc[i][j][0] = a_rstd * (acc[i][j][0] - a_mean * c1.x);                                              \
+                acc[i][j][1] = a_rstd * (acc[i][j][1] - a_mean * c1.y);                                              \
+                acc[i][j][2] = a_rstd * (acc[i][j][2] - a_mean * c1.z);                                              \
+                acc[i][j][3] = a_rstd * (acc[i][j][3] - a_mean * c1.w);                                              \
+            }                                                                                                        \
             if (FAST)                                                                                                \
                 (void)igemm_store4_fast<false, true, true, ACTC>(p, m, n, acc[i][j], dynv, make_uint2(0, 0), bpre[i]); \
             else                                                                                                     \
@@ -803,7 +817,11 @@ static void launch_igemm(const IgemmParams &p, bool pre, hipStream_t st)
     const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid((unsigned)(((tiles + 7) / 8) * 8));          // 1-D, a multiple of 8: see the tile map at the top of k_igemm
     static const bool no_plain = getenv("IFH_IGEMM_NO_PLAIN") != nullptr;     // tuning switch
-    if (p.fast_epi && !pre && p.taps == 1 && p.stride == 1 && p.pad == 0 && p.K % KT == 0 && p.T_out <= p.T_in && !p.zt_cout && !no_plain)
+    const bool plain = p.fast_epi && !pre && p.taps == 1 && p.stride == 1 && p.pad == 0 && p.K % KT == 0 && p.T_out <= p.T_in && !p.zt_cout;
+    if (p.aln_stats) {                       // the caller (ifh_conv_bf16) has checked `plain` and the tile shape
+        if (BM == 128 && BN == 128 && NWV == 4 && KT == 32)
+            hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, true, NWV, KT, true, (BM == 128 && BN == 128 && NWV == 4 && KT == 32)>), grid, dim3(64 * NWV), 0, st, p);
+    } else if (plain && !no_plain)
         hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, true, NWV, KT, true>), grid, dim3(64 * NWV), 0, st, p);
     else if (p.fast_epi) {
         if (pre)
@@ -821,6 +839,12 @@ static void launch_igemm(const IgemmParams &p, bool pre, hipStream_t st)
 }  // namespace ifh
 
 using namespace ifh;
+
+static int igemm_aln_rows()
+{
+    static const int v = getenv("IFH_IGEMM_ALN_ROWS") ? atoi(getenv("IFH_IGEMM_ALN_ROWS")) : 256;      // tuning switch
+    return v;
+}
 
 extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
 {
@@ -930,6 +954,13 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
             hipLaunchKernelGGL((k_gemm_m64<4, 2>), dim3((ct + 3) / 4), dim3(256), 0, st, p);
         else
             hipLaunchKernelGGL((k_gemm_m64<2, 3>), dim3((ct + 1) / 2), dim3(256), 0, st, p);
+    } else if (aln_only && !glu && M >= igemm_aln_rows() && d->n >= 8192 && p.fast_epi && !pre && d->taps == 1 && d->stride == 1 && d->pad == 0 &&
+               p.K % 32 == 0 && d->t_out <= d->t_in && !d->accumulate && !d->resid) {
+        // a wide LayerNorm-folded head over hundreds of rows (the vocabulary projection of a 5-beam Whisper step: 640 x 51 865,
+        // K = 512) is a throughput GEMM, not a decode-step one: 128 x 128 tiles of k_igemm with the normalisation applied in its
+        // epilogue (133 us as 8 110 tiles of 64 x 64 in k_gemm_dec, which moves twice the operand bytes from L2).  One accumulation
+        // chain instead of two: the logits' last bits differ from what the same rows give below this row count.
+        launch_igemm<128, 128, 2>(p, pre, st);
     } else if ((M <= 256 || ((ln_fold || d->decode_step) && M <= 1024)) && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre) {
         // (LayerNorm-folded launches exist only in this kernel: up to 1024 rows -- the 640 decode rows of a 5-beam search)
         const dim3 grid((d->n + 15) / 16, (unsigned)((M + 15) / 16));

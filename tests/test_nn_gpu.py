@@ -269,6 +269,38 @@ def test_skinny_gemm_ln_folded_at_beam_rows(dev, M, D):
         assert v < (8e-3 if k.startswith('aln') else 5e-3), (M, D, k, v)
 
 
+@pytest.mark.parametrize('M,D,NV', [(640, 512, 51872), (300, 768, 8208), (1024, 384, 12000)])
+def test_wide_ln_folded_head_on_the_large_gemm_kernel(dev, M, D, NV):
+    """A LayerNorm-folded projection onto >= 8192 columns over >= 256 rows -- the vocabulary head of the 5-beam Whisper-base decode
+    step the bench runs (640 x 51 865 padded to 51 872, K = 512) -- takes k_igemm's 128 x 128 tiles with the normalisation in its
+    epilogue (csrc/nn.hip) instead of the decode-step kernel: f32 logits against fp32 torch `layer_norm -> linear` on the rounded
+    rows, and against the same rows in 64-row pieces (the decode kernels: two accumulation chains instead of one, so close, not
+    equal); ragged last row and column tiles."""
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(M + NV)
+    rnd = lambda *s_, sc=1.0: bfr(torch.randn(*s_, generator=g) * sc)
+    stats = torch.zeros((1, 1024, 2), dtype=torch.int64, device=dev)
+    att, x0 = rnd(M, D), rnd(M, D)
+    wo, bo = rnd(D, D, sc=D ** -0.5), torch.randn(D, generator=g) * 0.1
+    g1, b1 = 1 + 0.2 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    t1 = torch.empty(M, D, dtype=BF, device=dev)
+    ops.linear(att.to(dev, BF), wo.to(dev, BF), bo.to(dev), t1, rows=M, k=D, n=D, resid=x0.to(dev, BF), stats_out=stats, stats_off=0, ln_dim=D)
+    w, b = rnd(NV, D, sc=D ** -0.5), torch.randn(NV, generator=g) * 0.1
+    wf, c2, c1 = ops.w_linear_ln(w, b, g1, b1, dev)
+    out = torch.full((M, NV), float('nan'), dtype=torch.float32, device=dev)
+    ops.linear(t1, wf, c2, out, rows=M, k=D, n=NV, aln=(stats, 0, c1), ln_dim=D)
+    ref = F.layer_norm(t1.float().cpu(), (D,), g1, b1, 1e-5) @ w.t() + b
+    got = out.cpu()
+    assert bool(torch.isfinite(got).all())
+    e = rel_l2(got, ref)
+    assert e < 8e-3, (M, D, NV, e)
+    pieces = torch.empty_like(out)
+    for r0 in range(0, M, 64):
+        r1 = min(M, r0 + 64)
+        ops.linear(t1[r0:r1], wf, c2, pieces[r0:r1], rows=r1 - r0, k=D, n=NV, aln=(stats, r0 * 2, c1), ln_dim=D)
+    assert rel_l2(got, pieces.cpu()) < 1e-4, rel_l2(got, pieces.cpu())
+
+
 @pytest.mark.parametrize('M', [128, 192, 257, 512, 1000])
 def test_gemm_dec_is_bit_identical_to_skinny(dev, M):
     """From 128 rows up the decode-step launches take the LDS-tiled k_gemm_dec instead of the weight-streaming k_gemm_skinny
