@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const 
 // [h K/2, (h + 1) K/2) -- exactly the two accumulation chains 2h, 2h + 1 of the four the streaming kernel splits a deep K into -- through
 // its own LDS image, so a launch is half as many chunk steps.  Group 1 hands its two chain tiles to group 0 through LDS, which adds
 // the four chains in chain order (c0, + c1, + c2, + c3: the streaming kernel's order) and runs the shared epilogue: same bits.
-__global__ __launch_bounds__(512, 1) void k_gemm_dec_deep(const IgemmParams p)
+__global__ __launch_bounds__(512, 1) void k_gemm_dec_deep(const IgemmParams p, const int cph /* chains per half: 1 or 2 */)
 {
     constexpr int BM = 32, BN = 32, KC = 256, LDK = KC + 8;
     constexpr int AV = BM * (KC / 8) / 256, BV = BN * (KC / 8) / 256;      // 4 + 4 16-byte vectors per thread per chunk
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512, 1) void k_gemm_dec_deep(const IgemmParams p)
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int M = p.nbatch * p.T_out;
     const int lrow = ltid >> 5, lcol = (ltid & 31) * 8;
-    const int khalf = p.K >> 1;                                  // host: K % 512 == 0, so a half is a whole number of chunks
+    const int khalf = p.K >> 1;                                  // host: K % 64 == 0 (the last chunk of a half may be short)
     const uint16_t *arow[AV], *brow[BV];
     const bool t1 = p.T_out == 1;
 #pragma unroll
@@ -398,10 +398,15 @@ __global__ __launch_bounds__(512, 1) void k_gemm_dec_deep(const IgemmParams p)
 #pragma unroll
     for (int i = 0; i < BV; i++) brow[i] = p.w + (int64_t)min(n0 + lrow + 8 * i, p.N - 1) * p.K + lcol + half * khalf;
     uint4 ra[AV], rb[BV];
+    const bool whole = khalf % KC == 0;
 #define IFH_DEEP_LOAD(K0)                                                                                      \
-    {                                                                                                          \
+    if (whole) {                                                                                               \
         _Pragma("unroll") for (int i = 0; i < AV; i++) ra[i] = ld_u32x4(arow[i] + (K0));                       \
         _Pragma("unroll") for (int i = 0; i < BV; i++) rb[i] = ld_u32x4(brow[i] + (K0));                       \
+    } else {                                                                                                   \
+        const bool kin_ = (K0) + lcol < khalf;                                                                 \
+        _Pragma("unroll") for (int i = 0; i < AV; i++) ra[i] = kin_ ? ld_u32x4(arow[i] + (K0)) : make_uint4(0, 0, 0, 0); \
+        _Pragma("unroll") for (int i = 0; i < BV; i++) rb[i] = kin_ ? ld_u32x4(brow[i] + (K0)) : make_uint4(0, 0, 0, 0); \
     }
     IFH_DEEP_LOAD(0)
     // epilogue operands (group 0 only: it runs the epilogue), requested behind the first chunk
@@ -430,21 +435,24 @@ __global__ __launch_bounds__(512, 1) void k_gemm_dec_deep(const IgemmParams p)
         }
     }
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, part0 = acc, part1 = acc;
-    const int nkh = khalf / 32, per = nkh / 2;                   // k-steps of this half; per chain (host: nk % 4 == 0)
-    const int nchunk = khalf / KC;
+    const int nkh = khalf / 32, per = nkh / cph;                 // k-steps of this half; per chain (host: nk % (2 cph) == 0)
+    const int nchunk = (khalf + KC - 1) / KC;
     for (int c = 0; c < nchunk; c++) {
 #pragma unroll
         for (int i = 0; i < AV; i++) *reinterpret_cast<uint4 *>(&As[(lrow + 8 * i) * LDK + lcol]) = ra[i];
 #pragma unroll
         for (int i = 0; i < BV; i++) *reinterpret_cast<uint4 *>(&Bs[(lrow + 8 * i) * LDK + lcol]) = rb[i];
         __syncthreads();
-        if (c + 1 < nchunk) IFH_DEEP_LOAD((c + 1) * KC)
-        for (int ks = 0; ks < KC / 32; ks++) {
+        if (c + 1 < nchunk) {
+            IFH_DEEP_LOAD((c + 1) * KC)
+        }
+        const int ks1 = min(KC / 32, nkh - c * (KC / 32));
+        for (int ks = 0; ks < ks1; ks++) {
             const bf16x8_t fa = *reinterpret_cast<const bf16x8_t *>(&Bs[(wn * 16 + fr) * LDK + ks * 32 + fg * 8]);
             const bf16x8_t fb = *reinterpret_cast<const bf16x8_t *>(&As[(wm * 16 + fr) * LDK + ks * 32 + fg * 8]);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
             const int kt1 = c * (KC / 32) + ks + 1;
-            if (kt1 == per) {                                    // end of this half's first chain
+            if (cph == 2 && kt1 == per) {                        // end of this half's first chain
                 part0 = acc;
                 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
@@ -462,10 +470,15 @@ __global__ __launch_bounds__(512, 1) void k_gemm_dec_deep(const IgemmParams p)
     __syncthreads();
     if (half == 1) return;
     f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
-    sum += part0;                                                // chain order: c0, c1 (this group), c2, c3 (the other)
-    sum += part1;
-    sum += xch[(0 * 4 + wid) * 64 + lane];
-    sum += xch[(1 * 4 + wid) * 64 + lane];
+    if (cph == 2) {                                              // chain order: c0, c1 (this group), c2, c3 (the other)
+        sum += part0;
+        sum += part1;
+        sum += xch[(0 * 4 + wid) * 64 + lane];
+        sum += xch[(1 * 4 + wid) * 64 + lane];
+    } else {                                                     // two chains: c0 (this group), c1 (the other)
+        sum += part1;
+        sum += xch[(1 * 4 + wid) * 64 + lane];
+    }
     if (ln_mode) {
         ln_epi4(p, em, n, exok, sum, edyn, ln_row(p, st_a, st_r), pc1, pbias, pgam, pbeta, presid, fg);
     } else if (exok && n < p.N) {
@@ -1084,8 +1097,13 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
             const int ksplit = p.K >= 2048 ? 4 : 2;
             // 64 x 64 tiles; 64 x 32 where that is what it takes to give every CU a workgroup
             const int64_t t64 = ((M + 63) / 64) * ((d->n + 63) / 64);
-            static const int deep_on = getenv("IFH_GEMM_DEC_DEEP") ? atoi(getenv("IFH_GEMM_DEC_DEEP")) : 1;        // tuning switch
-            if (deep_on && ksplit == 4 && p.K % 512 == 0 && (p.K / 32) % 4 == 0 && ((M + 63) / 64) * ((d->n + 31) / 32) <= 200) {
+            static const int deep_on = getenv("IFH_GEMM_DEC_DEEP") ? atoi(getenv("IFH_GEMM_DEC_DEEP")) : 0;        // tuning switch (see below: default off)
+            // deep_on: 1 = deep K only (two chains per half), 2 = also K < 2048 (one chain per half).  A latency switch: a stage
+            // running alone gets 2.5-5 % faster (TTS stage 125.1 -> 119.0 ms, fc2 17.1 -> 12.3 us at 256 rows), but the fully
+            // pipelined C3 cycle, which is bound by the SUM of the kernels' work, loses 2 % to the doubled waves per launch
+            // (10 340 x off, 10 085 x on, three alternating runs each): off by default.
+            if (((deep_on >= 1 && ksplit == 4) || (deep_on >= 2 && ksplit == 2)) && p.K % 64 == 0 && (p.K / 32) % ksplit == 0 &&
+                ((M + 63) / 64) * ((d->n + 31) / 32) <= 200) {
                 constexpr size_t bytes = 2 * (32 + 32) * (256 + 8) * 2;
                 static DeviceOnce attr_once;
                 int attr_dev = 0;
@@ -1094,7 +1112,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
                     if (e != hipSuccess) return check_hip(e, "gemm_dec_deep lds attr");
                     attr_once.done(attr_dev);
                 }
-                hipLaunchKernelGGL(k_gemm_dec_deep, dim3((M + 31) / 32, (d->n + 31) / 32), dim3(512), bytes, st, p);
+                hipLaunchKernelGGL(k_gemm_dec_deep, dim3((M + 31) / 32, (d->n + 31) / 32), dim3(512), bytes, st, p, ksplit / 2);
                 IFH_LAUNCH_CHECK("conv_bf16");
                 return IFH_OK;
             }
