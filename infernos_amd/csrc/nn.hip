@@ -1116,7 +1116,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
                 IFH_LAUNCH_CHECK("conv_bf16");
                 return IFH_OK;
             }
-            static const int64_t bm32_max = getenv("IFH_GEMM_DEC_BM32") ? atoll(getenv("IFH_GEMM_DEC_BM32")) : 150;   // tuning switch: 32-row tiles up to this many 64 x 32 workgroups
+            static const int64_t bm32_max = getenv("IFH_GEMM_DEC_BM32") ? atoll(getenv("IFH_GEMM_DEC_BM32")) : 200;   // tuning switch: 32-row tiles up to this many 64 x 32 workgroups (pipelined C3, three alternating runs each: 0 -> 10 006 x, 100 -> 10 001, 150 -> 10 177-10 279, 200 -> 10 313-10 326, 300 -> 10 194, 500 -> 10 101)
             if (t64 >= 200)
                 hipLaunchKernelGGL((k_gemm_dec<64>), dim3((M + 63) / 64, (d->n + 63) / 64), dim3(256), 0, st, p, ksplit);
             else if (((M + 63) / 64) * ((d->n + 31) / 32) <= bm32_max)
