@@ -278,7 +278,7 @@ class ContinuousTTS:
         dev = pp.device
         assert max_text <= 256, 'cross-attention over > 256 keys takes the 4-wave kernel: such texts go through the frozen-batch path'
         self.row_bucket = row_bucket
-        self.sync_every = int(os.environ.get('IFH_TTS_SYNC_EVERY', '0'))         # decoder steps queued at a time (0: all 16)
+        self.sync_every = int(os.environ.get('IFH_TTS_SYNC_EVERY', '8'))         # decoder steps queued at a time (0: all 16); 8: +2 % and a steadier tick p99 at C3
         with torch.cuda.device(dev):
             self.st = TTSRaggedState(pp.model, max_rows, max_text)
             # the decode chain is one latency-bound sequence of small dependent launches for ALL in-flight rows: on an ordinary
