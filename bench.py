@@ -283,6 +283,26 @@ def c5_share(dev, args, build, n_sessions=64, prompt_len=192, first_sentence=16,
     return res
 
 
+def self_launch(ngpus):
+    """`python bench.py --gpus N` without a launcher: one rank per GPU through torch.distributed.run on 127.0.0.1 and a
+    free port.  stdout of the ranks is passed through (rank 0 prints the one JSON line), stderr too."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    # compile once here (hipcc / make only: nothing in this process touches the GPU), so that the ranks find the library built
+    from infernos_amd import build as _b
+    _b.build(verbose=False)
+    subprocess.check_call(['make', '-s', '-C', os.path.join(ROOT, 'oracle')])
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // ngpus)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(ngpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -314,9 +334,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process (never exec) and before this
+        # process has made any GPU call; rank 0's JSON line is relayed, the exit code is the launcher's
+        # (replica fan-out: Cluster/InfernBenchActor.py:214-221)
+        sys.exit(self_launch(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d for --gpus %d' % (args.gpus, args.gpus))
+        raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import __graft_entry__ as ge
     if rank == 0:
@@ -338,6 +362,11 @@ def main():
         dist.barrier()
         # ingress (scatter, front-end thread) and egress (gather, main thread) get their own communicators
         g_in, g_out = dist.new_group(), dist.new_group()
+    gpu_ids = [local_rank]
+    if world > 1:                                       # which device every rank sits on (the line names them)
+        gl = [None] * world
+        dist.all_gather_object(gl, local_rank)
+        gpu_ids = [int(x) for x in gl]
     from infernos_amd import _lib
     from infernos_amd.pipeline import SpeechPipeline
     from infernos_amd.shard import gather_rows, scatter_frames
@@ -472,6 +501,7 @@ def main():
                        'stt_decode': ('beam search, %d beams (%d decode rows), 32 tokens' % (args.stt_beam, n_local * args.stt_beam))
                                      if args.stt_beam > 1 else 'greedy, 32 tokens'},
             'rccl_version': (list(torch.cuda.nccl.version()) if world > 1 and not dry else None),
+            'gpu_ids': gpu_ids,
             'launches_per_cycle': round(launches_per_cycle, 1),
             'launches_note': 'calls into stream-taking C-ABI entry points per utterance cycle inside the timed region, hipGraph replays '
                              'counted by the launches they hold (infernos_amd/_lib.py:CALLS)',

@@ -191,9 +191,16 @@ CALLS = [0]
 _HOST_ONLY = ('ifh_g711_tables_host',)
 
 
+_tls = threading.local()
+
+
 def _counted(fn):
     def call(*a):
-        CALLS[0] += 1
+        cap = getattr(_tls, 'cap', None)
+        if cap is None:
+            CALLS[0] += 1
+        else:                     # this thread is capturing a hipGraph: the launch is recorded, not run -- counted per replay
+            cap[0] += 1
         return fn(*a)
     call.__name__ = getattr(fn, '__name__', 'ifh')
     return call
@@ -201,22 +208,25 @@ def _counted(fn):
 
 class CountedGraph:
     """hipGraph of the launches `fn` issues on the current stream (thread-local capture), remembering how many C-ABI calls
-    it holds so that replays keep the CALLS statistic meaningful."""
+    it holds so that replays keep the CALLS statistic meaningful.  The count is this thread's own: launches other threads
+    issue during the capture stay in the running total and out of the graph's number."""
 
     def __init__(self, fn):
         import torch
         torch.cuda.synchronize()
         self.g = torch.cuda.CUDAGraph()
-        c0 = CALLS[0]
-        with torch.cuda.graph(self.g, capture_error_mode='thread_local'):          # records the launches; nothing executes until replay
-            fn()
-        self.n = CALLS[0] - c0
-        CALLS[0] = c0
+        prev, cap = getattr(_tls, 'cap', None), [0]
+        _tls.cap = cap
+        try:
+            with torch.cuda.graph(self.g, capture_error_mode='thread_local'):      # records the launches; nothing executes until replay
+                fn()
+        finally:
+            _tls.cap = prev
+        self.n = cap[0]
 
     def replay(self):
         self.g.replay()
         CALLS[0] += self.n
-
 
 
 class InfernosHipError(RuntimeError):

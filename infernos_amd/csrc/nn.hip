@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void k_transpose(const void *__restrict__ in, 
 }
 
 template <int BM, int BN, int WGM, int NWV = 4, int KT = 32>
-static void launch_igemm(const IgemmParams &p, bool pre, hipStream_t st)
+static int launch_igemm(const IgemmParams &p, bool pre, hipStream_t st)
 {
     const int M = p.nbatch * p.T_out;
     const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -942,6 +942,9 @@ static void launch_igemm(const IgemmParams &p, bool pre, hipStream_t st)
     if (p.aln_stats) {                       // the caller (ifh_conv_bf16) has checked `plain` and the tile shape
         if (BM == 128 && BN == 128 && NWV == 4 && KT == 32)
             hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, true, NWV, KT, true, (BM == 128 && BN == 128 && NWV == 4 && KT == 32)>), grid, dim3(64 * NWV), 0, st, p);
+        else {
+            return fail(IFH_EINVAL, "k_igemm: the LayerNorm-folded epilogue exists for the 128 x 128 x 4-wave x 32 tile only");
+        }
     } else if (plain && !no_plain)
         hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, true, NWV, KT, true>), grid, dim3(64 * NWV), 0, st, p);
     else if (p.fast_epi) {
@@ -955,6 +958,7 @@ static void launch_igemm(const IgemmParams &p, bool pre, hipStream_t st)
         else
             hipLaunchKernelGGL((k_igemm<BM, BN, WGM, false, false, NWV, KT>), grid, dim3(64 * NWV), 0, st, p);
     }
+    return IFH_OK;
 }
 
 }  // namespace ifh
@@ -1081,7 +1085,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         // K = 512) is a throughput GEMM, not a decode-step one: 128 x 128 tiles of k_igemm with the normalisation applied in its
         // epilogue (133 us as 8 110 tiles of 64 x 64 in k_gemm_dec, which moves twice the operand bytes from L2).  One accumulation
         // chain instead of two: the logits' last bits differ from what the same rows give below this row count.
-        launch_igemm<128, 128, 2>(p, pre, st);
+        if (int rc = launch_igemm<128, 128, 2>(p, pre, st)) return rc;
     } else if ((M <= 256 || ((ln_fold || d->decode_step) && M <= 1024)) && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre) {
         // (LayerNorm-folded launches exist only in this kernel: up to 1024 rows -- the 640 decode rows of a 5-beam search)
         const dim3 grid((d->n + 15) / 16, (unsigned)((M + 15) / 16));

@@ -406,7 +406,10 @@ class TTSRaggedState:
         T = -(-max_text // TTSBatchState.T_BUCKET) * TTSBatchState.T_BUCKET
         assert R <= 1024, 'the LayerNorm-folded decode GEMMs take at most 1024 rows per launch'
         self.model, self.R, self.T = model, R, T
-        self.smax = min(model.max_steps, int(T * 20.0 / 2) + 48)
+        # a multiple of 16 (an infer() call appends 16 rows): ContinuousTTS ends a group before a call that would pass smax, so
+        # no row ever appends at pos >= smax (a cache below 10 T + 48 rows cuts long utterances; the session gets its end marker)
+        self.smax = min(model.max_steps, int(T * 20.0 / 2) + 48) // 16 * 16
+        assert self.smax >= 32, 'SpeechT5.max_steps leaves no room for two infer() calls'
         z = lambda *s, dt=BF16: torch.zeros(s, dtype=dt, device=dev)
         self.pos = z(R, dt=torch.int32)
         self.active = z(R, dt=torch.uint8)

@@ -251,8 +251,16 @@ class TTSGroup:
         self.done, self.done_event, self.error = threading.Event(), None, None
 
     def result(self, timeout=None):
-        if not self.done.wait(timeout):
-            raise TimeoutError('TTS group still running')
+        """Waits in slices: a group whose engine thread has died (or was never started and is not being stepped by hand)
+        fails instead of waiting forever."""
+        import time
+        t_end = None if timeout is None else time.monotonic() + timeout
+        while not self.done.wait(0.25 if t_end is None else max(0.0, min(0.25, t_end - time.monotonic()))):
+            eng = getattr(self, '_engine', None)
+            if eng is not None and eng.failed is not None:
+                raise RuntimeError('ContinuousTTS: the engine thread has died') from eng.failed
+            if t_end is not None and time.monotonic() >= t_end:
+                raise TimeoutError('TTS group still running')
         if self.error is not None:
             raise self.error
         return self
@@ -296,6 +304,7 @@ class ContinuousTTS:
         self.h_fresh = [torch.zeros(R, dtype=torch.uint8).pin_memory() for _ in range(2)]
         self.render_bufs = {}
         self.thread, self.halt = None, False
+        self.failed = None                               # the exception that killed the engine thread (submit() then raises)
         self.calls_run = self.rows_run = 0               # statistics: engine calls, sum of row slots they covered
 
     # ---- any thread -----------------------------------------------------------------------------------------------
@@ -308,7 +317,10 @@ class ContinuousTTS:
         T = -(-t_true // 16) * 16
         if T > st.T or g > st.R:
             raise ValueError('ContinuousTTS: %d rows x %d tokens exceed the state (%d rows x %d tokens)' % (g, t_true, st.R, st.T))
+        if self.failed is not None:
+            raise RuntimeError('ContinuousTTS: the engine thread has died') from self.failed
         grp = TTSGroup(g, t_true, max_calls, dispatch, want_ulaw)
+        grp._engine = self
         with torch.cuda.device(dev):
             ids = torch.nn.functional.pad(input_ids, (0, T - t_true)) if T != t_true else input_ids
             enc = pp.model.encode(ids, lens)                                            # [g, T, 768] on the caller's stream
@@ -326,6 +338,8 @@ class ContinuousTTS:
                 t.record_stream(self.main)                   # consumed on the engine stream
             grp._admit['ready'].record(torch.cuda.current_stream(dev))
         with self.cv:
+            if self.failed is not None:                  # died between the check above and here
+                raise RuntimeError('ContinuousTTS: the engine thread has died') from self.failed
             self.pending.append(grp)
             self.cv.notify_all()
         return grp
@@ -444,6 +458,11 @@ class ContinuousTTS:
                         grp.dispatch[i] = None
             ended = bool(np.all((e >= 0) & (e <= end_idx)))
             out_of_cache = grp.idx + 16 > st.smax
+            if out_of_cache and not ended and grp.dispatch is not None:
+                for i, d in enumerate(grp.dispatch):      # the KV cache is full: the utterance is cut here, the session is told
+                    if d is not None:
+                        d(None)
+                        grp.dispatch[i] = None
             if ended or (grp.max_calls is not None and grp.calls >= grp.max_calls) or out_of_cache:
                 finished.append(grp)
         for grp in finished:
@@ -452,7 +471,14 @@ class ContinuousTTS:
                 self.free.extend(grp.slots)
             grp.done_event = self.ren_done[par]
             if grp.ulaw is not None:
-                grp.ulaw = grp.ulaw[:, :grp.calls * A]
+                # [n, max_calls*A] as the lanes path returns it: calls the group did not take (it ended early) are mu-law
+                # silence (0xFF), `valid`/`spans` say what is audio; without max_calls the width is what was produced
+                if grp.max_calls is not None and grp.calls < grp.max_calls:
+                    with torch.cuda.stream(self.side):
+                        grp.ulaw[:, grp.calls * A:grp.max_calls * A] = 0xFF
+                        grp.done_event = torch.cuda.Event()
+                        grp.done_event.record(self.side)
+                grp.ulaw = grp.ulaw[:, :(grp.max_calls or grp.calls) * A]
             grp.done.set()
         return True
 
@@ -522,12 +548,14 @@ class ContinuousTTS:
                         return
                 try:
                     self.step()
-                except BaseException as e:                  # fail every waiting group loudly, then re-raise
+                except BaseException as e:                  # fail every waiting group loudly, mark the engine dead, re-raise
                     with self.cv:
+                        self.failed = e
                         for grp in self.live + self.pending:
                             grp.error = e
                             grp.done.set()
                         self.live, self.pending = [], []
+                        self.free = list(range(self.st.R))
                     raise
         self.thread = threading.Thread(target=loop, daemon=True, name='ContinuousTTS')
         self.thread.start()

@@ -407,6 +407,71 @@ def test_gemm_dec_is_bit_identical_to_skinny(dev, M):
         both(head, [torch.zeros(M, 16, dtype=torch.float32, device=dev) if f32 else torch.zeros(M, 33 * 80, dtype=BF, device=dev)])
 
 
+def _gemm_dec_variant(M, N):
+    """the k_gemm_dec instantiation ifh_conv_bf16 selects from 128 rows up (csrc/nn.hip): <BN, BM>"""
+    mt, t64 = (M + 63) // 64, ((M + 63) // 64) * ((N + 63) // 64)
+    if t64 >= 200:
+        return (64, 64)
+    return (32, 32) if mt * ((N + 31) // 32) <= 200 else (32, 64)
+
+
+@pytest.mark.parametrize('M,N,K,want', [(384, 768, 768, (32, 32)), (640, 2304, 768, (64, 64)), (384, 1536, 768, (32, 64)),
+                                        (351, 768, 3072, (32, 32)), (1000, 3072, 768, (64, 64)), (130, 1552, 512, (32, 32)),
+                                        (257, 1536, 512, (32, 64))])
+def test_gemm_dec_each_tile_form_matches_torch(dev, M, N, K, want):
+    """One launch of every k_gemm_dec tile form (<32,32>, <64,64>, <32,64>; 2 and 4 accumulation chains; ragged rows and
+    columns) DIRECTLY against fp32 torch `x @ w.T + b` (+ GELU, + residual) -- not against another HIP kernel, so that a
+    change of the base kernel cannot move both sides of the bit-identity tests above."""
+    from infernos_amd import ops
+    assert _gemm_dec_variant(M, N) == want
+    g = torch.Generator().manual_seed(M + N + K)
+    x = bfr(torch.randn(M, K, generator=g))
+    w = bfr(torch.randn(N, K, generator=g) / K ** 0.5)
+    b = torch.randn(N, generator=g) * 0.1
+    r = bfr(torch.randn(M, N, generator=g))
+    xd, wd, bd, rd = x.to(dev, BF), w.to(dev, BF), b.to(dev), r.to(dev, BF)
+    for act, actc, resid in ((lambda v: v, 0, False), (F.gelu, 2, False), (lambda v: v, 0, True)):
+        out = torch.zeros(M + 1, N, dtype=BF, device=dev)
+        ops.linear(xd, wd, bd, out, rows=M, k=K, n=N, act=actc, resid=rd if resid else None, decode_step=True)
+        ref = act(x @ w.t() + b) + (r if resid else 0)
+        got = out[:M].float().cpu()
+        e = rel_l2(got, ref)
+        emax = float((got - ref).abs().max() / ref.abs().max())
+        assert e < 3e-3 and emax < 1.2e-2, (M, N, K, want, actc, resid, e, emax)
+        assert not bool(out[M].any()), 'row past M written'
+    o32 = torch.zeros(M, N, dtype=torch.float32, device=dev)                      # f32 output: no rounding of the result
+    ops.linear(xd, wd, bd, o32, rows=M, k=K, n=N, decode_step=True)
+    e = rel_l2(o32.cpu(), x @ w.t() + b)
+    assert e < 2e-5, (M, N, K, want, 'f32', e)
+
+
+@pytest.mark.parametrize('case', [dict(B=770, T=48, k=3, d=1, resid=True), dict(B=769, T=48, k=11, d=1), dict(B=5, T=48, k=7, d=3, resid=True),
+                                  dict(B=771, T=37, k=3, d=5, resid=True, scale=1 / 3, acc=True)])
+def test_conv_ring256_matches_torch(dev, case):
+    """ifh_conv_ring256_bf16 -- incl. the three-chunks-per-workgroup form k_conv_ring256<10,3,8> (>= 768 chunks, reach <= 8) --
+    DIRECTLY against fp32 torch conv1d(leaky_relu(x)) on the rounded operands."""
+    from infernos_amd import ops
+    B, T, k, d = case['B'], case['T'], case['k'], case['d']
+    g = torch.Generator().manual_seed(B * 7 + T + k + d)
+    x = bfr(torch.randn(B, T, 256, generator=g))
+    w = bfr(torch.randn(256, 256, k, generator=g) / (256 * k) ** 0.5)
+    b = torch.randn(256, generator=g) * 0.1
+    resid = bfr(torch.randn(B, T, 256, generator=g)) if case.get('resid') else None
+    prev = bfr(torch.randn(B, T, 256, generator=g))
+    scale, acc = case.get('scale', 1.0), case.get('acc', False)
+    ref = F.conv1d(bfr(F.leaky_relu(x, 0.1)).transpose(1, 2), w, b, padding=(k - 1) // 2 * d, dilation=d).transpose(1, 2)
+    if resid is not None:
+        ref = ref + resid
+    ref = ref * scale + (prev if acc else 0)
+    ws, nunits, bias = ops.w_chain_pack([(w, b)], dev, unit_bytes=16384)
+    out = prev.to(dev, BF).clone()
+    ops.conv_ring256(x.to(dev, BF), ws, bias.reshape(-1), out, nbatch=B, t=T, taps=k, dil=d, pre_slope=0.1,
+                     resid=None if resid is None else resid.to(dev, BF), scale=scale, accumulate=acc)
+    got = out.float().cpu()
+    e, emax = rel_l2(got, ref), float((got - ref).abs().max() / ref.abs().max())
+    assert e < 5e-3 and emax < 1.2e-2, (case, e, emax)
+
+
 @pytest.mark.parametrize('M,N,K,act,resid', [(36864, 1024, 512, 2, False), (36800, 1000, 512, 0, True), (4099, 520, 384, 1, False),
                                              (16384, 2304, 2048, 0, True)])
 def test_igemm_plain_tile_loads_match_torch(dev, M, N, K, act, resid):

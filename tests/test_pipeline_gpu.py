@@ -355,25 +355,26 @@ def test_baseline_config_full_cycle(built_lib, name, N, family, nheads, stt_beam
 
 
 def test_bench_two_ranks_on_one_gpu_dry_run(built_lib):
-    """The N > 1 bench path end to end -- torch.distributed.run with two ranks, sticky shards, ingress scatter / egress gather
+    """The N > 1 bench path end to end -- plain `python bench.py --gpus 2` (self-launched ranks), sticky shards, ingress scatter / egress gather
     on two communicators issued from the pipelined schedule, barrier + MAX-over-ranks timing, one JSON line from rank 0 -- on
     a single-GPU box: IFH_DRYRUN_ONE_GPU=1 puts both ranks on cuda:0 and runs the collectives over gloo."""
     import json
     import os
-    import socket
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, IFH_DRYRUN_ONE_GPU='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    # the plain command the driver uses at N = 1, with --gpus 2: bench.py starts its own ranks (child process)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
            '--config', 'C2', '--calls-per-gpu', '4', '--tts-lanes', '2', '--no-cpu-baseline', '--no-extra-configs']
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
     assert len(lines) == 1, r.stdout[-2000:]
     d = json.loads(lines[0])
+    assert d['gpu_ids'] == [0, 0]          # dry run: both ranks on cuda:0
     assert d['n_gpus'] == 2 and d['steps'] == 3 and d['config']['calls_total'] == 8 and d['config']['calls_per_gpu'] == 4
     assert d['value'] > 0 and d['scaling'] == 'weak' and abs(d['value'] - 8 * 10.0 / (d['ms_per_step'] * 1e-3)) < 0.01 * d['value']
     assert d['tts_samples_per_call'] == 10 * 4096 - 256 and 6.5 < d['stt_audio_seconds_per_call'] < 9.5
