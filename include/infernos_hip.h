@@ -402,6 +402,29 @@ typedef struct ifh_chain_desc {
 } ifh_chain_desc;
 int ifh_resblock_chain_bf16(const ifh_chain_desc *desc, ifh_stream_t stream);
 
+/* The residual blocks of one HiFi-GAN upsampling level in ONE launch (csrc/level.hip), weights stationary in registers:
+ *     for block j < nblocks (taps[j] in {3, 7, 11}):  y_j = chain_j(x)        (ifh_resblock_chain_bf16's function)
+ *     out = y_0 * out_scale (+ out if accumulate);  out = y_j * out_scale + out  for j >= 1
+ * i.e. what nblocks ifh_resblock_chain_bf16 launches with accumulate = (j > 0 || accumulate) compute, bit for bit
+ * (transformers modeling_speecht5.py HifiGanResidualBlock / SpeechT5HifiGan.forward: the mean over the three blocks of a
+ * level with out_scale = 1/3; reached from HelloSippyTTSRT/HelloSippyRTPipe.py:236).  wstream[j] / bias[j]: block j's
+ * fragment stream and biases exactly as ifh_chain_desc takes them (ops.w_chain_pack).  c = 32; taps = (3, 7, 11) or one block. */
+typedef struct ifh_level_desc {
+    const void *x;
+    int64_t x_bstride;
+    int32_t c, t, nbatch, nblocks;
+    int32_t taps[3];
+    int32_t accumulate;
+    const void *wstream[3];
+    const float *bias[3];
+    float slope;            /* LeakyReLU slope ahead of every convolution, (0, 1] */
+    float out_scale;
+    void *out;
+    int64_t out_bstride;
+    void *debug_prof;       /* NULL (diagnostic builds: device uint64[16], shader-clock sums per phase of a convolution) */
+} ifh_level_desc;
+int ifh_resblock_level_bf16(const ifh_level_desc *desc, ifh_stream_t stream);
+
 /* One stride-1 "same" convolution with 256 input and 256 output channels on short sequences (t <= 48: the first
  * HiFi-GAN level), two sequences per workgroup, weights DMA'd as pre-packed fragments (the stream layout of
  * ifh_chain_desc for ONE convolution: taps * 8 k-steps of 16 fragments = taps * 8 units of 16 KB, no padding):

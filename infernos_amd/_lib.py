@@ -91,6 +91,14 @@ class ChainDesc(ctypes.Structure):
                 ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp), ('out_bstride', _i64), ('debug_prof', _vp)]
 
 
+class LevelDesc(ctypes.Structure):
+    """ifh_level_desc (include/infernos_hip.h)"""
+    _fields_ = [('x', _vp), ('x_bstride', _i64), ('c', ctypes.c_int32), ('t', ctypes.c_int32), ('nbatch', ctypes.c_int32),
+                ('nblocks', ctypes.c_int32), ('taps', ctypes.c_int32 * 3), ('accumulate', ctypes.c_int32),
+                ('wstream', _vp * 3), ('bias', _vp * 3), ('slope', _f), ('out_scale', _f), ('out', _vp), ('out_bstride', _i64),
+                ('debug_prof', _vp)]
+
+
 class Ring256Desc(ctypes.Structure):
     """ifh_ring256_desc (include/infernos_hip.h)"""
     _fields_ = [('x', _vp), ('x_bstride', _i64), ('taps', ctypes.c_int32), ('dil', ctypes.c_int32), ('t', ctypes.c_int32),
@@ -149,6 +157,7 @@ SIGNATURES.update({
     'ifh_resblock_pair_bf16': (_i, [ctypes.POINTER(ResblockDesc), _vp]),
     'ifh_resblock_chain_bf16': (_i, [ctypes.POINTER(ChainDesc), _vp]),
     'ifh_conv_ring256_bf16': (_i, [ctypes.POINTER(Ring256Desc), _vp]),
+    'ifh_resblock_level_bf16': (_i, [ctypes.POINTER(LevelDesc), _vp]),
     'ifh_layernorm_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     'ifh_transpose_to_bf16': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     'ifh_attn_prefill_bf16': (_i, [ctypes.POINTER(AttnDesc), _vp]),

@@ -39,6 +39,8 @@ class HifiGan:
         # weights as one pre-packed fragment stream per block
         self.chain = {}
         self.fused_chain = os.environ.get('IFH_NO_CHAIN') is None           # tuning switch
+        # the C = 32 level: its three residual blocks as ONE launch with the weights stationary in registers (csrc/level.hip)
+        self.fused_level = os.environ.get('IFH_NO_LEVEL') is None           # tuning switch
         for i in range(1, 4):
             for j, k in enumerate((3, 7, 11)):
                 R = 'resblocks.%d.' % (i * 3 + j)
@@ -104,6 +106,11 @@ class HifiGan:
             t, c = t * 4, c // 2
             h, xn = B['h%d' % i], B['xn%d' % i]
             rbuf = (B['r0%d' % i], B['r1%d' % i])
+            if self.fused_level and self.fused_chain and c == 32:
+                ops.resblock_level(u, [(k, self.chain[(i, j)][0], self.chain[(i, j)][2]) for j, k in enumerate((3, 7, 11))], xn,
+                                   nbatch=n, t=t, c=c, slope=0.1, scale=1.0 / 3.0)
+                prev = xn
+                continue
             for j, k in enumerate((3, 7, 11)):
                 cur = u
                 if self.fused_chain and (i, j) in self.chain and (c < 128 or t <= 192):

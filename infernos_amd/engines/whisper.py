@@ -32,6 +32,7 @@ class Whisper:
         self.ff = sd[E + 'layers.0.fc1.weight'].shape[0]
         self.vocab = sd[Dc + 'embed_tokens.weight'].shape[0]
         self.max_tokens = min(max_tokens, sd[Dc + 'embed_positions.weight'].shape[0])
+        self.beam_cross_mfma = os.environ.get('IFH_BEAM_CROSS_VALU') is None     # tuning switch: the beams' cross-attention on k_attn_prefill
         self.c1 = (ops.w_conv(sd[E + 'conv1.weight'], dev), ops.w_bias(sd[E + 'conv1.bias'], dev))
         self.c2 = (ops.w_conv(sd[E + 'conv2.weight'], dev), ops.w_bias(sd[E + 'conv2.bias'], dev))
         self.enc_pos = sd[E + 'embed_positions.weight'].to(BF16).contiguous().to(dev)
@@ -168,6 +169,11 @@ class Whisper:
         if g == 1:
             ops.attn_decode(bufs['q'], ck, ck, bufs['att'], nbatch=Bn, nheads=H, max_keys=N_CTX, q_bs=d,
                             kv_bs=N_CTX * 2 * d, kv_ts=2 * d, o_bs=d, v_off=d)
+        elif self.beam_cross_mfma:                 # beams: the g rows of an utterance are the query rows of one flash-attention tile
+            # (k_attn_prefill streams the utterance's K/V once at 4.9 TB/s against 4.2 for the per-row kernel that shares the
+            # loads; another summation order than k_attn_decode's -- parity is held against the transformers fixture, not against it)
+            ops.attn_prefill(bufs['q'], ck, ck, bufs['att'], nbatch=Bn // g, nheads=H, tq=g, tk=N_CTX, v_off=d, q_ts=d,
+                             k_ts=2 * d, v_ts=2 * d, o_ts=d)
         else:                                      # beams: g consecutive rows share one utterance's cross K/V
             ops.attn_decode_shared(bufs['q'], ck, ck, bufs['att'], nbatch=Bn, nheads=H, max_keys=N_CTX, q_bs=d,
                                    kv_bs=N_CTX * 2 * d, kv_ts=2 * d, o_bs=d, v_off=d, kv_group=g)

@@ -81,6 +81,21 @@ def resblock_chain(x, wstream, nunits, bias, out, *, nbatch, t, c, taps, slope=0
     return out
 
 
+def resblock_level(x, blocks, out, *, nbatch, t, c, slope=0.1, scale=1.0, accumulate=False, prof=None):
+    """out = sum_j chain_j(x) * scale (+ out): the residual blocks of one HiFi-GAN level in ONE launch (ifh_resblock_level_bf16,
+    weights stationary in registers), bit-identical to len(blocks) resblock_chain launches with accumulate.
+    blocks = [(taps, wstream, bias), ...] with wstream/bias from w_chain_pack."""
+    d = _lib.LevelDesc()
+    d.x, d.x_bstride = _addr(x), t * c
+    d.c, d.t, d.nbatch, d.nblocks = c, t, nbatch, len(blocks)
+    for j, (taps, ws, bias) in enumerate(blocks):
+        d.taps[j], d.wstream[j], d.bias[j] = taps, _addr(ws), _addr(bias)
+    d.slope, d.out_scale, d.accumulate = slope, scale, int(accumulate)
+    d.out, d.out_bstride, d.debug_prof = _addr(out), t * c, _addr(prof)
+    _lib.check(_lib.lib().ifh_resblock_level_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_resblock_level_bf16')
+    return out
+
+
 def conv_ring256(x, wstream, bias, out, *, nbatch, t, taps, dil=1, pre_slope=1.0, resid=None, scale=1.0, accumulate=False):
     """One 256 -> 256 channel "same" convolution on sequences of t <= 48 rows (ifh_conv_ring256_bf16: two sequences per
     workgroup, weights DMA'd as fragments from w_chain_pack([(w, b)], unit_bytes=16384)); same bits as conv()."""

@@ -722,6 +722,58 @@ def test_resblock_chain_is_bit_identical_to_three_pairs(dev, case):
             float(diff.max()), bad.size(0), bad[:6].tolist()))
 
 
+def _torch_resblock(x, convs, slope=0.1):
+    """fp32 torch HifiGanResidualBlock.forward (transformers modeling_speecht5.py) on [B, T, C] with convs = 6 x (w, b)"""
+    y = x.transpose(1, 2)
+    for di, d in enumerate((1, 3, 5)):
+        (w1, b1), (w2, b2) = convs[2 * di], convs[2 * di + 1]
+        k = w1.size(2)
+        h = F.conv1d(F.leaky_relu(y, slope), w1, b1, padding=(k - 1) // 2 * d, dilation=d)
+        h = F.conv1d(F.leaky_relu(h, slope), w2, b2, padding=(k - 1) // 2)
+        y = y + h
+    return y.transpose(1, 2)
+
+
+@pytest.mark.parametrize('case', [
+    dict(B=3, T=3072, taps=(3, 7, 11)), dict(B=2, T=1000, taps=(3, 7, 11)), dict(B=5, T=48, taps=(3, 7, 11)), dict(B=2, T=777, taps=(11,)),
+    dict(B=3, T=769, taps=(7,), acc=True), dict(B=2, T=1536, taps=(3,)), dict(B=300, T=768, taps=(3, 7, 11), acc=True),
+    dict(B=2, T=3072, taps=(11,), acc=True),
+])
+def test_resblock_level_is_bit_identical_to_chain_launches(dev, case):
+    """ifh_resblock_level_bf16 (csrc/level.hip: weights stationary in registers, row-block-major, epilogues under the next row
+    block's MFMAs, every block of the level in one launch) against one ifh_resblock_chain_bf16 launch per block with
+    `accumulate` -- same k order and rounding points, so the same bits -- at whole-tile, ragged, multi-tile and tiny sequences;
+    and directly against fp32 torch (the mean over the blocks as SpeechT5HifiGan.forward takes it)."""
+    from infernos_amd import ops
+    B, T, taps, acc0 = case['B'], case['T'], case['taps'], case.get('acc', False)
+    c = 32
+    g = torch.Generator().manual_seed(B * 13 + T + sum(taps))
+    x = bfr(torch.randn(B, T, c, generator=g))
+    prev = bfr(torch.randn(B, T, c, generator=g))
+    blocks, convs_all = [], []
+    for k in taps:
+        convs = [(bfr(torch.randn(c, c, k, generator=g) / (c * k) ** 0.5), torch.randn(c, generator=g) * 0.1) for _ in range(6)]
+        ws, nu, bias = ops.w_chain_pack(convs, dev)
+        blocks.append((k, ws, nu, bias))
+        convs_all.append(convs)
+    xd = x.to(dev, BF)
+    ref = prev.to(dev, BF).clone()
+    for j, (k, ws, nu, bias) in enumerate(blocks):
+        ops.resblock_chain(xd, ws, nu, bias, ref, nbatch=B, t=T, c=c, taps=k, scale=1 / 3, accumulate=(j > 0 or acc0))
+    out = prev.to(dev, BF).clone()
+    ops.resblock_level(xd, [(k, ws, bias) for k, ws, nu, bias in blocks], out, nbatch=B, t=T, c=c, scale=1 / 3, accumulate=acc0)
+    torch.cuda.synchronize()
+    if not torch.equal(out.view(torch.int16), ref.view(torch.int16)):
+        diff = (out.float() - ref.float()).abs()
+        bad = torch.nonzero(diff.amax(dim=2) > 0)
+        raise AssertionError('level differs from chain launches: max abs %g at %d rows, first (batch,row) %s' % (
+            float(diff.max()), bad.size(0), bad[:8].tolist()))
+    if B <= 8:
+        want = sum(_torch_resblock(x, cv) for cv in convs_all) / 3 + (prev if acc0 else 0)
+        e = rel_l2(out.float().cpu(), want)
+        assert e < 1.5e-2, (case, e)            # six bf16 roundings of the stream per block, three blocks
+
+
 @pytest.mark.parametrize('case', [
     dict(B=4, T=48, k=3, d=1), dict(B=5, T=48, k=7, d=3, resid=True), dict(B=7, T=48, k=11, d=5, resid=True, scale=1 / 3, acc=True),
     dict(B=1, T=48, k=11, d=1), dict(B=3, T=37, k=7, d=5, resid=True), dict(B=600, T=48, k=11, d=3, resid=True),
