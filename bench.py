@@ -283,6 +283,74 @@ def c5_share(dev, args, build, n_sessions=64, prompt_len=192, first_sentence=16,
     return res
 
 
+def tts_harness(dev, n_sessions=50, tokens=64, max_rows=256):
+    """The reference's own TTS measurement (HelloSippyTTSRT/HelloSippyRTPipeTest.py:201-208, 226-235): 50 sessions each
+    `say` one prompt at once through the worker (here InfernTTSWorker(continuous=True) behind TTSSession, as the SIP side drives it);
+    per session  time_to_first_frame = first audio chunk delivered - request made,  time_to_last_frame likewise, and
+    rtr = (time_to_last_frame - time_to_first_frame) / (number_of_frames / 8000)  (< 1 = faster than real time).  Prompts are token
+    ids (no tokenizer offline), T_text = 64, seeded weights whose stop head is held off (stop_bias -20: the maxlen arm ends the
+    utterance after 640 decoder steps = 10.2 s of speech)."""
+    from infernos_amd.audio import AudioChunk
+    from infernos_amd.muxer import ASMarkerNewSent
+    from infernos_amd.tts import InfernTTSWorker, TTSRequest, TTSSession
+    from infernos_amd.weights import synth_state_dict
+
+    class IdsProcessor:
+        def __call__(self, text, return_tensors='pt'):
+            return {'input_ids': torch.tensor([[int(t) for t in text.split()]], dtype=torch.long)}
+    W = {'speecht5_tts': synth_state_dict('speecht5_tts', 0, stop_bias=-20.0), 'hifigan': synth_state_dict('hifigan', 0),
+         'amendment': synth_state_dict('amendment', 0)}
+    g = torch.Generator().manual_seed(7)
+    voices = [torch.randn(1, 512, generator=g) for _ in range(8)]
+    w = InfernTTSWorker('en', 8000, dev, weights=W, processor=IdsProcessor(), speaker_embeddings=voices, continuous=True,
+                        max_rows=max_rows, max_text=tokens)
+    w.max_batch_size = n_sessions
+    w.start()
+    res = {}
+    try:
+        for rnd in range(2):                              # round 0 loads the kernels and captures the graphs; round 1 is reported
+            done = threading.Event()
+            stat = [dict(first=None, last=None, frames=0) for _ in range(n_sessions)]
+            left = [n_sessions]
+            lock = threading.Lock()
+
+            def so(i, t0):
+                def f(chunk):
+                    now = time.perf_counter() - t0[0]
+                    st = stat[i]
+                    if isinstance(chunk, AudioChunk):
+                        if st['first'] is None:
+                            st['first'] = now
+                        st['frames'] += int(chunk.audio.numel())
+                    elif isinstance(chunk, ASMarkerNewSent):
+                        st['last'] = now
+                        with lock:
+                            left[0] -= 1
+                            if left[0] == 0:
+                                done.set()
+                return f
+            sess, t0 = [TTSSession(w, None) for _ in range(n_sessions)], [0.0]
+            for i, s_ in enumerate(sess):
+                s_.start(so(i, t0))
+            prompts = [' '.join(str(int(v)) for v in torch.randint(4, 80, (tokens,), generator=g)) for _ in range(n_sessions)]
+            t0[0] = time.perf_counter()
+            for i, s_ in enumerate(sess):
+                s_.say(TTSRequest(prompts[i], speaker_id=i % 8))
+            if not done.wait(600):
+                raise RuntimeError('tts_harness: sessions did not finish')
+            ttff = np.array([st['first'] for st in stat]) * 1e3
+            rtr = np.array([(st['last'] - st['first']) / (st['frames'] / 8000.0) for st in stat])
+            res = {'definition': 'HelloSippyTTSRT/HelloSippyRTPipeTest.py:201-208,226-235: per session time_to_first_frame and '
+                                 'rtr = (t_last - t_first) / (frames / 8000), all sessions speaking at once',
+                   'sessions': n_sessions, 'text_tokens': tokens, 'speech_seconds_per_session': round(float(np.mean([st['frames'] for st in stat])) / 8000.0, 2),
+                   'time_to_first_frame_ms': {'p50': round(float(np.percentile(ttff, 50)), 1), 'p99': round(float(np.percentile(ttff, 99)), 1)},
+                   'rtr': {'p50': round(float(np.percentile(rtr, 50)), 4), 'p99': round(float(np.percentile(rtr, 99)), 4)},
+                   'engine': 'InfernTTSWorker(continuous=True) behind TTSSession; one ragged decode batch of %d rows' % n_sessions}
+    finally:
+        w.stop()
+    return res
+
+
 def self_launch(ngpus):
     """`python bench.py --gpus N` without a launcher: one rank per GPU through torch.distributed.run on 127.0.0.1 and a
     free port.  stdout of the ranks is passed through (rank 0 prints the one JSON line), stderr too."""
@@ -326,8 +394,12 @@ def main():
                     'engine (ctranslate2 defaults, InfernSTTWorker.py:61-75; transformers formulation of the search, ctranslate2 '
                     'parity unpinned); 1 = greedy (its torch engine)')
     ap.add_argument('--c5-only', action='store_true', help='run only the configuration-5 per-GPU share (STT -> LLM -> TTS turn latency) and print it')
+    ap.add_argument('--tts-harness-only', action='store_true', help='run only the reference\'s own TTS measurement (50 sessions: time to first frame, rtr) and print it')
     ap.add_argument('--c5-sessions', type=int, default=64)
     ap.add_argument('--c5-llm', default='qwen2_1p5b', help='infernos_amd.weights.QWEN2_CONFIGS entry (random weights of that shape)')
+    ap.add_argument('--cu-reserve', type=int, default=int(os.environ.get('IFH_CU_RESERVE', '0')),
+                    help='CUs the persistent (one workgroup per CU) vocoder kernels leave free, so that the per-tick kernels always find a CU '
+                         '(ifh_set_cu_budget); 0 = none')
     ap.add_argument('--no-pipeline', action='store_true', help='run the stages of consecutive cycles strictly one after another')
     args = ap.parse_args()
 
@@ -372,6 +444,9 @@ def main():
     from infernos_amd.shard import gather_rows, scatter_frames
     from infernos_amd.codecs import G711Codec
 
+    if args.cu_reserve > 0:
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        _lib.check(_lib.lib().ifh_set_cu_budget(max(8, ncu - args.cu_reserve)), 'ifh_set_cu_budget')
     codec = G711Codec().to(dev)
 
     def enc(x):
@@ -399,6 +474,10 @@ def main():
         pipe.prime(frames_for(0))
         return pipe, frames_all, frames_for, egress, last
 
+    if args.tts_harness_only:
+        if rank == 0:
+            print(json.dumps({'tts_harness': tts_harness(dev)}))
+        return
     if args.c5_only:
         if rank == 0:
             print(json.dumps({'C5_share': c5_share(dev, args, build, n_sessions=args.c5_sessions, llm_family=args.c5_llm,
@@ -562,6 +641,8 @@ def main():
                            'stt_decode': 'greedy' if (beam or args.stt_beam) == 1 else '%d beams' % (beam or args.stt_beam)}
         d5 = child(['--c5-only', '--steps', '5', '--stt-beam', str(args.stt_beam)])
         extra['C5_share'] = d5.get('C5_share', d5)
+        dh = child(['--tts-harness-only'])
+        extra['tts_harness'] = dh.get('tts_harness', dh)
         out['other_configs'] = extra
     elif rank == 0:
         pipe.close()

@@ -316,5 +316,7 @@ __device__ __forceinline__ void ln_epi4(const IgemmParams &p, int m, int n, bool
 // conv.hip: LDS-resident-input convolution for the stride-1 residual-block shapes.
 // Returns true if it took the launch.
 bool try_launch_conv_direct(const IgemmParams &p, bool pre, hipStream_t st);
+// gemm_big.hip: DMA-ring matrix product for thousands of rows x whole 256 x 128 tiles.  Returns true if it took the launch.
+bool try_launch_gemm_big(const IgemmParams &p, bool pre, hipStream_t st);
 
 }  // namespace ifh

@@ -1152,6 +1152,8 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
             hipLaunchKernelGGL((k_gemm_skinny<4, 12, 1>), grid, dim3(256), 0, st, p);
         else
             hipLaunchKernelGGL((k_gemm_skinny<2, 12, 1>), grid, dim3(128), 0, st, p);
+    } else if (try_launch_gemm_big(p, pre, st)) {
+        // thousands of rows x whole 256 x 128 tiles: DMA ring, two workgroups per CU (gemm_big.hip)
     } else if (try_launch_conv_direct(p, pre, st)) {
         // residual-block shapes: input tile resident in LDS (conv.hip)
     } else if (d->n <= 32)

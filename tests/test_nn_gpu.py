@@ -503,6 +503,33 @@ def test_igemm_plain_tile_loads_match_torch(dev, M, N, K, act, resid):
         assert torch.equal(small.view(torch.int16), out[rows.to(dev)].contiguous().view(torch.int16)), 'K-tile width changed the bits'
 
 
+@pytest.mark.parametrize('M,N,K,act,resid', [(4096, 256, 64, 0, False), (8192, 512, 512, 2, False), (24576, 1536, 512, 0, False),
+                                             (12288, 512, 2048, 0, True), (8192, 768, 768, 1, True), (131072, 256, 96, 0, False)])
+def test_gemm_big_matches_torch_and_the_igemm_bits(dev, M, N, K, act, resid):
+    """k_gemm_big (csrc/gemm_big.hip: 256 x 128 tiles of four waves, operands by DMA into a three-stage ring, two workgroups per
+    CU) takes the matrix products with >= 4096 rows and whole tiles.  Against fp32 torch; and bit for bit against k_igemm, which
+    still takes the same product when four more columns are appended to w (N no multiple of 256): same k order, same epilogue."""
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = bfr(torch.randn(M, K, generator=g))
+    w = bfr(torch.randn(N + 4, K, generator=g) / K ** 0.5)
+    b = torch.randn(N + 4, generator=g) * 0.1
+    r = bfr(torch.randn(M, N + 4, generator=g)) if resid else None
+    xd, wd, bd = x.to(dev, BF), w.to(dev, BF), b.to(dev)
+    rd = r.to(dev, BF) if resid else None
+    out = torch.zeros(M, N, dtype=BF, device=dev)
+    ops.linear(xd, wd[:N], bd[:N], out, rows=M, k=K, n=N, act=act, resid=None if rd is None else rd[:, :N].contiguous())
+    ref = x @ w[:N].t() + b[:N]
+    ref = F.gelu(ref) if act == 2 else (F.relu(ref) if act == 1 else ref)
+    if resid:
+        ref = ref + r[:, :N]
+    e = rel_l2(out.float().cpu(), ref)
+    assert e < 4e-3, (M, N, K, e)
+    wide = torch.zeros(M, N + 4, dtype=BF, device=dev)
+    ops.linear(xd, wd, bd, wide, rows=M, k=K, n=N + 4, act=act, resid=rd)
+    assert torch.equal(out.view(torch.int16), wide[:, :N].contiguous().view(torch.int16)), (M, N, K)
+
+
 def test_cu_range_stream_runs_kernels(dev):
     """ifh_stream_create_cu_range (include/infernos_hip.h): a stream confined to a CU range computes what an ordinary one does,
     and the persistent kernels follow ifh_set_cu_budget (a chain launch sized to 64 CUs on a 64-CU stream: same bits)."""
