@@ -397,9 +397,9 @@ def main():
     ap.add_argument('--tts-harness-only', action='store_true', help='run only the reference\'s own TTS measurement (50 sessions: time to first frame, rtr) and print it')
     ap.add_argument('--c5-sessions', type=int, default=64)
     ap.add_argument('--c5-llm', default='qwen2_1p5b', help='infernos_amd.weights.QWEN2_CONFIGS entry (random weights of that shape)')
-    ap.add_argument('--cu-reserve', type=int, default=int(os.environ.get('IFH_CU_RESERVE', '0')),
-                    help='CUs the persistent (one workgroup per CU) vocoder kernels leave free, so that the per-tick kernels always find a CU '
-                         '(ifh_set_cu_budget); 0 = none')
+    ap.add_argument('--cu-reserve', type=int, default=None,
+                    help='CUs the persistent (one workgroup per CU) vocoder kernels leave to the decode chains and the per-tick kernels '
+                         '(SpeechPipeline.cu_reserve, default 96 / IFH_CU_RESERVE; 0 = none)')
     ap.add_argument('--no-pipeline', action='store_true', help='run the stages of consecutive cycles strictly one after another')
     args = ap.parse_args()
 
@@ -444,9 +444,6 @@ def main():
     from infernos_amd.shard import gather_rows, scatter_frames
     from infernos_amd.codecs import G711Codec
 
-    if args.cu_reserve > 0:
-        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
-        _lib.check(_lib.lib().ifh_set_cu_budget(max(8, ncu - args.cu_reserve)), 'ifh_set_cu_budget')
     codec = G711Codec().to(dev)
 
     def enc(x):
@@ -456,7 +453,7 @@ def main():
         _, family, _ = CONFIGS[cfg]
         pipe = SpeechPipeline(n_local, dev, whisper_family=family, tts_lanes=args.tts_lanes, tts_overlap=not args.no_tts_overlap,
                               tts_group=args.tts_group, front_lanes=args.front_lanes, stt_beam=args.stt_beam if beam is None else beam,
-                              tts_mode=args.tts_mode)
+                              tts_mode=args.tts_mode, cu_reserve=args.cu_reserve)
         n_total = n_local * world
         # every rank builds its own rows for the N=1 path; with N>1 rank 0 holds all rows and scatters
         if world == 1:
@@ -543,6 +540,9 @@ def main():
         if engine is not None and engine[0]:
             tts_rows = max(tts_rows, int(round(engine[1] / engine[0] / tts_rows)) * tts_rows)
         nchunks = 4 * tts_rows
+        # the kernel rooflines are taken on the WHOLE chip (in the timed region the vocoder ran on 256 - cu_reserve CUs by choice)
+        vocoder_cus = torch.cuda.get_device_properties(dev).multi_processor_count - pipe.cu_reserve
+        _lib.check(_lib.lib().ifh_set_cu_budget(0), 'ifh_set_cu_budget')
         voc_in = torch.randn(nchunks, 12, 80, device=dev).to(torch.bfloat16)
         t_voc = ev_time(lambda: pipe.tts.vocoder(voc_in), n=5)
         ach_tf = nchunks * VOCODER_GFLOP_PER_CHUNK / t_voc / 1e3
@@ -573,6 +573,7 @@ def main():
                        'parallelism': 'calls sharded %d/GPU, models replicated; RCCL scatter/gather of frames/output' % n_local,
                        'batching': 'across calls only (one utterance per call per batch)' if args.tts_group == 1 else
                                    'OFFLINE mode: %d consecutive utterances of the same calls per TTS batch' % args.tts_group,
+                       'vocoder_cus_in_timed_region': vocoder_cus,
                        'stage_pipelining': not args.no_pipeline, 'front_lanes': args.front_lanes, 'tts_lanes': args.tts_lanes,
                        'tts_rows_per_batch': n_local * args.tts_group, 'tts_mode': args.tts_mode,
                        'tts_rows_per_decode_step': (round(engine[1] / engine[0], 1) if engine is not None and engine[0] else

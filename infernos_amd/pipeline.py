@@ -82,13 +82,23 @@ class BatchedVAD:
 class SpeechPipeline:
     def __init__(self, ncalls: int, device=None, whisper_family='whisper_tiny', seed=0, n_text=64, n_infer=10,
                  n_new_tokens=32, tts_output_sr=8000, weights=None, tts_lanes=2, tts_overlap=True, tts_group=1,
-                 front_lanes=1, stt_beam=1, tts_mode='lanes'):
+                 front_lanes=1, stt_beam=1, tts_mode='lanes', cu_reserve=None):
         from .engines.whisper import Whisper
         from .features import WhisperLogMel
         from .tts import HelloSippyRTPipe
         from .weights import synth_state_dict
         self.device = dev = _lib.require_device(device)
         self.n, self.n_text, self.n_infer, self.n_new = ncalls, n_text, n_infer, n_new_tokens
+        # The persistent vocoder kernels (one workgroup per CU holding all of its LDS for 0.4-1.4 ms: chain.hip, level.hip) leave
+        # `cu_reserve` CUs alone: the decode chains (a TTS step, a Whisper token) are latency-bound sequences of small launches that
+        # otherwise wait for a CU with free LDS until a vocoder workgroup ends.  The renderer only has to keep up with the decoder
+        # (2.7 ms of vocoder per 12 ms of decoder steps), so it does not need the whole chip: C3 +3-4 %, TTS stage alone -8 %
+        # (IFH_CU_RESERVE; 0 = off).  Process-wide (ifh_set_cu_budget).
+        if cu_reserve is None:
+            cu_reserve = int(os.environ.get('IFH_CU_RESERVE', '96'))
+        self.cu_reserve = max(0, cu_reserve)
+        ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        _lib.check(_lib.lib().ifh_set_cu_budget(max(32, ncu - self.cu_reserve) if self.cu_reserve else 0), 'ifh_set_cu_budget')
         self.tts_overlap = tts_overlap      # render of chunk c on a second stream while chunk c+1 decodes (within a lane)
         self.tts_group = max(1, tts_group)  # utterance cycles synthesised as one TTS batch (rows = group * ncalls)
         self.block_ingest = os.environ.get('IFH_TICK_INGEST') is None
