@@ -385,8 +385,8 @@ def main():
     ap.add_argument('--tts-mode', choices=['continuous', 'lanes'], default='continuous',
                     help='continuous: ONE ragged TTS decode batch over every utterance batch in flight (rows at different decoder '
                          'positions, joined at infer() boundaries); lanes: one engine clone and launch chain per batch (round 2)')
-    ap.add_argument('--tts-lanes', type=int, default=3, help='utterance batches that may be in flight in the TTS stage together')
-    ap.add_argument('--front-lanes', type=int, default=3, help='ingest+STT lanes (cycles k, k+1, k+2 in flight together)')
+    ap.add_argument('--tts-lanes', type=int, default=5, help='utterance batches that may be in flight in the TTS stage together')
+    ap.add_argument('--front-lanes', type=int, default=4, help='ingest+STT lanes (cycles k, k+1, k+2 in flight together)')
     ap.add_argument('--tts-group', type=int, default=1, help='utterance cycles of the SAME calls synthesised as one TTS batch '
                     '(> 1 is an offline-throughput mode: a live call cannot have utterance k+1 before k has been spoken)')
     ap.add_argument('--no-tts-overlap', action='store_true', help='render on the lane stream instead of a second stream per lane')

@@ -98,7 +98,8 @@ class SpeechPipeline:
             cu_reserve = int(os.environ.get('IFH_CU_RESERVE', '96'))
         self.cu_reserve = max(0, cu_reserve)
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
-        _lib.check(_lib.lib().ifh_set_cu_budget(max(32, ncu - self.cu_reserve) if self.cu_reserve else 0), 'ifh_set_cu_budget')
+        if int(os.environ.get('IFH_BIG_CUS', '0')) <= 0:          # (that switch masks the throughput streams and sets the budget itself)
+            _lib.check(_lib.lib().ifh_set_cu_budget(max(32, ncu - self.cu_reserve) if self.cu_reserve else 0), 'ifh_set_cu_budget')
         self.tts_overlap = tts_overlap      # render of chunk c on a second stream while chunk c+1 decodes (within a lane)
         self.tts_group = max(1, tts_group)  # utterance cycles synthesised as one TTS batch (rows = group * ncalls)
         self.block_ingest = os.environ.get('IFH_TICK_INGEST') is None

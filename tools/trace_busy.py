@@ -44,13 +44,17 @@ for t, d in ev:
     last, lvl = t, lvl + d
 tt = sum(hist.values())
 print('kernels resident: ' + '  '.join('%s: %.1f %%' % (('%d' % k) if k < 4 else '4+', 100 * hist[k] / tt) for k in sorted(hist)))
-by = collections.defaultdict(lambda: [0, 0])
+by = collections.defaultdict(lambda: [0, 0, []])
 qs = collections.Counter()
 for s, e, k, q in rows:
     qs[q] += e - s
     by[k][0] += e - s
     by[k][1] += 1
-for k, (d, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:28]:
-    print('%6.1f ms %5.1f %% %7d x %7.1f us  %s' % (d * 1e-6, 100 * d / tot, n, d / n * 1e-3, k))
+    by[k][2].append(e - s)
+print('   total      share    launches   average   median      p99      max   kernel')
+for k, (d, n, ds) in sorted(by.items(), key=lambda kv: -kv[1][0])[:28]:
+    ds.sort()
+    print('%6.1f ms %5.1f %% %7d x %7.1f us %7.1f %8.1f %8.1f  %s' % (d * 1e-6, 100 * d / tot, n, d / n * 1e-3, ds[len(ds) // 2] * 1e-3,
+                                                                ds[min(len(ds) - 1, int(len(ds) * 0.99))] * 1e-3, ds[-1] * 1e-3, k))
 print('columns:', cols)
 print('busy per queue (ms):', {q: round(v * 1e-6, 1) for q, v in qs.most_common()})
