@@ -146,13 +146,29 @@ class SpeechPipeline:
         self.speakers = torch.randn(ncalls, 512, generator=g)
         self.text_ids = torch.randint(4, 80, (ncalls, n_text), generator=g, dtype=torch.int32)
         self._lane_streams = [torch.cuda.Stream(device=dev) for _ in self.tts_lanes]
-        self._side_streams = [torch.cuda.Stream(device=dev) for _ in self.tts_lanes]
-        self._side_stream = self._side_streams[0]
+        # (render streams of the lane schedule only: every stream created takes a slot in the round-robin over the hardware queues)
+        self._side_streams = [torch.cuda.Stream(device=dev) for _ in self.tts_lanes] if tts_mode == 'lanes' else None
+        self._side_stream = self._side_streams[0] if self._side_streams else None
         self.pcm8k = torch.empty((ncalls, 160), dtype=torch.float32, device=dev)
         self.pcm16k = torch.empty((ncalls, 320), dtype=torch.float32, device=dev)
         # front-end lanes: lane 0 is this object's own call table / VAD / Whisper buffers; further lanes are private
         # copies over the same weights, so that ingest+STT of consecutive cycles can overlap too (run_steps)
         self.front_lanes = [_FrontLane(self, first=True)] + [_FrontLane(self) for _ in range(max(1, front_lanes) - 1)]
+        # In continuous mode the lanes' submit work (SpeechT5 text encoder, cross K|V: ~1 ms per batch) shares ONE stream.
+        if tts_mode == 'continuous' and os.environ.get('IFH_ONE_SUBMIT_STREAM', '1') != '0':
+            self._lane_streams = [self._lane_streams[0]] * len(self._lane_streams)
+        # The process's streams are dealt over four hardware queues when they are first used; first use from several threads made
+        # the dealing -- and with it the cycle time, 109 or 118 ms -- a matter of thread timing.  Every stream is used once here, in
+        # a fixed order (IFH_STREAM_ORDER: F = front lanes, M / S = TTS decode / render, L = submit), from this thread.
+        order = os.environ.get('IFH_STREAM_ORDER', 'S,F,L,M')
+        named = {'F': [fl.stream for fl in self.front_lanes], 'L': list(dict.fromkeys(self._lane_streams)),
+                 'M': [e.main for e in getattr(self, 'ctts_all', [])], 'S': [e.side for e in getattr(self, 'ctts_all', [])]}
+        scratch = torch.zeros(64, device=dev)
+        for key in [k.strip() for k in order.split(',') if k.strip()]:
+            for st_ in named.get(key, []):
+                with torch.cuda.stream(st_):
+                    scratch.add_(1.0)
+                st_.synchronize()
 
     # ---- stage 1 -----------------------------------------------------------------------------
     def ingest(self, frames: torch.Tensor, fl=None, block=None):
@@ -273,7 +289,7 @@ class SpeechPipeline:
         valid = torch.zeros(nb, dtype=torch.int64)
         spans = []
         main = torch.cuda.current_stream(dev)
-        side = self._side_streams[lane] if overlap else main
+        side = self._side_streams[lane] if (overlap and self._side_streams) else main
         out.record_stream(side)                 # written on the render stream: the allocator must not recycle it early
         ren_done = [None, None]
         for c in range(self.n_infer):
@@ -516,7 +532,8 @@ class _FrontLane:
         self.lock = threading.Lock()                       # one cycle at a time per lane
         with torch.cuda.device(dev):
             self.stream = _lib.throughput_stream(dev)        # log-mel, encoder, cross K|V, prompt prefill
-            self.dec_stream = torch.cuda.Stream(device=dev, priority=-1)
+            # (created only when used: every stream takes a slot in the round-robin over the four hardware queues)
+            self.dec_stream = torch.cuda.Stream(device=dev, priority=-1) if pipe.stt_dec_prio else None
             if first:
                 self.calls, self.vad, self.whisper, self.logmel = pipe.calls, pipe.vad, pipe.whisper, pipe.logmel
                 self.pcm8k, self.pcm16k = pipe.pcm8k, pipe.pcm16k
