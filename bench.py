@@ -211,6 +211,7 @@ def time_steps(pipe, frames_for, nsteps, warmup, world, pipelined, egress, dry, 
         torch.cuda.synchronize()
     c0 = _lib.CALLS[0]
     e0 = (sum(e.calls_run for e in pipe.ctts_all), sum(e.rows_run for e in pipe.ctts_all)) if pipe.ctts is not None else None
+    p0 = [dict(e.prof) for e in pipe.ctts_all] if pipe.ctts is not None else []
     t0 = time.perf_counter()
     res = pipe.run_steps(frames_for, nsteps, pipelined=pipelined, on_cycle=egress)
     torch.cuda.synchronize()
@@ -221,6 +222,7 @@ def time_steps(pipe, frames_for, nsteps, warmup, world, pipelined, egress, dry, 
         torch.cuda._sleep(1000)
         torch.cuda.synchronize()
     time_steps.launches_per_step = (_lib.CALLS[0] - c0) / max(1, nsteps)
+    time_steps.engine_prof = None if e0 is None else {k: round(sum(e.prof.get(k, 0.0) - q.get(k, 0.0) for e, q in zip(pipe.ctts_all, p0)), 4) for k in ('admit', 'steps', 'render', 'ends_wait', 'book')}
     time_steps.engine = None if e0 is None else (sum(e.calls_run for e in pipe.ctts_all) - e0[0], sum(e.rows_run for e in pipe.ctts_all) - e0[1])
     if probe is not None:
         probe.stop()
@@ -586,6 +588,7 @@ def main():
             'launches_note': 'calls into stream-taking C-ABI entry points per utterance cycle inside the timed region, hipGraph replays '
                              'counted by the launches they hold (infernos_amd/_lib.py:CALLS)',
             'sequential_stage_ms': stage_ms,
+            'tts_engine_host_seconds': getattr(time_steps, 'engine_prof', None),
             'stt_audio_seconds_per_call': round(float(res['stt_seconds'].mean()), 3),
             'tts_samples_per_call': int(res['tts_samples'].float().mean()),
             'roofline': {'kernel': 'HiFi-GAN vocoder pass (%d chunks x 12 frames per launch group)' % nchunks,

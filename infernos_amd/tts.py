@@ -306,6 +306,7 @@ class ContinuousTTS:
         self.thread, self.halt = None, False
         self.failed = None                               # the exception that killed the engine thread (submit() then raises)
         self.calls_run = self.rows_run = 0               # statistics: engine calls, sum of row slots they covered
+        self.prof = {}                                   # statistics: host wall seconds of step() by phase
 
     # ---- any thread -----------------------------------------------------------------------------------------------
     def submit(self, input_ids, lens, speakers, max_calls=None, dispatch=None, want_ulaw=False) -> TTSGroup:
@@ -381,10 +382,14 @@ class ContinuousTTS:
     def step(self) -> bool:
         """One infer() call over every live row.  Returns False when nothing is live or pending."""
         pp, st, dev = self.pp, self.st, self.device
+        import time as _time
+        prof = self.prof
+        t_a = _time.perf_counter()
         with torch.cuda.device(dev), torch.cuda.stream(self.main):
             self._admit()
             if not self.live:
                 return False
+            t_b = _time.perf_counter()
             n = self._bucket()
             par = st.ncalls & 1
             if self.ren_done[par] is not None:
@@ -400,6 +405,7 @@ class ContinuousTTS:
             st.fresh[par].copy_(self.h_fresh[par], non_blocking=True)
             masks = pp.mask_source(16).to(dev).contiguous()
             ragged_decoder_steps(pp.model, st, masks, n, nsteps=16, threshold=pp.threshold, sync_every=self.sync_every)
+            t_c = _time.perf_counter()
             dec_done = torch.cuda.Event()
             dec_done.record(self.main)
             rr = pp.model_sr // pp.output_sr
@@ -431,7 +437,9 @@ class ContinuousTTS:
                 ev = torch.cuda.Event()
                 ev.record(self.side)
                 self.ren_done[par] = ev
+            t_d = _time.perf_counter()
             ends_all = st.ends_at[:n].cpu().numpy()              # waits for this call's decoder steps (the reference's .item())
+            t_e = _time.perf_counter()
         self.calls_run += 1
         self.rows_run += n
         finished = []
@@ -480,6 +488,11 @@ class ContinuousTTS:
                         grp.done_event.record(self.side)
                 grp.ulaw = grp.ulaw[:, :(grp.max_calls or grp.calls) * A]
             grp.done.set()
+        t_f = _time.perf_counter()
+        # host wall seconds of this call by phase: admission, queueing the 16 decoder steps (incl. the bounded-queue waits), queueing
+        # the render pass, waiting for the steps' end flags, per-group bookkeeping / dispatch
+        for k, v in (('admit', t_b - t_a), ('steps', t_c - t_b), ('render', t_d - t_c), ('ends_wait', t_e - t_d), ('book', t_f - t_e)):
+            prof[k] = prof.get(k, 0.0) + v
         return True
 
     def _render(self, par, n):

@@ -10,7 +10,7 @@ for r in csv.DictReader(open(f)):
         cols = list(r.keys())
     name = r['Kernel_Name']
     short = 'MARK spin_kernel' if 'spin_kernel' in name else name.split('(')[0][:70]
-    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), short, r.get('Queue_Id', '?')))
+    rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), short, r.get('Queue_Id', '?'), r.get('Stream_Id', '?')))
 rows.sort()
 marks = [r for r in rows if r[2].startswith('MARK')]
 if len(marks) >= 2:             # bench.py with IFH_TRACE_MARK=1: the timed region lies between the first and the last marker pair
@@ -26,7 +26,7 @@ else:
     rows = [r for r in rows if r[0] >= lo]
 wall = (t1 - lo) * 1e-6
 busy, cur_s, cur_e = 0, None, None
-for s, e, _, _ in rows:
+for s, e, _, _, _ in rows:
     if cur_e is None or s > cur_e:
         if cur_e is not None:
             busy += cur_e - cur_s
@@ -34,10 +34,10 @@ for s, e, _, _ in rows:
     else:
         cur_e = max(cur_e, e)
 busy += cur_e - cur_s
-tot = sum(e - s for s, e, _, _ in rows)
+tot = sum(e - s for s, e, _, _, _ in rows)
 print('window %.1f ms: GPU busy (union) %.1f ms = %.1f %%; sum of kernel durations %.1f ms (x%.2f of busy); %d launches = %.0f / s'
       % (wall, busy * 1e-6, 100 * busy * 1e-6 / wall, tot * 1e-6, tot / busy, len(rows), len(rows) / wall * 1e3))
-ev = sorted([(s_, 1) for s_, e_, _, _ in rows] + [(e_, -1) for s_, e_, _, _ in rows])
+ev = sorted([(s_, 1) for s_, e_, _, _, _ in rows] + [(e_, -1) for s_, e_, _, _, _ in rows])
 lvl, last, hist = 0, ev[0][0], collections.Counter()
 for t, d in ev:
     hist[min(lvl, 4)] += t - last
@@ -46,7 +46,7 @@ tt = sum(hist.values())
 print('kernels resident: ' + '  '.join('%s: %.1f %%' % (('%d' % k) if k < 4 else '4+', 100 * hist[k] / tt) for k in sorted(hist)))
 by = collections.defaultdict(lambda: [0, 0, []])
 qs = collections.Counter()
-for s, e, k, q in rows:
+for s, e, k, q, _sid in rows:
     qs[q] += e - s
     by[k][0] += e - s
     by[k][1] += 1
@@ -58,3 +58,21 @@ for k, (d, n, ds) in sorted(by.items(), key=lambda kv: -kv[1][0])[:28]:
                                                                 ds[min(len(ds) - 1, int(len(ds) * 0.99))] * 1e-3, ds[-1] * 1e-3, k))
 print('columns:', cols)
 print('busy per queue (ms):', {q: round(v * 1e-6, 1) for q, v in qs.most_common()})
+
+# per stream: kernels, busy time, and the gaps between consecutive kernels of the stream (a dependent launch chain's gaps are
+# what the command processor and the wait for CU slots add to it)
+bys = collections.defaultdict(list)
+for s, e, k, q, sid in rows:
+    bys[(q, sid)].append((s, e, k))
+print('per (queue, stream): launches, busy ms, gaps < 200 us: count / mean us / median us / sum ms; top kernels')
+for key, lst in sorted(bys.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[1])):
+    lst.sort()
+    busy_s = sum(e - s for s, e, _ in lst)
+    gaps = [lst[i + 1][0] - lst[i][1] for i in range(len(lst) - 1)]
+    g = sorted(x for x in gaps if 0 <= x < 200000)
+    names = collections.Counter(k for _, _, k in lst).most_common(3)
+    if len(lst) < 50:
+        continue
+    print('  q%s s%s: %6d launches, busy %7.1f ms, gaps %6d / %5.1f / %5.1f / %6.1f ms;  %s' % (
+        key[0], key[1], len(lst), busy_s * 1e-6, len(g), (sum(g) / max(1, len(g))) * 1e-3, (g[len(g) // 2] if g else 0) * 1e-3, sum(g) * 1e-6,
+        ', '.join('%s x%d' % (n[-28:], c) for n, c in names)))
