@@ -644,6 +644,31 @@ int ifh_stream_destroy(ifh_stream_t stream);
  * the device's count; 0 restores the device's count.  Process-wide. */
 int ifh_set_cu_budget(int n);
 
+/* ---- resident decode step (step.hip) ----
+ * One launch per SpeechT5 decoder step (HelloSippyTTSRT/HelloSippyRTPipe.py:196-229 loops 16 of them per infer() call) instead of
+ * the ~55 dependent launches of the step's GEMMs, attentions and stop rule.  The step is RECORDED once: between
+ * ifh_step_record_begin(stat_rows) and ifh_step_record_end() the calling thread's ifh_conv_bf16 / ifh_attn_decode_bf16 /
+ * ifh_tts_stop_advance_rows calls are appended to a phase table instead of being launched (stat_rows = rows per slot of the
+ * LayerNorm statistics array the stop rule clears).  ifh_step_run() then runs the table: row blocks of 32 rows, each walked through
+ * all phases by a cluster of `cw` workgroups that synchronise through an arrival counter of the context (no grid-wide barrier: every
+ * operation of the step is row-local).  Same bits as the launch chain.  A context serves one stream at a time. */
+typedef void *ifh_step_prog_t;
+typedef void *ifh_step_ctx_t;
+int ifh_step_record_begin(int stat_rows);
+int ifh_step_record_abort(void);
+int ifh_step_record_end(ifh_step_prog_t *prog_out, int *nphase_out);
+int ifh_step_prog_destroy(ifh_step_prog_t prog);
+int ifh_step_ctx_create(int max_rows, ifh_step_ctx_t *ctx_out);
+int ifh_step_ctx_destroy(ifh_step_ctx_t ctx);
+/* synchronises the device; *err_out = 1 when a cluster wait ran into its 2 s bound (the clusters were not co-resident: results of
+ * that launch are garbage; the counters are cleared); xcc_out (optional, n_xcc ints) = the XCC id each workgroup of the last
+ * launch with debug_xcc ran on */
+int ifh_step_ctx_status(ifh_step_ctx_t ctx, int *err_out, int *xcc_out, int n_xcc);
+/* debug bit 0: record the XCC ids; bit 1: accumulate cluster 0's per-phase clock ticks (read and cleared by ifh_step_ctx_prof:
+ * out256[2 ph] = 100 MHz ticks spent waiting for the cluster in front of phase ph, out256[2 ph + 1] = in the phase) */
+int ifh_step_run(ifh_step_prog_t prog, ifh_step_ctx_t ctx, int cw, int debug, ifh_stream_t stream);
+int ifh_step_ctx_prof(ifh_step_ctx_t ctx, unsigned long long *out256);
+
 #ifdef __cplusplus
 }
 #endif

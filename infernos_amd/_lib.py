@@ -190,6 +190,15 @@ SIGNATURES.update({
     'ifh_stream_create_cu_range': (_i, [_i, _i, ctypes.POINTER(ctypes.c_void_p)]),
     'ifh_stream_destroy': (_i, [_vp]),
     'ifh_set_cu_budget': (_i, [_i]),
+    'ifh_step_record_begin': (_i, [_i]),
+    'ifh_step_record_abort': (_i, []),
+    'ifh_step_record_end': (_i, [ctypes.POINTER(ctypes.c_void_p), c_i32p]),
+    'ifh_step_prog_destroy': (_i, [_vp]),
+    'ifh_step_ctx_create': (_i, [_i, ctypes.POINTER(ctypes.c_void_p)]),
+    'ifh_step_ctx_destroy': (_i, [_vp]),
+    'ifh_step_ctx_status': (_i, [_vp, c_i32p, c_i32p, _i]),
+    'ifh_step_run': (_i, [_vp, _vp, _i, _i, _vp]),
+    'ifh_step_ctx_prof': (_i, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
 })
 
 _lib = None
@@ -197,7 +206,7 @@ _lock = threading.Lock()
 # Statistic: calls into stream-taking entry points (~ kernel launches issued through the C ABI), including those replayed from
 # captured hipGraphs (CountedGraph); bench.py reports it per utterance cycle.
 CALLS = [0]
-_HOST_ONLY = ('ifh_g711_tables_host',)
+_HOST_ONLY = ('ifh_g711_tables_host', 'ifh_step_prog_destroy', 'ifh_step_ctx_destroy')
 
 
 _tls = threading.local()

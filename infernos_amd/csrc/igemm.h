@@ -111,6 +111,28 @@ __device__ __forceinline__ uint4 lrelu8(uint4 v, float slope)
 }
 
 
+// Output stores of the fused epilogues.  The resident decode step (step.hip) hands a phase's outputs to OTHER workgroups of the same
+// launch, so it compiles these with IFH_EPI_SC1: write-through (sc1) stores, which the consumers read back with sc1 loads after the
+// producers' arrival on the cluster counter (MI355X_MICROARCH.md, inter-workgroup visibility).  Everywhere else: plain stores.
+__device__ __forceinline__ void epi_store8(void *o, uint2 v)
+{
+#ifdef IFH_EPI_SC1
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(o), (unsigned long long)v.x | ((unsigned long long)v.y << 32),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *reinterpret_cast<uint2 *>(o) = v;
+#endif
+}
+__device__ __forceinline__ void epi_store16f(void *o, float4 v)
+{
+#ifdef IFH_EPI_SC1
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o), "v"(t) : "memory");
+#else
+    *reinterpret_cast<float4 *>(o) = v;
+#endif
+}
+
 // ---- fused epilogue for 4 consecutive output channels n..n+3 of output row m.
 // Two forms: the vector form (16-byte bias load, 8-byte residual load, 8/16-byte store) is inlined
 // into the kernels' unrolled accumulator loops and must stay SMALL -- when it grew, hipcc stopped
@@ -182,7 +204,7 @@ __device__ __forceinline__ uint2 igemm_store4_fast(const IgemmParams &p, int m, 
             const float4 prev = *reinterpret_cast<const float4 *>(o);
             v0 += prev.x; v1 += prev.y; v2 += prev.z; v3 += prev.w;
         }
-        *reinterpret_cast<float4 *>(o) = make_float4(v0, v1, v2, v3);
+        epi_store16f(o, make_float4(v0, v1, v2, v3));
         return make_uint2(0, 0);
     }
     uint16_t *o = reinterpret_cast<uint16_t *>(e.outp) + e.obase + n;
@@ -196,7 +218,7 @@ __device__ __forceinline__ uint2 igemm_store4_fast(const IgemmParams &p, int m, 
     uint2 pk;
     pk.x = f32x2_to_bf16x2(v0, v1);
     pk.y = f32x2_to_bf16x2(v2, v3);
-    if (STORE) *reinterpret_cast<uint2 *>(o) = pk;
+    if (STORE) epi_store8(o, pk);
     return pk;
 }
 
@@ -290,12 +312,12 @@ __device__ __forceinline__ void ln_epi4(const IgemmParams &p, int m, int n, bool
         }
         v0 *= p.out_scale; v1 *= p.out_scale; v2 *= p.out_scale; v3 *= p.out_scale;
         if (p.out_f32) {
-            *reinterpret_cast<float4 *>(reinterpret_cast<float *>(er.outp) + er.obase + n) = make_float4(v0, v1, v2, v3);
+            epi_store16f(reinterpret_cast<float *>(er.outp) + er.obase + n, make_float4(v0, v1, v2, v3));
         } else {
             uint2 pk;
             pk.x = f32x2_to_bf16x2(v0, v1);
             pk.y = f32x2_to_bf16x2(v2, v3);
-            *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(er.outp) + er.obase + n) = pk;
+            epi_store8(reinterpret_cast<uint16_t *>(er.outp) + er.obase + n, pk);
             v0 = __uint_as_float(pk.x << 16); v1 = __uint_as_float(pk.x & 0xffff0000u);   // what consumers will read
             v2 = __uint_as_float(pk.y << 16); v3 = __uint_as_float(pk.y & 0xffff0000u);
         }
@@ -312,6 +334,9 @@ __device__ __forceinline__ void ln_epi4(const IgemmParams &p, int m, int n, bool
         }
     }
 }
+
+// step.hip (see common.h: step_recording): a decode-step GEMM is appended to the phase table being recorded
+int step_record_gemm(const IgemmParams &p);
 
 // conv.hip: LDS-resident-input convolution for the stride-1 residual-block shapes.
 // Returns true if it took the launch.

@@ -1059,6 +1059,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     const int64_t M = (int64_t)d->nbatch * d->t_out;
     IFH_CHECK_ARG(M < (1ll << 31));
     hipStream_t st = as_stream(stream);
+    if (step_recording()) return step_record_gemm(p);        // resident decode step (step.hip): a phase, not a launch
     const bool ln_fold = d->aln_stats || d->rln_stats || d->stats_out;
     const bool aln_only = d->aln_stats && !d->rln_stats && !d->stats_out;     // k_gemm_m64 can consume row statistics, not produce them
     const bool glu = d->act == IFH_ACT_SILU_GLU;
