@@ -650,8 +650,8 @@ int ifh_set_cu_budget(int n);
  * ifh_step_record_begin(stat_rows) and ifh_step_record_end() the calling thread's ifh_conv_bf16 / ifh_attn_decode_bf16 /
  * ifh_tts_stop_advance_rows calls are appended to a phase table instead of being launched (stat_rows = rows per slot of the
  * LayerNorm statistics array the stop rule clears).  ifh_step_run() then runs the table: row blocks of 32 rows, each walked through
- * all phases by a cluster of `cw` workgroups that synchronise through an arrival counter of the context (no grid-wide barrier: every
- * operation of the step is row-local).  Same bits as the launch chain.  A context serves one stream at a time. */
+ * all phases by a cluster of `cw` workgroups that synchronise through arrival flags of the context (no grid-wide barrier: every
+ * operation of the step is row-local).  Same bits as the launch chain.  A context serves one decode state on one stream. */
 typedef void *ifh_step_prog_t;
 typedef void *ifh_step_ctx_t;
 int ifh_step_record_begin(int stat_rows);
@@ -664,8 +664,9 @@ int ifh_step_ctx_destroy(ifh_step_ctx_t ctx);
  * that launch are garbage; the counters are cleared); xcc_out (optional, n_xcc ints) = the XCC id each workgroup of the last
  * launch with debug_xcc ran on */
 int ifh_step_ctx_status(ifh_step_ctx_t ctx, int *err_out, int *xcc_out, int n_xcc);
-/* debug bit 0: record the XCC ids; bit 1: accumulate cluster 0's per-phase clock ticks (read and cleared by ifh_step_ctx_prof:
- * out256[2 ph] = 100 MHz ticks spent waiting for the cluster in front of phase ph, out256[2 ph + 1] = in the phase) */
+/* cw = workgroups per cluster (1..32).  debug bit 0: record the XCC ids; bit 1: accumulate cluster 0's per-phase clock ticks (read
+ * and cleared by ifh_step_ctx_prof: out256[2 ph] = 100 MHz ticks spent waiting for the cluster in front of phase ph,
+ * out256[2 ph + 1] = in the phase); bit 2: write-through hand-offs even when the cluster shares one XCD (test of that path) */
 int ifh_step_run(ifh_step_prog_t prog, ifh_step_ctx_t ctx, int cw, int debug, ifh_stream_t stream);
 int ifh_step_ctx_prof(ifh_step_ctx_t ctx, unsigned long long *out256);
 

@@ -112,13 +112,23 @@ __device__ __forceinline__ uint4 lrelu8(uint4 v, float slope)
 
 
 // Output stores of the fused epilogues.  The resident decode step (step.hip) hands a phase's outputs to OTHER workgroups of the same
-// launch, so it compiles these with IFH_EPI_SC1: write-through (sc1) stores, which the consumers read back with sc1 loads after the
-// producers' arrival on the cluster counter (MI355X_MICROARCH.md, inter-workgroup visibility).  Everywhere else: plain stores.
+// launch and compiles these with IFH_EPI_SC1: stores are write-through (sc1) unless the workgroup has established that its whole
+// cluster runs on one XCD, i.e. shares one L2 (g_epi_plain: plain stores that stay in that L2); the consumers read with sc1 loads
+// (never served by a CU's L1) after the producers' arrival flags (MI355X_MICROARCH.md, inter-workgroup visibility).  Its LayerNorm
+// row statistics are accumulated per workgroup in LDS (g_epi_stats) and handed over as per-workgroup partial sums -- 64-bit integer
+// sums, so the total is the one the atomics of the launch chain produce.  Everywhere else: plain stores, atomics.
+#ifdef IFH_EPI_SC1
+__shared__ int g_epi_plain;
+__shared__ unsigned long long g_epi_stats[32][2];      // [row of the 32-row block][sum, sum of squares], fixed point 2^16
+#endif
 __device__ __forceinline__ void epi_store8(void *o, uint2 v)
 {
 #ifdef IFH_EPI_SC1
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(o), (unsigned long long)v.x | ((unsigned long long)v.y << 32),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (g_epi_plain)
+        *reinterpret_cast<uint2 *>(o) = v;
+    else
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(o), (unsigned long long)v.x | ((unsigned long long)v.y << 32),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
     *reinterpret_cast<uint2 *>(o) = v;
 #endif
@@ -126,10 +136,25 @@ __device__ __forceinline__ void epi_store8(void *o, uint2 v)
 __device__ __forceinline__ void epi_store16f(void *o, float4 v)
 {
 #ifdef IFH_EPI_SC1
-    const f32x4 t = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o), "v"(t) : "memory");
+    if (g_epi_plain) {
+        *reinterpret_cast<float4 *>(o) = v;
+    } else {
+        const f32x4 t = {v.x, v.y, v.z, v.w};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(o), "v"(t) : "memory");
+    }
 #else
     *reinterpret_cast<float4 *>(o) = v;
+#endif
+}
+__device__ __forceinline__ void epi_stats_add(void *stats_out, int m, unsigned long long v1, unsigned long long v2)
+{
+#ifdef IFH_EPI_SC1
+    atomicAdd(&g_epi_stats[m & 31][0], v1);
+    atomicAdd(&g_epi_stats[m & 31][1], v2);
+#else
+    unsigned long long *so = reinterpret_cast<unsigned long long *>(stats_out) + 2 * m;
+    atomicAdd(so, v1);
+    atomicAdd(so + 1, v2);
 #endif
 }
 
@@ -327,11 +352,9 @@ __device__ __forceinline__ void ln_epi4(const IgemmParams &p, int m, int n, bool
         float s2 = ok ? (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3) : 0.0f;
         s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);      // the 4 lanes fg = 0..3 share row m
         s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-        if (fg == 0 && xok) {
-            unsigned long long *so = reinterpret_cast<unsigned long long *>(p.stats_out) + 2 * m;
-            atomicAdd(so, (unsigned long long)__double2ll_rn((double)s1 * 65536.0));
-            atomicAdd(so + 1, (unsigned long long)__double2ll_rn((double)s2 * 65536.0));
-        }
+        if (fg == 0 && xok)
+            epi_stats_add(p.stats_out, m, (unsigned long long)__double2ll_rn((double)s1 * 65536.0),
+                          (unsigned long long)__double2ll_rn((double)s2 * 65536.0));
     }
 }
 

@@ -38,6 +38,7 @@ class SpeechT5:
         # resident decode step (csrc/step.hip): one launch per step for the ragged batch; workgroups per 32-row cluster
         self.resident_step = os.environ.get('IFH_TTS_RESIDENT', '0') == '1'
         self.resident_cw = int(os.environ.get('IFH_TTS_RESIDENT_CW', '16'))
+        self.resident_wt = os.environ.get('IFH_TTS_RESIDENT_WT', '0') == '1'       # test switch: write-through hand-offs even when a cluster shares one XCD
         self._states = {}
         E = 'speecht5.encoder.'
         alpha_e = float(sd[E + 'prenet.encode_positions.alpha'])
@@ -520,7 +521,7 @@ def ragged_decoder_steps(model: 'SpeechT5', st: TTSRaggedState, masks: torch.Ten
                                                        st.stat_rows, model.device)
             if st.step_ctx is None:
                 st.step_ctx = ops.StepContext(st.R, model.device)
-            prog.run(st.step_ctx, cw=model.resident_cw)
+            prog.run(st.step_ctx, cw=model.resident_cw, write_through=model.resident_wt)
             if sync_every and (s + 1) % sync_every == 0 and s + 1 < nsteps:
                 torch.cuda.current_stream(model.device).synchronize()
         elif not use_graphs:

@@ -406,7 +406,8 @@ class StepContext:
         out = (ctypes.c_uint64 * 256)()
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().ifh_step_ctx_prof(self.h, out), 'ifh_step_ctx_prof')
-        return [(out[2 * i] / 100.0, out[2 * i + 1] / 100.0) for i in range(128)]
+        self.gemm_breakdown = [out[200 + i] / 100.0 for i in range(6)] + [int(out[206])]
+        return [(out[2 * i] / 100.0, out[2 * i + 1] / 100.0) for i in range(100)]
 
     def __del__(self):
         try:
@@ -437,9 +438,9 @@ class StepProgram:
             _lib.check(L.ifh_step_record_end(ctypes.byref(h), ctypes.byref(n)), 'ifh_step_record_end')
         self.h, self.nphase = h, n.value
 
-    def run(self, ctx: StepContext, cw: int = 16, debug_xcc: bool = False, prof: bool = False):
-        _lib.check(_lib.lib().ifh_step_run(self.h, ctx.h, int(cw), int(debug_xcc) | (2 if prof else 0), _lib.stream_ptr(self.device)),
-                   'ifh_step_run')
+    def run(self, ctx: StepContext, cw: int = 16, debug_xcc: bool = False, prof: bool = False, write_through: bool = False):
+        dbg = int(debug_xcc) | (2 if prof else 0) | (4 if write_through else 0)
+        _lib.check(_lib.lib().ifh_step_run(self.h, ctx.h, int(cw), dbg, _lib.stream_ptr(self.device)), 'ifh_step_run')
 
     def __del__(self):
         try:

@@ -46,8 +46,9 @@ def _randomise(st, n, T, seed):
     return masks
 
 
-@pytest.mark.parametrize('n,cw', [(48, 16), (160, 8), (512, 16), (336, 5)])
-def test_resident_step_is_bit_identical_to_the_launch_chain(built_lib, n, cw):
+@pytest.mark.parametrize('n,cw,wt', [(48, 16, False), (160, 8, False), (512, 16, False), (336, 5, False), (512, 16, True), (80, 32, True)])
+def test_resident_step_is_bit_identical_to_the_launch_chain(built_lib, n, cw, wt):
+    """wt: the write-through hand-off path (clusters spread over XCDs) forced on a cluster that shares one XCD"""
     from infernos_amd import _lib
     from infernos_amd.engines.speecht5 import TTSRaggedState, ragged_decoder_steps
     dev = _lib.require_device('cuda:0')
@@ -60,7 +61,7 @@ def test_resident_step_is_bit_identical_to_the_launch_chain(built_lib, n, cw):
     ta, tb = _tensors(a), _tensors(b)
     for k in ta:
         tb[k].copy_(ta[k])
-    model.resident_cw = cw
+    model.resident_cw, model.resident_wt = cw, wt
     for call in range(2):                                      # two infer() calls: 32 steps, both frame-buffer parities
         ragged_decoder_steps(model, a, masks, n, use_graphs=False, resident=False)
         ragged_decoder_steps(model, b, masks, n, resident=True)

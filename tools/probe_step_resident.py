@@ -58,7 +58,7 @@ prog = st.progs[(3, 0.5, st.ncalls & 1, n)] if (3, 0.5, st.ncalls & 1, n) in st.
 st.step_ctx.prof()
 reps = 20
 for _ in range(reps):
-    prog.run(st.step_ctx, cw=cws[-1], prof=True)
+    prog.run(st.step_ctx, cw=cws[-1], prof=True, write_through=pp.model.resident_wt)
     st.pos.fill_(100)
 pr = st.step_ctx.prof()
 print('per phase at %d rows, cw %d (us): wait / work' % (n, cws[-1]))
@@ -69,3 +69,7 @@ for i in range(prog.nphase):
     tb += b
     print('  %2d: %6.2f %6.2f' % (i, w, b), end='' if i % 4 != 3 else '\n')
 print('\n  sum wait %.1f us, work %.1f us' % (tw, tb))
+gb = st.step_ctx.gemm_breakdown
+ng = max(1, gb[6])
+print('  GEMM phases (%d in %d launches), mean us: table+prefetch issue %.2f | wait %.2f | stats+image %.2f | tasks %.2f | epilogue %.2f | partials+arrive %.2f'
+      % (ng, reps, gb[0] / ng, gb[1] / ng, gb[2] / ng, gb[3] / ng, gb[4] / ng, gb[5] / ng))
