@@ -147,7 +147,15 @@ class TickProbe(threading.Thread):
             self.calls, self.vad = CallTable(n, dev), BatchedVAD(n, dev)
             # the per-tick path is the real-time one: its few small kernels go to a high-priority hardware queue so that they
             # do not wait behind a lane's whole queued decode graph
-            self.stream = torch.cuda.Stream(device=dev, priority=-1)
+            # IFH_TICK_CUS="first,n" (tuning switch): a CU-range stream instead -- a hardware queue of its own, so that a tick's
+            # launches do not stand behind the decode steps the TTS engine has queued on the shared high-priority queue
+            tc = os.environ.get('IFH_TICK_CUS', '')
+            if tc:
+                from infernos_amd import _lib as _l
+                first, ncu = (int(x) for x in tc.split(','))
+                self.stream = _l.cu_range_stream(dev, first, ncu)
+            else:
+                self.stream = torch.cuda.Stream(device=dev, priority=-1)
             self.slots = torch.arange(n, dtype=torch.int32, device=dev)
             self.dfr = torch.empty((n, 160), dtype=torch.uint8, device=dev)
             self.p8, self.p16 = torch.empty((n, 160), device=dev), torch.empty((n, 320), device=dev)
@@ -593,13 +601,13 @@ def main():
             'tts_samples_per_call': int(res['tts_samples'].float().mean()),
             'roofline': {'kernel': 'HiFi-GAN vocoder pass (%d chunks x 12 frames per launch group)' % nchunks,
                          'bound': 'mfma', 'achieved': round(ach_tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': pmc('r03_vocoder_pmc.json', nchunks),
-                         'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r03_vocoder_pmc.json (1280-chunk pass; scaled by chunks if the pass sizes differ)',
+                         'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': pmc('r04_vocoder_pmc.json', nchunks),
+                         'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r04_vocoder_pmc.json (1280-chunk pass; scaled by chunks if the pass sizes differ)',
                          'seconds_per_vocoder_pass': t_voc},
             'roofline_logmel': {'kernel': 'k_logmel_fft (%d x 30 s windows -> raw log-mel [80,3000] f32 + window maximum)' % n_local, 'bound': 'hbm',
                                 'achieved': round(ach_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                'frac': round(ach_gbs / PEAK_HBM_GBS, 4), 'traffic': pmc('r03_logmel_pmc.json', n_local),
-                                'traffic_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r03_logmel_pmc.json',
+                                'frac': round(ach_gbs / PEAK_HBM_GBS, 4), 'traffic': pmc('r04_logmel_pmc.json', n_local),
+                                'traffic_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r04_logmel_pmc.json',
                                 'seconds': t_mel},
         }
         if lat is not None:

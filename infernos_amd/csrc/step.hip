@@ -96,17 +96,12 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void *base)
 {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, 0x7fffffff, 0x00020000);
 }
-// a load of handed-off bytes: never from this CU's L1.  Write-through mode: sc1 (agent scope; on this multi-XCD part that is a
-// round trip to memory).  Inside one XCD's L2 (g_epi_plain): non-temporal -- it bypasses the L1 and is served by the L2 the
-// producers' plain stores went to (MI355X_MICROARCH.md: nt loads "bypass L1 only"; tests/test_step_resident_gpu.py would see a
-// stale line at once: every activation buffer is rewritten by every layer).
+// a load of handed-off bytes: sc1 (agent scope), never served by this CU's L1 -- in both hand-off modes: a mode switch around
+// every load (the flag lives in LDS, so the compiler treats the branch as divergent and waits for each load where the two sides
+// join) cost the loads' overlap, and non-temporal loads measured no faster than sc1 ones inside one XCD
 __device__ __forceinline__ uint4 ld16_sc1(__amdgpu_buffer_rsrc_t r, int byte_off)
 {
-    u32x4 v;
-    if (g_epi_plain)
-        v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 2);
-    else
-        v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 // a store of handed-off bytes: plain inside one XCD's L2 (g_epi_plain), write-through otherwise
@@ -126,11 +121,7 @@ __device__ __forceinline__ uint4 ld16_sc1_nt(__amdgpu_buffer_rsrc_t r, int byte_
 }
 __device__ __forceinline__ uint2 ld8_sc1(const void *ptr)
 {
-    unsigned long long v;
-    if (g_epi_plain)
-        v = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long *>(ptr));
-    else
-        v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
 }
 __device__ __forceinline__ longlong2 as_ll2(uint4 t)
@@ -159,12 +150,7 @@ __device__ __forceinline__ void cluster_wait(const unsigned long long *flags, in
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         const unsigned long long *fp = flags + (int64_t)min(lane, cw - 1) * LINE;
         while (true) {
-            unsigned long long fv;
-            if (g_epi_plain)
-                fv = __builtin_nontemporal_load(fp);
-            else
-                fv = __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const bool behind = lane < cw && fv < target;
+            const bool behind = lane < cw && __hip_atomic_load(fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target;
             if (!__any(behind)) break;
             __builtin_amdgcn_s_sleep(1);
             if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {      // 2 s: the cluster is not co-resident
