@@ -165,6 +165,7 @@ class TickProbe(threading.Thread):
             self.has = torch.empty(n, dtype=torch.uint8, device=dev)
         self.host_out = torch.empty((n, 160), dtype=torch.uint8).pin_memory()
         self.lat, self.windows, self._nb = [], 0, 0
+        self.worst = (0.0, {})
         self._halt = threading.Event()
 
     def tick(self, t):
@@ -174,19 +175,27 @@ class TickProbe(threading.Thread):
         with torch.cuda.stream(self.stream):
             self.dfr.copy_(self.host_frames[t % TICKS], non_blocking=True)
             self.calls.tick(self.dfr, self.slots, self.p8, self.p16, want_ready=False)
+            b = time.perf_counter()
             self._nb += 160
             if self._nb >= 768:
                 self._nb -= 768
                 self.vad.step(self.calls.win)                       # includes its host sync: the VAD decision is on the host
                 self.windows += 1
+            c = time.perf_counter()
             S = self.tts_pcm.size(1)
             off = (t * 160) % (S - 160)
             trk = self.tts_pcm[:, off:off + 160].contiguous()
             _lib.check(L.ifh_mux_encode_f32_u8(_lib.ptr(trk), _lib.ptr(self.present), _lib.ptr(self.ndiv), n, 1, 160,
                                                _lib.ptr(self.enc), _lib.ptr(self.has), _lib.stream_ptr(dev)), 'ifh_mux_encode_f32_u8')
             self.host_out.copy_(self.enc, non_blocking=True)
+            d = time.perf_counter()
             self.stream.synchronize()
-        return (time.perf_counter() - a) * 1e3
+        e = time.perf_counter()
+        ms = (e - a) * 1e3
+        if ms > self.worst[0]:        # where the slowest tick spent its time: queueing ingest, VAD window (+ its sync), queueing the mix, final wait
+            self.worst = (ms, {'queue_ingest_ms': round((b - a) * 1e3, 2), 'vad_window_ms': round((c - b) * 1e3, 2),
+                               'queue_mix_ms': round((d - c) * 1e3, 2), 'final_wait_ms': round((e - d) * 1e3, 2)})
+        return ms
 
     def run(self):
         torch.cuda.set_device(self.dev)
@@ -505,6 +514,7 @@ def main():
             probe.tick(t)
         probe._t_next = 8
         probe.lat.clear()
+        probe.worst = (0.0, {})
     dt, res = time_steps(pipe, frames_for, args.steps, args.warmup, world, not args.no_pipeline, egress, dry, dev, probe)
     ms_per_step = dt / args.steps * 1e3
     value = n_total * UTT_SECONDS / (dt / args.steps)
@@ -613,6 +623,7 @@ def main():
         if lat is not None:
             out.update({'p50_tick_latency_ms': round(float(np.percentile(lat, 50)), 4),
                         'p99_tick_latency_ms': round(float(np.percentile(lat, 99)), 4),
+                        'worst_tick_ms': round(probe.worst[0], 3), 'worst_tick_split': probe.worst[1],
                         'tick_latency_note': '%d ticks of [%d,160] paced at 20 ms INSIDE the timed region (H2D -> ingest_tick -> VAD '
                                              'window+decision on %d of them -> mux_encode of real TTS rows -> D2H, host to host), '
                                              'while the TTS/STT lanes were running; the VAD network is a stand-in (ifh_vad_energy_prob: the '
