@@ -286,6 +286,8 @@ class ContinuousTTS:
         dev = pp.device
         assert max_text <= 256, 'cross-attention over > 256 keys takes the 4-wave kernel: such texts go through the frozen-batch path'
         self.row_bucket = row_bucket
+        self.host_wait = os.environ.get('IFH_TTS_HOST_WAIT', '0') == '1'      # tuning switch (see step()): measured without effect, off
+        self.admit_ready = os.environ.get('IFH_TTS_ADMIT_READY', '0') == '1'  # tuning switch (see _admit()): measured without effect, off
         self.sync_every = int(os.environ.get('IFH_TTS_SYNC_EVERY', '8'))         # decoder steps queued at a time (0: all 16); 8: +2 % and a steadier tick p99 at C3
         with torch.cuda.device(dev):
             self.st = TTSRaggedState(pp.model, max_rows, max_text)
@@ -349,12 +351,27 @@ class ContinuousTTS:
     def _admit(self):
         st, dev = self.st, self.device
         took = []
-        with self.cv:
-            while self.pending and len(self.free) >= self.pending[0].n:
-                grp = self.pending.pop(0)
-                self.free.sort()
-                grp.slots, self.free = self.free[:grp.n], self.free[grp.n:]
-                took.append(grp)
+        while True:
+            wait_ev = None
+            with self.cv:
+                while self.pending and len(self.free) >= self.pending[0].n:
+                    # A batch joins only once its text encoder / cross-K|V work (the submitter's stream, itself behind that
+                    # cycle's STT stage) HAS finished: waiting for it in the decode stream would stall every live row -- and,
+                    # being a barrier packet in the high-priority hardware queue, the real-time tick behind it -- for as long as
+                    # that takes.  It joins at a later infer() boundary instead; with nothing live the engine has nothing better
+                    # to do than wait (on the host, outside the lock).
+                    rdy = self.pending[0]._admit['ready']
+                    if self.admit_ready and not rdy.query():
+                        if not self.live and not took:
+                            wait_ev = rdy
+                        break
+                    grp = self.pending.pop(0)
+                    self.free.sort()
+                    grp.slots, self.free = self.free[:grp.n], self.free[grp.n:]
+                    took.append(grp)
+            if wait_ev is None:
+                break
+            wait_ev.synchronize()
         if not took:
             return
         R, T = st.R, st.T
@@ -393,7 +410,13 @@ class ContinuousTTS:
             n = self._bucket()
             par = st.ncalls & 1
             if self.ren_done[par] is not None:
-                self.main.wait_event(self.ren_done[par])         # the renderer of call c-2 has released this parity's buffers
+                # the renderer of call c-2 has released this parity's buffers.  Waited for on the HOST: as a stream wait it is a
+                # barrier packet in the high-priority hardware queue, and everything mapped to that queue -- the real-time tick's
+                # launches too -- stands behind it for as long as a render pass takes (the 40 ms worst ticks of round 4)
+                if self.host_wait:
+                    self.ren_done[par].synchronize()
+                else:
+                    self.main.wait_event(self.ren_done[par])
             self.h_active.zero_()
             self.h_fresh[par].zero_()
             for grp in self.live:

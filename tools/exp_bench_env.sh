@@ -7,10 +7,8 @@ except Exception as e:
     print("$name failed", e)
 PY
 }
-for rep in 1 2; do
-run base_$rep A=1
-run bm32_0_$rep IFH_GEMM_DEC_BM32=0
-run bm32_400_$rep IFH_GEMM_DEC_BM32=400
-EXTRA="--cu-reserve 64" run res64_$rep A=1
-EXTRA="--cu-reserve 128" run res128_$rep A=1
+for rep in 1 2 3; do
+run new_$rep A=1
+run old_$rep IFH_TTS_HOST_WAIT=0 IFH_TTS_ADMIT_READY=0
+run hostwait_only_$rep IFH_TTS_ADMIT_READY=0
 done
