@@ -198,7 +198,10 @@ bool try_launch_gemm_big(const IgemmParams &p, bool pre, hipStream_t st)
     g.out = (uint16_t *)p.out; g.ldc = p.ldc; g.M = (int)M; g.N = p.N; g.K = p.K;
     g.mtiles = (int)(M / GB_BM); g.ntiles = p.N / GB_BN;
     g.abl = getenv("IFH_GEMM_BIG_ABL") ? atoi(getenv("IFH_GEMM_BIG_ABL")) : 0;
-    constexpr size_t bytes = (size_t)GB_STAGES * GB_STAGE_BYTES;
+    // IFH_GEMM_BIG_LDS (tuning switch): request that many bytes of LDS instead -- above 80 KB a CU holds ONE workgroup of this kernel
+    // and half of its registers stay free for the decode chains' workgroups
+    static const size_t lds_req = getenv("IFH_GEMM_BIG_LDS") ? (size_t)atoll(getenv("IFH_GEMM_BIG_LDS")) : 0;
+    const size_t bytes = lds_req > (size_t)GB_STAGES * GB_STAGE_BYTES ? lds_req : (size_t)GB_STAGES * GB_STAGE_BYTES;
     static DeviceOnce attr_once;
     int attr_dev = 0;
     if (attr_once.needed(&attr_dev)) {

@@ -8,7 +8,7 @@ except Exception as e:
 PY
 }
 for rep in 1 2 3; do
-run new_$rep A=1
-run old_$rep IFH_TTS_HOST_WAIT=0 IFH_TTS_ADMIT_READY=0
-run hostwait_only_$rep IFH_TTS_ADMIT_READY=0
+run gb2_$rep A=1
+run gb1_$rep IFH_GEMM_BIG_LDS=90000
+EXTRA="--cu-reserve 64" run gb1_res64_$rep IFH_GEMM_BIG_LDS=90000
 done

@@ -76,3 +76,19 @@ for key, lst in sorted(bys.items(), key=lambda kv: -sum(e - s for s, e, _ in kv[
     print('  q%s s%s: %6d launches, busy %7.1f ms, gaps %6d / %5.1f / %5.1f / %6.1f ms;  %s' % (
         key[0], key[1], len(lst), busy_s * 1e-6, len(g), (sum(g) / max(1, len(g))) * 1e-3, (g[len(g) // 2] if g else 0) * 1e-3, sum(g) * 1e-6,
         ', '.join('%s x%d' % (n[-28:], c) for n, c in names)))
+
+# which kernels are resident ALONE (exactly one kernel on the chip), and in pairs: time by kernel name
+ev2 = sorted([(s_, 1, k) for s_, e_, k, _, _ in rows] + [(e_, -1, k) for s_, e_, k, _, _ in rows])
+active = collections.Counter()
+alone = collections.Counter()
+last = ev2[0][0]
+for t, d, k in ev2:
+    n = sum(active.values())
+    if n == 1 and t > last:
+        alone[next(iter(+active))] += t - last
+    last = t
+    active[k] += d
+tot_alone = sum(alone.values())
+print('resident alone: %.1f ms in all; by kernel:' % (tot_alone * 1e-6))
+for k, v in alone.most_common(12):
+    print('   %7.1f ms  %4.1f %%  %s' % (v * 1e-6, 100.0 * v / max(1, tot_alone), k))
