@@ -144,7 +144,11 @@ class TickProbe(threading.Thread):
         self.host_frames = host_frames                              # pinned u8 [TICKS, n, 160]
         self.tts_pcm = tts_pcm                                      # device f32 [n, S]: real TTS output rows
         with torch.cuda.device(dev):
-            self.calls, self.vad = CallTable(n, dev), BatchedVAD(n, dev)
+            # the detector of the per-tick path: a recurrent network shaped like the reference's (conv front end + 2 x LSTM(64), state
+            # [2,N,64] x 2 carried per call: csrc/vadnet.hip) so that the tick's latency contains a detector's cost; seeded weights --
+            # Silero's are not obtainable offline -- so its decisions are not used for anything
+            from infernos_amd.vad import RecurrentVADModel
+            self.calls, self.vad = CallTable(n, dev), BatchedVAD(n, dev, model=RecurrentVADModel(dev))
             # the per-tick path is the real-time one: its few small kernels go to a high-priority hardware queue so that they
             # do not wait behind a lane's whole queued decode graph
             # IFH_TICK_CUS="first,n" (tuning switch): a CU-range stream instead -- a hardware queue of its own, so that a tick's
@@ -626,9 +630,10 @@ def main():
                         'worst_tick_ms': round(probe.worst[0], 3), 'worst_tick_split': probe.worst[1],
                         'tick_latency_note': '%d ticks of [%d,160] paced at 20 ms INSIDE the timed region (H2D -> ingest_tick -> VAD '
                                              'window+decision on %d of them -> mux_encode of real TTS rows -> D2H, host to host), '
-                                             'while the TTS/STT lanes were running; the VAD network is a stand-in (ifh_vad_energy_prob: the '
-                                             'Silero v3.1 TorchScript model of Core/VAD/SileroVAD.py:44 is not available offline), so the '
-                                             'per-window model cost of a real detector is NOT in this figure' % (len(lat), n_local, probe.windows)})
+                                             'while the TTS/STT lanes were running; the VAD network is a stand-in SHAPED like the reference\'s detector (conv '
+                                             'front end + 2 x LSTM(64) with the per-call state [2,N,64] x 2 carried from window to window, '
+                                             'csrc/vadnet.hip, seeded weights: the Silero v3.1 TorchScript model of Core/VAD/SileroVAD.py:44 '
+                                             'is not available offline), so a detector of that cost class IS in this figure, Silero itself is not' % (len(lat), n_local, probe.windows)})
     # ---- the other single-GPU configurations, briefly (N = 1 only: extra keys, not the headline)
     if world == 1 and not args.no_extra_configs and not args.calls_per_gpu:
         pipe.close()

@@ -212,6 +212,14 @@ int ifh_mux_encode_f32_u8(const float *tracks, const uint8_t *present, const int
 #define IFH_EMIT_CAP 240000
 int ifh_vad_energy_prob(const float *win /* [ncap][768] */, const int32_t *slot, int n,
                         float *prob /* [n] */, ifh_stream_t stream);
+/* A recurrent speech-probability network SHAPED like the reference's detector (Core/VAD/SileroVAD.py:44-45: Silero VAD v3.1,
+ * third party, not obtainable offline -- PARITY UNPINNED against it): conv front end + two LSTM(64) layers whose state, two
+ * [2][n][64] tensors, is carried from window to window exactly as Core/VAD/SileroVADUtils.py:21-26,99,131 carry the model's.
+ * weights: ifh_vadnet_weight_floats() floats in the layout of csrc/vadnet.hip (infernos_amd.weights.synth_vadnet packs it).
+ * x f32 [n][768]; h_in / c_in / h_out / c_out f32 [2][n][64] (in and out may alias); prob f32 [n]. */
+int ifh_vadnet_weight_floats(void);
+int ifh_vadnet_prob(const float *x, int n, const float *weights, const float *h_in, const float *c_in, float *h_out,
+                    float *c_out, float *prob, ifh_stream_t stream);
 /* FSM only (VADIteratorB.__call__): updates st_i64[slot][0..2]; ev2 i64 [n][2] = {kind, pos} */
 int ifh_vad_fsm_step(const float *prob /* [n] */, const int32_t *slot, int n, int window, int sample_rate,
                      double threshold, int64_t *st_i64, int64_t *ev2, ifh_stream_t stream);

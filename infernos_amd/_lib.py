@@ -45,6 +45,8 @@ SIGNATURES = {
     'ifh_rtpsynth_skip': (_i, [_vp, _i, _i]),
     'ifh_rtpsynth_next_batch': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'ifh_vad_energy_prob': (_i, [_vp, _vp, _i, _vp, _vp]),
+    'ifh_vadnet_weight_floats': (_i, []),
+    'ifh_vadnet_prob': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ifh_vad_fsm_step': (_i, [_vp, _vp, _i, _i, _i, _d, _vp, _vp, _vp]),
     'ifh_vad_step': (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ifh_ingest_block': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp,

@@ -91,6 +91,51 @@ class EnergyVADModel:
         return prob
 
 
+class RecurrentVADModel:
+    """A stateful speech-probability model with the interface the reference's iterator drives (SileroVADUtils.py:99,131: the
+    recurrent state is injected into `model._c._h` / `._c` before a call and read back after it) and the SHAPE of the detector the
+    reference loads (SileroVAD.py:44-45: conv front end + 2 x LSTM(64), state [2,B,64] x 2): csrc/vadnet.hip.  The weights are
+    seeded, not Silero's (the model file is not obtainable offline): its probabilities mean nothing, its cost and its state
+    plumbing are the real thing.  PARITY UNPINNED against Silero; the arithmetic is pinned to the plain-PyTorch restatement the tests
+    hold (tests/test_vadnet_gpu.py)."""
+
+    class _State:
+        _h = None
+        _c = None
+        _last_sr = 0
+        _last_batch_size = 0
+
+    def __init__(self, device=None, seed: int = 0):
+        from .weights import pack_vadnet, synth_vadnet
+        self.device = _lib.require_device(device)
+        self.sd = synth_vadnet(seed)
+        self.blob = pack_vadnet(self.sd).to(self.device)
+        assert self.blob.numel() == _lib.lib().ifh_vadnet_weight_floats()
+        self._c = RecurrentVADModel._State()
+
+    def reset_states(self):
+        self._c._h = self._c._c = None
+        self._c._last_sr = self._c._last_batch_size = 0
+
+    def __call__(self, x: torch.Tensor, sr: int) -> torch.Tensor:
+        dev = self.device
+        x = x.to(dev, torch.float32).contiguous()
+        assert x.dim() == 2 and x.size(1) == WINDOW
+        n = x.size(0)
+        st = self._c
+        if st._h is None or st._h.size(1) != n or st._last_sr != sr:        # as the JIT model resets on a batch / rate change
+            st._h = torch.zeros((2, n, 64), dtype=torch.float32, device=dev)
+            st._c = torch.zeros((2, n, 64), dtype=torch.float32, device=dev)
+        h_in, c_in = st._h.to(dev, torch.float32).contiguous(), st._c.to(dev, torch.float32).contiguous()
+        h_out, c_out = torch.empty_like(h_in), torch.empty_like(c_in)
+        prob = torch.empty(n, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().ifh_vadnet_prob(_lib.ptr(x), n, _lib.ptr(self.blob), _lib.ptr(h_in), _lib.ptr(c_in), _lib.ptr(h_out),
+                                                  _lib.ptr(c_out), _lib.ptr(prob), _lib.stream_ptr(dev)), 'ifh_vadnet_prob')
+        st._h, st._c, st._last_sr, st._last_batch_size = h_out, c_out, sr, n
+        return prob
+
+
 class VADIteratorB:
     """Batched streaming VAD iterator (SileroVADUtils.py:30-133): model call + FSM."""
 

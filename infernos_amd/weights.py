@@ -192,3 +192,36 @@ def qwen2_random_on_device(cfg, device, seed=0):
         else:
             sd[name] = torch.randn(shape, generator=g, device=device, dtype=torch.bfloat16) / shape[1] ** 0.5
     return sd
+
+
+# ---- the recurrent VAD network of csrc/vadnet.hip (Silero-v3.1-SHAPED stand-in: the reference's model file is not obtainable) ----
+VADNET_SHAPES = {
+    'conv1.weight': (32, 1, 128), 'conv1.bias': (32,), 'conv2.weight': (64, 32, 3), 'conv2.bias': (64,),
+    'lstm.weight_ih_l0': (256, 64), 'lstm.weight_hh_l0': (256, 64), 'lstm.bias_ih_l0': (256,), 'lstm.bias_hh_l0': (256,),
+    'lstm.weight_ih_l1': (256, 64), 'lstm.weight_hh_l1': (256, 64), 'lstm.bias_ih_l1': (256,), 'lstm.bias_hh_l1': (256,),
+    'out.weight': (1, 64), 'out.bias': (1,),
+}
+
+
+def synth_vadnet(seed: int = 0):
+    """Seeded fp32 weights in torch's own module layouts (Conv1d / LSTM / Linear, uniform +-1/sqrt(fan_in) as torch initialises)."""
+    import torch
+    g = torch.Generator().manual_seed(1000 + seed)
+    sd = {}
+    for name, shape in VADNET_SHAPES.items():
+        fan = {'conv1': 128, 'conv2': 96, 'lstm': 64, 'out': 64}[name.split('.')[0]]
+        sd[name] = (torch.rand(shape, generator=g) * 2 - 1) / (fan ** 0.5)
+    return sd
+
+
+def pack_vadnet(sd):
+    """The weight blob ifh_vadnet_prob reads: every matrix transposed to [k][out] (consecutive lanes read consecutive outputs), the two
+    LSTM biases of a layer added up."""
+    import torch
+    parts = [sd['conv1.weight'][:, 0, :].t().contiguous().flatten(), sd['conv1.bias'],
+             sd['conv2.weight'].permute(2, 1, 0).contiguous().flatten(), sd['conv2.bias']]
+    for l in (0, 1):
+        parts += [sd['lstm.weight_ih_l%d' % l].t().contiguous().flatten(), sd['lstm.weight_hh_l%d' % l].t().contiguous().flatten(),
+                  sd['lstm.bias_ih_l%d' % l] + sd['lstm.bias_hh_l%d' % l]]
+    parts += [sd['out.weight'].flatten(), sd['out.bias']]
+    return torch.cat([p.float().flatten() for p in parts]).contiguous()

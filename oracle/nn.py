@@ -574,3 +574,30 @@ def sample_pick(ids, probs, u):
     cdf = probs.cumsum(-1)
     i = int((cdf > u * float(cdf[-1])).nonzero()[0]) if bool((cdf > u * float(cdf[-1])).any()) else len(ids) - 1
     return int(ids[i])
+
+
+# ---- the recurrent VAD network of infernos_amd/csrc/vadnet.hip ------------------------------------------------------------------
+def vadnet(x, sd, h, c):
+    """Speech probability of a 768-sample window per row and the new recurrent state.  The network is a Silero-v3.1-SHAPED
+    stand-in (Core/VAD/SileroVAD.py:44-45 loads a third-party TorchScript file that is not in the reference tree: PARITY UNPINNED
+    against it): Conv1d(1->32, k128, s64) + ReLU -> Conv1d(32->64, k3, s2, p1) + ReLU -> 2 x LSTM(64) over the 6 steps with the
+    state (h, c) [2, B, 64] carried between calls (SileroVADUtils.py:21-26,99,131) -> Linear(64->1) -> sigmoid -> mean over steps.
+    x f32 [B, 768]; sd = infernos_amd.weights.synth_vadnet(); returns (prob [B], h', c').  Pinned to torch.nn modules holding the same
+    weights by tests/test_vadnet_oracle.py."""
+    import torch
+    import torch.nn.functional as F
+    f1 = F.relu(F.conv1d(x[:, None, :].float(), sd['conv1.weight'], sd['conv1.bias'], stride=64))            # [B, 32, 11]
+    f2 = F.relu(F.conv1d(f1, sd['conv2.weight'], sd['conv2.bias'], stride=2, padding=1))                     # [B, 64, 6]
+    h, c = [h[0].clone().float(), h[1].clone().float()], [c[0].clone().float(), c[1].clone().float()]
+    ys = []
+    for s in range(f2.size(2)):
+        inp = f2[:, :, s]
+        for l in (0, 1):
+            g = inp @ sd['lstm.weight_ih_l%d' % l].t() + sd['lstm.bias_ih_l%d' % l] + h[l] @ sd['lstm.weight_hh_l%d' % l].t() + \
+                sd['lstm.bias_hh_l%d' % l]
+            i, f, gg, o = g.chunk(4, dim=1)
+            c[l] = torch.sigmoid(f) * c[l] + torch.sigmoid(i) * torch.tanh(gg)
+            h[l] = torch.sigmoid(o) * torch.tanh(c[l])
+            inp = h[l]
+        ys.append(torch.sigmoid(h[1] @ sd['out.weight'].t() + sd['out.bias'])[:, 0])
+    return torch.stack(ys, 1).mean(1), torch.stack(h), torch.stack(c)
