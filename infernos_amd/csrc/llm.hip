@@ -9,6 +9,8 @@
 //                    0 .. key_len[token]-1 of the token's cache row.  The same kernel serves prefill (one launch over all
 //                    prompt tokens, key_len = position + 1: causal) and decode.
 //   k_silu_mul       silu(gate) * up on the fused gate|up projection.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace ifh {
@@ -94,11 +96,15 @@ __global__ __launch_bounds__(NW * 64) void k_attn_gqa(const uint16_t *__restrict
                                                       const uint16_t *__restrict__ cache, int64_t cache_bs,
                                                       int64_t cache_ts, int v_off, uint16_t *__restrict__ out,
                                                       int64_t o_ts, const int32_t *__restrict__ key_len, int T,
-                                                      float scale)
+                                                      float scale, int gtot, int nsplit)
 {
+    // G = the query heads THIS workgroup serves: a kv head's gtot query heads are cut into nsplit workgroups of G (each re-reads the
+    // K/V rows; a decode step of 64 tokens x 2 kv heads is otherwise 128 workgroups on 256 CUs, and VALU-bound at G = 6).  The
+    // arithmetic of a query head does not depend on the cut.
     constexpr int HD = 64 * HDV, DV = 8 * HDV;
     __shared__ float comb[NW][G][8][2 + DV];
-    const int i = blockIdx.y, kvh = blockIdx.x;
+    const int i = blockIdx.y, kvh = blockIdx.x / nsplit;
+    const int h0 = kvh * gtot + (blockIdx.x - kvh * nsplit) * G;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int c = lane & 7, g = lane >> 3;
     const int klen = key_len[i];
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_gqa(const uint16_t *__restrict
     for (int r = 0; r < G; r++) {
 #pragma unroll
         for (int hv = 0; hv < HDV; hv++) {
-            const uint4 t = *reinterpret_cast<const uint4 *>(q + (int64_t)i * q_ts + (kvh * G + r) * HD + hv * 64 + 8 * c);
+            const uint4 t = *reinterpret_cast<const uint4 *>(q + (int64_t)i * q_ts + (h0 + r) * HD + hv * 64 + 8 * c);
             const uint32_t *u = reinterpret_cast<const uint32_t *>(&t);
 #pragma unroll
             for (int e = 0; e < 4; e++) {
@@ -237,7 +243,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_gqa(const uint16_t *__restrict
                 pk.y = f32x2_to_bf16x2(o[r][hv * 8 + 2] * inv, o[r][hv * 8 + 3] * inv);
                 pk.z = f32x2_to_bf16x2(o[r][hv * 8 + 4] * inv, o[r][hv * 8 + 5] * inv);
                 pk.w = f32x2_to_bf16x2(o[r][hv * 8 + 6] * inv, o[r][hv * 8 + 7] * inv);
-                *reinterpret_cast<uint4 *>(out + (int64_t)i * o_ts + (kvh * G + r) * HD + hv * 64 + 8 * c) = pk;
+                *reinterpret_cast<uint4 *>(out + (int64_t)i * o_ts + (h0 + r) * HD + hv * 64 + 8 * c) = pk;
             }
         }
     }
@@ -285,17 +291,18 @@ __global__ void k_add_i32_vec(int32_t *__restrict__ v, const int32_t *__restrict
 }
 
 template <int G, int HDV>
-static void attn_gqa_launch(const ifh_gqa_desc *d, hipStream_t st)
+static void attn_gqa_launch(const ifh_gqa_desc *d, hipStream_t st, int gtot)
 {
-    dim3 grid(d->nkv, d->ntokens);
+    const int nsplit = gtot / G;
+    dim3 grid(d->nkv * nsplit, d->ntokens);
     if (d->max_keys > 256)      // (8 waves per (token, kv head) measured slower: 27.8 vs 21.5 us at 192-256 keys, G = 6)
         hipLaunchKernelGGL((k_attn_gqa<4, G, HDV>), grid, dim3(256), 0, st, (const uint16_t *)d->q, d->q_ts,
                            (const uint16_t *)d->cache, d->cache_bs, d->cache_ts, d->v_off, (uint16_t *)d->out, d->o_ts,
-                           d->key_len, d->tokens_per_row, d->scale);
+                           d->key_len, d->tokens_per_row, d->scale, gtot, nsplit);
     else
         hipLaunchKernelGGL((k_attn_gqa<1, G, HDV>), grid, dim3(64), 0, st, (const uint16_t *)d->q, d->q_ts,
                            (const uint16_t *)d->cache, d->cache_bs, d->cache_ts, d->v_off, (uint16_t *)d->out, d->o_ts,
-                           d->key_len, d->tokens_per_row, d->scale);
+                           d->key_len, d->tokens_per_row, d->scale, gtot, nsplit);
 }
 
 }  // namespace ifh
@@ -345,12 +352,24 @@ extern "C" int ifh_attn_gqa_bf16(const ifh_gqa_desc *d, ifh_stream_t stream)
     const int G = d->nheads / d->nkv;
     IFH_CHECK_ARG(G <= 8);
     hipStream_t st = as_stream(stream);
+    // query heads per workgroup: the whole group while that fills the chip twice over, else the largest divisor of G that does (a
+    // decode step: few tokens); IFH_GQA_GS overrides (tuning switch)
+    static const int gs_env = getenv("IFH_GQA_GS") ? atoi(getenv("IFH_GQA_GS")) : 0;
+    int gs = G;
+    if (gs_env > 0 && G % gs_env == 0)
+        gs = gs_env;
+    else
+        while (gs > 1 && (int64_t)d->nkv * (G / gs) * d->ntokens < 2 * device_cu_count_physical()) {
+            int nx = gs - 1;
+            while (nx > 1 && G % nx) nx--;
+            gs = nx;
+        }
 #define IFH_GQA(GG)                                                      \
     case GG:                                                             \
-        if (d->head_dim == 128) attn_gqa_launch<GG, 2>(d, st);           \
-        else attn_gqa_launch<GG, 1>(d, st);                              \
+        if (d->head_dim == 128) attn_gqa_launch<GG, 2>(d, st, G);        \
+        else attn_gqa_launch<GG, 1>(d, st, G);                           \
         break;
-    switch (G) {
+    switch (gs) {
         IFH_GQA(1) IFH_GQA(2) IFH_GQA(3) IFH_GQA(4) IFH_GQA(5) IFH_GQA(6) IFH_GQA(7) IFH_GQA(8)
     }
 #undef IFH_GQA
