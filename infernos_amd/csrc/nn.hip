@@ -9,6 +9,10 @@
 // up holding 4 consecutive output channels of one output row -> 8/16-byte stores.
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+#include <vector>
+
 #include "igemm.h"
 
 namespace ifh {
@@ -190,8 +194,11 @@ __device__ unsigned long long g_dec_prof[8];
 // BM = 32 (round 3): a launch of fewer workgroups than CUs is one workgroup per CU whose four waves move in lock-step through
 // issue / wait / LDS store / fragment reads (profiles/NOTES.md): half the rows per workgroup = twice the workgroups, each phase 2/3
 // as long.
-template <int BN, int BM = 64>
-__global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const int ksplit)
+// SPLITZ (round 4; LLM down projection, K = 8960 at <= 64 rows): blockIdx.z = one accumulation chain -- the k range that wave z of
+// the streaming kernel walks -- and instead of the epilogue the workgroup leaves its f32 partial tile in `ws` [chains][M][N];
+// k_splitk_finish adds the chains in chain order and runs the shared epilogue: the streaming kernel's bits from 4 x the workgroups.
+template <int BN, int BM = 64, bool SPLITZ = false>
+__global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const int ksplit, float *__restrict__ ws = nullptr)
 {
 #ifdef IFH_DEC_PROF
     unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
@@ -231,14 +238,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const 
         bval[i] = n < p.N;
         brow[i] = p.w + (int64_t)(bval[i] ? n : p.N - 1) * p.K + lcol;
     }
-    const bool whole = p.K % KC == 0;
+    // the k range of this workgroup: all of K, or (SPLITZ) chain blockIdx.z of ksplit
+    const int nk_all = p.K / 32;
+    const int per_z = (nk_all + ksplit - 1) / ksplit;
+    const int kbeg = SPLITZ ? (int)blockIdx.z * per_z * 32 : 0;
+    const int kend = SPLITZ ? min(p.K, kbeg + per_z * 32) : p.K;
+    const bool whole = (kend - kbeg) % KC == 0;
     uint4 ra[AV], rb[BV];
 #define IFH_DEC_LOAD(K0)                                                                                       \
     if (whole) {                                                                                               \
         _Pragma("unroll") for (int i = 0; i < AV; i++) ra[i] = ld_u32x4(arow[i] + (K0));                       \
         _Pragma("unroll") for (int i = 0; i < BV; i++) rb[i] = ld_u32x4(brow[i] + (K0));                       \
     } else {                                                                                                   \
-        const bool kin_ = (K0) + lcol < p.K;                                                                   \
+        const bool kin_ = (K0) + lcol < kend;                                                                  \
         _Pragma("unroll") for (int i = 0; i < AV; i++)                                                         \
             ra[i] = kin_ ? ld_u32x4(arow[i] + (K0)) : make_uint4(0, 0, 0, 0);                                  \
         _Pragma("unroll") for (int i = 0; i < BV; i++)                                                         \
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const 
             *reinterpret_cast<uint4 *>(&Bs[(lrow + 8 * i) * LDK + lcol]) = rb[i];                              \
     }
     DEC_STAMP(0)
-    IFH_DEC_LOAD(0)
+    IFH_DEC_LOAD(kbeg)
     DEC_STAMP(1)
     // epilogue operands, requested behind the first chunk (as the streaming kernel requests them ahead of its K loop)
     const bool ln_mode = p.aln_stats || p.rln_stats || p.stats_out;
@@ -301,10 +313,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const 
             acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
             sum[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
-    const int nk = p.K / 32;
-    const int per = (nk + ksplit - 1) / ksplit;      // k-steps per accumulation chain (= per wave of the streaming kernel)
+    const int nk = (kend - kbeg) / 32;
+    const int per = SPLITZ ? nk : (nk + ksplit - 1) / ksplit;      // k-steps per accumulation chain (= per wave of the streaming kernel)
     int next_flush = per;
-    const int nchunk = (p.K + KC - 1) / KC;
+    const int nchunk = (kend - kbeg + KC - 1) / KC;
     DEC_STAMP(2)
     for (int c = 0; c < nchunk; c++) {
         IFH_DEC_STORE();
@@ -313,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const 
             DEC_STAMP(3)
         }
         if (c + 1 < nchunk) {                                   // the next chunk's round trip overlaps this chunk's MFMAs
-            IFH_DEC_LOAD((c + 1) * KC)
+            IFH_DEC_LOAD(kbeg + (c + 1) * KC)
         }
         const int ks1 = min(KC / 32, nk - c * (KC / 32));
         for (int ks = 0; ks < ks1; ks++) {
@@ -346,6 +358,18 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const 
     DEC_STAMP(4)
 #undef IFH_DEC_LOAD
 #undef IFH_DEC_STORE
+    if (SPLITZ) {
+#pragma unroll
+        for (int j = 0; j < MT; j++)
+#pragma unroll
+            for (int i = 0; i < NT; i++) {
+                const int n = n0 + wn * WN + i * 16 + 4 * fg;
+                if (exok[j] && n < p.N)
+                    *reinterpret_cast<float4 *>(ws + ((int64_t)blockIdx.z * M + em[j]) * p.N + n) =
+                        make_float4(sum[i][j][0], sum[i][j][1], sum[i][j][2], sum[i][j][3]);
+            }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < MT; j++) {
         const LnRow lr = ln_row(p, st_a[j], st_r[j]);
@@ -366,6 +390,97 @@ __global__ __launch_bounds__(256, 2) void k_gemm_dec(const IgemmParams p, const 
 #ifdef IFH_DEC_PROF
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(&g_dec_prof[7], 1ull);
 #endif
+}
+
+// the chains of a SPLITZ launch added in chain order + the streaming kernel's epilogue: one wave per 16 x 16 output tile, a lane holds
+// 4 consecutive columns of one row exactly as in k_gemm_skinny, whose epilogue operands it fetches the same way
+__global__ __launch_bounds__(64) void k_splitk_finish(const IgemmParams p, const float *__restrict__ ws, const int nchains)
+{
+    const int lane = threadIdx.x, fr = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+    const int M = p.nbatch * p.T_out;
+    const int em = m0 + fr, n = n0 + 4 * fg;
+    const bool exok = em < M;
+    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (exok && n < p.N)
+        for (int z = 0; z < nchains; z++) {
+            const float4 v = *reinterpret_cast<const float4 *>(ws + ((int64_t)z * M + em) * p.N + n);
+            s += (f32x4){v.x, v.y, v.z, v.w};
+        }
+    const int edyn = dyn_value(p, exok ? em : 0);
+    const bool ln_mode = p.aln_stats || p.rln_stats || p.stats_out;
+    if (ln_mode) {
+        longlong2 st_a = make_longlong2(0, 0), st_r = make_longlong2(0, 0);
+        float4 pc1 = make_float4(0.f, 0.f, 0.f, 0.f), pbias = pc1, pgam = pc1, pbeta = pc1;
+        uint2 presid = make_uint2(0, 0);
+        if (exok) {
+            if (p.aln_stats) st_a = reinterpret_cast<const longlong2 *>(p.aln_stats)[em];
+            if (p.rln_stats) st_r = reinterpret_cast<const longlong2 *>(p.rln_stats)[em];
+        }
+        if (exok && n < p.N) {
+            if (p.aln_stats && !p.ln_rms) pc1 = *reinterpret_cast<const float4 *>(p.aln_c1 + n);
+            if (p.bias) pbias = *reinterpret_cast<const float4 *>(p.bias + n);
+            if (p.resid) {
+                presid = *reinterpret_cast<const uint2 *>(p.resid + epi_row(p, em, n, edyn).rbase + n);
+                if (p.rln_stats) {
+                    pgam = *reinterpret_cast<const float4 *>(p.rln_gamma + n);
+                    pbeta = *reinterpret_cast<const float4 *>(p.rln_beta + n);
+                }
+            }
+        }
+        ln_epi4(p, em, n, exok, s, edyn, ln_row(p, st_a, st_r), pc1, pbias, pgam, pbeta, presid, fg);
+    } else if (exok && n < p.N) {
+        if (p.fast_epi)
+            igemm_store4<true>(p, em, n, s, edyn);
+        else
+            igemm_store4<false>(p, em, n, s, edyn);
+    }
+}
+
+// f32 workspaces of the SPLITZ launches: a small pool per device, a buffer per stream (launches of one stream are ordered; different
+// streams never share one).  The pool is allocated by the first ifh_conv_bf16 call of a device that is NOT inside a stream capture
+// (hipMalloc invalidates a capture); a stream that finds no pool or no free buffer takes the streaming kernel instead.
+constexpr int kWsBufs = 8;
+constexpr size_t kWsFloats = (size_t)4 * 64 * 8192;          // 4 chains x 64 rows x 8192 columns = 8 MB
+struct SplitkPool {
+    std::atomic<bool> ready{false};
+    float *buf[kWsBufs] = {};
+    hipStream_t owner[kWsBufs] = {};
+    int used = 0;
+    std::mutex mu;
+};
+static SplitkPool g_ws_pool[64];
+
+static void splitk_pool_prepare(hipStream_t st)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    SplitkPool &pl = g_ws_pool[dev];
+    if (pl.ready.load(std::memory_order_acquire)) return;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
+    std::lock_guard<std::mutex> lk(pl.mu);
+    if (pl.ready.load(std::memory_order_relaxed)) return;
+    for (int i = 0; i < kWsBufs; i++)
+        if (hipMalloc((void **)&pl.buf[i], kWsFloats * sizeof(float)) != hipSuccess) {
+            (void)hipGetLastError();
+            return;                               // (no pool: every launch keeps the streaming kernel)
+        }
+    pl.ready.store(true, std::memory_order_release);
+}
+
+static float *splitk_workspace(hipStream_t st, size_t floats)
+{
+    int dev = 0;
+    if (floats > kWsFloats || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    SplitkPool &pl = g_ws_pool[dev];
+    if (!pl.ready.load(std::memory_order_acquire)) return nullptr;
+    std::lock_guard<std::mutex> lk(pl.mu);
+    for (int i = 0; i < pl.used; i++)
+        if (pl.owner[i] == st) return pl.buf[i];
+    if (pl.used == kWsBufs) return nullptr;
+    pl.owner[pl.used] = st;
+    return pl.buf[pl.used++];
 }
 
 // ---- k_gemm_dec for deep K (K >= 2048: SpeechT5 fc2 at 3072, Whisper fc2 at 2048), 32 x 32 tiles ----
@@ -1060,6 +1175,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     IFH_CHECK_ARG(M < (1ll << 31));
     hipStream_t st = as_stream(stream);
     if (step_recording()) return step_record_gemm(p);        // resident decode step (step.hip): a phase, not a launch
+    splitk_pool_prepare(st);                                 // (once per device, outside stream captures)
     const bool ln_fold = d->aln_stats || d->rln_stats || d->stats_out;
     const bool aln_only = d->aln_stats && !d->rln_stats && !d->stats_out;     // k_gemm_m64 can consume row statistics, not produce them
     const bool glu = d->act == IFH_ACT_SILU_GLU;
@@ -1098,6 +1214,21 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         // From a few hundred rows up the step is no longer launch-bound and the streaming kernel's L2 traffic (all of W per 32
         // rows) is what a launch costs: the LDS-tiled kernel with the same accumulation chains takes over (same bits).
         static const int dec_rows = getenv("IFH_GEMM_DEC_ROWS") ? atoi(getenv("IFH_GEMM_DEC_ROWS")) : 128;   // tuning switch
+        // a deep narrow layer at decode batch (the LLM's down projection: 1536 x 8960 at 64 rows) is 96 x 4 workgroups of the
+        // streaming kernel re-reading 4 x the weights and 96 x the activations from L2 (34 us for 27.5 MB of weights): the LDS-tiled
+        // kernel with one of the four accumulation chains per workgroup (blockIdx.z) + a finishing pass -- the same chains added in
+        // the same order, hence the same bits
+        static const int splitk_on = getenv("IFH_GEMM_SPLITK") ? atoi(getenv("IFH_GEMM_SPLITK")) : 1;        // tuning switch
+        if (splitk_on && M > 16 && M <= 64 && p.K >= 4096 && p.K % 32 == 0 && d->n % 32 == 0 && d->n >= 512 && p.vec_ok && !glu) {
+            const int chains = 4;
+            float *ws = splitk_workspace(st, (size_t)chains * M * d->n);
+            if (ws) {
+                hipLaunchKernelGGL((k_gemm_dec<32, 64, true>), dim3(1, (d->n + 31) / 32, chains), dim3(256), 0, st, p, chains, ws);
+                hipLaunchKernelGGL(k_splitk_finish, dim3((d->n + 15) / 16, (unsigned)((M + 15) / 16)), dim3(64), 0, st, p, (const float *)ws, chains);
+                IFH_LAUNCH_CHECK("conv_bf16");
+                return IFH_OK;
+            }
+        }
         if (M >= dec_rows && p.K % 32 == 0 && p.K >= 64 && (!ln_fold || d->n % 16 == 0)) {
             const int ksplit = p.K >= 2048 ? 4 : 2;
             // 64 x 64 tiles; 64 x 32 where that is what it takes to give every CU a workgroup

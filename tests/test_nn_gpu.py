@@ -1329,3 +1329,35 @@ def test_whisper_teacher_forced_logits_every_step(dev, golden_dir, family, Bn):
     print('%s B=%d: encoder rel_l2 %.3e; worst teacher-forced logit error = %.2f x the bar (1.5 x HF-bf16 error %.1e..%.1e)'
           % (family, Bn, e_enc, worst, min(meta['bf16_vs_fp32_rel_l2']), max(meta['bf16_vs_fp32_rel_l2'])))
     assert e_enc < 1.5 * meta['enc_bf16_vs_fp32_rel_l2'], (e_enc, meta['enc_bf16_vs_fp32_rel_l2'])
+
+
+@pytest.mark.parametrize('M,N,K', [(64, 1536, 8960), (40, 512, 4096), (33, 2048, 5120)])
+def test_splitk_chain_form_is_bit_identical_to_the_streaming_kernel(dev, M, N, K):
+    """A deep narrow layer at decode batch (the LLM's down projection, 1536 x 8960 at 64 rows: Cluster/InfernLLMWorker.py:108-118's
+    generate() step) runs as k_gemm_dec<32,64,SPLITZ> -- one of the streaming kernel's four accumulation chains per workgroup --
+    + k_splitk_finish (csrc/nn.hip).  Rows in pieces of 16 always take the streaming kernel: same bits, with a residual, with the
+    RMS statistics of the output rows (the form the Qwen2 step uses) and against fp32 torch."""
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = bfr(torch.randn(M, K, generator=g) * 0.5).to(dev, BF)
+    w = bfr(torch.randn(N, K, generator=g) / K ** 0.5).to(dev, BF)
+    r = bfr(torch.randn(M, N, generator=g)).to(dev, BF)
+    for mode in ('plain', 'resid+stats'):
+        outs, stats = [], []
+        for piece in (M, 16):
+            o = torch.zeros(M, N, dtype=BF, device=dev)
+            st = torch.zeros(max(64, M), 2, dtype=torch.int64, device=dev)
+            for r0 in range(0, M, piece):
+                r1 = min(M, r0 + piece)
+                if mode == 'plain':
+                    ops.linear(x[r0:r1], w, None, o[r0:r1], rows=r1 - r0, k=K, n=N)
+                else:
+                    ops.linear(x[r0:r1], w, None, o[r0:r1], rows=r1 - r0, k=K, n=N, resid=r[r0:r1], resid_ld=N,
+                               stats_out=st, stats_off=r0 * 2, ln_dim=N, ln_rms=True)
+            outs.append(o)
+            stats.append(st)
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), (mode, int((outs[0] != outs[1]).sum()))
+        assert torch.equal(stats[0], stats[1]), mode
+        ref = x.float() @ w.float().t() + (r.float() if mode != 'plain' else 0.0)
+        assert rel_l2(outs[0].float().cpu(), ref.cpu()) < 6e-3
