@@ -92,3 +92,26 @@ tot_alone = sum(alone.values())
 print('resident alone: %.1f ms in all; by kernel:' % (tot_alone * 1e-6))
 for k, v in alone.most_common(12):
     print('   %7.1f ms  %4.1f %%  %s' % (v * 1e-6, 100.0 * v / max(1, tot_alone), k))
+
+
+# launches that cannot fill the chip: kernels by time spent in launches of fewer than 256 workgroups
+import csv as _csv
+small = collections.defaultdict(lambda: [0, 0, 0])
+for r in _csv.DictReader(open(f)):
+    s_, e_ = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    if s_ < lo or s_ > t1:
+        continue
+    try:
+        wgs = (int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X']))) * (int(r['Grid_Size_Y']) // max(1, int(r['Workgroup_Size_Y']))) * \
+              (int(r['Grid_Size_Z']) // max(1, int(r['Workgroup_Size_Z'])))
+    except (KeyError, ValueError):
+        continue
+    if wgs < 256:
+        k = r['Kernel_Name'].split('(')[0][:70]
+        b = small[k]
+        b[0] += e_ - s_
+        b[1] += 1
+        b[2] += wgs
+print('launches of < 256 workgroups: time / launches / mean workgroups, by kernel')
+for k, (d, n, w) in sorted(small.items(), key=lambda kv: -kv[1][0])[:14]:
+    print('   %7.1f ms  %6d x  %5.0f wgs  %s' % (d * 1e-6, n, w / max(1, n), k))
