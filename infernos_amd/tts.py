@@ -311,9 +311,16 @@ class ContinuousTTS:
         self.prof = {}                                   # statistics: host wall seconds of step() by phase
 
     # ---- any thread -----------------------------------------------------------------------------------------------
-    def submit(self, input_ids, lens, speakers, max_calls=None, dispatch=None, want_ulaw=False) -> TTSGroup:
+    def submit_each(self, input_ids, lens, speakers, dispatch):
+        """submit() for utterances that arrived together but are each a group of their own (one utterance = one group: its maximum
+        length follows its OWN text length, as in a batch of one -- what the worker does with a queue of requests): the text
+        encoder and the cross-K|V projection run ONCE over all of them (50 sessions speaking at once were 50 encoder passes,
+        65 of the 75 ms to their first frame), every row becomes a TTSGroup over its slice.  dispatch: one callable per row."""
+        return self.submit(input_ids, lens, speakers, dispatch=dispatch, split_rows=True)
+
+    def submit(self, input_ids, lens, speakers, max_calls=None, dispatch=None, want_ulaw=False, split_rows=False):
         """input_ids int [g,T] right-padded, lens int [g], speakers float [g,512].  max_calls bounds the infer() calls
-        the group takes part in (None: until every row has ended)."""
+        the group takes part in (None: until every row has ended).  Returns the TTSGroup (split_rows: one per row, as a list)."""
         from .engines.speecht5 import D, KVP
         pp, st, dev = self.pp, self.st, self.device
         g, t_true = input_ids.shape
@@ -322,8 +329,15 @@ class ContinuousTTS:
             raise ValueError('ContinuousTTS: %d rows x %d tokens exceed the state (%d rows x %d tokens)' % (g, t_true, st.R, st.T))
         if self.failed is not None:
             raise RuntimeError('ContinuousTTS: the engine thread has died') from self.failed
-        grp = TTSGroup(g, t_true, max_calls, dispatch, want_ulaw)
-        grp._engine = self
+        lens_h = [int(v) for v in lens.tolist()] if split_rows else None
+        if split_rows:
+            assert dispatch is not None and len(dispatch) == g and not want_ulaw
+            grps = [TTSGroup(1, lens_h[i], max_calls, [dispatch[i]], False) for i in range(g)]
+        else:
+            grps = [TTSGroup(g, t_true, max_calls, dispatch, want_ulaw)]
+        for grp in grps:
+            grp._engine = self
+        grp = grps[0]
         with torch.cuda.device(dev):
             ids = torch.nn.functional.pad(input_ids, (0, T - t_true)) if T != t_true else input_ids
             enc = pp.model.encode(ids, lens)                                            # [g, T, 768] on the caller's stream
@@ -336,16 +350,21 @@ class ContinuousTTS:
             spn = torch.empty((g, 512), dtype=torch.bfloat16, device=dev)
             _lib.check(_lib.lib().ifh_l2norm_rows_bf16(ops._addr(spk), 512, g, ops._addr(spn), 512, _lib.stream_ptr(dev)),
                        'ifh_l2norm_rows_bf16')
-            grp._admit = dict(T=T, kvs=kvs, spn=spn, lens=lens.to(dev, torch.int32), ready=torch.cuda.Event())
-            for t in kvs + [spn, grp._admit['lens']]:
+            lens_d, ready = lens.to(dev, torch.int32), torch.cuda.Event()
+            for t in kvs + [spn, lens_d]:
                 t.record_stream(self.main)                   # consumed on the engine stream
-            grp._admit['ready'].record(torch.cuda.current_stream(dev))
+            if split_rows:
+                for i, gi in enumerate(grps):                # row i of the one encoder pass (views of the batch tensors)
+                    gi._admit = dict(T=T, kvs=[kv[i:i + 1] for kv in kvs], spn=spn[i:i + 1], lens=lens_d[i:i + 1], ready=ready)
+            else:
+                grp._admit = dict(T=T, kvs=kvs, spn=spn, lens=lens_d, ready=ready)
+            ready.record(torch.cuda.current_stream(dev))
         with self.cv:
             if self.failed is not None:                  # died between the check above and here
                 raise RuntimeError('ContinuousTTS: the engine thread has died') from self.failed
-            self.pending.append(grp)
+            self.pending.extend(grps)
             self.cv.notify_all()
-        return grp
+        return grps if split_rows else grp
 
     # ---- engine thread --------------------------------------------------------------------------------------------
     def _admit(self):
@@ -718,9 +737,9 @@ class InfernTTSWorker(InfernBatchedWorker):
                         ids[i, :n] = st.inputs[0].to(torch.int32)
                         lens[i] = n
                     spk = torch.cat([st.speaker_embeddings.reshape(1, 512).float() for st in fits])
-                    # one utterance = one group: its maxlen follows its own text length, as in a batch of one
-                    for i, st in enumerate(fits):
-                        eng.submit(ids[i:i + 1, :int(lens[i])], lens[i:i + 1], spk[i:i + 1], dispatch=[st.dispatch])
+                    # one utterance = one group: its maxlen follows its own text length, as in a batch of one; the encoder work of
+                    # the requests that arrived together is one pass
+                    eng.submit_each(ids, lens, spk, [st.dispatch for st in fits])
                 if rest:
                     self.process_batch([r for _, r in rest])
             if stop:
