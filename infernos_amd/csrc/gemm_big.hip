@@ -153,6 +153,13 @@ __global__ __launch_bounds__(256, 2) void k_gemm_big(const GemmBigParams p)
                 const float4 bv = *reinterpret_cast<const float4 *>(p.bias + n);
                 v0 += bv.x; v1 += bv.y; v2 += bv.z; v3 += bv.w;
             }
+            if (ACT == ACT_SILU_GLU) {
+                // interleaved (gate, up) weight rows: the lane's four columns are two pairs -> two outputs of the half-width result
+                // (k_gemm_m64's arithmetic, nn.hip); they go to the first half of the transposition row
+                const float o0 = v0 / (1.0f + __expf(-v0)) * v1, o1 = v2 / (1.0f + __expf(-v2)) * v3;
+                *reinterpret_cast<uint32_t *>(wbuf + (j * 16 + fr) * EROW + (i * 16 + 4 * fg)) = f32x2_to_bf16x2(o0, o1);
+                continue;
+            }
             if (ACT != ACT_NONE) {
                 v0 = apply_act_c<ACT>(v0, ACT, 0.0f); v1 = apply_act_c<ACT>(v1, ACT, 0.0f);
                 v2 = apply_act_c<ACT>(v2, ACT, 0.0f); v3 = apply_act_c<ACT>(v3, ACT, 0.0f);
@@ -166,6 +173,16 @@ __global__ __launch_bounds__(256, 2) void k_gemm_big(const GemmBigParams p)
             }
             *reinterpret_cast<uint2 *>(slot) = make_uint2(f32x2_to_bf16x2(v0, v1), f32x2_to_bf16x2(v2, v3));
         }
+    }
+    if (ACT == ACT_SILU_GLU) {                         // 64 outputs per row of the sub-tile: 128 bytes, eight 16-byte pieces
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const int row = it * 4 + trow;
+            if (tch < 8)
+                *reinterpret_cast<uint4 *>(p.out + (int64_t)(mrow0 + row) * p.ldc + (ncol0 >> 1) + tch * 8) =
+                    *reinterpret_cast<const uint4 *>(wbuf + row * EROW + tch * 16);
+        }
+        return;
     }
 #pragma unroll
     for (int it = 0; it < 16; it++) {
@@ -183,7 +200,8 @@ bool try_launch_gemm_big(const IgemmParams &p, bool pre, hipStream_t st)
         p.K < 2 * GB_BK)
         return false;
     if (p.out_f32 || p.colmask || p.accumulate || p.n_split || p.dyn || p.aln_stats || p.rln_stats || p.stats_out || p.zt_cout ||
-        p.out_scale != 1.0f || p.ostride != 1 || p.ooff != 0 || !(p.act == ACT_NONE || p.act == ACT_GELU || p.act == ACT_RELU))
+        p.out_scale != 1.0f || p.ostride != 1 || p.ooff != 0 ||
+        !(p.act == ACT_NONE || p.act == ACT_GELU || p.act == ACT_RELU || p.act == ACT_SILU_GLU) || (p.act == ACT_SILU_GLU && p.resid))
         return false;
     // dense [nbatch * T][..] views only: rows of consecutive batch entries are ld apart like the rows inside one
     if (p.x_bstride != (int64_t)p.T_in * p.lda || p.out_bstride != (int64_t)p.T_out * p.ldc ||
@@ -208,12 +226,14 @@ bool try_launch_gemm_big(const IgemmParams &p, bool pre, hipStream_t st)
         hipError_t e = hipFuncSetAttribute((const void *)k_gemm_big<ACT_NONE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_gemm_big<ACT_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_gemm_big<ACT_RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_gemm_big<ACT_SILU_GLU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) return false;
         attr_once.done(attr_dev);
     }
     const dim3 grid((unsigned)(g.mtiles * g.ntiles));
     if (p.act == ACT_GELU) hipLaunchKernelGGL(k_gemm_big<ACT_GELU>, grid, dim3(256), bytes, st, g);
     else if (p.act == ACT_RELU) hipLaunchKernelGGL(k_gemm_big<ACT_RELU>, grid, dim3(256), bytes, st, g);
+    else if (p.act == ACT_SILU_GLU) hipLaunchKernelGGL(k_gemm_big<ACT_SILU_GLU>, grid, dim3(256), bytes, st, g);
     else hipLaunchKernelGGL(k_gemm_big<ACT_NONE>, grid, dim3(256), bytes, st, g);
     return true;
 }

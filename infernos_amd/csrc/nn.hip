@@ -1179,6 +1179,15 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     const bool ln_fold = d->aln_stats || d->rln_stats || d->stats_out;
     const bool aln_only = d->aln_stats && !d->rln_stats && !d->stats_out;     // k_gemm_m64 can consume row statistics, not produce them
     const bool glu = d->act == IFH_ACT_SILU_GLU;
+    if (glu && M > 64) {
+        // thousands of rows (LLM prefill): the SiLU-gate epilogue exists in the DMA-ring kernel (gemm_big.hip) for whole 256 x 128 tiles
+        IFH_CHECK_ARG(!ln_fold && !d->bias);
+        if (try_launch_gemm_big(p, pre, st)) {
+            IFH_LAUNCH_CHECK("conv_bf16");
+            return IFH_OK;
+        }
+        return fail(IFH_EINVAL, "conv_bf16: the SiLU-gate epilogue takes 17..64 rows, or whole 256 x 128 tiles from 4096 rows up");
+    }
     if (glu)
         IFH_CHECK_ARG(M <= 64 && M > 16 && d->n >= 8192 && d->n % 16 == 0 && !d->resid && !d->accumulate && !d->out_f32 &&
                       !d->colmask && d->n_split == 0 && d->t_out == (int)M && d->ostride == 1 && d->ooff == 0 && !d->dyn_pos &&

@@ -129,8 +129,12 @@ class Qwen2:
                          head_dim=self.hd, max_pos=self.max_tokens, max_keys=max_keys)
             ops.linear(att, L['wo'], None, x, rows=rows, k=self.nh * self.hd, n=d, resid=x)
             ops.rmsnorm(x, self.ones, h, rows, d, self.eps)
-            ops.linear(h, L['wgu'], None, gu, rows=rows, k=d, n=2 * self.ff)
-            ops.silu_mul(gu, ff, rows, self.ff, interleaved=True)
+            if rows >= 4096 and rows % 128 == 0 and (2 * self.ff) % 256 == 0:
+                # prefill: SiLU(gate) * up in the epilogue of the DMA-ring GEMM -- the [rows, 2 ffn] product is never written
+                ops.linear(h, L['wgu'], None, ff, rows=rows, k=d, n=2 * self.ff, ldc=self.ff, act=ops.ACT_SILU_GLU)
+            else:
+                ops.linear(h, L['wgu'], None, gu, rows=rows, k=d, n=2 * self.ff)
+                ops.silu_mul(gu, ff, rows, self.ff, interleaved=True)
             ops.linear(ff, L['wd'], None, x, rows=rows, k=self.ff, n=d, resid=x)
 
     def _layers_fused(self, st, B):

@@ -1361,3 +1361,24 @@ def test_splitk_chain_form_is_bit_identical_to_the_streaming_kernel(dev, M, N, K
         assert torch.equal(stats[0], stats[1]), mode
         ref = x.float() @ w.float().t() + (r.float() if mode != 'plain' else 0.0)
         assert rel_l2(outs[0].float().cpu(), ref.cpu()) < 6e-3
+
+
+def test_gemm_big_silu_gate_epilogue_matches_torch(dev):
+    """LLM prefill's gate|up product (Qwen2MLP: down(silu(gate(x)) * up(x)), reached from Cluster/InfernLLMWorker.py:108-118) with the
+    SiLU-gate epilogue inside the DMA-ring GEMM (csrc/gemm_big.hip, ACT_SILU_GLU: weight rows interleaved gate_j, up_j; the [rows, 2 ffn]
+    product is never written) against fp32 torch, and against the unfused pair of launches at bf16 resolution."""
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(4)
+    M, K, F2 = 4096, 512, 1024
+    x = bfr(torch.randn(M, K, generator=g)).to(dev, BF)
+    w = bfr(torch.randn(F2, K, generator=g) / K ** 0.5).to(dev, BF)
+    out = torch.zeros(M, F2 // 2, dtype=BF, device=dev)
+    ops.linear(x, w, None, out, rows=M, k=K, n=F2, ldc=F2 // 2, act=ops.ACT_SILU_GLU)
+    y = x.float() @ w.float().t()
+    ref = torch.nn.functional.silu(y[:, 0::2]) * y[:, 1::2]
+    assert rel_l2(out.float().cpu(), ref.cpu()) < 4e-3, rel_l2(out.float().cpu(), ref.cpu())
+    gu = torch.zeros(M, F2, dtype=BF, device=dev)
+    ff = torch.zeros(M, F2 // 2, dtype=BF, device=dev)
+    ops.linear(x, w, None, gu, rows=M, k=K, n=F2)
+    ops.silu_mul(gu, ff, M, F2 // 2, interleaved=True)
+    assert rel_l2(out.float().cpu(), ff.float().cpu()) < 8e-3
