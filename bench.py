@@ -170,6 +170,10 @@ class TickProbe(threading.Thread):
         self.host_out = torch.empty((n, 160), dtype=torch.uint8).pin_memory()
         self.lat, self.windows, self._nb = [], 0, 0
         self.worst = (0.0, {})
+        # timing events (marker packets) between the tick's operations: bit 0 after the H2D copy, 1 after the ingest kernel, 2 after the
+        # mix kernel, 3 after the D2H copy.  ANY one of them takes the slowest tick from 40-60 ms to 4-8 ms (six alternating runs:
+        # mask 0 p99 56.7 ms, masks 1 / 2 / 4 / 8 / 15 p99 3.6-4.6 ms); why is not understood (profiles/NOTES.md) -- kept as measured
+        self.evmask = int(os.environ.get('IFH_TICK_EVS', '8'))
         self._halt = threading.Event()
 
     def tick(self, t):
@@ -177,8 +181,13 @@ class TickProbe(threading.Thread):
         L, dev, n = _lib.lib(), self.dev, self.n
         a = time.perf_counter()
         with torch.cuda.stream(self.stream):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record(self.stream)                                 # (completes as soon as the queue reaches it: nothing is in front)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
             self.dfr.copy_(self.host_frames[t % TICKS], non_blocking=True)
+            if self.evmask & 1: evs[0].record(self.stream)           # after the H2D copy
             self.calls.tick(self.dfr, self.slots, self.p8, self.p16, want_ready=False)
+            if self.evmask & 2: evs[1].record(self.stream)           # after the ingest kernel
             b = time.perf_counter()
             self._nb += 160
             if self._nb >= 768:
@@ -191,14 +200,20 @@ class TickProbe(threading.Thread):
             trk = self.tts_pcm[:, off:off + 160].contiguous()
             _lib.check(L.ifh_mux_encode_f32_u8(_lib.ptr(trk), _lib.ptr(self.present), _lib.ptr(self.ndiv), n, 1, 160,
                                                _lib.ptr(self.enc), _lib.ptr(self.has), _lib.stream_ptr(dev)), 'ifh_mux_encode_f32_u8')
+            if self.evmask & 4: evs[2].record(self.stream)           # after the VAD window (if any) and the mix kernel
             self.host_out.copy_(self.enc, non_blocking=True)
+            if self.evmask & 8: evs[3].record(self.stream)           # after the D2H copy
             d = time.perf_counter()
+            ev1.record(self.stream)
             self.stream.synchronize()
         e = time.perf_counter()
         ms = (e - a) * 1e3
-        if ms > self.worst[0]:        # where the slowest tick spent its time: queueing ingest, VAD window (+ its sync), queueing the mix, final wait
+        if ms > self.worst[0]:        # where the slowest tick spent its time: queueing ingest, VAD window (+ its sync), queueing the mix, final wait;
+            # gpu_first_to_last_ms = from the moment the hardware queue reached the tick's first packet to its last kernel's end
             self.worst = (ms, {'queue_ingest_ms': round((b - a) * 1e3, 2), 'vad_window_ms': round((c - b) * 1e3, 2),
-                               'queue_mix_ms': round((d - c) * 1e3, 2), 'final_wait_ms': round((e - d) * 1e3, 2)})
+                               'queue_mix_ms': round((d - c) * 1e3, 2), 'final_wait_ms': round((e - d) * 1e3, 2),
+                               'gpu_first_to_last_ms': round(ev0.elapsed_time(ev1), 2),
+                               'gpu_after_h2d_ingest_vadmix_d2h_ms': [round(ev0.elapsed_time(x), 2) if self.evmask >> i & 1 else None for i, x in enumerate(evs)]})
         return ms
 
     def run(self):
@@ -231,6 +246,7 @@ def time_steps(pipe, frames_for, nsteps, warmup, world, pipelined, egress, dry, 
         torch.cuda._sleep(1000)
         torch.cuda.synchronize()
     c0 = _lib.CALLS[0]
+    g0 = _lib.CountedGraph.captures[0]
     e0 = (sum(e.calls_run for e in pipe.ctts_all), sum(e.rows_run for e in pipe.ctts_all)) if pipe.ctts is not None else None
     p0 = [dict(e.prof) for e in pipe.ctts_all] if pipe.ctts is not None else []
     t0 = time.perf_counter()
@@ -243,6 +259,7 @@ def time_steps(pipe, frames_for, nsteps, warmup, world, pipelined, egress, dry, 
         torch.cuda._sleep(1000)
         torch.cuda.synchronize()
     time_steps.launches_per_step = (_lib.CALLS[0] - c0) / max(1, nsteps)
+    time_steps.graph_captures = _lib.CountedGraph.captures[0] - g0
     time_steps.engine_prof = None if e0 is None else {k: round(sum(e.prof.get(k, 0.0) - q.get(k, 0.0) for e, q in zip(pipe.ctts_all, p0)), 4) for k in ('admit', 'steps', 'render', 'ends_wait', 'book')}
     time_steps.engine = None if e0 is None else (sum(e.calls_run for e in pipe.ctts_all) - e0[0], sum(e.rows_run for e in pipe.ctts_all) - e0[1])
     if probe is not None:
@@ -610,6 +627,7 @@ def main():
             'launches_note': 'calls into stream-taking C-ABI entry points per utterance cycle inside the timed region, hipGraph replays '
                              'counted by the launches they hold (infernos_amd/_lib.py:CALLS)',
             'sequential_stage_ms': stage_ms,
+            'graph_captures_in_timed_region': getattr(time_steps, 'graph_captures', None),
             'tts_engine_host_seconds': getattr(time_steps, 'engine_prof', None),
             'stt_audio_seconds_per_call': round(float(res['stt_seconds'].mean()), 3),
             'tts_samples_per_call': int(res['tts_samples'].float().mean()),

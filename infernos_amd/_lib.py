@@ -231,8 +231,11 @@ class CountedGraph:
     it holds so that replays keep the CALLS statistic meaningful.  The count is this thread's own: launches other threads
     issue during the capture stay in the running total and out of the graph's number."""
 
+    captures = [0]               # statistic: graphs captured so far (a capture inside a serving loop synchronises the device)
+
     def __init__(self, fn):
         import torch
+        CountedGraph.captures[0] += 1
         torch.cuda.synchronize()
         self.g = torch.cuda.CUDAGraph()
         prev, cap = getattr(_tls, 'cap', None), [0]
