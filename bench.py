@@ -136,7 +136,7 @@ class TickProbe(threading.Thread):
     host -> device -> ifh_ingest_tick (+ VAD window step and decision whenever 768 samples complete) and the next 20 ms of
     TTS output goes ifh_mux_encode_f32_u8 -> host; the latency of a tick is hand-over until both are back on the host."""
 
-    def __init__(self, dev, n, host_frames, tts_pcm, period=0.020):
+    def __init__(self, dev, n, host_frames, tts_pcm, period=0.020, vad_model='recurrent'):
         super().__init__(daemon=True)
         from infernos_amd.frontend import CallTable
         from infernos_amd.pipeline import BatchedVAD
@@ -144,11 +144,12 @@ class TickProbe(threading.Thread):
         self.host_frames = host_frames                              # pinned u8 [TICKS, n, 160]
         self.tts_pcm = tts_pcm                                      # device f32 [n, S]: real TTS output rows
         with torch.cuda.device(dev):
-            # the detector of the per-tick path: a recurrent network shaped like the reference's (conv front end + 2 x LSTM(64), state
-            # [2,N,64] x 2 carried per call: csrc/vadnet.hip) so that the tick's latency contains a detector's cost; seeded weights --
-            # Silero's are not obtainable offline -- so its decisions are not used for anything
+            # the detector of the per-tick path = the throughput path's (--vad-model): by default the recurrent network shaped like the
+            # reference's (conv front end + 2 x LSTM(64), state [2,N,64] x 2 carried per call: csrc/vadnet.hip) with the distilled weights --
+            # Silero's are not obtainable offline
             from infernos_amd.vad import RecurrentVADModel
-            self.calls, self.vad = CallTable(n, dev), BatchedVAD(n, dev, model=RecurrentVADModel(dev))
+            self.calls = CallTable(n, dev)
+            self.vad = BatchedVAD(n, dev, model=RecurrentVADModel(dev, weights='distilled') if vad_model == 'recurrent' else None)
             # the per-tick path is the real-time one: its few small kernels go to a high-priority hardware queue so that they
             # do not wait behind a lane's whole queued decode graph
             # IFH_TICK_CUS="first,n" (tuning switch): a CU-range stream instead -- a hardware queue of its own, so that a tick's
@@ -167,13 +168,15 @@ class TickProbe(threading.Thread):
             self.ndiv = torch.ones(n, dtype=torch.int32, device=dev)
             self.enc = torch.empty((n, 160), dtype=torch.uint8, device=dev)
             self.has = torch.empty(n, dtype=torch.uint8, device=dev)
-        self.host_out = torch.empty((n, 160), dtype=torch.uint8).pin_memory()
+        from infernos_amd.frontend import TickEgress
+        self.egress = TickEgress(n, 160, dev)                        # the product's hand-back: D2H copy + marker packet (frontend.py)
+        self.host_out = self.egress.host
         self.lat, self.windows, self._nb = [], 0, 0
         self.worst = (0.0, {})
-        # timing events (marker packets) between the tick's operations: bit 0 after the H2D copy, 1 after the ingest kernel, 2 after the
-        # mix kernel, 3 after the D2H copy.  ANY one of them takes the slowest tick from 40-60 ms to 4-8 ms (six alternating runs:
-        # mask 0 p99 56.7 ms, masks 1 / 2 / 4 / 8 / 15 p99 3.6-4.6 ms); why is not understood (profiles/NOTES.md) -- kept as measured
-        self.evmask = int(os.environ.get('IFH_TICK_EVS', '8'))
+        # extra timing events (marker packets) between the tick's operations, for experiments: bit 0 after the H2D copy, 1 after the
+        # ingest kernel, 2 after the mix kernel.  (Round 4: ANY one marker takes the slowest tick from 40-60 ms to 4-8 ms; the one that
+        # ships sits behind the D2H copy, inside frontend.TickEgress -- the product's hand-back, which this probe calls.)
+        self.evmask = int(os.environ.get('IFH_TICK_EVS', '0'))
         self._halt = threading.Event()
 
     def tick(self, t):
@@ -201,11 +204,10 @@ class TickProbe(threading.Thread):
             _lib.check(L.ifh_mux_encode_f32_u8(_lib.ptr(trk), _lib.ptr(self.present), _lib.ptr(self.ndiv), n, 1, 160,
                                                _lib.ptr(self.enc), _lib.ptr(self.has), _lib.stream_ptr(dev)), 'ifh_mux_encode_f32_u8')
             if self.evmask & 4: evs[2].record(self.stream)           # after the VAD window (if any) and the mix kernel
-            self.host_out.copy_(self.enc, non_blocking=True)
-            if self.evmask & 8: evs[3].record(self.stream)           # after the D2H copy
+            self.egress.push(self.enc)                              # D2H copy + the marker packet behind it
             d = time.perf_counter()
             ev1.record(self.stream)
-            self.stream.synchronize()
+            self.egress.wait()
         e = time.perf_counter()
         ms = (e - a) * 1e3
         if ms > self.worst[0]:        # where the slowest tick spent its time: queueing ingest, VAD window (+ its sync), queueing the mix, final wait;
@@ -440,6 +442,10 @@ def main():
     ap.add_argument('--cu-reserve', type=int, default=None,
                     help='CUs the persistent (one workgroup per CU) vocoder kernels leave to the decode chains and the per-tick kernels '
                          '(SpeechPipeline.cu_reserve, default 96 / IFH_CU_RESERVE; 0 = none)')
+    ap.add_argument('--vad-model', choices=['recurrent', 'energy'], default='recurrent',
+                    help='probability model of the VAD step in the throughput path AND the tick probe: recurrent = conv + 2 x LSTM(64) network on '
+                         'every 768-sample window of every call with the per-call state carried (csrc/vadnet.hip, distilled weights; the '
+                         'reference runs its network there: Core/VAD/SileroVAD.py:78-80); energy = the stateless energy rule')
     ap.add_argument('--no-pipeline', action='store_true', help='run the stages of consecutive cycles strictly one after another')
     args = ap.parse_args()
 
@@ -493,7 +499,7 @@ def main():
         _, family, _ = CONFIGS[cfg]
         pipe = SpeechPipeline(n_local, dev, whisper_family=family, tts_lanes=args.tts_lanes, tts_overlap=not args.no_tts_overlap,
                               tts_group=args.tts_group, front_lanes=args.front_lanes, stt_beam=args.stt_beam if beam is None else beam,
-                              tts_mode=args.tts_mode, cu_reserve=args.cu_reserve)
+                              tts_mode=args.tts_mode, cu_reserve=args.cu_reserve, vad_model=args.vad_model)
         n_total = n_local * world
         # every rank builds its own rows for the N=1 path; with N>1 rank 0 holds all rows and scatters
         if world == 1:
@@ -530,7 +536,7 @@ def main():
         tts_pcm = torch.empty(ul.shape, dtype=torch.float32, device=dev)
         _lib.check(_lib.lib().ifh_g711_decode_u8_f32(_lib.ptr(ul.contiguous()), _lib.ptr(tts_pcm), ul.numel(), _lib.stream_ptr(dev)),
                    'ifh_g711_decode_u8_f32')
-        probe = TickProbe(dev, n_local, host_frames, tts_pcm)
+        probe = TickProbe(dev, n_local, host_frames, tts_pcm, vad_model=args.vad_model)
         for t in range(8):                                          # load its kernels before the timed region
             probe.tick(t)
         probe._t_next = 8
@@ -609,7 +615,9 @@ def main():
             'value': round(value, 2), 'unit': 'x real-time (call-seconds/s)', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 2), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': CONFIGS[args.config][2] % n_local, 'calls_per_gpu': n_local, 'calls_total': n_total,
+            'config': {'workload': (CONFIGS[args.config][2] % n_local).replace('ingest+VAD', 'ingest+VAD (LSTM detector on every window)'
+                                                                                if args.vad_model == 'recurrent' else 'ingest+VAD (energy rule)'),
+                       'calls_per_gpu': n_local, 'calls_total': n_total,
                        'utterance_seconds': UTT_SECONDS, 'weights': 'seeded random (HF shapes)',
                        'parallelism': 'calls sharded %d/GPU, models replicated; RCCL scatter/gather of frames/output' % n_local,
                        'batching': 'across calls only (one utterance per call per batch)' if args.tts_group == 1 else
@@ -619,6 +627,10 @@ def main():
                        'tts_rows_per_batch': n_local * args.tts_group, 'tts_mode': args.tts_mode,
                        'tts_rows_per_decode_step': (round(engine[1] / engine[0], 1) if engine is not None and engine[0] else
                                                     n_local * args.tts_group),
+                       'vad_model': ('conv + 2 x LSTM(64) network (csrc/vadnet.hip: k_vadnet on every 768-sample window of every call inside '
+                                     'ifh_ingest_block_net, per-call state [2,N,64] x 2 carried; weights distilled from the energy rule on synthetic '
+                                     'call audio -- Silero v3.1 itself, Core/VAD/SileroVAD.py:44, is not obtainable offline)'
+                                     if args.vad_model == 'recurrent' else 'stateless energy rule (ifh_vad_energy_prob)'),
                        'stt_decode': ('beam search, %d beams (%d decode rows), 32 tokens' % (args.stt_beam, n_local * args.stt_beam))
                                      if args.stt_beam > 1 else 'greedy, 32 tokens'},
             'rccl_version': (list(torch.cuda.nccl.version()) if world > 1 and not dry else None),
@@ -648,19 +660,20 @@ def main():
                         'worst_tick_ms': round(probe.worst[0], 3), 'worst_tick_split': probe.worst[1],
                         'tick_latency_note': '%d ticks of [%d,160] paced at 20 ms INSIDE the timed region (H2D -> ingest_tick -> VAD '
                                              'window+decision on %d of them -> mux_encode of real TTS rows -> D2H, host to host), '
-                                             'while the TTS/STT lanes were running; the VAD network is a stand-in SHAPED like the reference\'s detector (conv '
-                                             'front end + 2 x LSTM(64) with the per-call state [2,N,64] x 2 carried from window to window, '
-                                             'csrc/vadnet.hip, seeded weights: the Silero v3.1 TorchScript model of Core/VAD/SileroVAD.py:44 '
-                                             'is not available offline), so a detector of that cost class IS in this figure, Silero itself is not' % (len(lat), n_local, probe.windows)})
+                                             'while the TTS/STT lanes were running; the hand-back is the product\'s frontend.TickEgress (D2H copy + one marker packet behind it); the probe\'s VAD model is the one of the throughput path (config.vad_model: '
+                                             '%s), so the tick figure and `value` contain the same detector; Silero v3.1 itself '
+                                             '(Core/VAD/SileroVAD.py:44) is not available offline' % (len(lat), n_local, probe.windows, args.vad_model)})
     # ---- the other single-GPU configurations, briefly (N = 1 only: extra keys, not the headline)
     if world == 1 and not args.no_extra_configs and not args.calls_per_gpu:
         pipe.close()
         del pipe, frames_all, probe
         torch.cuda.empty_cache()
         extra = {}
-        runs = [(c, c, None) for c in ('C2', 'C4', 'C3') if c != args.config]
+        runs = [(c, c, None, args.vad_model) for c in ('C2', 'C4', 'C3') if c != args.config]
         if args.stt_beam > 1:            # SURVEY.md 8(d)'s workload as written (greedy, 32 tokens): keeps rounds comparable
-            runs.append((args.config + '_greedy', args.config, 1))
+            runs.append((args.config + '_greedy', args.config, 1, args.vad_model))
+        if args.vad_model != 'energy':   # the headline's configuration with the round 1-4 energy rule in the VAD step: keeps rounds comparable
+            runs.append((args.config + '_energy_vad', args.config, None, 'energy'))
         k2 = max(4, min(args.steps, 12))
         # every extra configuration in a fresh child process (started, not exec'ed: this process keeps the GPU): a pipeline built
         # in a process that has already run another one measured 15-30 % slower than the same pipeline alone
@@ -675,16 +688,17 @@ def main():
             if r.returncode != 0 or not lines:
                 return {'error': (r.stderr or r.stdout)[-400:]}
             return json.loads(lines[-1])
-        for name, cfg, beam in runs:
+        for name, cfg, beam, vadm in runs:
             n2 = CONFIGS[cfg][0]
-            d2 = child(['--config', cfg, '--steps', str(k2), '--warmup', '2', '--stt-beam', str(beam or args.stt_beam)])
+            d2 = child(['--config', cfg, '--steps', str(k2), '--warmup', '2', '--stt-beam', str(beam or args.stt_beam), '--vad-model', vadm])
             if 'error' in d2:
                 extra[name] = d2
                 continue
             extra[name] = {'workload': CONFIGS[cfg][2] % n2, 'value': d2['value'], 'steps': k2, 'ms_per_step': d2['ms_per_step'],
                            'tts_rows_per_batch': n2 * args.tts_group,
                            'tts_rows_per_decode_step': d2['config'].get('tts_rows_per_decode_step'),
-                           'stt_decode': 'greedy' if (beam or args.stt_beam) == 1 else '%d beams' % (beam or args.stt_beam)}
+                           'stt_decode': 'greedy' if (beam or args.stt_beam) == 1 else '%d beams' % (beam or args.stt_beam),
+                           'vad_model': vadm}
         d5 = child(['--c5-only', '--steps', '5', '--stt-beam', str(args.stt_beam)])
         extra['C5_share'] = d5.get('C5_share', d5)
         dh = child(['--tts-harness-only'])

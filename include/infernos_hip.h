@@ -240,6 +240,14 @@ int ifh_ingest_block(const uint8_t *frames, int nticks, const int32_t *slot, int
                      float *prob, int sample_rate, double threshold, int64_t *st_i64, int32_t *buf_len, float *abuf,
                      int64_t *ev, float *emit, float *arena, int64_t arena_cap, int64_t *log4, int log_cap, int *nlog,
                      int64_t *arena_used, ifh_stream_t stream);
+/* The same driver with the recurrent network of ifh_vadnet_prob as the probability model (the reference runs its network on every
+ * window of every call: Core/VAD/SileroVAD.py:78-80, SileroVADUtils.py:99,131): vad_weights = the ifh_vadnet_weight_floats() blob,
+ * vad_h / vad_c f32 [2][n][64] = the per-call recurrent state in the order of `slot`, updated in place window by window. */
+int ifh_ingest_block_net(const uint8_t *frames, int nticks, const int32_t *slot, int n, uint8_t *fifo, int32_t *fifo_len,
+                         float *win, int32_t *win_ready, float *hist, float *pcm8k, float *pcm16k, ifh_resampler_t rs8to16,
+                         float *prob, int sample_rate, double threshold, int64_t *st_i64, int32_t *buf_len, float *abuf,
+                         int64_t *ev, float *emit, float *arena, int64_t arena_cap, int64_t *log4, int log_cap, int *nlog,
+                         int64_t *arena_used, const float *vad_weights, float *vad_h, float *vad_c, ifh_stream_t stream);
 
 /* ---------------------------------------------------------------------------------
  * Whisper log-mel       replaces Cluster/InfernSTTWorker.py:114 (WhisperProcessor ->
@@ -354,6 +362,11 @@ typedef struct ifh_conv_desc {
     int32_t convt_cout;    /* > 0: w is a ConvTranspose1d(k=8, stride=4, padding=2) in its fused one-launch form -- 3 taps, n =
                             * 4*convt_cout columns, column block r = output phase r, whose unused tap (tap 2 for r < 2, tap 0 for
                             * r >= 2) is all zeros: the kernel then skips those products (same bits, a third less matrix work) */
+    void *splitk_ws;       /* optional f32 workspace OWNED BY THE CALLER (its decode state: one per stream / captured graph that may run
+                            * concurrently), splitk_ws_floats >= 4 * rows * n: a deep narrow decode launch (17..64 rows, K >= 4096: the
+                            * LLM's down projection) then runs as one accumulation chain per workgroup + a finishing pass (same bits as
+                            * the streaming kernel, 1.7 x faster).  NULL: the streaming kernel.  The library holds no workspace of its own */
+    int64_t splitk_ws_floats;
 } ifh_conv_desc;
 int ifh_conv_bf16(const ifh_conv_desc *desc, ifh_stream_t stream);
 
@@ -409,6 +422,31 @@ typedef struct ifh_chain_desc {
                              * [14] workgroup lifetime, [15] workgroups (tools/probe_chain.py) */
 } ifh_chain_desc;
 int ifh_resblock_chain_bf16(const ifh_chain_desc *desc, ifh_stream_t stream);
+/* The same residual block over WHOLE sequences held in ONE LDS image that every convolution overwrites in place (csrc/seq.hip):
+ * nothing is recomputed at tile edges and only the weights stream.  Bit-identical to ifh_resblock_chain_bf16.  Shapes: (c, t) =
+ * (64, 768), (128, 192) or (256, 48) -- the HiFi-GAN levels of a 12-frame chunk -- with taps 3, 7 or 11 (not 3 at c = 64:
+ * ifh_resblock_seq_supported); wstream = the fragment
+ * stream of ops.w_chain_pack zero padded to whole units of ifh_resblock_seq_unit_bytes(c) bytes (8 KB; 16 KB at c = 256), nunits
+ * counted in those units. */
+typedef struct ifh_seq_desc {
+    const void *x;
+    int64_t x_bstride;
+    int32_t c, taps, t, nbatch;
+    const void *wstream;
+    int32_t nunits;
+    const float *bias;
+    float slope;            /* LeakyReLU slope ahead of every convolution, (0, 1] */
+    float out_scale;
+    int32_t accumulate;
+    void *out;
+    int64_t out_bstride;
+    void *debug_prof;       /* NULL, or device uint64[8] (zeroed by the caller): diagnostic shader-clock sums of wave 0 of every workgroup --
+                             * [0] tile top, [1] K loops, [2] waiting for the other waves behind a K loop, [3] conv1 / [4] conv2 epilogues,
+                             * [5] last epilogue, [6] tiles, [7] workgroup lifetime (tools/probe_seq.py) */
+} ifh_seq_desc;
+int ifh_resblock_seq_unit_bytes(int c);
+int ifh_resblock_seq_supported(int c, int t, int taps);       /* 1 if ifh_resblock_seq_bf16 serves this shape */
+int ifh_resblock_seq_bf16(const ifh_seq_desc *desc, ifh_stream_t stream);
 
 /* The residual blocks of one HiFi-GAN upsampling level in ONE launch (csrc/level.hip), weights stationary in registers:
  *     for block j < nblocks (taps[j] in {3, 7, 11}):  y_j = chain_j(x)        (ifh_resblock_chain_bf16's function)

@@ -51,6 +51,8 @@ SIGNATURES = {
     'ifh_vad_step': (_i, [_vp, _vp, _vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ifh_ingest_block': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp,
                               _vp, _i64, _vp, _i, _vp, _vp, _vp]),
+    'ifh_ingest_block_net': (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp, _vp, _vp,
+                                  _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'ifh_logmel_create': (_i, [_i, ctypes.POINTER(_vp)]),
     'ifh_logmel_destroy': (_i, [_vp]),
     'ifh_logmel_filters_host': (_i, [_vp, _vp]),
@@ -76,7 +78,8 @@ class ConvDesc(ctypes.Structure):
                 ('ooff2', ctypes.c_int32), ('dyn_ooff2_mul', ctypes.c_int32),
                 ('aln_stats', _vp), ('aln_c1', _vp), ('rln_stats', _vp), ('rln_gamma', _vp), ('rln_beta', _vp),
                 ('stats_out', _vp), ('ln_dim', ctypes.c_int32), ('ln_eps', _f), ('ln_rms', ctypes.c_int32),
-                ('dyn_stride', ctypes.c_int32), ('decode_step', ctypes.c_int32), ('convt_cout', ctypes.c_int32)]
+                ('dyn_stride', ctypes.c_int32), ('decode_step', ctypes.c_int32), ('convt_cout', ctypes.c_int32),
+                ('splitk_ws', _vp), ('splitk_ws_floats', _i64)]
 
 
 class ResblockDesc(ctypes.Structure):
@@ -88,6 +91,13 @@ class ResblockDesc(ctypes.Structure):
 
 class ChainDesc(ctypes.Structure):
     """ifh_chain_desc (include/infernos_hip.h)"""
+    _fields_ = [('x', _vp), ('x_bstride', _i64), ('c', ctypes.c_int32), ('taps', ctypes.c_int32), ('t', ctypes.c_int32),
+                ('nbatch', ctypes.c_int32), ('wstream', _vp), ('nunits', ctypes.c_int32), ('bias', _vp), ('slope', _f),
+                ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp), ('out_bstride', _i64), ('debug_prof', _vp)]
+
+
+class SeqDesc(ctypes.Structure):
+    """ifh_seq_desc (include/infernos_hip.h)"""
     _fields_ = [('x', _vp), ('x_bstride', _i64), ('c', ctypes.c_int32), ('taps', ctypes.c_int32), ('t', ctypes.c_int32),
                 ('nbatch', ctypes.c_int32), ('wstream', _vp), ('nunits', ctypes.c_int32), ('bias', _vp), ('slope', _f),
                 ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp), ('out_bstride', _i64), ('debug_prof', _vp)]
@@ -158,6 +168,9 @@ SIGNATURES.update({
     'ifh_conv_bf16': (_i, [ctypes.POINTER(ConvDesc), _vp]),
     'ifh_resblock_pair_bf16': (_i, [ctypes.POINTER(ResblockDesc), _vp]),
     'ifh_resblock_chain_bf16': (_i, [ctypes.POINTER(ChainDesc), _vp]),
+    'ifh_resblock_seq_bf16': (_i, [ctypes.POINTER(SeqDesc), _vp]),
+    'ifh_resblock_seq_unit_bytes': (_i, [_i]),
+    'ifh_resblock_seq_supported': (_i, [_i, _i, _i]),
     'ifh_conv_ring256_bf16': (_i, [ctypes.POINTER(Ring256Desc), _vp]),
     'ifh_resblock_level_bf16': (_i, [ctypes.POINTER(LevelDesc), _vp]),
     'ifh_layernorm_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

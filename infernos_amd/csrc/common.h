@@ -79,6 +79,9 @@ int step_record_attn(const void *q, int64_t q_bs, const void *k, const void *v, 
 int step_record_stop(const float *prob_logits, int64_t *ends_at, int n, float threshold, int ends_inc, int32_t *pos,
                      const uint8_t *active, const int32_t *minmax, int logits_ld, void *zero_buf, int64_t zero_bytes);
 
+// vadnet.hip: one recurrent-VAD window step for n calls (window rows by slot, state rows [2][n][64] by call index, updated in place)
+void launch_vadnet_slots(const float *win, const int32_t *slot, int n, const float *weights, float *h, float *c, float *prob, hipStream_t st);
+
 constexpr int kWave = 64;
 
 // ---- bf16 helpers (raw uint16 storage) ------------------------------------------------

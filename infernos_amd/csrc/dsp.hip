@@ -705,12 +705,13 @@ extern "C" int ifh_vad_step(const float *win, const float *prob, const int32_t *
 // (device) and logged on the host.  All n slots must hold the same number of FIFO bytes on entry (calls
 // ticking in lock-step), as they do when every call receives one frame per tick.
 // =========================================================================================
-extern "C" int ifh_ingest_block(const uint8_t *frames, int nticks, const int32_t *slot, int n, uint8_t *fifo,
-                                int32_t *fifo_len, float *win, int32_t *win_ready, float *hist, float *pcm8k,
-                                float *pcm16k, ifh_resampler_t rs8to16, float *prob, int sample_rate, double threshold,
-                                int64_t *st_i64, int32_t *buf_len, float *abuf, int64_t *ev, float *emit, float *arena,
-                                int64_t arena_cap, int64_t *log4, int log_cap, int *nlog, int64_t *arena_used,
-                                ifh_stream_t stream)
+// vad_w == nullptr: the energy rule; else the recurrent network (vadnet.hip) with its per-call state vad_h / vad_c [2][n][64]
+static int ingest_block_impl(const uint8_t *frames, int nticks, const int32_t *slot, int n, uint8_t *fifo,
+                             int32_t *fifo_len, float *win, int32_t *win_ready, float *hist, float *pcm8k,
+                             float *pcm16k, ifh_resampler_t rs8to16, float *prob, int sample_rate, double threshold,
+                             int64_t *st_i64, int32_t *buf_len, float *abuf, int64_t *ev, float *emit, float *arena,
+                             int64_t arena_cap, int64_t *log4, int log_cap, int *nlog, int64_t *arena_used,
+                             const float *vad_w, float *vad_h, float *vad_c, ifh_stream_t stream)
 {
     IFH_CHECK_ARG(n >= 0 && nticks >= 0 && nlog && arena_used);
     *nlog = 0;
@@ -786,7 +787,10 @@ extern "C" int ifh_ingest_block(const uint8_t *frames, int nticks, const int32_t
             const int rc = consume(nwin - 1);
             if (rc != IFH_OK) return rc;
         }
-        hipLaunchKernelGGL(k_vad_energy_prob, dim3(n), dim3(64), 0, st, win, slot, prob);
+        if (vad_w)
+            launch_vadnet_slots(win, slot, n, vad_w, vad_h, vad_c, prob, st);
+        else
+            hipLaunchKernelGGL(k_vad_energy_prob, dim3(n), dim3(64), 0, st, win, slot, prob);
         hipLaunchKernelGGL(k_vad_step, dim3(n), dim3(256), 0, st, win, prob, slot, sample_rate, threshold, st_i64, buf_len,
                            abuf, ev, emit);
         e = hipMemcpyAsync(pin.buf + (size_t)(nwin & 1) * n * 8, ev, (size_t)n * 64, hipMemcpyDeviceToHost, st);
@@ -802,4 +806,29 @@ extern "C" int ifh_ingest_block(const uint8_t *frames, int nticks, const int32_t
     *nlog = nl;
     *arena_used = used;
     return IFH_OK;
+}
+
+extern "C" int ifh_ingest_block(const uint8_t *frames, int nticks, const int32_t *slot, int n, uint8_t *fifo,
+                                int32_t *fifo_len, float *win, int32_t *win_ready, float *hist, float *pcm8k,
+                                float *pcm16k, ifh_resampler_t rs8to16, float *prob, int sample_rate, double threshold,
+                                int64_t *st_i64, int32_t *buf_len, float *abuf, int64_t *ev, float *emit, float *arena,
+                                int64_t arena_cap, int64_t *log4, int log_cap, int *nlog, int64_t *arena_used,
+                                ifh_stream_t stream)
+{
+    return ingest_block_impl(frames, nticks, slot, n, fifo, fifo_len, win, win_ready, hist, pcm8k, pcm16k, rs8to16, prob, sample_rate,
+                             threshold, st_i64, buf_len, abuf, ev, emit, arena, arena_cap, log4, log_cap, nlog, arena_used, nullptr,
+                             nullptr, nullptr, stream);
+}
+
+extern "C" int ifh_ingest_block_net(const uint8_t *frames, int nticks, const int32_t *slot, int n, uint8_t *fifo,
+                                    int32_t *fifo_len, float *win, int32_t *win_ready, float *hist, float *pcm8k,
+                                    float *pcm16k, ifh_resampler_t rs8to16, float *prob, int sample_rate, double threshold,
+                                    int64_t *st_i64, int32_t *buf_len, float *abuf, int64_t *ev, float *emit, float *arena,
+                                    int64_t arena_cap, int64_t *log4, int log_cap, int *nlog, int64_t *arena_used,
+                                    const float *vad_weights, float *vad_h, float *vad_c, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(vad_weights && vad_h && vad_c);
+    return ingest_block_impl(frames, nticks, slot, n, fifo, fifo_len, win, win_ready, hist, pcm8k, pcm16k, rs8to16, prob, sample_rate,
+                             threshold, st_i64, buf_len, abuf, ev, emit, arena, arena_cap, log4, log_cap, nlog, arena_used, vad_weights,
+                             vad_h, vad_c, stream);
 }

@@ -437,52 +437,6 @@ __global__ __launch_bounds__(64) void k_splitk_finish(const IgemmParams p, const
     }
 }
 
-// f32 workspaces of the SPLITZ launches: a small pool per device, a buffer per stream (launches of one stream are ordered; different
-// streams never share one).  The pool is allocated by the first ifh_conv_bf16 call of a device that is NOT inside a stream capture
-// (hipMalloc invalidates a capture); a stream that finds no pool or no free buffer takes the streaming kernel instead.
-constexpr int kWsBufs = 8;
-constexpr size_t kWsFloats = (size_t)4 * 64 * 8192;          // 4 chains x 64 rows x 8192 columns = 8 MB
-struct SplitkPool {
-    std::atomic<bool> ready{false};
-    float *buf[kWsBufs] = {};
-    hipStream_t owner[kWsBufs] = {};
-    int used = 0;
-    std::mutex mu;
-};
-static SplitkPool g_ws_pool[64];
-
-static void splitk_pool_prepare(hipStream_t st)
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
-    SplitkPool &pl = g_ws_pool[dev];
-    if (pl.ready.load(std::memory_order_acquire)) return;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return;
-    std::lock_guard<std::mutex> lk(pl.mu);
-    if (pl.ready.load(std::memory_order_relaxed)) return;
-    for (int i = 0; i < kWsBufs; i++)
-        if (hipMalloc((void **)&pl.buf[i], kWsFloats * sizeof(float)) != hipSuccess) {
-            (void)hipGetLastError();
-            return;                               // (no pool: every launch keeps the streaming kernel)
-        }
-    pl.ready.store(true, std::memory_order_release);
-}
-
-static float *splitk_workspace(hipStream_t st, size_t floats)
-{
-    int dev = 0;
-    if (floats > kWsFloats || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    SplitkPool &pl = g_ws_pool[dev];
-    if (!pl.ready.load(std::memory_order_acquire)) return nullptr;
-    std::lock_guard<std::mutex> lk(pl.mu);
-    for (int i = 0; i < pl.used; i++)
-        if (pl.owner[i] == st) return pl.buf[i];
-    if (pl.used == kWsBufs) return nullptr;
-    pl.owner[pl.used] = st;
-    return pl.buf[pl.used++];
-}
-
 // ---- k_gemm_dec for deep K (K >= 2048: SpeechT5 fc2 at 3072, Whisper fc2 at 2048), 32 x 32 tiles ----
 // A decode-step launch is a serial walk over K in 256-wide chunks whose cost is per chunk, not per byte (profiles/NOTES.md: fc2 spent
 // 35 000 of its 47 000 shader clocks in 12 chunks).  Here the workgroup is TWO groups of four waves: group h walks the half
@@ -1175,7 +1129,6 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     IFH_CHECK_ARG(M < (1ll << 31));
     hipStream_t st = as_stream(stream);
     if (step_recording()) return step_record_gemm(p);        // resident decode step (step.hip): a phase, not a launch
-    splitk_pool_prepare(st);                                 // (once per device, outside stream captures)
     const bool ln_fold = d->aln_stats || d->rln_stats || d->stats_out;
     const bool aln_only = d->aln_stats && !d->rln_stats && !d->stats_out;     // k_gemm_m64 can consume row statistics, not produce them
     const bool glu = d->act == IFH_ACT_SILU_GLU;
@@ -1230,7 +1183,10 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         static const int splitk_on = getenv("IFH_GEMM_SPLITK") ? atoi(getenv("IFH_GEMM_SPLITK")) : 1;        // tuning switch
         if (splitk_on && M > 16 && M <= 64 && p.K >= 4096 && p.K % 32 == 0 && d->n % 32 == 0 && d->n >= 512 && p.vec_ok && !glu) {
             const int chains = 4;
-            float *ws = splitk_workspace(st, (size_t)chains * M * d->n);
+            // the workspace belongs to the caller's decode state (ifh_conv_desc.splitk_ws): captured graphs that replay concurrently on
+            // different streams each carry their own; the library keeps none
+            float *ws = (d->splitk_ws && d->splitk_ws_floats >= (int64_t)chains * M * d->n && (((uintptr_t)d->splitk_ws) & 15) == 0)
+                            ? (float *)d->splitk_ws : nullptr;
             if (ws) {
                 hipLaunchKernelGGL((k_gemm_dec<32, 64, true>), dim3(1, (d->n + 31) / 32, chains), dim3(256), 0, st, p, chains, ws);
                 hipLaunchKernelGGL(k_splitk_finish, dim3((d->n + 15) / 16, (unsigned)((M + 15) / 16)), dim3(64), 0, st, p, (const float *)ws, chains);

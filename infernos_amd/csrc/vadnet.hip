@@ -27,13 +27,16 @@ constexpr int VN_OFF_W1 = 0, VN_OFF_B1 = VN_OFF_W1 + VN_K1 * VN_C1, VN_OFF_W2 = 
 
 __device__ __forceinline__ float vn_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-__global__ __launch_bounds__(256) void k_vadnet(const float *__restrict__ x, int n, const float *__restrict__ w,
-                                                const float *__restrict__ h_in, const float *__restrict__ c_in,
-                                                float *__restrict__ h_out, float *__restrict__ c_out, float *__restrict__ prob)
+// x row of call b: slot ? slot[b] : b (the block driver's window table is indexed by call slot); state and prob rows: b.
+// h_out / c_out may be h_in / c_in: a workgroup reads its own rows before it writes them and touches no others.
+__global__ __launch_bounds__(256) void k_vadnet(const float *x, const int32_t *__restrict__ slot, int n, const float *__restrict__ w,
+                                                const float *h_in, const float *c_in, float *h_out, float *c_out,
+                                                float *__restrict__ prob)
 {
     __shared__ float xs[VN_WIN], f1[VN_T1][VN_C1], f2[VN_T2][VN_C2], hs[2][VN_H], cs[2][VN_H], gs[VN_G], ys[VN_T2];
     const int b = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < VN_WIN; i += 256) xs[i] = x[(int64_t)b * VN_WIN + i];
+    const int64_t xrow = slot ? slot[b] : b;
+    for (int i = tid; i < VN_WIN; i += 256) xs[i] = x[xrow * VN_WIN + i];
     if (tid < 2 * VN_H) {
         const int l = tid / VN_H, j = tid % VN_H;
         hs[l][j] = h_in[((int64_t)l * n + b) * VN_H + j];
@@ -98,6 +101,12 @@ __global__ __launch_bounds__(256) void k_vadnet(const float *__restrict__ x, int
     }
 }
 
+// dsp.hip (ifh_ingest_block_net): the window step of the block driver, state updated in place
+void launch_vadnet_slots(const float *win, const int32_t *slot, int n, const float *weights, float *h, float *c, float *prob, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_vadnet, dim3(n), dim3(256), 0, st, win, slot, n, weights, h, c, h, c, prob);
+}
+
 }  // namespace ifh
 
 using namespace ifh;
@@ -110,7 +119,7 @@ extern "C" int ifh_vadnet_prob(const float *x, int n, const float *weights, cons
     IFH_CHECK_ARG(n >= 0);
     if (n == 0) return IFH_OK;
     IFH_CHECK_ARG(x && weights && h_in && c_in && h_out && c_out && prob);
-    hipLaunchKernelGGL(k_vadnet, dim3(n), dim3(256), 0, as_stream(stream), x, n, weights, h_in, c_in, h_out, c_out, prob);
+    hipLaunchKernelGGL(k_vadnet, dim3(n), dim3(256), 0, as_stream(stream), x, (const int32_t *)nullptr, n, weights, h_in, c_in, h_out, c_out, prob);
     IFH_LAUNCH_CHECK("vadnet_prob");
     return IFH_OK;
 }

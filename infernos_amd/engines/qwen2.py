@@ -111,6 +111,9 @@ class Qwen2:
                 sscratch=torch.zeros(B * 260, dtype=torch.uint8, device=dev),
                 stats=torch.zeros((2 * len(self.layers), max(64, -(-B // 16) * 16), 2), dtype=torch.int64, device=dev),
                 tick=torch.zeros(1, dtype=torch.int32, device=dev),
+                # f32 workspace of the down projection's split-K form (ifh_conv_desc.splitk_ws): part of THIS decode state, so that the
+                # captured step graphs of different states / engines never share one
+                skws=torch.empty(4 * max(B, 16) * d, dtype=torch.float32, device=dev),
                 toks=torch.zeros(B, dtype=torch.int32, device=dev), graph=None, eager_steps=0)
             b = self._bufs[B]
             b['logits'] = b['logits_full'][:, :self.vocab]
@@ -163,9 +166,9 @@ class Qwen2:
                        ln_dim=d, ln_eps=self.eps, ln_rms=True)
             if li + 1 < len(self.layers):
                 ops.linear(ff, L['wd'], None, x, rows=B, k=self.ff, n=d, resid=x, stats_out=stats, stats_off=s1 + 2 * SO, ln_dim=d,
-                           ln_eps=self.eps, ln_rms=True)
+                           ln_eps=self.eps, ln_rms=True, splitk_ws=st['skws'])
             else:
-                ops.linear(ff, L['wd'], None, x, rows=B, k=self.ff, n=d, resid=x)
+                ops.linear(ff, L['wd'], None, x, rows=B, k=self.ff, n=d, resid=x, splitk_ws=st['skws'])
 
     def _head(self, st, x, B, argmax):
         ops.rmsnorm(x, self.norm, st['h'], B, self.d, self.eps)

@@ -49,6 +49,22 @@ class HifiGan:
                     convs.append((sd[R + 'convs1.%d.weight' % d], sd[R + 'convs1.%d.bias' % d]))
                     convs.append((sd[R + 'convs2.%d.weight' % d], sd[R + 'convs2.%d.bias' % d]))
                 self.chain[(i, j)] = ops.w_chain_pack(convs, dev)
+        # whole-sequence blocks (csrc/seq.hip: one LDS image overwritten in place, nothing recomputed) where the level's shape is one
+        # of (c, t) = (256, 48), (128, 192), (64, 768); IFH_SEQ_LEVELS = the channel counts that take it (tuning switch; default 64 and
+        # 256: at C = 128 the chain kernel's one-chunk tiles measure faster, 943 against 1 095 us per level at 1 280 chunks)
+        self.seq = {}
+        self.seq_levels = tuple(int(v) for v in os.environ.get('IFH_SEQ_LEVELS', '64,256').split(',') if v)
+        for i, c in ((0, 256), (1, 128), (2, 64)):
+            for j, k in enumerate((3, 7, 11)):
+                if ops.seq_unit_bytes(c) == 8192:
+                    self.seq[(i, j)] = self.chain[(i, j)]                       # the same fragment stream
+                else:
+                    R = 'resblocks.%d.' % (i * 3 + j)
+                    convs = []
+                    for d in range(3):
+                        convs.append((sd[R + 'convs1.%d.weight' % d], sd[R + 'convs1.%d.bias' % d]))
+                        convs.append((sd[R + 'convs2.%d.weight' % d], sd[R + 'convs2.%d.bias' % d]))
+                    self.seq[(i, j)] = ops.w_chain_pack(convs, dev, unit_bytes=ops.seq_unit_bytes(c))
         # the C = 256 level: every convolution as its own fragment stream for ifh_conv_ring256_bf16 (two chunks per workgroup)
         self.ring = {}
         self.fused_ring = os.environ.get('IFH_NO_RING256') is None          # tuning switch
@@ -87,6 +103,57 @@ class HifiGan:
         b['audio'] = torch.empty((n, t), dtype=BF16, device=dev)
         return b
 
+    def level(self, i, u, B, n, t, c):
+        """The three residual blocks (k = 3, 7, 11) of upsampling level i over u bf16 [n, t, c] -> their mean (B['xn%d' % i])."""
+        h, xn = B['h%d' % i], B['xn%d' % i]
+        rbuf = (B['r0%d' % i], B['r1%d' % i])
+        if self.fused_level and self.fused_chain and c == 32:
+            ops.resblock_level(u, [(k, self.chain[(i, j)][0], self.chain[(i, j)][2]) for j, k in enumerate((3, 7, 11))], xn,
+                               nbatch=n, t=t, c=c, slope=0.1, scale=1.0 / 3.0)
+            return xn
+        for j, k in enumerate((3, 7, 11)):
+            cur = u
+            if c in self.seq_levels and ops.seq_supported(c, t, k):
+                ws, nunits, bias = self.seq[(i, j)]
+                ops.resblock_seq(u, ws, nunits, bias, xn, nbatch=n, t=t, c=c, taps=k, slope=0.1, scale=1.0 / 3.0, accumulate=(j > 0))
+                continue
+            if self.fused_chain and (i, j) in self.chain and (c < 128 or t <= 192):
+                ws, nunits, bias = self.chain[(i, j)]
+                ops.resblock_chain(u, ws, nunits, bias, xn, nbatch=n, t=t, c=c, taps=k, slope=0.1, scale=1.0 / 3.0,
+                                   accumulate=(j > 0))
+                continue
+            for di, d in enumerate((1, 3, 5)):
+                w1, b1, w2, b2 = self.res[i][j][di]
+                if self.fused_ring and c == 256 and t <= 48 and i == 0:
+                    last = di == 2
+                    nxt = xn if last else rbuf[di]
+                    (ws1, rb1), (ws2, rb2) = self.ring[(j, di, 1)], self.ring[(j, di, 2)]
+                    ops.conv_ring256(cur, ws1, rb1, h, nbatch=n, t=t, taps=k, dil=d, pre_slope=0.1)
+                    ops.conv_ring256(h, ws2, rb2, nxt, nbatch=n, t=t, taps=k, dil=1, pre_slope=0.1, resid=cur,
+                                     scale=(1.0 / 3.0 if last else 1.0), accumulate=(last and j > 0))
+                    cur = nxt
+                    continue
+                # both convolutions in one launch, intermediate kept in LDS (same bits) -- except at C = 256 with
+                # >= 512 batch entries, where two launches measure 1.2-1.35x faster (tools/probe_resblock.py 768)
+                if self.fused_pairs and not (c == 256 and n >= 512):
+                    last = di == 2
+                    nxt = xn if last else rbuf[di]
+                    ops.resblock_pair(cur, w1, b1, w2, b2, nxt, nbatch=n, t=t, c=c, taps=k, dil=d, slope=0.1,
+                                      scale=(1.0 / 3.0 if last else 1.0), accumulate=(last and j > 0))
+                    cur = nxt
+                    continue
+                ops.conv(cur, w1, b1, h, nbatch=n, t_in=t, t_out=t, cin=c, n=c, taps=k, dil=d, pad=(k * d - d) // 2,
+                         pre_slope=0.1)
+                if di < 2:
+                    nxt = rbuf[di]
+                    ops.conv(h, w2, b2, nxt, nbatch=n, t_in=t, t_out=t, cin=c, n=c, taps=k, pad=(k - 1) // 2,
+                             pre_slope=0.1, resid=cur)
+                    cur = nxt
+                else:       # last dilation: fold the /3 mean over the three resblocks into the epilogue
+                    ops.conv(h, w2, b2, xn, nbatch=n, t_in=t, t_out=t, cin=c, n=c, taps=k, pad=(k - 1) // 2,
+                             pre_slope=0.1, resid=cur, scale=1.0 / 3.0, accumulate=(j > 0))
+        return xn
+
     def __call__(self, voc_in: torch.Tensor, cache=None) -> torch.Tensor:
         """voc_in bf16 [N, T, 80], already (x-mean)/scale normalised -> bf16 [N, 256*T]"""
         n, t0, _ = voc_in.shape
@@ -104,51 +171,7 @@ class HifiGan:
                     ops.conv(prev, w, ub, u, nbatch=n, t_in=t, t_out=t, cin=c, n=c // 2, taps=2, pad=pad, pre_slope=0.1,
                              ostride=4, ooff=r)
             t, c = t * 4, c // 2
-            h, xn = B['h%d' % i], B['xn%d' % i]
-            rbuf = (B['r0%d' % i], B['r1%d' % i])
-            if self.fused_level and self.fused_chain and c == 32:
-                ops.resblock_level(u, [(k, self.chain[(i, j)][0], self.chain[(i, j)][2]) for j, k in enumerate((3, 7, 11))], xn,
-                                   nbatch=n, t=t, c=c, slope=0.1, scale=1.0 / 3.0)
-                prev = xn
-                continue
-            for j, k in enumerate((3, 7, 11)):
-                cur = u
-                if self.fused_chain and (i, j) in self.chain and (c < 128 or t <= 192):
-                    ws, nunits, bias = self.chain[(i, j)]
-                    ops.resblock_chain(u, ws, nunits, bias, xn, nbatch=n, t=t, c=c, taps=k, slope=0.1, scale=1.0 / 3.0,
-                                       accumulate=(j > 0))
-                    continue
-                for di, d in enumerate((1, 3, 5)):
-                    w1, b1, w2, b2 = self.res[i][j][di]
-                    if self.fused_ring and c == 256 and t <= 48 and i == 0:
-                        last = di == 2
-                        nxt = xn if last else rbuf[di]
-                        (ws1, rb1), (ws2, rb2) = self.ring[(j, di, 1)], self.ring[(j, di, 2)]
-                        ops.conv_ring256(cur, ws1, rb1, h, nbatch=n, t=t, taps=k, dil=d, pre_slope=0.1)
-                        ops.conv_ring256(h, ws2, rb2, nxt, nbatch=n, t=t, taps=k, dil=1, pre_slope=0.1, resid=cur,
-                                         scale=(1.0 / 3.0 if last else 1.0), accumulate=(last and j > 0))
-                        cur = nxt
-                        continue
-                    # both convolutions in one launch, intermediate kept in LDS (same bits) -- except at C = 256 with
-                    # >= 512 batch entries, where two launches measure 1.2-1.35x faster (tools/probe_resblock.py 768)
-                    if self.fused_pairs and not (c == 256 and n >= 512):
-                        last = di == 2
-                        nxt = xn if last else rbuf[di]
-                        ops.resblock_pair(cur, w1, b1, w2, b2, nxt, nbatch=n, t=t, c=c, taps=k, dil=d, slope=0.1,
-                                          scale=(1.0 / 3.0 if last else 1.0), accumulate=(last and j > 0))
-                        cur = nxt
-                        continue
-                    ops.conv(cur, w1, b1, h, nbatch=n, t_in=t, t_out=t, cin=c, n=c, taps=k, dil=d, pad=(k * d - d) // 2,
-                             pre_slope=0.1)
-                    if di < 2:
-                        nxt = rbuf[di]
-                        ops.conv(h, w2, b2, nxt, nbatch=n, t_in=t, t_out=t, cin=c, n=c, taps=k, pad=(k - 1) // 2,
-                                 pre_slope=0.1, resid=cur)
-                        cur = nxt
-                    else:       # last dilation: fold the /3 mean over the three resblocks into the epilogue
-                        ops.conv(h, w2, b2, xn, nbatch=n, t_in=t, t_out=t, cin=c, n=c, taps=k, pad=(k - 1) // 2,
-                                 pre_slope=0.1, resid=cur, scale=1.0 / 3.0, accumulate=(j > 0))
-            prev = xn
+            prev = self.level(i, u, B, n, t, c)
         audio = B['audio']
         _lib.check(_lib.lib().ifh_hifigan_post_bf16(ops._addr(prev), ops._addr(self.post_w), self.post_b, ops._addr(audio),
                                                     n, t, 0.01, _lib.stream_ptr(self.device)), 'ifh_hifigan_post_bf16')

@@ -59,3 +59,37 @@ def mux_encode(tracks: torch.Tensor, present: torch.Tensor, ndiv: torch.Tensor):
         _lib.check(_lib.lib().ifh_mux_encode_f32_u8(_lib.ptr(tracks), _lib.ptr(present), _lib.ptr(ndiv), n, K, L, _lib.ptr(out),
                                                     _lib.ptr(has), _lib.stream_ptr(dev)), 'ifh_mux_encode_f32_u8')
     return out, has
+
+
+class TickEgress:
+    """Hand-back of a tick's encoded frames to the host: the last step of the per-tick path (the reference hands each call's bytes
+    to its RTP sender thread, RTP/RTPOutputWorker.py:84-149; here one [n, L] matrix per tick goes to a pinned host buffer).
+
+    `push(enc)` queues the device-to-host copy on the current stream and records ONE timing event -- a marker packet -- behind it;
+    `wait()` blocks until the stream has passed it and returns the host buffer.  The marker is not decoration: with the serving
+    engines running beside the tick, a copy that is followed directly by the blocking wait left 1-2 ticks per 100 waiting 35-65 ms
+    inside the tick's own hardware queue (round 4: eleven alternating runs, p99 40-57 ms without the marker, 3.6-7.2 ms with it;
+    the queue reaches the tick's first packet at once, the stall sits between its last kernel and the completion signal of the
+    copy).  What the extra packet changes in the queue processor is not understood; it is kept where every per-tick caller gets it --
+    bench.py's tick probe calls this class (IFH_TICK_MARKER=0 takes it out, for measurements)."""
+
+    def __init__(self, n: int, L: int = 160, device=None):
+        import os
+        self.device = _lib.require_device(device)
+        self.host = torch.empty((n, L), dtype=torch.uint8).pin_memory()
+        self.marker = os.environ.get('IFH_TICK_MARKER', '1') != '0'
+        self._ev = torch.cuda.Event(enable_timing=True) if self.marker else None
+        self._stream = None
+
+    def push(self, enc: torch.Tensor):
+        assert enc.dtype == torch.uint8 and enc.shape == self.host.shape and enc.is_cuda
+        self._stream = torch.cuda.current_stream(self.device)
+        self.host.copy_(enc, non_blocking=True)
+        if self.marker:
+            self._ev.record(self._stream)
+        return self
+
+    def wait(self) -> torch.Tensor:
+        if self._stream is not None:
+            self._stream.synchronize()
+        return self.host

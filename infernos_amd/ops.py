@@ -24,8 +24,8 @@ def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=
          resid=None, resid_off=0, resid_ld=None, resid_bstride=None, scale=1.0, accumulate=False,
          out_off=0, ldc=None, out_bstride=None, ostride=1, ooff=0, dyn_pos=None, dyn_ooff_mul=0, dyn_resid_mul=0, dyn_stride=0, decode_step=False, convt_cout=0,
          n_split=0, out2=None, out2_bstride=0, ldc2=0, ooff2=0, dyn_ooff2_mul=0,
-         aln=None, rln=None, stats_out=None, stats_off=0, ln_dim=0, ln_eps=1e-5, ln_rms=False):
-    # aln = (stats, stats_off, c1); rln = (stats, stats_off, gamma, beta)
+         aln=None, rln=None, stats_out=None, stats_off=0, ln_dim=0, ln_eps=1e-5, ln_rms=False, splitk_ws=None):
+    # aln = (stats, stats_off, c1); rln = (stats, stats_off, gamma, beta); splitk_ws = f32 workspace of the caller's decode state
     """One implicit-GEMM launch (see ifh_conv_desc).  Strides default to dense [nbatch][t][c]."""
     d = ConvDesc()
     lda = cin if lda is None else lda
@@ -45,6 +45,7 @@ def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=
     d.ldc, d.ostride, d.ooff = ldc, ostride, ooff
     d.dyn_pos, d.dyn_ooff_mul, d.dyn_resid_mul, d.dyn_stride = _addr(dyn_pos), dyn_ooff_mul, dyn_resid_mul, dyn_stride
     d.decode_step, d.convt_cout = int(decode_step), convt_cout
+    d.splitk_ws, d.splitk_ws_floats = _addr(splitk_ws), (splitk_ws.numel() if splitk_ws is not None else 0)
     d.n_split, d.out2, d.out2_bstride, d.ldc2, d.ooff2, d.dyn_ooff2_mul = n_split, _addr(out2), out2_bstride, ldc2, ooff2, dyn_ooff2_mul
     if aln is not None:
         d.aln_stats, d.aln_c1 = _addr(aln[0], aln[1]), _addr(aln[2])
@@ -79,6 +80,29 @@ def resblock_chain(x, wstream, nunits, bias, out, *, nbatch, t, c, taps, slope=0
     d.out, d.out_bstride, d.debug_prof = _addr(out), t * c, _addr(prof)
     _lib.check(_lib.lib().ifh_resblock_chain_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_resblock_chain_bf16')
     return out
+
+
+def resblock_seq(x, wstream, nunits, bias, out, *, nbatch, t, c, taps, slope=0.1, scale=1.0, accumulate=False, prof=None):
+    """out = chain(x) * scale (+ out) like resblock_chain, over whole sequences in one LDS image overwritten in place
+    (ifh_resblock_seq_bf16: (c, t) = (64, 768), (128, 192), (256, 48)); bit-identical to resblock_chain.  wstream/nunits/bias from
+    w_chain_pack(convs, dev, unit_bytes=seq_unit_bytes(c))."""
+    d = _lib.SeqDesc()
+    d.x, d.x_bstride = _addr(x), t * c
+    d.c, d.taps, d.t, d.nbatch = c, taps, t, nbatch
+    d.wstream, d.nunits, d.bias = _addr(wstream), nunits, _addr(bias)
+    d.slope, d.out_scale, d.accumulate = slope, scale, int(accumulate)
+    d.out, d.out_bstride = _addr(out), t * c
+    d.debug_prof = _addr(prof)
+    _lib.check(_lib.lib().ifh_resblock_seq_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_resblock_seq_bf16')
+    return out
+
+
+def seq_unit_bytes(c):
+    return int(_lib.lib().ifh_resblock_seq_unit_bytes(int(c)))
+
+
+def seq_supported(c, t, taps):
+    return bool(_lib.lib().ifh_resblock_seq_supported(int(c), int(t), int(taps)))
 
 
 def resblock_level(x, blocks, out, *, nbatch, t, c, slope=0.1, scale=1.0, accumulate=False, prof=None):

@@ -8,7 +8,7 @@ Stages of one utterance cycle (`step`):
   ingest : T ticks of [N,160] mu-law frames -> ifh_ingest_tick; each completed 768-sample
            window -> VAD probability (pluggable; stand-in) -> ifh_vad_step -> VadAudioChunks
   stt    : per call merge chunks (VadAudioChunk.append) -> 8k->16k resample -> log-mel ->
-           Whisper encoder -> greedy decode (fixed token budget)
+           Whisper encoder -> 5-beam search (the reference default engine's decode) or greedy (fixed token budget)
   t2t    : identity stub on token ids (BASELINE config 3 calls it "T2T stub")
   tts    : SpeechT5 encoder once, then n_infer x HelloSippyRTPipe.infer (16 decoder steps,
            postnet, HiFi-GAN, amendment, 16k->8k), trimmed per the reference's dispatch offsets,
@@ -82,7 +82,7 @@ class BatchedVAD:
 class SpeechPipeline:
     def __init__(self, ncalls: int, device=None, whisper_family='whisper_tiny', seed=0, n_text=64, n_infer=10,
                  n_new_tokens=32, tts_output_sr=8000, weights=None, tts_lanes=2, tts_overlap=True, tts_group=1,
-                 front_lanes=1, stt_beam=1, tts_mode='lanes', cu_reserve=None):
+                 front_lanes=1, stt_beam=1, tts_mode='lanes', cu_reserve=None, vad_model=None):
         from .engines.whisper import Whisper
         from .features import WhisperLogMel
         from .tts import HelloSippyRTPipe
@@ -103,11 +103,17 @@ class SpeechPipeline:
         self.tts_overlap = tts_overlap      # render of chunk c on a second stream while chunk c+1 decodes (within a lane)
         self.tts_group = max(1, tts_group)  # utterance cycles synthesised as one TTS batch (rows = group * ncalls)
         self.block_ingest = os.environ.get('IFH_TICK_INGEST') is None
+        # The probability model of the VAD step (Core/VAD/SileroVAD.py:78-80 runs its network on every 768-sample window of every call):
+        # None / 'energy' = the stateless energy rule (ifh_vad_energy_prob); 'recurrent' = the conv + 2 x LSTM(64) network of
+        # csrc/vadnet.hip with the distilled weights and the per-call [2,N,64] x 2 state, driven window by window from
+        # ifh_ingest_block_net; or a factory `f(device) -> model(x, sr)` (any other model takes the per-tick path).
+        self.vad_model = os.environ.get('IFH_VAD_MODEL', vad_model) if not callable(vad_model) else vad_model
+        assert self.vad_model in (None, 'energy', 'recurrent') or callable(self.vad_model)
         self.stt_beam = int(stt_beam)      # 1: greedy (the reference's torch engine); 5: its default engine's beam search
         self.stt_dec_prio = os.environ.get('IFH_STT_DEC_PRIO', '0') != '0'
         with torch.cuda.device(dev):
             self.calls = CallTable(ncalls, dev)
-            self.vad = BatchedVAD(ncalls, dev)
+            self.vad = BatchedVAD(ncalls, dev, model=self._new_vad_model())
             self.codec = G711Codec().to(dev)
             self.up = get_resampler(8000, 16000, str(dev))
             w = weights or {}
@@ -170,6 +176,14 @@ class SpeechPipeline:
                     scratch.add_(1.0)
                 st_.synchronize()
 
+    def _new_vad_model(self):
+        if self.vad_model in (None, 'energy'):
+            return None
+        if self.vad_model == 'recurrent':
+            from .vad import RecurrentVADModel
+            return RecurrentVADModel(self.device, weights='distilled')
+        return self.vad_model(self.device)
+
     # ---- stage 1 -----------------------------------------------------------------------------
     def ingest(self, frames: torch.Tensor, fl=None, block=None):
         """frames u8 [T,N,160] on the device -> per-call list of VadAudioChunk.  With the built-in probability model the
@@ -178,7 +192,8 @@ class SpeechPipeline:
         fl = self.front_lanes[0] if fl is None else fl
         T = frames.size(0)
         chunks = [[] for _ in range(self.n)]
-        if (self.block_ingest if block is None else block) and fl.vad.model is None and T:
+        from .vad import RecurrentVADModel
+        if (self.block_ingest if block is None else block) and T and (fl.vad.model is None or isinstance(fl.vad.model, RecurrentVADModel)):
             return self._ingest_block(frames.contiguous(), fl, chunks)
         nbytes = int(fl.calls.fifo_len[0]) if T else 0
         for t in range(T):
@@ -195,14 +210,18 @@ class SpeechPipeline:
         if v.arena is None:
             v.arena = torch.empty(self.n * EMIT_CAP, dtype=torch.float32, device=dev)
         nlog, used = ctypes.c_int(0), ctypes.c_int64(0)
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().ifh_ingest_block(
-                _lib.ptr(frames), frames.size(0), _lib.ptr(self.slots), self.n, _lib.ptr(c.fifo), _lib.ptr(c.fifo_len),
+        args = [_lib.ptr(frames), frames.size(0), _lib.ptr(self.slots), self.n, _lib.ptr(c.fifo), _lib.ptr(c.fifo_len),
                 _lib.ptr(c.win), _lib.ptr(c.win_ready), _lib.ptr(c.hist), _lib.ptr(fl.pcm8k), _lib.ptr(fl.pcm16k),
                 c._rs.handle, _lib.ptr(v.prob), v.input_sr, float(v.threshold), _lib.ptr(v.st), _lib.ptr(v.blen),
                 _lib.ptr(v.abuf), _lib.ptr(v.ev), _lib.ptr(v.emit), _lib.ptr(v.arena), v.arena.numel(),
-                ctypes.c_void_p(v.log.data_ptr()), LOG_CAP, ctypes.byref(nlog), ctypes.byref(used), _lib.stream_ptr(dev)),
-                'ifh_ingest_block')
+                ctypes.c_void_p(v.log.data_ptr()), LOG_CAP, ctypes.byref(nlog), ctypes.byref(used)]
+        with torch.cuda.device(dev):
+            if v.model is None:
+                _lib.check(_lib.lib().ifh_ingest_block(*args, _lib.stream_ptr(dev)), 'ifh_ingest_block')
+            else:       # the recurrent network on every window, its per-call state (v.mh, v.mc) updated in place
+                assert v.mh.is_contiguous() and v.mc.is_contiguous()
+                _lib.check(_lib.lib().ifh_ingest_block_net(*args, _lib.ptr(v.model.blob), _lib.ptr(v.mh), _lib.ptr(v.mc),
+                                                           _lib.stream_ptr(dev)), 'ifh_ingest_block_net')
         for i, ipos, ln, off in v.log[:nlog.value].tolist():
             chunks[i].append(VadAudioChunk(v.arena[off:off + ln].clone(), v.input_sr, ipos))
         return chunks
@@ -336,7 +355,7 @@ class SpeechPipeline:
         fl.vad.st.zero_()
         fl.vad.st[:, 3] = -1
         fl.vad.blen.zero_()
-        fl.vad.mh = torch.zeros_like(fl.vad.mh)
+        fl.vad.mh = torch.zeros_like(fl.vad.mh)      # (new tensors: the per-tick path hands the old ones to the model object)
         fl.vad.mc = torch.zeros_like(fl.vad.mc)
 
     def front_group(self, frames_list, fl=None):
@@ -538,7 +557,7 @@ class _FrontLane:
                 self.calls, self.vad, self.whisper, self.logmel = pipe.calls, pipe.vad, pipe.whisper, pipe.logmel
                 self.pcm8k, self.pcm16k = pipe.pcm8k, pipe.pcm16k
             else:
-                self.calls, self.vad = CallTable(pipe.n, dev), BatchedVAD(pipe.n, dev)
+                self.calls, self.vad = CallTable(pipe.n, dev), BatchedVAD(pipe.n, dev, model=pipe._new_vad_model())
                 self.whisper = copy.copy(pipe.whisper)     # same weight tensors, private activation / KV buffers and graphs
                 self.whisper._enc_bufs, self.whisper._dec_bufs = {}, {}
                 self.logmel = WhisperLogMel(pipe.whisper.n_mel, dev)

@@ -105,10 +105,12 @@ class RecurrentVADModel:
         _last_sr = 0
         _last_batch_size = 0
 
-    def __init__(self, device=None, seed: int = 0):
-        from .weights import pack_vadnet, synth_vadnet
+    def __init__(self, device=None, seed: int = 0, weights=None):
+        """weights: None -> seeded (cost and state plumbing only); 'distilled' -> the weights fitted to the energy rule
+        (weights.load_vadnet_distilled: usable decisions); or a state dict in torch's module layouts."""
+        from .weights import load_vadnet_distilled, pack_vadnet, synth_vadnet
         self.device = _lib.require_device(device)
-        self.sd = synth_vadnet(seed)
+        self.sd = synth_vadnet(seed) if weights is None else (load_vadnet_distilled() if isinstance(weights, str) else weights)
         self.blob = pack_vadnet(self.sd).to(self.device)
         assert self.blob.numel() == _lib.lib().ifh_vadnet_weight_floats()
         self._c = RecurrentVADModel._State()

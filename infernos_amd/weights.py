@@ -214,6 +214,19 @@ def synth_vadnet(seed: int = 0):
     return sd
 
 
+def load_vadnet_distilled():
+    """The weights `tools/train_vadnet.py` fitted to the energy rule of ifh_vad_energy_prob on synthetic call audio (torch module
+    layouts, fp32; infernos_amd/vadnet_distilled.npz): a detector of the reference's architecture whose decisions can be used.  Not
+    Silero's weights (Core/VAD/SileroVAD.py:44 -- the model file is not obtainable offline): PARITY UNPINNED against it."""
+    import os
+    import numpy as np
+    import torch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'vadnet_distilled.npz'))
+    sd = {k: torch.from_numpy(np.ascontiguousarray(z[k])).float() for k in VADNET_SHAPES}
+    assert all(tuple(sd[k].shape) == v for k, v in VADNET_SHAPES.items())
+    return sd
+
+
 def pack_vadnet(sd):
     """The weight blob ifh_vadnet_prob reads: every matrix transposed to [k][out] (consecutive lanes read consecutive outputs), the two
     LSTM biases of a layer added up."""

@@ -1,0 +1,34 @@
+"""CPU: the kernels that read LDS through inline asm (hand-counted waits) must not have their asm destinations touched before the
+data has arrived.  To hipcc an asm load's destination is written when the statement ends; under register pressure it copied or
+spilled such a register right behind the read (round 5, csrc/seq.hip: a bias register and activation fragments stored to scratch
+before their data had landed -- silently wrong sums on the GPU).  tools/lint_asm_loads.py walks the assembly listing for exactly
+that; this test compiles the listing of csrc/seq.hip for gfx950 (hipcc cross-compiles without a GPU) and requires zero findings."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_seq_kernels_do_not_touch_asm_read_destinations_early(tmp_path):
+    from infernos_amd import build as b
+    out = str(tmp_path / 'seq.s')
+    flags = [f for f in b.FLAGS if f not in ('-fPIC', '-Wall')]
+    subprocess.check_call([b.HIPCC] + flags + ['-S', '--cuda-device-only', '-o', out, os.path.join(b.CSRC, 'seq.hip')],
+                          stderr=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'lint_asm_loads.py'), out], capture_output=True, text=True)
+    assert r.returncode == 0 and 'lint_asm_loads: 0 hazard(s)' in r.stdout, r.stdout[-2000:]
+
+
+def test_lint_finds_a_planted_hazard(tmp_path):
+    """the checker itself: a register spilled between its ds_read and the wait is reported, the same code with the wait first is not"""
+    bad = tmp_path / 'bad.s'
+    bad.write_text('_Zkern:\n\tds_read_b128 v[8:11], v20 offset:0\n\tscratch_store_dwordx4 off, v[8:11], off offset:16\n'
+                   '\ts_waitcnt lgkmcnt(0)\n\tv_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[4:7], v[0:3]\n\ts_endpgm\n')
+    good = tmp_path / 'good.s'
+    good.write_text('_Zkern:\n\tds_read_b128 v[8:11], v20 offset:0\n\tds_read_b128 v[12:15], v20 offset:64\n\ts_waitcnt lgkmcnt(1)\n'
+                    '\tv_mfma_f32_16x16x32_bf16 v[0:3], v[8:11], v[4:7], v[0:3]\n\ts_waitcnt lgkmcnt(0)\n'
+                    '\tscratch_store_dwordx4 off, v[12:15], off offset:16\n\ts_endpgm\n')
+    lint = os.path.join(ROOT, 'tools', 'lint_asm_loads.py')
+    assert subprocess.run([sys.executable, lint, str(bad)], capture_output=True).returncode == 1
+    assert subprocess.run([sys.executable, lint, str(good)], capture_output=True).returncode == 0

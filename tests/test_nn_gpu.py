@@ -749,6 +749,57 @@ def test_resblock_chain_is_bit_identical_to_three_pairs(dev, case):
             float(diff.max()), bad.size(0), bad[:6].tolist()))
 
 
+@pytest.mark.parametrize('case', [
+    dict(B=3, c=64, k=7), dict(B=2, c=64, k=7, acc=True), dict(B=5, c=64, k=11, acc=True), dict(B=300, c=64, k=11),
+    dict(B=4, c=128, k=3, acc=True), dict(B=5, c=128, k=7), dict(B=1, c=128, k=11, acc=True), dict(B=515, c=128, k=11),
+    dict(B=4, c=256, k=3), dict(B=7, c=256, k=7, acc=True), dict(B=2, c=256, k=11, acc=True), dict(B=1, c=256, k=11), dict(B=1030, c=256, k=3, acc=True),
+])
+def test_resblock_seq_is_bit_identical_to_three_pairs(dev, case):
+    """ifh_resblock_seq_bf16 (csrc/seq.hip: whole sequences in ONE LDS image that every convolution overwrites in place, nothing
+    recomputed, a wave = MT x 4 tiles with its weight fragments taken pass by pass) against the three ifh_resblock_pair_bf16 launches
+    of the block: same rounding points and accumulation order, so the bits must agree -- at the three level shapes it serves
+    (c, t) = (64, 768), (128, 192), (256, 48), with odd sequence counts (a short last tile at two sequences per workgroup), several
+    tiles per persistent workgroup and the scaled accumulate epilogue."""
+    from infernos_amd import ops
+    B, c, k = case['B'], case['c'], case['k']
+    T = {64: 768, 128: 192, 256: 48}[c]
+    acc = case.get('acc', False)
+    g = torch.Generator().manual_seed(T * 3 + c + k + B)
+    x = torch.randn(B, T, c, generator=g).to(BF).to(dev)
+    convs, dev_w = [], []
+    for d in (1, 3, 5):
+        for _ in range(2):
+            w = bfr(torch.randn(c, c, k, generator=g) / (c * k) ** 0.5)
+            b = torch.randn(c, generator=g) * 0.1
+            convs.append((w, b))
+            dev_w.append((ops.w_conv(w, dev), b.to(dev)))
+    prev = torch.randn(B, T, c, generator=g).to(BF).to(dev)
+    ref = prev.clone()
+    cur = x
+    tmp = [torch.empty_like(x), torch.empty_like(x)]
+    for di, d in enumerate((1, 3, 5)):
+        (w1, b1), (w2, b2) = dev_w[2 * di], dev_w[2 * di + 1]
+        last = di == 2
+        nxt = ref if last else tmp[di]
+        ops.resblock_pair(cur, w1, b1, w2, b2, nxt, nbatch=B, t=T, c=c, taps=k, dil=d, slope=0.1,
+                          scale=(1.0 / 3.0 if last else 1.0), accumulate=(last and acc))
+        cur = nxt
+    ws, nunits, bias = ops.w_chain_pack(convs, dev, unit_bytes=ops.seq_unit_bytes(c))
+    out = prev.clone()
+    x0 = x.clone()
+    for _ in range(2):                                       # twice: the second launch must not depend on what the first left behind
+        out.copy_(prev)
+        ops.resblock_seq(x, ws, nunits, bias, out, nbatch=B, t=T, c=c, taps=k, slope=0.1, scale=1.0 / 3.0, accumulate=acc)
+    torch.cuda.synchronize()
+    assert torch.equal(x, x0)
+    same = torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    if not same:
+        diff = (out.float() - ref.float()).abs()
+        bad = torch.nonzero(diff.amax(dim=2) > 0)
+        raise AssertionError('seq differs from pairs: max abs %g at %d rows, first (batch,row) %s' % (
+            float(diff.max()), bad.size(0), bad[:6].tolist()))
+
+
 def _torch_resblock(x, convs, slope=0.1):
     """fp32 torch HifiGanResidualBlock.forward (transformers modeling_speecht5.py) on [B, T, C] with convs = 6 x (w, b)"""
     y = x.transpose(1, 2)

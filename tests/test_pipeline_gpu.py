@@ -153,14 +153,18 @@ def test_continuous_tts_schedule_matches_sequential_lane_schedule(built_lib, lan
         pipe.ctts.stop()
 
 
-def test_block_ingest_equals_per_tick_ingest(built_lib):
-    """ifh_ingest_block (the tick loop driven from one host call) emits exactly the chunks of the per-tick path."""
+@pytest.mark.parametrize('vad_model', [None, 'recurrent'])
+def test_block_ingest_equals_per_tick_ingest(built_lib, vad_model):
+    """ifh_ingest_block / ifh_ingest_block_net (the tick loop driven from one host call) emit exactly the chunks of the per-tick path --
+    with the energy rule and with the recurrent network (conv + 2 x LSTM(64), per-call state carried window to window:
+    Core/VAD/SileroVAD.py:78-80, SileroVADUtils.py:99,131), whose state tables must also end up equal."""
     from infernos_amd import _lib
     from infernos_amd.pipeline import SpeechPipeline
     from infernos_amd.synth import synth_utterance
     dev = _lib.require_device('cuda:0')
     N = 4
-    pipe = SpeechPipeline(N, dev, n_infer=1, n_new_tokens=2, tts_lanes=1)
+    pipe = SpeechPipeline(N, dev, n_infer=1, n_new_tokens=2, tts_lanes=1, vad_model=vad_model)
+    assert (pipe.vad.model is None) == (vad_model is None)
     x = np.stack([synth_utterance(1000 + i, 10.0) for i in range(N)])
     ulaw = odsp.g711_encode(x)
     frames = torch.from_numpy(np.ascontiguousarray(ulaw.reshape(N, 500, 160).transpose(1, 0, 2))).to(dev)
@@ -170,16 +174,85 @@ def test_block_ingest_equals_per_tick_ingest(built_lib):
         a = pipe.ingest(frames[:250], block=block)            # two calls: the FIFO / VAD state carries over
         b = pipe.ingest(frames[250:], block=block)
         res.append([[(c.ipos, c.audio.cpu().numpy()) for c in la + lb] for la, lb in zip(a, b)])
-        st = (pipe.vad.st.cpu().numpy().copy(), pipe.vad.blen.cpu().numpy().copy(), pipe.calls.fifo_len.cpu().numpy().copy())
+        st = (pipe.vad.st.cpu().numpy().copy(), pipe.vad.blen.cpu().numpy().copy(), pipe.calls.fifo_len.cpu().numpy().copy(),
+              pipe.vad.mh.cpu().numpy().copy(), pipe.vad.mc.cpu().numpy().copy())
         res.append(st)
     tick, tick_st, blk, blk_st = res
     assert sum(len(l) for l in tick) >= N
+    if vad_model is not None:
+        assert np.abs(blk_st[3]).max() > 0              # the network's state moved
     for lt, lb in zip(tick, blk):
         assert [p for p, _ in lt] == [p for p, _ in lb]
         for (_, at), (_, ab) in zip(lt, lb):
             assert np.array_equal(at, ab)
     for u, v in zip(tick_st, blk_st):
         assert np.array_equal(u, v)
+
+
+def test_paced_ticks_beside_the_running_engines_keep_their_tail(built_lib):
+    """The per-tick path as a caller of the library runs it -- H2D frame matrix -> CallTable.tick -> mux_encode ->
+    frontend.TickEgress (D2H copy + the marker packet behind it) -> wait -- paced at 20 ms on a high-priority stream while a
+    pipelined SpeechPipeline (front lanes + the continuous TTS engine) keeps the GPU busy.  Round 4 saw 1-2 ticks per 100 wait
+    40-57 ms in their own hardware queue without the marker and 3.6-7.2 ms with it; the marker now lives in the product
+    (TickEgress), and this test holds the tail: p50 < 3 ms, p99 < 25 ms over 300 ticks (the measured figures go to
+    gpurun_out/tick_tail.json)."""
+    import json
+    import os
+    import threading
+    import time
+    from infernos_amd import _lib
+    from infernos_amd.frontend import CallTable, TickEgress, mux_encode
+    from infernos_amd.pipeline import SpeechPipeline
+    from infernos_amd.synth import synth_utterance
+    dev = _lib.require_device('cuda:0')
+    N = 64
+    x = np.stack([synth_utterance(1000 + i, 10.0) for i in range(N)])
+    ulaw = odsp.g711_encode(x)
+    frames = torch.from_numpy(np.ascontiguousarray(ulaw.reshape(N, 500, 160).transpose(1, 0, 2))).to(dev)
+    pipe = SpeechPipeline(N, dev, whisper_family='whisper_tiny', n_infer=10, n_new_tokens=16, tts_lanes=3, front_lanes=2,
+                          stt_beam=5, tts_mode='continuous', vad_model='recurrent')
+    lat = []
+    try:
+        pipe.prime(frames)
+        stop = threading.Event()
+
+        def load():
+            torch.cuda.set_device(dev)
+            while not stop.is_set():
+                pipe.run_steps(lambda k: frames, 4, pipelined=True)
+        th = threading.Thread(target=load, daemon=True)
+        th.start()
+        time.sleep(0.5)
+        calls, egress = CallTable(N, dev), TickEgress(N, 160, dev)
+        host_in = torch.from_numpy(np.ascontiguousarray(ulaw.reshape(N, 500, 160).transpose(1, 0, 2))).pin_memory()
+        stream = torch.cuda.Stream(device=dev, priority=-1)
+        slots = torch.arange(N, dtype=torch.int32, device=dev)
+        dfr = torch.empty((N, 160), dtype=torch.uint8, device=dev)
+        p8, p16 = torch.empty((N, 160), device=dev), torch.empty((N, 320), device=dev)
+        present, ndiv = torch.ones((N, 1), dtype=torch.uint8, device=dev), torch.ones(N, dtype=torch.int32, device=dev)
+        t0 = time.perf_counter()
+        for t in range(300):
+            due = t0 + t * 0.020
+            now = time.perf_counter()
+            if due > now:
+                time.sleep(due - now)
+            a = time.perf_counter()
+            with torch.cuda.stream(stream):
+                dfr.copy_(host_in[t % 500], non_blocking=True)
+                calls.tick(dfr, slots, p8, p16, want_ready=False)
+                enc, _ = mux_encode(p8[:, None, :], present, ndiv)
+                egress.push(enc).wait()
+            lat.append((time.perf_counter() - a) * 1e3)
+        stop.set()
+        th.join(120)
+        assert np.array_equal(egress.host.numpy(), odsp.g711_encode(odsp.g711_decode(ulaw.reshape(N, 500, 160)[:, 299 % 500])))
+    finally:
+        pipe.close()
+    lat = np.array(lat)
+    p50, p99 = float(np.percentile(lat, 50)), float(np.percentile(lat, 99))
+    os.makedirs('gpurun_out', exist_ok=True)
+    json.dump({'ticks': len(lat), 'calls': N, 'p50_ms': p50, 'p99_ms': p99, 'worst_ms': float(lat.max())}, open('gpurun_out/tick_tail.json', 'w'))
+    assert p50 < 3.0 and p99 < 25.0, (p50, p99, float(lat.max()))
 
 
 def test_config4_front_end_256_calls_per_gpu(built_lib):

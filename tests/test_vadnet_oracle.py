@@ -32,3 +32,33 @@ def test_vadnet_oracle_matches_torch_modules():
         assert 0.0 < float(p.min()) and float(p.max()) < 1.0
     blob = pack_vadnet(sd)
     assert blob.dtype == torch.float32 and blob.numel() == 128 * 32 + 32 + 3 * 32 * 64 + 64 + 2 * (2 * 64 * 256 + 256) + 64 + 1
+
+
+def test_distilled_vadnet_follows_the_energy_rule_on_call_audio():
+    """The weights the throughput path runs (infernos_amd/vadnet_distilled.npz, fitted by tools/train_vadnet.py) make the network a
+    usable detector: on the benchmark's own call audio, seen through G.711 as the serving path sees it and with the LSTM state carried
+    window to window, its decisions at the FSM's two thresholds (0.5 and 0.5 - 0.15, SileroVADUtils.py:105-130) are those of the
+    energy rule of ifh_vad_energy_prob.  (Not Silero's weights -- unobtainable offline: parity unpinned against them.)"""
+    import numpy as np
+    from infernos_amd.synth import synth_utterance
+    from infernos_amd.weights import load_vadnet_distilled
+    from oracle import dsp as odsp
+    from oracle.nn import vadnet
+    sd = load_vadnet_distilled()
+    N = 6
+    x = np.stack([synth_utterance(1000 + i, 10.0) for i in range(N)])
+    pcm = odsp.g711_decode(odsp.g711_encode(x))
+    W = pcm.shape[1] // 768
+    win = torch.from_numpy(pcm[:, :W * 768].reshape(N, W, 768))
+    h, c = torch.zeros(2, N, 64), torch.zeros(2, N, 64)
+    ps = []
+    with torch.no_grad():
+        for w in range(W):
+            p, h, c = vadnet(win[:, w], sd, h, c)
+            ps.append(p)
+    ps = torch.stack(ps, 1).numpy()
+    e = (win.double() ** 2).mean(2)
+    pe = torch.sigmoid(0.5 * (10 * torch.log10(e + 1e-10) + 30)).numpy()
+    assert ((ps > 0.5) == (pe > 0.5)).mean() >= 0.97
+    assert ((ps > 0.35) == (pe > 0.35)).mean() >= 0.97
+    assert (ps[:, :8] < 0.35).all() and (ps[:, -8:] < 0.35).all()        # the second of silence at either end stays silence
