@@ -215,7 +215,11 @@ bool try_launch_gemm_big(const IgemmParams &p, bool pre, hipStream_t st)
     g.x = p.x; g.lda = p.lda; g.w = p.w; g.bias = p.bias; g.resid = p.resid; g.ldr = p.resid_ld;
     g.out = (uint16_t *)p.out; g.ldc = p.ldc; g.M = (int)M; g.N = p.N; g.K = p.K;
     g.mtiles = (int)(M / GB_BM); g.ntiles = p.N / GB_BN;
+#ifdef GB_DEV_ABL          /* tools builds only: ablations chosen by IFH_GEMM_BIG_ABL (wrong results) */
     g.abl = getenv("IFH_GEMM_BIG_ABL") ? atoi(getenv("IFH_GEMM_BIG_ABL")) : 0;
+#else
+    g.abl = 0;
+#endif
     // IFH_GEMM_BIG_LDS (tuning switch): request that many bytes of LDS instead -- above 80 KB a CU holds ONE workgroup of this kernel
     // and half of its registers stay free for the decode chains' workgroups
     static const size_t lds_req = getenv("IFH_GEMM_BIG_LDS") ? (size_t)atoll(getenv("IFH_GEMM_BIG_LDS")) : 0;

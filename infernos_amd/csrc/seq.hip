@@ -133,9 +133,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_seq(const
     constexpr int WGM = NW / WGN;
     static_assert(NH == 1 || NH == 2, "a k-step over all of a wave's row tiles at once, or as two half-steps");
     constexpr int MH = MT / NH;                        // row tiles per step
-    constexpr int RW = (HSEQ ? MH : MT) * 16;          // rows of a sequence a wave owns
+    constexpr int MS = HSEQ ? MT / 2 : MT;             // row tiles of ONE sequence a wave owns
+    constexpr int RW = MS * 16;                        // rows of a sequence a wave owns
     constexpr int WPS = TSEQ / RW;                     // row groups per sequence
-    static_assert(MT % NH == 0 && (!HSEQ || NH == 2) && WGM * WGN == NW && WGN * NT * 16 == C && TSEQ % RW == 0, "tile shape");
+    static_assert(MT % NH == 0 && MT % 2 == 0 && WGM * WGN == NW && WGN * NT * 16 == C && TSEQ % RW == 0, "tile shape");
     static_assert(HSEQ ? (NSEQ == 2 && WGM == WPS) : (WGM == NSEQ * WPS), "row groups");
     static_assert(NRING >= 2 && UNITB % (NW * 1024) == 0, "ring");
     constexpr int SB = (C + 16) * 2;                   // row stride: C*2 + 32 bytes = 2 (mod 4) sixteen-byte slots -> conflict-free fragment reads
@@ -163,9 +164,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_seq(const
     const int srow = (HSEQ ? wm : wm % WPS) * RW + fr; // its lane's first row inside the sequence
     // row tile j of the wave (j >= MH: second half): byte offset in the image from row tile 0; its sequence; its row tile inside that
     struct J {
-        static constexpr int off(int j) { return HSEQ ? (j / MH) * SROWS * SB + (j % MH) * 16 * SB : j * 16 * SB; }
-        static constexpr int seq(int j) { return HSEQ ? j / MH : 0; }
-        static constexpr int row(int j) { return HSEQ ? j % MH : j; }
+        static constexpr int off(int j) { return HSEQ ? (j / MS) * SROWS * SB + (j % MS) * 16 * SB : j * 16 * SB; }
+        static constexpr int seq(int j) { return HSEQ ? j / MS : 0; }
+        static constexpr int row(int j) { return HSEQ ? j % MS : j; }
     };
     constexpr int NSD = HSEQ ? 2 : 1;                  // sequences (buffer descriptors) per wave
 
@@ -651,9 +652,16 @@ extern "C" int ifh_resblock_seq_bf16(const ifh_seq_desc *d, ifh_stream_t stream)
     SEQ_CASE(128, 3, 192, 2, 8, 2, 4, 6, 1, false, 4, 8192)
     // C = 256: two 48-row sequences per workgroup, four waves (512 registers) of both sequences x 64 channels, a half-step per
     // sequence; a k-step of weights is one 16 KB unit
-    SEQ_CASE(256, 11, 48, 2, 4, 4, 4, 6, 2, true, 4, 16384)
-    SEQ_CASE(256, 7, 48, 2, 4, 4, 4, 6, 2, true, 4, 16384)
-    SEQ_CASE(256, 3, 48, 2, 4, 4, 4, 6, 2, true, 4, 16384)
+    static const int nh256 = getenv("IFH_SEQ256_NH") ? atoi(getenv("IFH_SEQ256_NH")) : 2;     // tuning switch: half-steps (a sequence each) or full steps
+    if (nh256 == 2) {
+        SEQ_CASE(256, 11, 48, 2, 4, 4, 4, 6, 2, true, 4, 16384)
+        SEQ_CASE(256, 7, 48, 2, 4, 4, 4, 6, 2, true, 4, 16384)
+        SEQ_CASE(256, 3, 48, 2, 4, 4, 4, 6, 2, true, 4, 16384)
+    } else {
+        SEQ_CASE(256, 11, 48, 2, 4, 4, 4, 6, 1, true, 4, 16384)
+        SEQ_CASE(256, 7, 48, 2, 4, 4, 4, 6, 1, true, 4, 16384)
+        SEQ_CASE(256, 3, 48, 2, 4, 4, 4, 6, 1, true, 4, 16384)
+    }
 #undef SEQ_CASE
     if (rc != IFH_OK) return rc;
     IFH_LAUNCH_CHECK("resblock_seq_bf16");

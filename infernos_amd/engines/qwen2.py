@@ -92,6 +92,7 @@ class Qwen2:
         self.cos_sin = torch.stack([fr.cos(), fr.sin()], -1).contiguous().to(dev)
         self._bufs = {}
         self.fuse = os.environ.get('IFH_LLM_NO_FUSE') is None      # tuning switch: explicit RMSNorm / SiLU launches instead
+        self.glu_prefill = True                                      # prefill's gate|up with the SiLU-gate epilogue, until the library declines it
         self.bucket_batches = True
 
     # ---- buffers ------------------------------------------------------------------------------
@@ -132,10 +133,16 @@ class Qwen2:
                          head_dim=self.hd, max_pos=self.max_tokens, max_keys=max_keys)
             ops.linear(att, L['wo'], None, x, rows=rows, k=self.nh * self.hd, n=d, resid=x)
             ops.rmsnorm(x, self.ones, h, rows, d, self.eps)
-            if rows >= 4096 and rows % 128 == 0 and (2 * self.ff) % 256 == 0:
-                # prefill: SiLU(gate) * up in the epilogue of the DMA-ring GEMM -- the [rows, 2 ffn] product is never written
-                ops.linear(h, L['wgu'], None, ff, rows=rows, k=d, n=2 * self.ff, ldc=self.ff, act=ops.ACT_SILU_GLU)
-            else:
+            fused = self.glu_prefill and rows >= 4096 and rows % 128 == 0 and (2 * self.ff) % 256 == 0
+            if fused:
+                # prefill: SiLU(gate) * up in the epilogue of the DMA-ring GEMM -- the [rows, 2 ffn] product is never written.  The library
+                # may decline the shape (its own row threshold IFH_GEMM_BIG_ROWS, view alignment, the 4 GiB DMA-offset limit): it says so
+                # before launching anything, and the two-launch form below takes over for good.
+                try:
+                    ops.linear(h, L['wgu'], None, ff, rows=rows, k=d, n=2 * self.ff, ldc=self.ff, act=ops.ACT_SILU_GLU)
+                except _lib.InfernosHipError:
+                    self.glu_prefill = fused = False
+            if not fused:
                 ops.linear(h, L['wgu'], None, gu, rows=rows, k=d, n=2 * self.ff)
                 ops.silu_mul(gu, ff, rows, self.ff, interleaved=True)
             ops.linear(ff, L['wd'], None, x, rows=rows, k=self.ff, n=d, resid=x)

@@ -98,8 +98,10 @@ class SpeechPipeline:
             cu_reserve = int(os.environ.get('IFH_CU_RESERVE', '96'))
         self.cu_reserve = max(0, cu_reserve)
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+        self._budget_set = False
         if int(os.environ.get('IFH_BIG_CUS', '0')) <= 0:          # (that switch masks the throughput streams and sets the budget itself)
             _lib.check(_lib.lib().ifh_set_cu_budget(max(32, ncu - self.cu_reserve) if self.cu_reserve else 0), 'ifh_set_cu_budget')
+            self._budget_set = bool(self.cu_reserve)              # process-wide: close() gives the CUs back
         self.tts_overlap = tts_overlap      # render of chunk c on a second stream while chunk c+1 decodes (within a lane)
         self.tts_group = max(1, tts_group)  # utterance cycles synthesised as one TTS batch (rows = group * ncalls)
         self.block_ingest = os.environ.get('IFH_TICK_INGEST') is None
@@ -498,7 +500,11 @@ class SpeechPipeline:
         return out
 
     def close(self):
-        """stop the continuous TTS engine thread (its state holds the KV caches of every row slot)"""
+        """stop the continuous TTS engine thread (its state holds the KV caches of every row slot) and give back the CUs the
+        persistent kernels were kept off (the budget is process-wide: a pipeline that set it restores "all CUs")"""
+        if getattr(self, '_budget_set', False):
+            _lib.check(_lib.lib().ifh_set_cu_budget(0), 'ifh_set_cu_budget')
+            self._budget_set = False
         if self.ctts is not None:
             for eng in self.ctts_all:
                 eng.stop()

@@ -486,9 +486,15 @@ def _rope(x, cos, sin):
 
 def qwen2_forward(sd, cfg, tokens, pos0, caches):
     """tokens int64 [B, T] starting at position pos0 (same for every row; ragged batches are run row by row);
-    caches: list per layer of {} / {'k','v'} [B, kv_heads, S, hd].  Returns logits f32 [B, T, vocab]."""
+    caches: list per layer of {} / {'k','v'} [B, kv_heads, S, hd].  Returns logits f32 [B, T, vocab].
+    With `sd` cast to bfloat16 (_cast) the arithmetic follows transformers' Qwen2 modules run in that dtype (modeling_qwen2.py:
+    RMSNorm and softmax in fp32 and cast back, rotary cos / sin cast to the activations' dtype) -- the "reference engine in bf16"
+    whose error against the fp32 run sets the device bar at depths the transformers fixtures (2-3 layers) do not reach."""
     d, hd, nh, nkv = cfg['hidden'], cfg['head_dim'], cfg['heads'], cfg['kv_heads']
     B, T = tokens.shape
+    dt = sd['model.embed_tokens.weight'].dtype
+    if dt != torch.float32:
+        return _qwen2_forward_lowp(sd, cfg, tokens, pos0, caches, dt)
     cos, sin = rope_cos_sin(pos0 + T, hd, cfg['rope_theta'])
     cos, sin = cos[pos0:], sin[pos0:]
     x = F.embedding(tokens, sd['model.embed_tokens.weight'])
@@ -515,6 +521,42 @@ def qwen2_forward(sd, cfg, tokens, pos0, caches):
                          sd[L + 'mlp.down_proj.weight'])
     x = rms_norm(sd['model.norm.weight'], x, cfg['rms_eps'])
     return F.linear(x, sd.get('lm_head.weight', sd['model.embed_tokens.weight']))
+
+
+def _qwen2_forward_lowp(sd, cfg, tokens, pos0, caches, dt):
+    """qwen2_forward with weights and activations in `dt` (bfloat16), the way transformers runs the model in that dtype"""
+    d, hd, nh, nkv = cfg['hidden'], cfg['head_dim'], cfg['heads'], cfg['kv_heads']
+    B, T = tokens.shape
+    cos, sin = rope_cos_sin(pos0 + T, hd, cfg['rope_theta'])
+    cos, sin = cos[pos0:].to(dt), sin[pos0:].to(dt)
+
+    def norm(w, x):
+        xf = x.float()
+        return w * (xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + cfg['rms_eps'])).to(dt)
+    x = F.embedding(tokens, sd['model.embed_tokens.weight'])
+    for i in range(cfg['layers']):
+        L = 'model.layers.%d.' % i
+        h = norm(sd[L + 'input_layernorm.weight'], x)
+        q = linear(sd, L + 'self_attn.q_proj', h).view(B, T, nh, hd).transpose(1, 2)
+        k = linear(sd, L + 'self_attn.k_proj', h).view(B, T, nkv, hd).transpose(1, 2)
+        v = linear(sd, L + 'self_attn.v_proj', h).view(B, T, nkv, hd).transpose(1, 2)
+        q, k = _rope(q, cos, sin), _rope(k, cos, sin)
+        c = caches[i]
+        if 'k' in c:
+            k, v = torch.cat([c['k'], k], 2), torch.cat([c['v'], v], 2)
+        c['k'], c['v'] = k, v
+        S = k.size(2)
+        kr, vr = k.repeat_interleave(nh // nkv, 1), v.repeat_interleave(nh // nkv, 1)
+        w = (q @ kr.transpose(-1, -2)) * hd ** -0.5
+        m = torch.ones(T, S, dtype=torch.bool).tril(S - T)
+        w = w.masked_fill(~m, float('-inf'))
+        o = (torch.softmax(w.float(), -1).to(dt) @ vr).transpose(1, 2).reshape(B, T, nh * hd)
+        x = x + F.linear(o, sd[L + 'self_attn.o_proj.weight'])
+        h = norm(sd[L + 'post_attention_layernorm.weight'], x)
+        x = x + F.linear(F.silu(F.linear(h, sd[L + 'mlp.gate_proj.weight'])) * F.linear(h, sd[L + 'mlp.up_proj.weight']),
+                         sd[L + 'mlp.down_proj.weight'])
+    x = norm(sd['model.norm.weight'], x)
+    return F.linear(x, sd.get('lm_head.weight', sd['model.embed_tokens.weight'])).float()
 
 
 def qwen2_greedy(sd, cfg, prompts, n_new, eos_ids=()):

@@ -307,9 +307,11 @@ def test_whisper_generate_beam_matches_transformers_fixture(dev, golden_dir):
     assert torch.equal(a[0], b_[0]) and torch.equal(a[1], b_[1]) and torch.allclose(a[2], b_[2])
 
 
-# hypotheses (of 16 sampled) identical to the transformers fixture in round 4 on MI355X; must not fall (the rest are near-tied
-# reorderings inside the fixture-derived bf16 logit bar)
-BASE_BEAM_EXACT_FLOOR = 7
+# The bar on hypotheses identical to the transformers fixture is a RATE (at least half of the sampled ones, as for the tiny model
+# above); every hypothesis that differs is shown below to be a near-tie -- its fp32 teacher-forced score lies within the
+# fixture-derived bf16 logit error of the fixture's best.  Round 4 had replaced the rate by the count it observed (7 of 8) when the
+# beams' cross-attention moved to the MFMA kernel, whose summation order differs; instead the test now runs BOTH cross-attention
+# kernels and holds the MFMA one (the default) to the VALU one's count minus one flipped tie.
 
 
 def test_whisper_base_beam_at_bench_batch_128(dev, golden_dir):
@@ -340,44 +342,51 @@ def test_whisper_base_beam_at_bench_batch_128(dev, golden_dir):
     enc = model.encode(mel)
     melc = mel[:4].float().cpu()
     prompt = torch.tensor([meta['prompt']] * B, dtype=torch.int32)
-    exact = total = 0
     tok_tol = _token_logprob_tol(golden_dir, 'whisper_base')
-    for ci, c in enumerate(mb['cases']):
-        sup = torch.zeros(V)
-        sup[50257:] = float('-inf')
-        sup[c['eos']] = 0.0
-        runs = []
-        for use_graphs in (False, True, True):                  # eager, capture, replay
-            runs.append(model.generate_beam(enc, prompt, c['n_new'], beams=K, eos_id=c['eos'], length_penalty=c['lp'],
-                                            suppress=sup, no_speech_id=50362, check_every=8, use_graphs=use_graphs))
-        for a, b_ in zip(runs[0][:3], runs[2][:3]):
-            assert torch.equal(a, b_), 'graph replay differs from the eager search'
-        toks, lens, scores, nsp = (t.cpu() for t in runs[2])
-        assert torch.equal(toks[:64], toks[64:]) and torch.equal(lens[:64], lens[64:]) and torch.equal(scores[:64], scores[64:])
-        assert torch.equal(nsp[:64], nsp[64:])
-        glen = g['base_len%d' % ci]
-        for b in range(4):
-            mine = toks[b, :lens[b]].tolist()
-            ref = g['base_seq%d' % ci][b, :glen[b]].tolist()
-            n = max(1, len(mine))
-            norm = n ** c['lp']
-            tol = tok_tol * n / norm                            # per-token log-prob tolerance derived from the fixture
-            with torch.no_grad():
-                ts = _teacher_score(sd, melc[b:b + 1], meta['prompt'], mine, mb['nheads'], sup, None) / norm
-            assert abs(ts - float(scores[b])) < tol, (ci, b, ts, float(scores[b]), tol)
-            total += 1
-            if mine == ref:
-                exact += 1
-                assert abs(float(scores[b]) - float(g['base_score%d' % ci][b])) < tol
-            else:
-                rn = max(1, len(ref))
-                assert ts > float(g['base_score%d' % ci][b]) - tok_tol * max(n / norm, rn / rn ** c['lp']), (ci, b, mine, ref, ts)
-    print('base beam at 640 rows: %d / %d sampled hypotheses identical to the transformers fixture' % (exact, total))
+    counts = {}
+    for mfma in (False, True):
+      model.beam_cross_mfma = mfma                              # the beams' cross-attention: k_attn_decode_shared / k_attn_prefill
+      model._dec_bufs = {}                                      # (captured graphs hold the other kernel)
+      exact = total = 0
+      for ci, c in enumerate(mb['cases']):
+          sup = torch.zeros(V)
+          sup[50257:] = float('-inf')
+          sup[c['eos']] = 0.0
+          runs = []
+          for use_graphs in (False, True, True):                  # eager, capture, replay
+              runs.append(model.generate_beam(enc, prompt, c['n_new'], beams=K, eos_id=c['eos'], length_penalty=c['lp'],
+                                              suppress=sup, no_speech_id=50362, check_every=8, use_graphs=use_graphs))
+          for a, b_ in zip(runs[0][:3], runs[2][:3]):
+              assert torch.equal(a, b_), 'graph replay differs from the eager search'
+          toks, lens, scores, nsp = (t.cpu() for t in runs[2])
+          assert torch.equal(toks[:64], toks[64:]) and torch.equal(lens[:64], lens[64:]) and torch.equal(scores[:64], scores[64:])
+          assert torch.equal(nsp[:64], nsp[64:])
+          glen = g['base_len%d' % ci]
+          for b in range(4):
+              mine = toks[b, :lens[b]].tolist()
+              ref = g['base_seq%d' % ci][b, :glen[b]].tolist()
+              n = max(1, len(mine))
+              norm = n ** c['lp']
+              tol = tok_tol * n / norm                            # per-token log-prob tolerance derived from the fixture
+              with torch.no_grad():
+                  ts = _teacher_score(sd, melc[b:b + 1], meta['prompt'], mine, mb['nheads'], sup, None) / norm
+              assert abs(ts - float(scores[b])) < tol, (ci, b, ts, float(scores[b]), tol)
+              total += 1
+              if mine == ref:
+                  exact += 1
+                  assert abs(float(scores[b]) - float(g['base_score%d' % ci][b])) < tol
+              else:
+                  rn = max(1, len(ref))
+                  assert ts > float(g['base_score%d' % ci][b]) - tok_tol * max(n / norm, rn / rn ** c['lp']), (ci, b, mine, ref, ts)
+      counts[mfma] = (exact, total)
+    (ev, total), (em, _) = counts[False], counts[True]
+    print('base beam at 640 rows: %d (MFMA cross-attention) / %d (VALU) of %d sampled hypotheses identical to the transformers fixture' % (em, ev, total))
     rec = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     if os.path.isdir(rec):                       # the count is the number that shows a kernel regression first: recorded per run
         with open(os.path.join(rec, 'beam_exact_matches.json'), 'w') as f:
-            json.dump({'exact': exact, 'total': total, 'floor': BASE_BEAM_EXACT_FLOOR}, f)
-    assert exact >= BASE_BEAM_EXACT_FLOOR, (exact, total)
+            json.dump({'exact_mfma': em, 'exact_valu': ev, 'total': total, 'floor': total // 2}, f)
+    assert em >= total // 2 and ev >= total // 2, (em, ev, total)
+    assert em >= ev - 1, (em, ev, total)
 
 
 def test_whisper_generate_beam_one_beam_is_greedy(dev):

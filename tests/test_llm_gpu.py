@@ -443,6 +443,17 @@ def test_qwen2_config5_share_at_full_depth_matches_oracle(dev, golden_dir):
             o_new.append(new)
             ref.append(torch.stack(lg))
     ref = torch.stack(ref)                                                   # [8, n_new, V]
+    # The bar.  The transformers fixtures measure a bf16 engine's error on 2-3-layer models (1.0-1.1e-2); 28 layers accumulate more.  So
+    # the reference-engine-in-bf16 error is measured HERE, at this depth: the oracle with weights and activations in bfloat16 the way
+    # transformers runs Qwen2 in that dtype (oracle.nn._qwen2_forward_lowp), on two of the sampled sessions' prompts, against its fp32 run
+    # (on 2-layer models that restatement reproduces the fixture's figure: tests/test_oracle_nn.py).
+    sd16 = onn._cast(sd, torch.bfloat16)
+    e16 = []
+    with torch.no_grad():
+        for j in (0, 4):
+            lg16 = onn.qwen2_forward(sd16, cfg, torch.tensor([prompts[rows[j]]]), 0, [{} for _ in range(cfg['layers'])])[0, -1]
+            e16.append(rel_l2(lg16, ref[j, 0]))
+    del sd16
     model = Qwen2(sd, cfg, dev, max_tokens=256)
     del sd
     forced = torch.zeros((B, n_new), dtype=torch.int32)
@@ -457,15 +468,19 @@ def test_qwen2_config5_share_at_full_depth_matches_oracle(dev, golden_dir):
         model.step(st, B, argmax=False)
         got.append(st['logits'][rows].cpu().clone())
     got = torch.stack(got, 1)
-    meta = json.load(open(os.path.join(golden_dir, 'qwen2_meta.json')))
-    bar = 1.5 * max(float(v['hf_bf16_rel_l2']) for v in meta.values() if isinstance(v, dict))
+    bar = 1.5 * max(e16)
     worst = 0.0
     for t in range(n_new):
         for j in range(len(rows)):
             e = rel_l2(got[j, t], ref[j, t])
             worst = max(worst, e)
             assert e < bar, (rows[j], t, e, bar)
-    print('qwen2 1.5B, 28 layers, 64 sessions x 184..192 tokens: worst logit rel-L2 over 8 sessions x 5 positions %.3e (bar %.3e)' % (worst, bar))
+    print('qwen2 1.5B, 28 layers, 64 sessions x 184..192 tokens: worst logit rel-L2 over 8 sessions x 5 positions %.3e; the oracle in bf16 '
+          'at this depth %.3e / %.3e -> bar %.3e' % (worst, e16[0], e16[1], bar))
+    rec = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(rec):
+        with open(os.path.join(rec, 'c5_share_parity.json'), 'w') as f:
+            json.dump({'worst_rel_l2': worst, 'oracle_bf16_rel_l2': e16, 'bar': bar, 'sessions': B, 'sampled': rows, 'positions': n_new}, f)
     top = ref[:, 0].topk(2).values
     for j in range(len(rows)):
         if float(top[j, 0] - top[j, 1]) > 0.1:

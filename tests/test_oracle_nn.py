@@ -153,3 +153,25 @@ def test_sampling_distribution_matches_transformers_warpers(golden_dir):
             assert ids.tolist() == g['ids%d' % ci][r, :n].tolist()
             np.testing.assert_allclose(p.numpy(), g['probs%d' % ci][r, :n], atol=1e-6)
             assert onn.sample_pick(ids, p, 0.0) == int(ids[0]) and onn.sample_pick(ids, p, 0.999999) == int(ids[-1])
+
+
+def test_qwen2_bf16_restatement_reproduces_the_fixture_bf16_error(golden_dir):
+    """oracle.nn.qwen2_forward with bfloat16 weights follows transformers' Qwen2 modules run in that dtype; its error against the fp32
+    run must be the one the transformers fixture recorded for the same seeded weights (hf_bf16_rel_l2, tools/gen_golden_nn.py) -- that
+    makes it usable as "the reference engine in bf16" at depths no fixture reaches (tests/test_llm_gpu.py: the 28-layer configuration-5
+    share measures its bar with it)."""
+    import json
+    import os
+    from infernos_amd.weights import synth_state_dict, QWEN2_CONFIGS
+    meta = json.load(open(os.path.join(golden_dir, 'qwen2_meta.json')))
+    for fam in ('qwen2_tiny', 'qwen2_tiny64'):
+        m, cfg = meta[fam], QWEN2_CONFIGS[fam]
+        sd = synth_state_dict(fam, m['seed'])
+        sd16 = onn._cast(sd, torch.bfloat16)
+        es = []
+        with torch.no_grad():
+            for p in m['prompts']:
+                a = onn.qwen2_forward(sd, cfg, torch.tensor([p]), 0, [{} for _ in range(cfg['layers'])])[0]
+                b = onn.qwen2_forward(sd16, cfg, torch.tensor([p]), 0, [{} for _ in range(cfg['layers'])])[0]
+                es.append(float((b.double() - a.double()).norm() / a.double().norm()))
+        assert 0.75 * m['hf_bf16_rel_l2'] < max(es) < 1.25 * m['hf_bf16_rel_l2'], (fam, es, m['hf_bf16_rel_l2'])

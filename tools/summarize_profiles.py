@@ -31,7 +31,7 @@ def main():
         nF, sF, bF = pmc_sum(dF, 'FETCH_SIZE', passes)
         nW, sW, bW = pmc_sum(dW, 'WRITE_SIZE', passes)
         res = {
-            'command': 'rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 tools/probe_%s.py %d %d  (tools/prof_r03.sh; last of %d passes)' % (what, passes, chunks, passes),
+            'command': 'rocprofv3 --pmc {FETCH_SIZE|WRITE_SIZE} --kernel-trace --output-format csv -- python3 tools/probe_%s.py %d %d  (tools/prof_r05.sh; last of %d passes)' % (what, passes, chunks, passes),
             'workload': ('one HiFi-GAN vocoder pass, %d chunks x 12 frames (bench.py roofline leg)' % chunks) if what == 'vocoder'
                         else ('one log-mel launch (ifh_logmel_run_raw), %d windows of 30 s -> raw [80,3000] f32 + window maxima (bench.py roofline_logmel leg)' % chunks),
             'chunks_per_pass': chunks,
