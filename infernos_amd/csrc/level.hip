@@ -101,6 +101,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
     static_assert(PF >= 1 && PF <= 3, "prefetch depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
+    // ABL & 16: phase clocks of wave 0, summed locally and added to p.prof once as the workgroup ends (an atomic per stamp -- a vector
+    // memory operation in front of the kernel's own vmcnt waits -- tripled the kernel's time and put most of it into the W-wait stamp)
+    unsigned long long pf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, g = lane >> 4;
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
 #define LV_STAMP(IDX)                                                      \
     if constexpr ((ABL & 16) != 0) {                                       \
         const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
-        if (tid == 0) atomicAdd(p.prof + (IDX), now_ - tprev);             \
+        pf[IDX] += now_ - tprev;                                           \
         tprev = now_;                                                      \
     }
             // what this convolution derives from (tq, d, tnext) is derived HERE: opaque copies keep hipcc from hoisting row addresses
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
             __builtin_amdgcn_sched_barrier(0);
             cpar ^= 1;
             LV_STAMP(5)                                // [5] the last row block's epilogue (exposed)
-            if constexpr ((ABL & 16) != 0) { if (tid == 0) atomicAdd(p.prof + 6, 1ull); }      // [6] convolutions
+            if constexpr ((ABL & 16) != 0) pf[6] += 1;                 // [6] convolutions
 #undef LV_STAMP
         };
 
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
             });
             if constexpr ((ABL & 16) != 0) {
                 const unsigned long long now_ = __builtin_amdgcn_s_memtime();
-                if (tid == 0) atomicAdd(p.prof + 7, now_ - tblk);         // [7] block top (x image fill)
+                pf[7] += now_ - tblk;                                     // [7] block top (x image fill)
             }
             const __amdgpu_buffer_rsrc_t xnext = srd(batch_base(p.x, p.x_bstride, tile_nx));
             const int tnext = tile_t0(tile_nx) + r0;
@@ -451,6 +454,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
                   NBLK > 2 ? p.w[2] : p.w[0], NBLK > 2 ? tile : tile_next);
         if constexpr (B2 > 0)
             block(std::integral_constant<int, B2>{}, std::integral_constant<int, B0 * KSUB>{}, std::true_type{}, p.w[2], p.bias[2], p.w[0], tile_next);
+    }
+    if constexpr ((ABL & 16) != 0) {
+        if (tid == 0)
+            for (int i = 0; i < 8; i++) atomicAdd(p.prof + i, pf[i]);
     }
 #undef LV_READ
 #undef LV_WREAD
@@ -523,6 +530,8 @@ extern "C" int ifh_resblock_level_bf16(const ifh_level_desc *d, ifh_stream_t str
         const int abl = getenv("IFH_LEVEL_ABL") ? atoi(getenv("IFH_LEVEL_ABL")) : 0;
 #define LEVEL_ABL(V) if (abl == V && t0 == 11 && t1 == 0) return launch_level<32, 8, 8, 1, 7, 64, 3, 11, 0, 0, false, V>(p, st);
         LEVEL_ABL(1) LEVEL_ABL(4) LEVEL_ABL(8) LEVEL_ABL(12) LEVEL_ABL(13) LEVEL_ABL(16)
+        if (abl == 16 && t1 == 0 && t0 == 3) return launch_level<32, 8, 8, 1, 7, 64, 3, 3, 0, 0, false, 16>(p, st);
+        if (abl == 16 && t1 == 0 && t0 == 7) return launch_level<32, 8, 8, 1, 7, 64, 3, 7, 0, 0, false, 16>(p, st);
 #undef LEVEL_ABL
 #endif
 #ifdef LV_DEV_ONLY

@@ -17,7 +17,7 @@ if os.environ.get('LV_CHILD'):
     n = int(sys.argv[1])
     dev = _lib.require_device('cuda:0')
     g = torch.Generator().manual_seed(0)
-    c, T, k = 32, 3072, 11
+    c, T, k = 32, 3072, int(os.environ.get('LV_TAPS', '11'))
     x = torch.randn(n, T, c, generator=g).to(BF).to(dev)
     convs = [((torch.randn(c, c, k, generator=g) / (c * k) ** 0.5).to(BF).float(), torch.randn(c, generator=g) * 0.1) for _ in range(6)]
     ws, nu, bias = ops.w_chain_pack(convs, dev)
@@ -31,7 +31,7 @@ if os.environ.get('LV_CHILD'):
         fn()
     e1.record(); torch.cuda.synchronize()
     t = e0.elapsed_time(e1) / 8 * 1e-3
-    print('ABL=%-3s %8.1f us  %7.1f TF/s' % (os.environ.get('IFH_LEVEL_ABL', '0'), t * 1e6, 6 * 2.0 * n * T * c * c * k / t / 1e12))
+    print('k=%-2d ABL=%-3s %8.1f us  %7.1f TF/s' % (k, os.environ.get('IFH_LEVEL_ABL', '0'), t * 1e6, 6 * 2.0 * n * T * c * c * k / t / 1e12))
     if prof is not None:
         pr = prof.cpu().tolist()
         nc = max(1, pr[6])
@@ -39,7 +39,8 @@ if os.environ.get('LV_CHILD'):
             pr[0] // nc, pr[1] // nc, pr[2] // nc, pr[3] // nc, pr[4] // nc, pr[5] // nc, pr[7] * 6 // nc, nc))
 else:
     n = sys.argv[1] if len(sys.argv) > 1 else '1280'
-    for abl in ('0', '1', '4', '8', '12', '13', '16'):
-        env = dict(os.environ, LV_CHILD='1', IFH_LEVEL_ABL=abl)
+    runs = [('0', '11'), ('1', '11'), ('4', '11'), ('12', '11'), ('13', '11'), ('16', '11'), ('0', '7'), ('16', '7'), ('0', '3'), ('16', '3')]
+    for abl, taps in runs:
+        env = dict(os.environ, LV_CHILD='1', IFH_LEVEL_ABL=abl, LV_TAPS=taps)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), n], env=env, capture_output=True, text=True)
         print('\n'.join((r.stdout.strip().splitlines() or [r.stderr[-300:]])[-2:]))
