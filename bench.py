@@ -609,6 +609,12 @@ def main():
                 return None
             pj = json.load(open(f))
             return pj['hbm_bytes_per_pass'] * per / pj['chunks_per_pass']
+
+        def pmc_field(name, key):
+            f = os.path.join(ROOT, 'profiles', name)
+            if not os.path.exists(f):
+                return None
+            return json.load(open(f)).get(key)
         lat = np.array(probe.lat) if probe is not None and probe.lat else None
         out = {
             'metric': 'real-time-factor x concurrent calls (STT+TTS on 20 ms G.711 frames)',
@@ -645,13 +651,16 @@ def main():
             'tts_samples_per_call': int(res['tts_samples'].float().mean()),
             'roofline': {'kernel': 'HiFi-GAN vocoder pass (%d chunks x 12 frames per launch group)' % nchunks,
                          'bound': 'mfma', 'achieved': round(ach_tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': pmc('r04_vocoder_pmc.json', nchunks),
-                         'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r04_vocoder_pmc.json (1280-chunk pass; scaled by chunks if the pass sizes differ)',
+                         'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': pmc('r05_vocoder_pmc.json', nchunks),
+                         'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r05_vocoder_pmc.json (1280-chunk pass; scaled by chunks if the pass sizes differ; the x2 over-counts the 8-byte-per-lane loads of the residual-block kernels, see the note in that file)',
                          'seconds_per_vocoder_pass': t_voc},
             'roofline_logmel': {'kernel': 'k_logmel_fft (%d x 30 s windows -> raw log-mel [80,3000] f32 + window maximum)' % n_local, 'bound': 'hbm',
                                 'achieved': round(ach_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                'frac': round(ach_gbs / PEAK_HBM_GBS, 4), 'traffic': pmc('r04_logmel_pmc.json', n_local),
-                                'traffic_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r04_logmel_pmc.json',
+                                'frac': round(ach_gbs / PEAK_HBM_GBS, 4), 'traffic': pmc('r05_logmel_pmc.json', n_local),
+                                'traffic_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r05_logmel_pmc.json',
+                                'valu_frac': pmc_field('r05_logmel_pmc.json', 'valu_frac'),
+                                'valu_note': 'SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x shader clocks of the launch) of k_logmel_fft from the separate --pmc passes (profiles/r05_logmel_pmc.json: sq_reading) -- the vector ALUs '
+                                             'are busy this share of the time a CU is occupied; the kernel is issue-bound on its FFT arithmetic, not on HBM',
                                 'seconds': t_mel},
         }
         if lat is not None:
