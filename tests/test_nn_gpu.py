@@ -504,11 +504,15 @@ def test_igemm_plain_tile_loads_match_torch(dev, M, N, K, act, resid):
 
 
 @pytest.mark.parametrize('M,N,K,act,resid', [(4096, 256, 64, 0, False), (8192, 512, 512, 2, False), (24576, 1536, 512, 0, False),
-                                             (12288, 512, 2048, 0, True), (8192, 768, 768, 1, True), (131072, 256, 96, 0, False)])
+                                             (12288, 512, 2048, 0, True), (8192, 768, 768, 1, True), (131072, 256, 96, 0, False),
+                                             (65536, 512, 512, 0, True), (32768, 2048, 512, 2, False), (4224, 512, 256, 0, False)])
 def test_gemm_big_matches_torch_and_the_igemm_bits(dev, M, N, K, act, resid):
-    """k_gemm_big (csrc/gemm_big.hip: 256 x 128 tiles of four waves, operands by DMA into a three-stage ring, two workgroups per
-    CU) takes the matrix products with >= 4096 rows and whole tiles.  Against fp32 torch; and bit for bit against k_igemm, which
-    still takes the same product when four more columns are appended to w (N no multiple of 256): same k order, same epilogue."""
+    """The matrix products with >= 4096 rows and whole tiles: k_gemm_big8 (csrc/gemm_big8.hip: one persistent workgroup of eight
+    waves per CU, 256 x 256 tiles, whole-line DMA pieces into a two-stage ring, epilogue through the idle slot; rows in 256s, K in
+    128s from 256 -- the cases with 512 and 1 024 tiles make a workgroup walk several, with and without residual) and k_gemm_big
+    (csrc/gemm_big.hip: 256 x 128 tiles of four waves, two workgroups per CU; the other shapes, e.g. 4 224 rows or K = 64 / 96).
+    Against fp32 torch; and bit for bit against k_igemm, which still takes the same product when four more columns are appended to
+    w (N no multiple of 256): same k order, same epilogue."""
     from infernos_amd import ops
     g = torch.Generator().manual_seed(M + N + K)
     x = bfr(torch.randn(M, K, generator=g))

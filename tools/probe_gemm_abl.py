@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Ablation timings of k_gemm_big8 at the Whisper-base encoder shapes -- needs tools/build_gemm_abl.sh's library.
-IFH_GEMM_BIG_ABL bits: 1 no DMA after a tile's first stages, 2 no MFMAs, 4 no epilogue (results are wrong by design)."""
+IFH_GEMM_BIG_ABL bits: 1 no DMA after a tile's first stages, 2 no MFMAs, 4 no epilogue, 16 no output stores (results are wrong by
+design); 8 = phase clocks of wave 0 (K loop, waits in front of the stage barriers, the barriers, epilogue), printed per launch."""
 import os
 import subprocess
 import sys
@@ -30,11 +31,10 @@ if os.environ.get('GB_CHILD'):
         us = e0.elapsed_time(e1) / 10 * 1e3
         print('ABL=%s %-10s %6.0f us = %5.0f TF/s' % (os.environ.get('IFH_GEMM_BIG_ABL', '0'), name, us, 2.0 * M * K * N / us / 1e6))
 else:
-    runs = [(a, '1') for a in (sys.argv[1].split(',') if len(sys.argv) > 1 else ('0', '1', '2', '4', '5', '6', '3'))] + [('8', '1'), ('8', '0'), ('0', '0')]
-    for abl, stag in runs:
-        env = dict(os.environ, GB_CHILD='1', IFH_GEMM_BIG_ABL=abl, IFH_GEMM_BIG8_STAGGER=stag)
+    runs = [a for a in (sys.argv[1].split(',') if len(sys.argv) > 1 else ('0', '1', '2', '4', '5', '6', '3', '16', '17'))] + ['8']
+    for abl in runs:
+        env = dict(os.environ, GB_CHILD='1', IFH_GEMM_BIG_ABL=abl)
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
-        print('-- stagger', stag)
         print('\n'.join((r.stdout.strip().splitlines() or [r.stderr[-300:]])[-4:]))
         if abl == '8':
             seen = set()
