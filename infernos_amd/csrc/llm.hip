@@ -8,10 +8,17 @@
 //   k_attn_gqa       one query token per (token, kv head): the G query heads of a kv head share every K/V load; keys
 //                    0 .. key_len[token]-1 of the token's cache row.  The same kernel serves prefill (one launch over all
 //                    prompt tokens, key_len = position + 1: causal) and decode.
+//   k_attn_gqa_prefill  the same attention for the prompt (tokens_per_row >= 16) on the matrix cores: a workgroup = 16 consecutive query
+//                    tokens of one row x one kv head, one wave per query head of the group; 64-key K/V tiles in LDS shared by the
+//                    waves; flash-style online softmax in the layout of attn.hip's k_attn_prefill (S^T = K.Q^T, O^T = V^T.P^T).
 //   k_silu_mul       silu(gate) * up on the fused gate|up projection.
 #include <stdlib.h>
 
 #include "common.h"
+#include "attn_core.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace ifh {
 
@@ -290,6 +297,160 @@ __global__ void k_add_i32_vec(int32_t *__restrict__ v, const int32_t *__restrict
     if (i < n && (!mask || mask[i])) v[i] += delta;
 }
 
+// Prompt attention on the matrix cores (Cluster/InfernLLMWorker.py:103-119: the first forward of generate() over the whole context).
+// The per-token kernel above spends 476 us per layer on 64 rows x 192 tokens (a quarter of the layer): every query token re-reads its
+// row's K/V from L2 and multiplies on the vector ALUs.  Here 16 query tokens x G heads share each 64-key tile: G waves, wave g = query
+// head kvh * G + g; lane (fr, fg) holds query fr's scores of keys 16 c + 4 fg + r of a tile (softmax over a query = over 4 lanes and
+// 16 registers), P is rounded to bf16 for the second product (as a bf16 model does); masks: key index < key_len[token] (causal and
+// padding rows alike), tiles past the block's largest key_len are skipped.  V stays row-major in LDS and is read transposed by
+// ds_read_b64_tr_b16, as in attn.hip.
+template <int HDV>
+__global__ __launch_bounds__(512) void k_attn_gqa_prefill(const uint16_t *__restrict__ q, int64_t q_ts, const uint16_t *__restrict__ cache,
+                                                          int64_t cache_bs, int64_t cache_ts, int v_off, uint16_t *__restrict__ out,
+                                                          int64_t o_ts, const int32_t *__restrict__ key_len, int T, float scale, int G)
+{
+    constexpr int HDT = 64 * HDV, KLD = HDT + 8, KT = 64, NS = 2 * HDV, ND = 4 * HDV, RV = HDT / 8;
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[KT * KLD];
+    __shared__ __attribute__((aligned(16))) uint16_t Vs[KT * KLD];
+    const int b = blockIdx.z, kvh = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, nthreads = blockDim.x;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int t = blockIdx.x * 16 + fr;
+    const bool qok = t < T;
+    const int64_t tok = (int64_t)b * T + (qok ? t : T - 1);
+    const int klen = qok ? key_len[tok] : 0;
+    int kmax = klen;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) kmax = max(kmax, __shfl_xor(kmax, o, 64));
+    kmax = __builtin_amdgcn_readfirstlane(kmax);
+    const int h = kvh * G + wid;
+
+    bf16x8_t qf[NS];
+    {
+        const uint16_t *qp = q + tok * q_ts + (int64_t)h * HDT;
+#pragma unroll
+        for (int s = 0; s < NS; s++) qf[s] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4 *>(qp + 32 * s + 8 * fg));
+    }
+    f32x4 o[ND];
+#pragma unroll
+    for (int i = 0; i < ND; i++) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun = -1e30f, lrun = 0.0f;
+    const uint16_t *kb = cache + (int64_t)b * cache_bs + (int64_t)kvh * HDT, *vb = kb + v_off;
+    constexpr float kLog2e = 1.4426950408889634f;
+    const float c1 = scale * kLog2e;
+
+    const int ntile = (kmax + KT - 1) / KT;
+    for (int kt = 0; kt < ntile; kt++) {
+        const int kbase = kt * KT;
+        __syncthreads();
+        for (int v = tid; v < KT * RV; v += nthreads) {
+            const int key = v / RV, dv = (v - key * RV) * 8, kg = kbase + key;
+            uint4 kk = make_uint4(0, 0, 0, 0), vv = kk;
+            if (kg < kmax) {
+                kk = *reinterpret_cast<const uint4 *>(kb + (int64_t)kg * cache_ts + dv);
+                vv = *reinterpret_cast<const uint4 *>(vb + (int64_t)kg * cache_ts + dv);
+            }
+            *reinterpret_cast<uint4 *>(&Ks[key * KLD + dv]) = kk;
+            *reinterpret_cast<uint4 *>(&Vs[key * KLD + dv]) = vv;
+        }
+        __syncthreads();
+        // S^T tiles: 4 x (16 keys x 16 queries)
+        f32x4 s[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            s[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ds = 0; ds < NS; ds++) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t *>(&Ks[(c * 16 + fr) * KLD + ds * 32 + fg * 8]);
+                s[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ds], s[c], 0, 0, 0);
+            }
+        }
+        float mloc = -1e30f;
+        if (kbase + KT > klen) {           // (lane-wise: a query whose keys end inside this tile, or before it)
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int kidx = kbase + c * 16 + 4 * fg + r;
+                    s[c][r] = kidx < klen ? s[c][r] : -1e30f;
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) mloc = fmaxf(fmaxf(mloc, fmaxf(s[c][0], s[c][1])), fmaxf(s[c][2], s[c][3]));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mnew = fmaxf(mrun, mloc);
+        // exp(scale (x - m)) = exp2(x c1 - m c1): one fma + the hardware's native exp2 per score
+        const float mscaled = mnew * c1;
+        const float alpha = __builtin_amdgcn_exp2f(mrun * c1 - mscaled);
+        float lsum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[c][r], c1, -mscaled));
+                s[c][r] = pv;
+                lsum += pv;
+            }
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        lrun = lrun * alpha + lsum;
+        mrun = mnew;
+#pragma unroll
+        for (int i = 0; i < ND; i++) {
+            o[i][0] *= alpha;
+            o[i][1] *= alpha;
+            o[i][2] *= alpha;
+            o[i][3] *= alpha;
+        }
+        // O^T += V^T . P^T (attn.hip, k_attn_prefill: the operand layout and the transposed LDS read)
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            uint4 pb;
+            pb.x = pack2(s[2 * ks][0], s[2 * ks][1]);
+            pb.y = pack2(s[2 * ks][2], s[2 * ks][3]);
+            pb.z = pack2(s[2 * ks + 1][0], s[2 * ks + 1][1]);
+            pb.w = pack2(s[2 * ks + 1][2], s[2 * ks + 1][3]);
+            const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pb);
+            const uint32_t vaddr = (uint32_t)(uintptr_t)(&Vs[(ks * 32 + 4 * fg + (fr >> 2)) * KLD + 4 * (fr & 3)]);
+#pragma unroll
+            for (int d4 = 0; d4 < ND; d4 += 4) {
+                uint2 lo[4], hi[4];
+#pragma unroll
+                for (int dt = 0; dt < 4; dt++) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[dt]) : "v"(vaddr), "n"((d4 + dt) * 32) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[dt]) : "v"(vaddr), "n"((d4 + dt) * 32 + 16 * KLD * 2) : "memory");
+                }
+                // (the wait names the eight results as in/out operands: the MFMAs below depend on IT, not only on the read statements)
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])
+                             :
+                             : "memory");
+#pragma unroll
+                for (int dt = 0; dt < 4; dt++) {
+                    uint4 va;
+                    va.x = lo[dt].x;
+                    va.y = lo[dt].y;
+                    va.z = hi[dt].x;
+                    va.w = hi[dt].y;
+                    o[d4 + dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, va), pf, o[d4 + dt], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (qok) {
+        const float inv = lrun > 0.0f ? 1.0f / lrun : 0.0f;
+        uint16_t *op = out + tok * o_ts + (int64_t)h * HDT;
+#pragma unroll
+        for (int dt = 0; dt < ND; dt++) {
+            uint2 pk;
+            pk.x = pack2(o[dt][0] * inv, o[dt][1] * inv);
+            pk.y = pack2(o[dt][2] * inv, o[dt][3] * inv);
+            *reinterpret_cast<uint2 *>(op + dt * 16 + 4 * fg) = pk;
+        }
+    }
+}
+
 template <int G, int HDV>
 static void attn_gqa_launch(const ifh_gqa_desc *d, hipStream_t st, int gtot)
 {
@@ -352,6 +513,19 @@ extern "C" int ifh_attn_gqa_bf16(const ifh_gqa_desc *d, ifh_stream_t stream)
     const int G = d->nheads / d->nkv;
     IFH_CHECK_ARG(G <= 8);
     hipStream_t st = as_stream(stream);
+    // a prompt (16 or more tokens per row): the matrix-core kernel, 16 query tokens x G heads per workgroup
+    static const int mfma_on = getenv("IFH_GQA_PREFILL_MFMA") ? atoi(getenv("IFH_GQA_PREFILL_MFMA")) : 1;       // tuning switch
+    if (mfma_on && d->tokens_per_row >= 16 && d->ntokens % d->tokens_per_row == 0) {
+        const dim3 grid((unsigned)((d->tokens_per_row + 15) / 16), (unsigned)d->nkv, (unsigned)(d->ntokens / d->tokens_per_row));
+        if (d->head_dim == 128)
+            hipLaunchKernelGGL(k_attn_gqa_prefill<2>, grid, dim3(G * 64), 0, st, (const uint16_t *)d->q, d->q_ts, (const uint16_t *)d->cache,
+                               d->cache_bs, d->cache_ts, d->v_off, (uint16_t *)d->out, d->o_ts, d->key_len, d->tokens_per_row, d->scale, G);
+        else
+            hipLaunchKernelGGL(k_attn_gqa_prefill<1>, grid, dim3(G * 64), 0, st, (const uint16_t *)d->q, d->q_ts, (const uint16_t *)d->cache,
+                               d->cache_bs, d->cache_ts, d->v_off, (uint16_t *)d->out, d->o_ts, d->key_len, d->tokens_per_row, d->scale, G);
+        IFH_LAUNCH_CHECK("attn_gqa_prefill");
+        return IFH_OK;
+    }
     // query heads per workgroup: the whole group while that fills the chip twice over, else the largest divisor of G that does (a
     // decode step: few tokens); IFH_GQA_GS overrides (tuning switch)
     static const int gs_env = getenv("IFH_GQA_GS") ? atoi(getenv("IFH_GQA_GS")) : 0;

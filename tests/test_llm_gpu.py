@@ -77,10 +77,12 @@ def test_rope_append(dev, nh, nkv, hd, B, T):
 
 @pytest.mark.parametrize('nh,nkv,hd,B,T,S', [(12, 2, 128, 3, 1, 300), (4, 2, 128, 2, 6, 40), (4, 1, 64, 3, 5, 33),
                                              (7, 1, 128, 2, 1, 700), (8, 1, 64, 1, 3, 20), (5, 5, 64, 2, 2, 17),
-                                             (3, 1, 128, 4, 1, 9)])
+                                             (3, 1, 128, 4, 1, 9), (12, 2, 128, 3, 50, 200), (4, 1, 64, 2, 37, 100),
+                                             (16, 2, 128, 1, 16, 70), (14, 2, 64, 2, 192, 192)])
 def test_attn_gqa(dev, nh, nkv, hd, B, T, S):
-    """single-token grouped-query attention against softmax(q k^T / sqrt(hd)) v in fp32, ragged key counts, one and four
-    waves per (token, kv head), prefill-style (T tokens per cache row) and decode-style addressing"""
+    """grouped-query attention against softmax(q k^T / sqrt(hd)) v in fp32, ragged key counts: the per-token kernel with one and four
+    waves per (token, kv head), prefill-style (T tokens per cache row) and decode-style addressing; from 16 tokens per row on the
+    matrix-core prompt kernel (k_attn_gqa_prefill: 16 query tokens x the group's heads per workgroup, 64-key tiles)"""
     from infernos_amd import ops
     g = torch.Generator().manual_seed(nh + S)
     nq = (nh + 2 * nkv) * hd
