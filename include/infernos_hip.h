@@ -367,8 +367,18 @@ typedef struct ifh_conv_desc {
                             * LLM's down projection) then runs as one accumulation chain per workgroup + a finishing pass (same bits as
                             * the streaming kernel, 1.7 x faster).  NULL: the streaming kernel.  The library holds no workspace of its own */
     int64_t splitk_ws_floats;
+    void *argmax_keys;     /* optional uint64 [rows], ZERO before the launch: the launch also leaves, per output row, the key
+                            * (order-preserving bits of the largest value << 32) | (0xffffffff - its column) -- the greedy pick of a
+                            * vocabulary head without a second pass over the logits (Cluster/InfernLLMWorker.py:103-119: generate()'s
+                            * arg-max).  Ties go to the lowest column.  Only where ifh_conv_argmax_supported says so (a wide f32-output
+                            * matrix product of 17..64 rows without bias / activation / residual); ifh_argmax_keys_finish turns the
+                            * keys into token ids and zeroes them again */
 } ifh_conv_desc;
 int ifh_conv_bf16(const ifh_conv_desc *desc, ifh_stream_t stream);
+/* 1 if a launch of this shape (rows x n x k matrix product, f32 output) fills ifh_conv_desc.argmax_keys */
+int ifh_conv_argmax_supported(int rows, int n, int k);
+/* tokens[i] = the column held in keys[i] (0 if the key is still zero); keys[i] = 0 */
+int ifh_argmax_keys_finish(void *keys, int32_t *tokens, int n, ifh_stream_t stream);
 
 /* One HiFi-GAN residual pair in a single launch (transformers modeling_speecht5.py
  * HifiGanResidualBlock.forward loop body, called from SpeechT5HifiGan.forward :3040-3047 via

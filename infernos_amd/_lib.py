@@ -79,7 +79,7 @@ class ConvDesc(ctypes.Structure):
                 ('aln_stats', _vp), ('aln_c1', _vp), ('rln_stats', _vp), ('rln_gamma', _vp), ('rln_beta', _vp),
                 ('stats_out', _vp), ('ln_dim', ctypes.c_int32), ('ln_eps', _f), ('ln_rms', ctypes.c_int32),
                 ('dyn_stride', ctypes.c_int32), ('decode_step', ctypes.c_int32), ('convt_cout', ctypes.c_int32),
-                ('splitk_ws', _vp), ('splitk_ws_floats', _i64)]
+                ('splitk_ws', _vp), ('splitk_ws_floats', _i64), ('argmax_keys', _vp)]
 
 
 class ResblockDesc(ctypes.Structure):
@@ -193,6 +193,8 @@ SIGNATURES.update({
     'ifh_g722_encode': (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _i64, _i, _vp]),
     'ifh_g722_decode': (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _i64, _i, _vp]),
     'ifh_argmax_pick_f32': (_i, [_vp, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp]),
+    'ifh_conv_argmax_supported': (_i, [_i, _i, _i]),
+    'ifh_argmax_keys_finish': (_i, [_vp, _vp, _i, _vp]),
     'ifh_tts_stop_update': (_i, [_vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp]),
     'ifh_tts_stop_advance': (_i, [_vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp, _i64, _vp, _vp]),
     'ifh_tts_chunks_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

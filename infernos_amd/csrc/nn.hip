@@ -631,7 +631,9 @@ __global__ __launch_bounds__(256) void k_gemm_m64(const IgemmParams p)
 #pragma unroll
         for (int r = 0; r < MT; r++) *reinterpret_cast<f32x4 *>(&red[wid][t * MT + r][lane][0]) = acc[t][r];
     __syncthreads();
-    // wave w finishes tiles w, w + 4, ...: column tile = tile / MT, row tile = tile % MT
+    // wave w finishes tiles w, w + 4, ...: column tile = tile / MT, row tile = tile % MT = w -- the rows 16 w .. 16 w + 15 over all
+    // of the block's columns, so a row's largest value inside the block is found by its four lanes alone (arg-max keys)
+    unsigned long long best = 0;
 #pragma unroll
     for (int i = 0; i < NTB; i++) {
         const int tile = wid + NW * i;
@@ -639,6 +641,18 @@ __global__ __launch_bounds__(256) void k_gemm_m64(const IgemmParams p)
 #pragma unroll
         for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w][tile][lane][0]);
         const int m = 16 * (tile % MT) + fr, n = n0 + 16 * (tile / MT) + 4 * fg;
+        if (p.amax_keys && m < M) {
+            // (the launcher admits no bias / activation / residual / scale here: s is what igemm_store4 stores)
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (n + e < p.N) {
+                    const uint32_t u = __float_as_uint(s[e]);
+                    const uint32_t ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                    const unsigned long long key = ((unsigned long long)ord << 32) | (uint32_t)(0xffffffffu - (uint32_t)(n + e));
+                    best = key > best ? key : best;
+                }
+            }
+        }
         if (m < M && n < p.N) {
             const int dynv = dyn_value(p, m);
             if (p.aln_stats) {
@@ -668,6 +682,23 @@ __global__ __launch_bounds__(256) void k_gemm_m64(const IgemmParams p)
             else
                 igemm_store4<false>(p, m, n, s, dynv);
         }
+    }
+    if (p.amax_keys) {
+        unsigned long long o = __shfl_xor(best, 16, 64);
+        best = o > best ? o : best;
+        o = __shfl_xor(best, 32, 64);
+        best = o > best ? o : best;
+        if (fg == 0 && 16 * wid + fr < M && best) atomicMax(p.amax_keys + 16 * wid + fr, best);
+    }
+}
+
+__global__ void k_argmax_keys_finish(unsigned long long *__restrict__ keys, int32_t *__restrict__ tokens, int n)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) {
+        const unsigned long long k = keys[i];
+        tokens[i] = k ? (int32_t)(0xffffffffu - (uint32_t)k) : 0;
+        keys[i] = 0;
     }
 }
 
@@ -1040,6 +1071,21 @@ static int igemm_aln_rows()
     return v;
 }
 
+extern "C" int ifh_conv_argmax_supported(int rows, int n, int k)
+{
+    return rows > 16 && rows <= 64 && n >= 8192 && (int64_t)n * k >= (int64_t)4096 * 1024 && k % 8 == 0;
+}
+
+extern "C" int ifh_argmax_keys_finish(void *keys, int32_t *tokens, int n, ifh_stream_t stream)
+{
+    IFH_CHECK_ARG(n >= 0);
+    if (n == 0) return IFH_OK;
+    IFH_CHECK_ARG(keys && tokens && (((uintptr_t)keys) & 7) == 0);
+    hipLaunchKernelGGL(k_argmax_keys_finish, dim3((n + 63) / 64), dim3(64), 0, as_stream(stream), (unsigned long long *)keys, tokens, n);
+    IFH_LAUNCH_CHECK("argmax_keys_finish");
+    return IFH_OK;
+}
+
 extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
 {
     IFH_CHECK_ARG(d);
@@ -1115,6 +1161,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         IFH_CHECK_ARG(!d->rln_stats || (d->rln_gamma && d->rln_beta && d->resid));
     }
     p.zt_cout = 0;
+    p.amax_keys = (unsigned long long *)d->argmax_keys;
     if (d->convt_cout) {
         IFH_CHECK_ARG(d->taps == 3 && d->n == 4 * d->convt_cout && d->cin % 32 == 0 && d->stride == 1 && d->dil == 1);
         p.zt_cout = d->convt_cout;
@@ -1145,8 +1192,12 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         IFH_CHECK_ARG(M <= 64 && M > 16 && d->n >= 8192 && d->n % 16 == 0 && !d->resid && !d->accumulate && !d->out_f32 &&
                       !d->colmask && d->n_split == 0 && d->t_out == (int)M && d->ostride == 1 && d->ooff == 0 && !d->dyn_pos &&
                       d->out_scale == 1.0f && !d->rln_stats && !d->stats_out && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre);
-    if (M <= 64 && M > 16 && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre && (!ln_fold || aln_only) && d->n >= 8192 &&
-        ((int64_t)d->n * p.K >= (int64_t)4096 * 1024 || glu)) {
+    const bool wide_m64 = M <= 64 && M > 16 && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre && (!ln_fold || aln_only) && d->n >= 8192 &&
+                          ((int64_t)d->n * p.K >= (int64_t)4096 * 1024 || glu);
+    if (d->argmax_keys)       // arg-max keys exist in k_gemm_m64's epilogue only, on the values as stored (ifh_conv_argmax_supported)
+        IFH_CHECK_ARG(wide_m64 && !glu && d->out_f32 && !d->bias && !d->resid && !d->accumulate && !d->colmask && d->act == IFH_ACT_NONE &&
+                      d->out_scale == 1.0f && d->n_split == 0 && d->nbatch == 1 && (((uintptr_t)d->argmax_keys) & 7) == 0);
+    if (wide_m64) {
         // LLM-sized wide layer at decode batch (gate|up 17920 x 1536, the vocabulary head): every weight byte once
         // (k_gemm_m64).  Narrow deep layers (down 1536 x 8960: 96 column tiles) stay with the 16 x 16-tile kernel below:
         // one block per column tile leaves 160 CUs idle and measured slower (41.8 vs 34.2 us).

@@ -115,6 +115,7 @@ class Qwen2:
                 # f32 workspace of the down projection's split-K form (ifh_conv_desc.splitk_ws): part of THIS decode state, so that the
                 # captured step graphs of different states / engines never share one
                 skws=torch.empty(4 * max(B, 16) * d, dtype=torch.float32, device=dev),
+                amax=torch.zeros(B, dtype=torch.int64, device=dev),        # arg-max keys of the head (zero between launches)
                 toks=torch.zeros(B, dtype=torch.int32, device=dev), graph=None, eager_steps=0)
             b = self._bufs[B]
             b['logits'] = b['logits_full'][:, :self.vocab]
@@ -179,6 +180,12 @@ class Qwen2:
 
     def _head(self, st, x, B, argmax):
         ops.rmsnorm(x, self.norm, st['h'], B, self.d, self.eps)
+        if argmax and ops.argmax_supported(B, self.vocab, self.d):
+            # the greedy pick inside the head's epilogue (per-row keys by atomic max; ifh_conv_desc.argmax_keys) + a 64-thread launch
+            # that turns the keys into token ids and re-arms them: no second pass over the [B, vocab] logits
+            ops.linear(st['h'], self.head, None, st['logits_full'], rows=B, k=self.d, n=self.vocab, ldc=self.vpad, argmax_keys=st['amax'])
+            ops.argmax_keys_finish(st['amax'], st['toks'], B)
+            return
         ops.linear(st['h'], self.head, None, st['logits_full'], rows=B, k=self.d, n=self.vocab, ldc=self.vpad)
         if argmax:
             ops.argmax_pick(st['logits_full'], vocab=self.vocab, nrows=B, ld=self.vpad, argmax_out=st['toks'])

@@ -24,8 +24,9 @@ def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=
          resid=None, resid_off=0, resid_ld=None, resid_bstride=None, scale=1.0, accumulate=False,
          out_off=0, ldc=None, out_bstride=None, ostride=1, ooff=0, dyn_pos=None, dyn_ooff_mul=0, dyn_resid_mul=0, dyn_stride=0, decode_step=False, convt_cout=0,
          n_split=0, out2=None, out2_bstride=0, ldc2=0, ooff2=0, dyn_ooff2_mul=0,
-         aln=None, rln=None, stats_out=None, stats_off=0, ln_dim=0, ln_eps=1e-5, ln_rms=False, splitk_ws=None):
-    # aln = (stats, stats_off, c1); rln = (stats, stats_off, gamma, beta); splitk_ws = f32 workspace of the caller's decode state
+         aln=None, rln=None, stats_out=None, stats_off=0, ln_dim=0, ln_eps=1e-5, ln_rms=False, splitk_ws=None, argmax_keys=None):
+    # aln = (stats, stats_off, c1); rln = (stats, stats_off, gamma, beta); splitk_ws = f32 workspace of the caller's decode state;
+    # argmax_keys = zeroed int64 [rows] (ifh_conv_desc.argmax_keys; argmax_supported(), argmax_keys_finish())
     """One implicit-GEMM launch (see ifh_conv_desc).  Strides default to dense [nbatch][t][c]."""
     d = ConvDesc()
     lda = cin if lda is None else lda
@@ -46,6 +47,7 @@ def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=
     d.dyn_pos, d.dyn_ooff_mul, d.dyn_resid_mul, d.dyn_stride = _addr(dyn_pos), dyn_ooff_mul, dyn_resid_mul, dyn_stride
     d.decode_step, d.convt_cout = int(decode_step), convt_cout
     d.splitk_ws, d.splitk_ws_floats = _addr(splitk_ws), (splitk_ws.numel() if splitk_ws is not None else 0)
+    d.argmax_keys = _addr(argmax_keys)
     d.n_split, d.out2, d.out2_bstride, d.ldc2, d.ooff2, d.dyn_ooff2_mul = n_split, _addr(out2), out2_bstride, ldc2, ooff2, dyn_ooff2_mul
     if aln is not None:
         d.aln_stats, d.aln_c1 = _addr(aln[0], aln[1]), _addr(aln[2])
@@ -295,6 +297,16 @@ def argmax_pick(logits, *, vocab, nrows, ld=None, argmax_out=None, pick_token=0,
     _lib.check(_lib.lib().ifh_argmax_pick_f32(_addr(logits), vocab if ld is None else ld, vocab, nrows, pick_token,
                                               _addr(argmax_out, out_off), _addr(pick_prob_out), _addr(dyn_pos), dyn_out_mul,
                                               _lib.stream_ptr(logits.device)), 'ifh_argmax_pick_f32')
+
+
+def argmax_supported(rows, n, k):
+    """does a rows x n x k matrix product with f32 output fill ifh_conv_desc.argmax_keys?"""
+    return bool(_lib.lib().ifh_conv_argmax_supported(rows, n, k))
+
+
+def argmax_keys_finish(keys, tokens, n):
+    """tokens[i] = the column in keys[i]; keys[i] = 0 (ifh_argmax_keys_finish)"""
+    _lib.check(_lib.lib().ifh_argmax_keys_finish(_addr(keys), _addr(tokens), n, _lib.stream_ptr(tokens.device)), 'ifh_argmax_keys_finish')
 
 
 def add_i32(value, delta, zero=None):

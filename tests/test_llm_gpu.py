@@ -106,6 +106,37 @@ def test_attn_gqa(dev, nh, nkv, hd, B, T, S):
     print('attn_gqa ok', nh, nkv, hd, T, S)
 
 
+@pytest.mark.parametrize('B,n,k', [(40, 8200, 512), (64, 9000, 1536), (17, 8192, 512)])
+def test_head_argmax_keys_equal_the_separate_argmax(dev, B, n, k):
+    """The greedy pick of generate() (Cluster/InfernLLMWorker.py:103-119) inside the vocabulary head's epilogue (ifh_conv_desc.argmax_keys:
+    per-row atomic max over (value, column) keys) against ifh_argmax_pick_f32 on the logits the same launch wrote; ties -- two equal
+    weight rows that win for some rows -- go to the lowest column in both; the keys are zero again after ifh_argmax_keys_finish."""
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(B + n)
+    h = torch.randn(B, k, generator=g).to(BF)
+    w = (torch.randn(n, k, generator=g) / k ** 0.5).to(BF)
+    w[4000] = (h[3].float() * 0.5).to(BF)                 # a clear winner for row 3 ... twice
+    w[17] = w[4000]
+    w[n - 1] = (h[5].float() * 0.5).to(BF)                 # the last column wins row 5
+    assert ops.argmax_supported(B, n, k)
+    hd, wd = h.to(dev), w.to(dev)
+    ld = (n + 15) // 16 * 16
+    logits = torch.zeros(B, ld, dtype=torch.float32, device=dev)
+    keys = torch.zeros(B, dtype=torch.int64, device=dev)
+    toks = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    ops.linear(hd, wd, None, logits, rows=B, k=k, n=n, ldc=ld, argmax_keys=keys)
+    ops.argmax_keys_finish(keys, toks, B)
+    ref = torch.full((B,), -1, dtype=torch.int32, device=dev)
+    ops.argmax_pick(logits, vocab=n, nrows=B, ld=ld, argmax_out=ref)
+    assert torch.equal(toks, ref)
+    assert int(toks[3]) == 17 and int(toks[5]) == n - 1
+    assert torch.equal(toks.long().cpu(), logits[:, :n].cpu().argmax(1))
+    assert int(keys.abs().sum()) == 0
+    plain = torch.zeros_like(logits)
+    ops.linear(hd, wd, None, plain, rows=B, k=k, n=n, ldc=ld)
+    assert torch.equal(plain, logits)                      # the keys do not change what is stored
+
+
 def test_silu_mul_and_lengths(dev):
     from infernos_amd import ops
     g = torch.Generator().manual_seed(5)
