@@ -422,7 +422,10 @@ bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st)
         attr_once.done(attr_dev);
     }
     const int total = g.mtiles * g.ntiles;
-    int grid = device_cu_count() & ~7;
+    // one workgroup per CU of the device -- or of the budget the caller has set for persistent kernels (ifh_set_cu_budget);
+    // IFH_GEMM_BIG8_CUS (tuning switch): that many instead
+    static const int cus_env = getenv("IFH_GEMM_BIG8_CUS") ? atoi(getenv("IFH_GEMM_BIG8_CUS")) : 0;
+    int grid = (cus_env > 0 ? cus_env : device_cu_count()) & ~7;
     if (grid < 8) grid = 8;
     if (grid > total) grid = total < 8 ? total : (total & ~7);
     // with fewer than 8 tiles the XCD interleave below degenerates: one workgroup per tile

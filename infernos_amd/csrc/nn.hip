@@ -1201,6 +1201,10 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         // LLM-sized wide layer at decode batch (gate|up 17920 x 1536, the vocabulary head): every weight byte once
         // (k_gemm_m64).  Narrow deep layers (down 1536 x 8960: 96 column tiles) stay with the 16 x 16-tile kernel below:
         // one block per column tile leaves 160 CUs idle and measured slower (41.8 vs 34.2 us).
+        if (try_launch_gemm_m64d(p, st)) {            // whole-line DMA form (gemm_m64d.hip)
+            IFH_LAUNCH_CHECK("conv_bf16");
+            return IFH_OK;
+        }
         const int ct = (d->n + 15) / 16;
         // column tiles per block: 4 wherever that still gives a block per CU.  Fewer (more, smaller blocks) was measured
         // slower at every size (gate|up 27.9 / 29.2 / 37.4 us, head 159 / 200 / 296 us for 4 / 2 / 1): each block re-reads the

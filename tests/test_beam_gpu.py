@@ -224,9 +224,11 @@ def _token_logprob_tol(golden_dir, family='whisper_tiny'):
     return 1.5 * p99 * max(1.0, scale)
 
 
-def _teacher_score(sd, mel, prompt_row, new_tokens, nheads, sup, bsup):
-    """sum log p of `new_tokens` under the fp32 oracle (masks as the search applies them)"""
-    enc = onn.whisper_encoder(sd, mel, nheads)
+def _teacher_score(sd, mel, prompt_row, new_tokens, nheads, sup, bsup, enc=None):
+    """sum log p of `new_tokens` under the fp32 oracle (masks as the search applies them); enc: the oracle encoder's output for `mel`
+    if the caller already has it"""
+    if enc is None:
+        enc = onn.whisper_encoder(sd, mel, nheads)
     nl = 0
     while ('model.decoder.layers.%d.fc1.weight' % nl) in sd:
         nl += 1
@@ -317,9 +319,9 @@ def test_whisper_generate_beam_matches_transformers_fixture(dev, golden_dir):
 def test_whisper_base_beam_at_bench_batch_128(dev, golden_dir):
     """The decode bench.py times: Whisper-BASE, 128 utterances x 5 beams = 640 decode rows (LayerNorm-folded skinny
     GEMMs at 640 rows, small-grid k_igemm for layer 0's q|k|v, the beams' shared cross-attention, device search step and
-    KV gather), 32 new tokens.  Utterances 0-3 are the fixture's (transformers generate(num_beams=5) on the seeded
-    base weights, tools/gen_golden_nn.py:gen_whisper_beam; `oracle.nn.whisper_beam` equals it exactly); the other 124
-    rows carry other audio.  Per sampled utterance: the hypothesis is the fixture's, or -- where bf16 logit error
+    KV gather), 32 new tokens.  The first 16 utterances are the fixture's (transformers generate(num_beams=5) on the seeded
+    base weights, two stop-token cases = 32 hypotheses, tools/gen_golden_nn.py:gen_whisper_beam; `oracle.nn.whisper_beam` equals
+    it exactly); the other rows carry other audio.  Per sampled utterance: the hypothesis is the fixture's, or -- where bf16 logit error
     reorders near-tied beams -- scores within the logit error of the fixture's best under the fp32 oracle; and the score the
     device reports is the teacher-forced fp32 score of what it returned.  Also: the batch-position invariance of the 640-row
     step (utterances 64.. repeat 0..) and graph replay == eager."""
@@ -340,9 +342,12 @@ def test_whisper_base_beam_at_bench_batch_128(dev, golden_dir):
     x8 = torch.from_numpy(np.stack([synth_utterance(s_, 10.0) for s_ in seeds])).to(dev)
     mel = WhisperLogMel(80, dev)(rs(x8))
     enc = model.encode(mel)
-    melc = mel[:4].float().cpu()
+    nfx = len(mb['audio_seeds'])                                # the fixture's utterances: the first rows of the batch
+    melc = mel[:nfx].float().cpu()
     prompt = torch.tensor([meta['prompt']] * B, dtype=torch.int32)
     tok_tol = _token_logprob_tol(golden_dir, 'whisper_base')
+    with torch.no_grad():
+        encs = [onn.whisper_encoder(sd, melc[b:b + 1], mb['nheads']) for b in range(nfx)]       # fp32 oracle, once per utterance
     counts = {}
     for mfma in (False, True):
       model.beam_cross_mfma = mfma                              # the beams' cross-attention: k_attn_decode_shared / k_attn_prefill
@@ -362,14 +367,14 @@ def test_whisper_base_beam_at_bench_batch_128(dev, golden_dir):
           assert torch.equal(toks[:64], toks[64:]) and torch.equal(lens[:64], lens[64:]) and torch.equal(scores[:64], scores[64:])
           assert torch.equal(nsp[:64], nsp[64:])
           glen = g['base_len%d' % ci]
-          for b in range(4):
+          for b in range(nfx):
               mine = toks[b, :lens[b]].tolist()
               ref = g['base_seq%d' % ci][b, :glen[b]].tolist()
               n = max(1, len(mine))
               norm = n ** c['lp']
               tol = tok_tol * n / norm                            # per-token log-prob tolerance derived from the fixture
               with torch.no_grad():
-                  ts = _teacher_score(sd, melc[b:b + 1], meta['prompt'], mine, mb['nheads'], sup, None) / norm
+                  ts = _teacher_score(sd, melc[b:b + 1], meta['prompt'], mine, mb['nheads'], sup, None, enc=encs[b]) / norm
               assert abs(ts - float(scores[b])) < tol, (ci, b, ts, float(scores[b]), tol)
               total += 1
               if mine == ref:
@@ -384,9 +389,11 @@ def test_whisper_base_beam_at_bench_batch_128(dev, golden_dir):
     rec = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     if os.path.isdir(rec):                       # the count is the number that shows a kernel regression first: recorded per run
         with open(os.path.join(rec, 'beam_exact_matches.json'), 'w') as f:
-            json.dump({'exact_mfma': em, 'exact_valu': ev, 'total': total, 'floor': total // 2}, f)
-    assert em >= total // 2 and ev >= total // 2, (em, ev, total)
-    assert em >= ev - 1, (em, ev, total)
+            json.dump({'exact_mfma': em, 'exact_valu': ev, 'total': total, 'floor': (3 * total + 3) // 4}, f)
+    # the floor is a RATE over the 32 sampled hypotheses (bf16 logit error reorders near-tied beams on some; those pass the score
+    # checks above): three quarters identical, on either cross-attention kernel, and the two kernels within two of each other
+    assert 4 * em >= 3 * total and 4 * ev >= 3 * total, (em, ev, total)
+    assert abs(em - ev) <= 2, (em, ev, total)
 
 
 def test_whisper_generate_beam_one_beam_is_greedy(dev):

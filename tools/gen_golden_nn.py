@@ -355,14 +355,14 @@ def gen_whisper_beam():
         arrays['score%d' % ci] = out.sequences_scores.numpy()
         meta.append(c)
     # ---- Whisper-BASE (BASELINE config 3), the search bench.py times: 5 beams, 32 new tokens, length_penalty 1; four
-    # utterances; a second case ends early on an eos taken from the first case's output
+    # x four utterances; a second case ends early on an eos taken from the first case's output
     base_cfg = dict(d_model=512, encoder_layers=6, decoder_layers=6, encoder_attention_heads=8, decoder_attention_heads=8,
                     encoder_ffn_dim=2048, decoder_ffn_dim=2048)
     sdb = synth_state_dict('whisper_base', 1)
     mb = WhisperForConditionalGeneration(WhisperConfig(**base_cfg))
     mb.load_state_dict(sdb, strict=True)
     mb.eval()
-    bseeds = [1000, 1001, 1002, 1003]
+    bseeds = list(range(1000, 1016))           # 16 utterances x 2 cases = 32 hypotheses (round 5: the exact-match count as a rate)
     bauds = [dsp.resample(synth_utterance(a, 10.0), 8000, 16000) for a in bseeds]
     bmel = torch.from_numpy(fe(bauds, sampling_rate=16000, return_tensors='np').input_features)
     bprompt = torch.tensor([PROMPT] * len(bseeds))
