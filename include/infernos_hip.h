@@ -638,6 +638,10 @@ typedef struct ifh_gqa_desc {
     const int32_t *key_len;    /* int32 [ntokens] */
     int32_t ntokens, tokens_per_row, nheads, nkv, head_dim, max_keys;
     float scale;
+    const float *rope_cos_sin; /* optional ([max_pos][head_dim/2][2] cos, sin; tokens_per_row 1, head_dim 128): the launch also applies the
+                                * rotary embedding to q and to the token's k (columns nheads*head_dim.. of its q row: the fused q|k|v
+                                * projection) at position key_len[i] - 1 and appends k | v to the cache there -- what ifh_rope_append_bf16
+                                * does for a decode step, in the same launch and with the same bits; `cache` is written */
 } ifh_gqa_desc;
 int ifh_attn_gqa_bf16(const ifh_gqa_desc *desc, ifh_stream_t stream);
 /* out[r, j] = silu(gate[r, j]) * up[r, j]   (Qwen2MLP); bf16, ffn % 8 == 0.  gate_up row = [gate | up] (interleaved 0) or

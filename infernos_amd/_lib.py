@@ -132,7 +132,7 @@ class GqaDesc(ctypes.Structure):
     _fields_ = [('q', _vp), ('q_ts', _i64), ('cache', _vp), ('cache_bs', _i64), ('cache_ts', _i64), ('v_off', ctypes.c_int32),
                 ('out', _vp), ('o_ts', _i64), ('key_len', _vp), ('ntokens', ctypes.c_int32), ('tokens_per_row', ctypes.c_int32),
                 ('nheads', ctypes.c_int32), ('nkv', ctypes.c_int32), ('head_dim', ctypes.c_int32), ('max_keys', ctypes.c_int32),
-                ('scale', _f)]
+                ('scale', _f), ('rope_cos_sin', _vp)]
 
 
 class RtpHdr(ctypes.Structure):

@@ -20,7 +20,10 @@ namespace ifh {
 
 constexpr int M64D_SLOTS = 4, M64D_STAGE = 16 * 1024;
 
-__global__ __launch_bounds__(256, 2) void k_gemm_m64d(const IgemmParams p)
+// ws != null: split-K form -- workgroup (x, z) multiplies stages [z per_z, (z + 1) per_z) and leaves its raw f32 partial tile in
+// ws[z][M][N]; k_splitk_finish (nn.hip) adds the parts in z order and runs the epilogue (a deep narrow layer: the LLM's down projection,
+// 1536 x 8960 -- 24 column blocks alone would leave 232 CUs idle)
+__global__ __launch_bounds__(256, 2) void k_gemm_m64d(const IgemmParams p, float *__restrict__ ws, const int per_z)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -28,7 +31,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_m64d(const IgemmParams p)
     const int fr = lane & 15, fg = lane >> 4;
     const int n0 = blockIdx.x * 64;
     const int M = p.nbatch * p.T_out;
-    const int nst = p.K / 64;
+    const int nst_all = p.K / 64;
+    const int s_beg = ws ? (int)blockIdx.y * per_z : 0;
+    const int nst = ws ? min(per_z, nst_all - s_beg) : nst_all;
 
     // DMA units of this wave: w units 2 wid, 2 wid + 1 (rows n0 + 16 wid + 8 q + lane / 8), x units likewise (rows 16 wid + 8 q + lane / 8);
     // rows past N / M are clamped (their products are never stored)
@@ -49,8 +54,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_m64d(const IgemmParams p)
                      : "=&s"(keep_) : "v"(VOFF), "s"(BASE), "s"(DST) : "memory");                                        \
     } while (0)
     auto issue = [&](int stage, int slot) {
-        const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.w) + (int64_t)stage * 128;
-        const unsigned char *xb = reinterpret_cast<const unsigned char *>(p.x) + (int64_t)stage * 128;
+        const unsigned char *wb = reinterpret_cast<const unsigned char *>(p.w) + (int64_t)(s_beg + stage) * 128;
+        const unsigned char *xb = reinterpret_cast<const unsigned char *>(p.x) + (int64_t)(s_beg + stage) * 128;
         const int dst = slot * M64D_STAGE + (2 * wid) * 1024;
         M64D_DMA(vw[0], wb, dst);
         M64D_DMA(vw[1], wb, dst + 1024);
@@ -98,6 +103,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_m64d(const IgemmParams p)
 
     // ---- epilogue (k_gemm_m64's): lane (fr, fg) holds columns n .. n + 3 of row m = 16 r + fr
     const int n = n0 + 16 * wid + 4 * fg;
+    if (ws) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int m = 16 * r + fr;
+            if (m < M && n < p.N)
+                *reinterpret_cast<float4 *>(ws + ((int64_t)blockIdx.y * M + m) * p.N + n) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        }
+        return;
+    }
     unsigned long long best[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -169,12 +183,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_m64d(const IgemmParams p)
     }
 }
 
-// true if it took the launch: nn.hip has checked what k_gemm_m64 takes (17..64 rows, one tap, wide layer, epilogue); here: K in 64s,
-// 16-byte addressable operands, 32-bit DMA offsets
-bool try_launch_gemm_m64d(const IgemmParams &p, hipStream_t st)
+static bool m64d_ready(const IgemmParams &p, int64_t M)
 {
-    static const int on = getenv("IFH_GEMM_M64D") ? atoi(getenv("IFH_GEMM_M64D")) : 1;      // tuning switch: 0 = k_gemm_m64
-    const int64_t M = (int64_t)p.nbatch * p.T_out;
+    static const int on = getenv("IFH_GEMM_M64D") ? atoi(getenv("IFH_GEMM_M64D")) : 1;      // tuning switch: 0 = the register-fragment kernels
     if (!on || p.K % 64 || p.K < 64 || (((uintptr_t)p.x) & 15) || (((uintptr_t)p.w) & 15) || p.lda % 8 || p.x_bstride % 8 || !p.vec_ok) return false;
     if ((int64_t)p.N * p.K * 2 >= (1ll << 32) || ((int64_t)(p.nbatch - 1) * p.x_bstride + (int64_t)p.T_out * p.lda) * 2 >= (1ll << 32)) return false;
     if (M < 1 || M > 64) return false;
@@ -185,8 +196,34 @@ bool try_launch_gemm_m64d(const IgemmParams &p, hipStream_t st)
         if (hipFuncSetAttribute((const void *)k_gemm_m64d, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
         attr_once.done(attr_dev);
     }
-    hipLaunchKernelGGL(k_gemm_m64d, dim3((unsigned)((p.N + 63) / 64)), dim3(256), bytes, st, p);
     return true;
+}
+
+// true if it took the launch: nn.hip has checked what k_gemm_m64 takes (17..64 rows, one tap, wide layer, epilogue); here: K in 64s,
+// 16-byte addressable operands, 32-bit DMA offsets
+bool try_launch_gemm_m64d(const IgemmParams &p, hipStream_t st)
+{
+    const int64_t M = (int64_t)p.nbatch * p.T_out;
+    if (!m64d_ready(p, M)) return false;
+    hipLaunchKernelGGL(k_gemm_m64d, dim3((unsigned)((p.N + 63) / 64)), dim3(256), M64D_SLOTS * M64D_STAGE, st, p, (float *)nullptr, 0);
+    return true;
+}
+
+// the split-K form: the number of parts (0 = not taken) -- as many as give every CU two workgroups, at least four stages each, as the
+// caller's workspace holds (ws_floats >= parts * rows * n); the caller then runs k_splitk_finish over `parts`
+int try_launch_gemm_m64d_splitk(const IgemmParams &p, float *ws, int64_t ws_floats, hipStream_t st)
+{
+    const int64_t M = (int64_t)p.nbatch * p.T_out;
+    if (!ws || (((uintptr_t)ws) & 15) || p.N % 4 || !m64d_ready(p, M)) return 0;
+    const int nb = (p.N + 63) / 64, nst = p.K / 64;
+    int parts = (2 * device_cu_count_physical() + nb - 1) / nb;
+    if (parts > nst / 4) parts = nst / 4;
+    if ((int64_t)parts * M * p.N > ws_floats) parts = (int)(ws_floats / (M * p.N));
+    if (parts < 2) return 0;
+    const int per_z = (nst + parts - 1) / parts;
+    parts = (nst + per_z - 1) / per_z;                   // no empty part
+    hipLaunchKernelGGL(k_gemm_m64d, dim3((unsigned)nb, (unsigned)parts), dim3(256), M64D_SLOTS * M64D_STAGE, st, p, ws, per_z);
+    return parts;
 }
 
 }  // namespace ifh

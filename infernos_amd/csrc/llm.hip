@@ -98,13 +98,20 @@ __global__ __launch_bounds__(256) void k_rope_append(uint16_t *__restrict__ qkv,
 // Grouped-query decode attention.  A wave is 8 key-groups x 8 lanes; a lane owns 8*HDV of the 64*HDV head dims (HDV
 // 16-byte loads per key for K and for V).  Structure of k_attn_decode (attn.hip): per key-group online softmax over its
 // keys, merged over the 8 groups and the NW waves at the end.
-template <int NW, int G, int HDV>
+// ROPE (head_dim 128, one token per row: a decode step): the launch also does what k_rope_append does for the step's token -- the
+// rotary embedding of q (in registers; a lane's 8 + 8 dims are exactly the pairs (j, j + 64)) and of the token's k, rounded to bf16 at
+// the same points, the rotated k and the v appended to the cache at position key_len - 1 (by the first workgroup of the kv head) -- and
+// every workgroup uses the fresh k / v for that key instead of reading the cache: the same bits as the two launches, one launch less
+// per layer.
+template <int NW, int G, int HDV, bool ROPE = false>
 __global__ __launch_bounds__(NW * 64) void k_attn_gqa(const uint16_t *__restrict__ q, int64_t q_ts,
-                                                      const uint16_t *__restrict__ cache, int64_t cache_bs,
+                                                      uint16_t *__restrict__ cache, int64_t cache_bs,
                                                       int64_t cache_ts, int v_off, uint16_t *__restrict__ out,
                                                       int64_t o_ts, const int32_t *__restrict__ key_len, int T,
-                                                      float scale, int gtot, int nsplit)
+                                                      float scale, int gtot, int nsplit, const float *__restrict__ rope_cs = nullptr,
+                                                      int k_col = 0, int v_col = 0)
 {
+    static_assert(!ROPE || HDV == 2, "the fused rotary embedding pairs dims (j, j + 64) inside a lane: head_dim 128");
     // G = the query heads THIS workgroup serves: a kv head's gtot query heads are cut into nsplit workgroups of G (each re-reads the
     // K/V rows; a decode step of 64 tokens x 2 kv heads is otherwise 128 workgroups on 256 CUs, and VALU-bound at G = 6).  The
     // arithmetic of a query head does not depend on the cut.
@@ -116,12 +123,50 @@ __global__ __launch_bounds__(NW * 64) void k_attn_gqa(const uint16_t *__restrict
     const int c = lane & 7, g = lane >> 3;
     const int klen = key_len[i];
     float qv[G][DV];
+    float rc[8], rs[8];                                 // ROPE: cos / sin of this lane's eight pairs at the token's position
+    uint4 kfresh[HDV], vfresh[HDV];                     // ROPE: the step's own key (rotated) and value rows, this lane's dims
+    // a pair (a = x[j], b = x[j + 64]) of packed bf16 rows lo / hi -> rotated, rounded as k_rope_append rounds
+    auto rot8 = [&](const uint4 lo, const uint4 hi, uint4 &olo, uint4 &ohi) {
+        const uint32_t *ul = reinterpret_cast<const uint32_t *>(&lo), *uh = reinterpret_cast<const uint32_t *>(&hi);
+        uint32_t *pl = reinterpret_cast<uint32_t *>(&olo), *ph = reinterpret_cast<uint32_t *>(&ohi);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const float a0 = __uint_as_float(ul[e] << 16), a1 = __uint_as_float(ul[e] & 0xffff0000u);
+            const float b0 = __uint_as_float(uh[e] << 16), b1 = __uint_as_float(uh[e] & 0xffff0000u);
+            const uint32_t r00 = f32_to_bf16(a0 * rc[2 * e] - b0 * rs[2 * e]), r01 = f32_to_bf16(a1 * rc[2 * e + 1] - b1 * rs[2 * e + 1]);
+            const uint32_t r10 = f32_to_bf16(b0 * rc[2 * e] + a0 * rs[2 * e]), r11 = f32_to_bf16(b1 * rc[2 * e + 1] + a1 * rs[2 * e + 1]);
+            pl[e] = r00 | (r01 << 16);
+            ph[e] = r10 | (r11 << 16);
+        }
+    };
+    if (ROPE) {
+        const float *cp = rope_cs + ((int64_t)(klen - 1) * 64 + 8 * c) * 2;
+#pragma unroll
+        for (int e4 = 0; e4 < 4; e4++) {
+            const float4 t4 = *reinterpret_cast<const float4 *>(cp + 4 * e4);
+            rc[2 * e4] = t4.x; rs[2 * e4] = t4.y; rc[2 * e4 + 1] = t4.z; rs[2 * e4 + 1] = t4.w;
+        }
+        const uint16_t *kr = q + (int64_t)i * q_ts + k_col + kvh * HD + 8 * c, *vr = q + (int64_t)i * q_ts + v_col + kvh * HD + 8 * c;
+        rot8(*reinterpret_cast<const uint4 *>(kr), *reinterpret_cast<const uint4 *>(kr + 64), kfresh[0], kfresh[HDV - 1]);
+        vfresh[0] = *reinterpret_cast<const uint4 *>(vr);
+        vfresh[HDV - 1] = *reinterpret_cast<const uint4 *>(vr + 64);
+        if (blockIdx.x == kvh * nsplit && wid == 0 && g == 0) {      // one workgroup per kv head appends the token to the cache
+            uint16_t *kd = cache + (int64_t)(i / T) * cache_bs + (int64_t)(klen - 1) * cache_ts + kvh * HD + 8 * c;
+            *reinterpret_cast<uint4 *>(kd) = kfresh[0];
+            *reinterpret_cast<uint4 *>(kd + 64) = kfresh[HDV - 1];
+            *reinterpret_cast<uint4 *>(kd + v_off) = vfresh[0];
+            *reinterpret_cast<uint4 *>(kd + v_off + 64) = vfresh[HDV - 1];
+        }
+    }
 #pragma unroll
     for (int r = 0; r < G; r++) {
+        uint4 tq[HDV];
+#pragma unroll
+        for (int hv = 0; hv < HDV; hv++) tq[hv] = *reinterpret_cast<const uint4 *>(q + (int64_t)i * q_ts + (h0 + r) * HD + hv * 64 + 8 * c);
+        if (ROPE) rot8(tq[0], tq[HDV - 1], tq[0], tq[HDV - 1]);
 #pragma unroll
         for (int hv = 0; hv < HDV; hv++) {
-            const uint4 t = *reinterpret_cast<const uint4 *>(q + (int64_t)i * q_ts + (h0 + r) * HD + hv * 64 + 8 * c);
-            const uint32_t *u = reinterpret_cast<const uint32_t *>(&t);
+            const uint32_t *u = reinterpret_cast<const uint32_t *>(&tq[hv]);
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 qv[r][hv * 8 + 2 * e] = __uint_as_float(u[e] << 16) * scale;
@@ -152,6 +197,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn_gqa(const uint16_t *__restrict
                 if (key < klen) {
                     kk[u][hv] = *reinterpret_cast<const uint4 *>(kb + (int64_t)key * cache_ts + hv * 64);
                     vv[u][hv] = *reinterpret_cast<const uint4 *>(vb + (int64_t)key * cache_ts + hv * 64);
+                }
+                if (ROPE && key == klen - 1) {               // the step's own token: from registers, whatever the cache row holds yet
+                    kk[u][hv] = kfresh[hv];
+                    vv[u][hv] = vfresh[hv];
                 }
             }
         }
@@ -456,13 +505,27 @@ static void attn_gqa_launch(const ifh_gqa_desc *d, hipStream_t st, int gtot)
 {
     const int nsplit = gtot / G;
     dim3 grid(d->nkv * nsplit, d->ntokens);
+    if constexpr (HDV == 2) {
+        if (d->rope_cos_sin) {
+            const int k_col = d->nheads * d->head_dim, v_col = (d->nheads + d->nkv) * d->head_dim;
+            if (d->max_keys > 256)
+                hipLaunchKernelGGL((k_attn_gqa<4, G, HDV, true>), grid, dim3(256), 0, st, (const uint16_t *)d->q, d->q_ts, (uint16_t *)d->cache,
+                                   d->cache_bs, d->cache_ts, d->v_off, (uint16_t *)d->out, d->o_ts, d->key_len, d->tokens_per_row, d->scale, gtot,
+                                   nsplit, d->rope_cos_sin, k_col, v_col);
+            else
+                hipLaunchKernelGGL((k_attn_gqa<1, G, HDV, true>), grid, dim3(64), 0, st, (const uint16_t *)d->q, d->q_ts, (uint16_t *)d->cache,
+                                   d->cache_bs, d->cache_ts, d->v_off, (uint16_t *)d->out, d->o_ts, d->key_len, d->tokens_per_row, d->scale, gtot,
+                                   nsplit, d->rope_cos_sin, k_col, v_col);
+            return;
+        }
+    }
     if (d->max_keys > 256)      // (8 waves per (token, kv head) measured slower: 27.8 vs 21.5 us at 192-256 keys, G = 6)
         hipLaunchKernelGGL((k_attn_gqa<4, G, HDV>), grid, dim3(256), 0, st, (const uint16_t *)d->q, d->q_ts,
-                           (const uint16_t *)d->cache, d->cache_bs, d->cache_ts, d->v_off, (uint16_t *)d->out, d->o_ts,
+                           (uint16_t *)d->cache, d->cache_bs, d->cache_ts, d->v_off, (uint16_t *)d->out, d->o_ts,
                            d->key_len, d->tokens_per_row, d->scale, gtot, nsplit);
     else
         hipLaunchKernelGGL((k_attn_gqa<1, G, HDV>), grid, dim3(64), 0, st, (const uint16_t *)d->q, d->q_ts,
-                           (const uint16_t *)d->cache, d->cache_bs, d->cache_ts, d->v_off, (uint16_t *)d->out, d->o_ts,
+                           (uint16_t *)d->cache, d->cache_bs, d->cache_ts, d->v_off, (uint16_t *)d->out, d->o_ts,
                            d->key_len, d->tokens_per_row, d->scale, gtot, nsplit);
 }
 
@@ -512,6 +575,8 @@ extern "C" int ifh_attn_gqa_bf16(const ifh_gqa_desc *d, ifh_stream_t stream)
     IFH_CHECK_ARG(d->q_ts % 8 == 0 && d->o_ts % 8 == 0 && d->cache_bs % 8 == 0 && d->cache_ts % 8 == 0 && d->v_off % 8 == 0);
     const int G = d->nheads / d->nkv;
     IFH_CHECK_ARG(G <= 8);
+    // the fused rotary embedding + KV append: a decode step (one token per row) at head_dim 128, a 16-byte addressable table
+    IFH_CHECK_ARG(!d->rope_cos_sin || (d->tokens_per_row == 1 && d->head_dim == 128 && (((uintptr_t)d->rope_cos_sin) & 15) == 0));
     hipStream_t st = as_stream(stream);
     // a prompt (16 or more tokens per row): the matrix-core kernel, 16 query tokens x G heads per workgroup
     static const int mfma_on = getenv("IFH_GQA_PREFILL_MFMA") ? atoi(getenv("IFH_GQA_PREFILL_MFMA")) : 1;       // tuning switch

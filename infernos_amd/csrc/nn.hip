@@ -1237,6 +1237,16 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         // the same order, hence the same bits
         static const int splitk_on = getenv("IFH_GEMM_SPLITK") ? atoi(getenv("IFH_GEMM_SPLITK")) : 1;        // tuning switch
         if (splitk_on && M > 16 && M <= 64 && p.K >= 4096 && p.K % 32 == 0 && d->n % 32 == 0 && d->n >= 512 && p.vec_ok && !glu) {
+            // whole-line DMA form (gemm_m64d.hip): as many K parts as the caller's workspace holds, one chain each, added in part order
+            // by the same finishing pass (its sums differ in the last bits from the four-chain forms below)
+            if (d->splitk_ws && !d->argmax_keys) {
+                const int parts = try_launch_gemm_m64d_splitk(p, (float *)d->splitk_ws, d->splitk_ws_floats, st);
+                if (parts > 0) {
+                    hipLaunchKernelGGL(k_splitk_finish, dim3((d->n + 15) / 16, (unsigned)((M + 15) / 16)), dim3(64), 0, st, p, (const float *)d->splitk_ws, parts);
+                    IFH_LAUNCH_CHECK("conv_bf16");
+                    return IFH_OK;
+                }
+            }
             const int chains = 4;
             // the workspace belongs to the caller's decode state (ifh_conv_desc.splitk_ws): captured graphs that replay concurrently on
             // different streams each carry their own; the library keeps none

@@ -114,7 +114,7 @@ class Qwen2:
                 tick=torch.zeros(1, dtype=torch.int32, device=dev),
                 # f32 workspace of the down projection's split-K form (ifh_conv_desc.splitk_ws): part of THIS decode state, so that the
                 # captured step graphs of different states / engines never share one
-                skws=torch.empty(4 * max(B, 16) * d, dtype=torch.float32, device=dev),
+                skws=torch.empty(24 * max(B, 16) * d, dtype=torch.float32, device=dev),
                 amax=torch.zeros(B, dtype=torch.int64, device=dev),        # arg-max keys of the head (zero between launches)
                 toks=torch.zeros(B, dtype=torch.int32, device=dev), graph=None, eager_steps=0)
             b = self._bufs[B]
@@ -164,10 +164,15 @@ class Qwen2:
             else:
                 ops.linear(x, L['wqkv'], L['bqkv'], qkv, rows=B, k=d, n=self.nq, aln=(stats, s1, None), ln_dim=d, ln_eps=self.eps,
                            ln_rms=True)
-            ops.rope_append(qkv, self.cos_sin, cache, pos0, ones, nrows=B, tokens_per_row=1, nheads=self.nh, nkv=self.nkv,
-                            head_dim=self.hd, max_pos=self.max_tokens)
-            ops.attn_gqa(qkv, cache, att, key_len, ntokens=B, tokens_per_row=1, nheads=self.nh, nkv=self.nkv, head_dim=self.hd,
-                         max_pos=self.max_tokens, max_keys=self.max_tokens)
+            if self.hd == 128:
+                # rotary embedding + KV append inside the attention launch (ifh_gqa_desc.rope_cos_sin: the same bits, one launch less)
+                ops.attn_gqa(qkv, cache, att, key_len, ntokens=B, tokens_per_row=1, nheads=self.nh, nkv=self.nkv, head_dim=self.hd,
+                             max_pos=self.max_tokens, max_keys=self.max_tokens, rope_cos_sin=self.cos_sin)
+            else:
+                ops.rope_append(qkv, self.cos_sin, cache, pos0, ones, nrows=B, tokens_per_row=1, nheads=self.nh, nkv=self.nkv,
+                                head_dim=self.hd, max_pos=self.max_tokens)
+                ops.attn_gqa(qkv, cache, att, key_len, ntokens=B, tokens_per_row=1, nheads=self.nh, nkv=self.nkv, head_dim=self.hd,
+                             max_pos=self.max_tokens, max_keys=self.max_tokens)
             ops.linear(att, L['wo'], None, x, rows=B, k=self.nh * self.hd, n=d, resid=x, stats_out=stats, stats_off=s2, ln_dim=d,
                        ln_eps=self.eps, ln_rms=True)
             ops.linear(x, L['wgu'], None, ff, rows=B, k=d, n=2 * self.ff, ldc=self.ff, act=ops.ACT_SILU_GLU, aln=(stats, s2, None),

@@ -198,7 +198,7 @@ def rope_append(qkv, cos_sin, cache, pos0, nvalid, *, nrows, tokens_per_row, nhe
                                                head_dim, _lib.stream_ptr(qkv.device)), 'ifh_rope_append_bf16')
 
 
-def attn_gqa(qkv, cache, out, key_len, *, ntokens, tokens_per_row, nheads, nkv, head_dim, max_pos, max_keys):
+def attn_gqa(qkv, cache, out, key_len, *, ntokens, tokens_per_row, nheads, nkv, head_dim, max_pos, max_keys, rope_cos_sin=None):
     """grouped-query attention of single query tokens against the KV cache (ifh_attn_gqa_bf16); q = the first
     nheads*head_dim columns of the fused projection"""
     d = _lib.GqaDesc()
@@ -207,6 +207,7 @@ def attn_gqa(qkv, cache, out, key_len, *, ntokens, tokens_per_row, nheads, nkv, 
     d.out, d.o_ts, d.key_len = _addr(out), nheads * head_dim, _addr(key_len)
     d.ntokens, d.tokens_per_row, d.nheads, d.nkv, d.head_dim = ntokens, tokens_per_row, nheads, nkv, head_dim
     d.max_keys, d.scale = max_keys, head_dim ** -0.5
+    d.rope_cos_sin = _addr(rope_cos_sin)         # decode step: rotary embedding + KV append inside this launch (ifh_gqa_desc)
     _lib.check(_lib.lib().ifh_attn_gqa_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_attn_gqa_bf16')
     return out
 

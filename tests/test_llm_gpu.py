@@ -75,6 +75,37 @@ def test_rope_append(dev, nh, nkv, hd, B, T):
     assert torch.equal(cache, exp_cache)
 
 
+@pytest.mark.parametrize('nh,nkv,B,S', [(12, 2, 64, 300), (4, 2, 5, 40), (7, 1, 3, 700), (16, 2, 33, 257)])
+def test_attn_gqa_with_fused_rope_is_bit_identical_to_rope_append_then_attention(dev, nh, nkv, B, S):
+    """A decode step's rotary embedding + KV append inside the attention launch (ifh_gqa_desc.rope_cos_sin; head_dim 128) against the
+    two launches it replaces: the same attention output and the same cache, bit for bit -- ragged positions, the group cut over one
+    and several workgroups per kv head, one and four waves per workgroup."""
+    from infernos_amd import ops
+    hd = 128
+    g = torch.Generator().manual_seed(nh + S)
+    nq = (nh + 2 * nkv) * hd
+    qkv = torch.randn(B, nq, generator=g).to(BF).to(dev)
+    cos, sin = onn.rope_cos_sin(S, hd, 1.0e6)
+    cs = torch.stack([cos, sin], -1).contiguous().to(dev)
+    cache0 = torch.randn(B, S, 2 * nkv * hd, generator=g).to(BF).to(dev)
+    pos = torch.randint(0, S, (B,), generator=g).int()
+    pos[0] = S - 1
+    pos[-1] = 0
+    pos, key_len = pos.to(dev), (pos + 1).to(dev)
+    ones = torch.ones(B, dtype=torch.int32, device=dev)
+    q2, c2 = qkv.clone(), cache0.clone()
+    ops.rope_append(q2, cs, c2, pos, ones, nrows=B, tokens_per_row=1, nheads=nh, nkv=nkv, head_dim=hd, max_pos=S)
+    ref = torch.zeros(B, nh * hd, dtype=BF, device=dev)
+    ops.attn_gqa(q2, c2, ref, key_len, ntokens=B, tokens_per_row=1, nheads=nh, nkv=nkv, head_dim=hd, max_pos=S, max_keys=S)
+    q1, c1 = qkv.clone(), cache0.clone()
+    out = torch.zeros_like(ref)
+    ops.attn_gqa(q1, c1, out, key_len, ntokens=B, tokens_per_row=1, nheads=nh, nkv=nkv, head_dim=hd, max_pos=S, max_keys=S, rope_cos_sin=cs)
+    torch.cuda.synchronize()
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    assert torch.equal(c1.view(torch.int16), c2.view(torch.int16))
+    assert torch.equal(q1, qkv)                               # (the fused launch leaves the projection row as it was)
+
+
 @pytest.mark.parametrize('nh,nkv,hd,B,T,S', [(12, 2, 128, 3, 1, 300), (4, 2, 128, 2, 6, 40), (4, 1, 64, 3, 5, 33),
                                              (7, 1, 128, 2, 1, 700), (8, 1, 64, 1, 3, 20), (5, 5, 64, 2, 2, 17),
                                              (3, 1, 128, 4, 1, 9), (12, 2, 128, 3, 50, 200), (4, 1, 64, 2, 37, 100),

@@ -1416,6 +1416,20 @@ def test_splitk_chain_form_is_bit_identical_to_the_streaming_kernel(dev, M, N, K
         assert torch.equal(stats[0], stats[1]), mode
         ref = x.float() @ w.float().t() + (r.float() if mode != 'plain' else 0.0)
         assert rel_l2(outs[0].float().cpu(), ref.cpu()) < 6e-3
+        # with a workspace of the caller's (ifh_conv_desc.splitk_ws): the whole-line DMA kernel over K parts + the same finishing pass
+        # (csrc/gemm_m64d.hip; one chain per part: the last bits differ from the four-chain forms) -- against fp32 torch and the above
+        ws = torch.empty(24 * M * N, dtype=torch.float32, device=dev)
+        o = torch.zeros(M, N, dtype=BF, device=dev)
+        st = torch.zeros(max(64, M), 2, dtype=torch.int64, device=dev)
+        if mode == 'plain':
+            ops.linear(x, w, None, o, rows=M, k=K, n=N, splitk_ws=ws)
+        else:
+            ops.linear(x, w, None, o, rows=M, k=K, n=N, resid=r, resid_ld=N, stats_out=st, stats_off=0, ln_dim=N, ln_rms=True, splitk_ws=ws)
+        torch.cuda.synchronize()
+        assert rel_l2(o.float().cpu(), ref.cpu()) < 6e-3
+        assert rel_l2(o.float().cpu(), outs[0].float().cpu()) < 3e-3
+        if mode != 'plain':
+            assert float((st[:M].double() - stats[0][:M].double()).abs().max()) <= 0.02 * float(stats[0][:M].double().abs().max())
 
 
 def test_gemm_big_silu_gate_epilogue_matches_torch(dev):
