@@ -32,9 +32,6 @@
 #include <stdio.h>
 #include <stdlib.h>
 
-#include <map>
-#include <mutex>
-
 #include "igemm.h"
 
 namespace ifh {
@@ -50,7 +47,6 @@ struct GemmBig8Params {
     int ldc;
     int M, N, K;
     int mtiles, ntiles;
-    unsigned *sched;             // tile tickets: [8] one counter per XCD group of workgroups, [8] workgroups done (null: static round-robin)
     long long *prof;             // tools builds: [0] K-loop clocks, [1] epilogue, [2] entry barrier, [3] tiles (wave 0 of every workgroup)
     int abl;                     // tools builds (GB_DEV_ABL, wrong results): 1 no DMA after a tile's first stage, 2 no MFMAs, 4 no epilogue, 16 no output stores
 };
@@ -58,8 +54,7 @@ struct GemmBig8Params {
 constexpr int G8_BN = 256, G8_BM = 256, G8_DK = 64;
 constexpr int G8_RING = 2 * 64 * 1024;                     // unit u of slot sl at u * 2048 + sl * 1024
 constexpr int G8_BIAS = G8_RING;                           // bias of the tile's columns: [tile parity][wave][128] f32
-constexpr int G8_NEXT = G8_RING + 2 * 8 * 512;             // the next tile of the workgroup (one word)
-constexpr int G8_LDS = G8_NEXT + 16;
+constexpr int G8_LDS = G8_RING + 2 * 8 * 512;
 
 template <int N>
 __device__ __forceinline__ void g8_wait_vm()
@@ -88,33 +83,8 @@ __global__ __launch_bounds__(512, 2) void k_gemm_big8(const GemmBig8Params p)
     // contiguous run of tiles, column tile fastest: the column tiles of the same rows of x run side by side on one L2
     const int total = p.mtiles * p.ntiles, G = gridDim.x;
     const int nds = p.K / G8_DK;                       // stages per tile: even, >= 4; stage s lives in slot s % 2
-    // With tickets (p.sched) a workgroup takes its tiles from the counter of its XCD group's eighth of the tile list, then from the
-    // others': inside a running pipeline a persistent workgroup may get its CU late (other kernels hold the LDS), and with the static
-    // round-robin it would then walk its whole share alone -- launches of 100 us took 280 us on average, 3 ms at worst.
-    const int per8 = (total + 7) >> 3;
-    int *const nxw = reinterpret_cast<int *>(lds + G8_NEXT);
-    auto take_from = [&](int y0) {                     // one lane: the next tile of group y0's range, else of the following groups', else -1
-        for (int k = 0; k < 8; k++) {
-            const int y = (y0 + k) & 7, lo = y * per8, hi = min(total, lo + per8);
-            if (lo >= hi) continue;
-            const unsigned tk = atomicAdd(p.sched + y, 1u);
-            if (lo + (int)tk < hi) return lo + (int)tk;
-        }
-        return -1;
-    };
-    auto leave = [&]() {                               // the last workgroup to leave re-arms the counters for the stream's next launch
-        if (p.sched && tid == 0 && atomicAdd(p.sched + 8, 1u) == (unsigned)G - 1u) {
-            for (int k = 0; k < 9; k++) atomicExch(p.sched + k, 0u);
-        }
-    };
     int t = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    if (p.sched) {
-        if (tid == 0) nxw[0] = take_from(blockIdx.x & 7);
-        __syncthreads();
-        t = nxw[0];
-        __syncthreads();
-        if (t < 0) { leave(); return; }
-    } else if (t >= total) return;
+    if (t >= total) return;
 
     // DMA: unit u of a stage (u < 32: rows n0 + 8 u .. of w; else rows m0 + 8 (u - 32) .. of x) is one wave-instruction: lane l fetches
     // the 16 bytes that belong at LDS position (row l / 8, chunk l % 8), i.e. source chunk (l % 8) ^ 2 (row / 2).  This wave's units:
@@ -239,19 +209,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_big8(const GemmBig8Params p)
     } while (0)
 
     for (;;) {
-        // the next tile: static (t + G), or a ticket requested here and published in front of the first stage barrier (where the queue
-        // has just been drained anyway); every wave reads it behind the second
-        unsigned ticket = 0;
-        if (p.sched && tid == 0) ticket = atomicAdd(p.sched + (blockIdx.x & 7), 1u);
-        auto publish_next = [&]() {
-            if (p.sched && tid == 0) {
-                const int lo = (blockIdx.x & 7) * per8, hi = min(total, lo + per8);
-                nxw[0] = lo + (int)ticket < hi ? lo + (int)ticket : take_from((blockIdx.x + 1) & 7);
-            }
-        };
-        int tnext = t + G;
-        bool has_next = tnext < total;
-        if (!p.sched && has_next) nxt = tile_src(tnext);
+        const int tnext = t + G;
+        const bool has_next = tnext < total;
+        if (has_next) nxt = tile_src(tnext);
 #pragma unroll
         for (int i = 0; i < 8; i++)
 #pragma unroll
@@ -281,15 +241,10 @@ __global__ __launch_bounds__(512, 2) void k_gemm_big8(const GemmBig8Params p)
         // ---- all but the last two stages.  A stage's barrier waits for the next stage's pieces: nothing younger is in the queue.
         int s0 = 0;
         do {
-            G8_STAGE(0, (g8_wait_vm<0>(), (s0 == 0 ? publish_next() : (void)0)), issue_piece(cur, s0 + 1, 1, 4 + q), issue_piece(cur, s0 + 2, 0, q), true);
+            G8_STAGE(0, g8_wait_vm<0>(), issue_piece(cur, s0 + 1, 1, 4 + q), issue_piece(cur, s0 + 2, 0, q), true);
             G8_STAGE(1, g8_wait_vm<0>(), issue_piece(cur, s0 + 2, 0, 4 + q), issue_piece(cur, s0 + 3, 1, q), true);
             s0 += 2;
         } while (s0 < nds - 2);
-        if (p.sched) {
-            tnext = __builtin_amdgcn_readfirstlane(nxw[0]);
-            has_next = tnext >= 0;
-            if (has_next) nxt = tile_src(tnext);
-        }
         // ---- the last two start the next tile: its stage 0 (and bias) into slot 0; slot 1 stays free for the epilogue
         G8_STAGE(0, g8_wait_vm<0>(), issue_piece(cur, s0 + 1, 1, 4 + q), if (has_next) issue_piece(nxt, 0, 0, q), true);
         // (with a residual: the geometry of the epilogue and the residual rows of its first two pieces, started under the tile's last
@@ -411,7 +366,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_big8(const GemmBig8Params p)
         cur = nxt;
         par ^= 1;
     }
-    leave();
 #ifdef GB_DEV_ABL
     if ((abl & 8) && p.prof && tid == 0) {
         atomicAdd((unsigned long long *)p.prof + 0, (unsigned long long)pf_k);
@@ -430,37 +384,6 @@ __global__ __launch_bounds__(512, 2) void k_gemm_big8(const GemmBig8Params p)
 #undef G8_MID_STAMP
 }
 
-// Ticket counters of the dynamic tile order: 16 words per STREAM (launches of one stream never overlap; the last workgroup of a launch
-// re-arms them), from one zeroed allocation per device.  Not during stream capture (a captured launch may later run beside another
-// replay that was captured on the same stream): those keep the static order.
-static unsigned *big8_sched_slot(hipStream_t st)
-{
-    static const int on = getenv("IFH_GEMM_BIG8_TICKETS") ? atoi(getenv("IFH_GEMM_BIG8_TICKETS")) : 1;      // tuning switch
-    if (!on) return nullptr;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
-    constexpr int NSLOT = 256;
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, int> slot_of;
-    static unsigned *base[64] = {};
-    static int used[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    if (!base[dev]) {
-        unsigned *b = nullptr;
-        if (hipMalloc((void **)&b, NSLOT * 16 * sizeof(unsigned)) != hipSuccess) return nullptr;
-        if (hipMemset(b, 0, NSLOT * 16 * sizeof(unsigned)) != hipSuccess) { (void)hipFree(b); return nullptr; }
-        base[dev] = b;
-    }
-    auto it = slot_of.find({dev, st});
-    if (it == slot_of.end()) {
-        if (used[dev] >= NSLOT) return nullptr;
-        it = slot_of.emplace(std::make_pair(dev, st), used[dev]++).first;
-    }
-    return base[dev] + it->second * 16;
-}
-
 // true if it took the launch (try_launch_gemm_big has checked the epilogue and the views; here: whole 256 x 256 tiles, K in 128s)
 bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st)
 {
@@ -471,7 +394,6 @@ bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st)
     g.out = (uint16_t *)p.out; g.ldc = p.ldc; g.M = (int)M; g.N = p.N; g.K = p.K;
     g.mtiles = (int)(M / G8_BM); g.ntiles = p.N / G8_BN;
     g.prof = nullptr;
-    g.sched = nullptr;
 #ifdef GB_DEV_ABL          /* tools builds only: ablations chosen by IFH_GEMM_BIG_ABL (wrong results; 8 = phase clocks, printed per launch) */
     g.abl = getenv("IFH_GEMM_BIG_ABL") ? atoi(getenv("IFH_GEMM_BIG_ABL")) : 0;
     static long long *prof_buf = nullptr;
@@ -512,7 +434,6 @@ bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st)
         // first = (b & 7) * (G >> 3) + (b >> 3) needs G >= 8; run as 8 workgroups, the surplus ones return at once
         grid = 8;
     }
-    if (total > grid) g.sched = big8_sched_slot(st);          // (one tile per workgroup: nothing to schedule)
     const bool ok = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(512), args, G8_LDS, st) == hipSuccess;
 #ifdef GB_DEV_ABL
     if (ok && g.prof) {

@@ -500,6 +500,229 @@ __global__ __launch_bounds__(512) void k_attn_gqa_prefill(const uint16_t *__rest
     }
 }
 
+// Decode attention of a head_dim-128 model on the matrix cores: ONE workgroup per (token, kv head), the group's G <= 16 query heads as
+// the 16 "query rows" of k_attn_gqa_prefill's layout, so the K / V rows of the token's cache row are read ONCE for all of them (the
+// per-head workgroups of k_attn_gqa re-read them per query head: 79 MB per layer at 64 tokens x 200 keys, 18 us).  Four waves take
+// the 32-key tiles in turn (wave-private LDS tiles, no barrier in the loop) and merge their (max, sum, O) at the end.  ROPE as in
+// k_attn_gqa: rotary embedding of q (a lane's fragments s and s + 2 are the pairs (j, j + 64)) and of the step's own key, which the
+// wave that owns its tile writes into the tile (and into the cache) in place of the cache row.
+template <bool ROPE>
+__global__ __launch_bounds__(256, 2) void k_attn_gqa_decode_mfma(const uint16_t *__restrict__ q, int64_t q_ts, uint16_t *__restrict__ cache,
+                                                                 int64_t cache_bs, int64_t cache_ts, int v_off, uint16_t *__restrict__ out,
+                                                                 int64_t o_ts, const int32_t *__restrict__ key_len, float scale, int G,
+                                                                 const float *__restrict__ rope_cs, int k_col, int v_col)
+{
+    constexpr int HDT = 128, KLD = HDT + 8, KT = 32, NS = 4, ND = 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int i = blockIdx.y, kvh = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    uint16_t *Ks = reinterpret_cast<uint16_t *>(smem) + wid * (2 * KT * KLD), *Vs = Ks + KT * KLD;
+    const int klen = key_len[i];
+    const bool hok = fr < G;
+    const int h = kvh * G + (hok ? fr : 0);
+    const uint16_t *qrow = q + (int64_t)i * q_ts;
+
+    // Q fragments (B operand of S^T = K.Q^T): head fr, dims 32 s + 8 fg .. + 8; rows past the group are zero
+    bf16x8_t qf[NS];
+    {
+        uint4 tq[NS];
+#pragma unroll
+        for (int s = 0; s < NS; s++) tq[s] = hok ? *reinterpret_cast<const uint4 *>(qrow + (int64_t)h * HDT + 32 * s + 8 * fg) : make_uint4(0, 0, 0, 0);
+        if (ROPE) {
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const float *cp = rope_cs + ((int64_t)(klen - 1) * 64 + 32 * s + 8 * fg) * 2;
+                uint32_t *ul = reinterpret_cast<uint32_t *>(&tq[s]), *uh = reinterpret_cast<uint32_t *>(&tq[s + 2]);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float4 cs4 = *reinterpret_cast<const float4 *>(cp + 4 * e);       // cos, sin of dims 2 e, 2 e + 1
+                    const float a0 = __uint_as_float(ul[e] << 16), a1 = __uint_as_float(ul[e] & 0xffff0000u);
+                    const float b0 = __uint_as_float(uh[e] << 16), b1 = __uint_as_float(uh[e] & 0xffff0000u);
+                    const uint32_t r00 = f32_to_bf16(a0 * cs4.x - b0 * cs4.y), r01 = f32_to_bf16(a1 * cs4.z - b1 * cs4.w);
+                    const uint32_t r10 = f32_to_bf16(b0 * cs4.x + a0 * cs4.y), r11 = f32_to_bf16(b1 * cs4.z + a1 * cs4.w);
+                    ul[e] = r00 | (r01 << 16);
+                    uh[e] = r10 | (r11 << 16);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; s++) qf[s] = __builtin_bit_cast(bf16x8_t, tq[s]);
+    }
+    f32x4 o[ND];
+#pragma unroll
+    for (int d = 0; d < ND; d++) o[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun = -1e30f, lrun = 0.0f;
+    const uint16_t *kb = cache + (int64_t)i * cache_bs + (int64_t)kvh * HDT, *vb = kb + v_off;
+    constexpr float kLog2e = 1.4426950408889634f;
+    const float c1 = scale * kLog2e;
+    const int ntile = (klen + KT - 1) / KT;
+
+    for (int kt = wid; kt < ntile; kt += 4) {
+        const int kbase = kt * KT;
+        // the tile: 32 keys x 16 chunks of 16 bytes for K and for V; lane l takes chunks l % 16 of keys l / 16 + 4 it
+        uint4 kk[8], vv[8];
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int key = (lane >> 4) + 4 * it, kg = kbase + key, dv = (lane & 15) * 8;
+            kk[it] = make_uint4(0, 0, 0, 0);
+            vv[it] = kk[it];
+            if (kg < klen && !(ROPE && kg == klen - 1)) {
+                kk[it] = *reinterpret_cast<const uint4 *>(kb + (int64_t)kg * cache_ts + dv);
+                vv[it] = *reinterpret_cast<const uint4 *>(vb + (int64_t)kg * cache_ts + dv);
+            }
+        }
+        if (ROPE && klen - 1 >= kbase && klen - 1 < kbase + KT) {
+            // the step's own token: chunk c = lane % 16 of its rotated key (partner chunk c ^ 8) and of its value, by the lanes that
+            // hold that key's slot (lane / 16 + 4 it == (klen - 1) - kbase); appended to the cache as well
+            const int rowl = klen - 1 - kbase, c = lane & 15, cl = c & 7;
+            if ((lane >> 4) == (rowl & 3)) {
+                const uint16_t *kr = qrow + k_col + kvh * HDT, *vr = qrow + v_col + kvh * HDT;
+                const uint4 lo = *reinterpret_cast<const uint4 *>(kr + 8 * cl), hi = *reinterpret_cast<const uint4 *>(kr + 64 + 8 * cl);
+                const float *cp = rope_cs + ((int64_t)(klen - 1) * 64 + 8 * cl) * 2;
+                const uint32_t *ul = reinterpret_cast<const uint32_t *>(&lo), *uh = reinterpret_cast<const uint32_t *>(&hi);
+                uint4 rk;
+                uint32_t *pr = reinterpret_cast<uint32_t *>(&rk);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const float4 cs4 = *reinterpret_cast<const float4 *>(cp + 4 * e);
+                    const float a0 = __uint_as_float(ul[e] << 16), a1 = __uint_as_float(ul[e] & 0xffff0000u);
+                    const float b0 = __uint_as_float(uh[e] << 16), b1 = __uint_as_float(uh[e] & 0xffff0000u);
+                    const uint32_t r00 = f32_to_bf16(a0 * cs4.x - b0 * cs4.y), r01 = f32_to_bf16(a1 * cs4.z - b1 * cs4.w);
+                    const uint32_t r10 = f32_to_bf16(b0 * cs4.x + a0 * cs4.y), r11 = f32_to_bf16(b1 * cs4.z + a1 * cs4.w);
+                    pr[e] = c < 8 ? (r00 | (r01 << 16)) : (r10 | (r11 << 16));
+                }
+                const uint4 rv = *reinterpret_cast<const uint4 *>(vr + 8 * c);
+                uint16_t *kd = cache + (int64_t)i * cache_bs + (int64_t)(klen - 1) * cache_ts + kvh * HDT + 8 * c;
+                *reinterpret_cast<uint4 *>(kd) = rk;
+                *reinterpret_cast<uint4 *>(kd + v_off) = rv;
+#pragma unroll
+                for (int it = 0; it < 8; it++)
+                    if (it == (rowl >> 2)) { kk[it] = rk; vv[it] = rv; }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int key = (lane >> 4) + 4 * it, dv = (lane & 15) * 8;
+            *reinterpret_cast<uint4 *>(&Ks[key * KLD + dv]) = kk[it];
+            *reinterpret_cast<uint4 *>(&Vs[key * KLD + dv]) = vv[it];
+        }
+        // (wave-private tile: the wave's own LDS writes are ordered before its reads)
+        f32x4 s[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            s[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ds = 0; ds < NS; ds++) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t *>(&Ks[(c * 16 + fr) * KLD + ds * 32 + fg * 8]);
+                s[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ds], s[c], 0, 0, 0);
+            }
+        }
+        float mloc = -1e30f;
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int kidx = kbase + c * 16 + 4 * fg + r;
+                s[c][r] = kidx < klen ? s[c][r] : -1e30f;
+                mloc = fmaxf(mloc, s[c][r]);
+            }
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float mnew = fmaxf(mrun, mloc);
+        const float mscaled = mnew * c1;
+        const float alpha = __builtin_amdgcn_exp2f(mrun * c1 - mscaled);
+        float lsum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[c][r], c1, -mscaled));
+                s[c][r] = pv;
+                lsum += pv;
+            }
+        lsum += __shfl_xor(lsum, 16, 64);
+        lsum += __shfl_xor(lsum, 32, 64);
+        lrun = lrun * alpha + lsum;
+        mrun = mnew;
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+            o[d][0] *= alpha; o[d][1] *= alpha; o[d][2] *= alpha; o[d][3] *= alpha;
+        }
+        uint4 pb;
+        pb.x = pack2(s[0][0], s[0][1]);
+        pb.y = pack2(s[0][2], s[0][3]);
+        pb.z = pack2(s[1][0], s[1][1]);
+        pb.w = pack2(s[1][2], s[1][3]);
+        const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pb);
+        const uint32_t vaddr = (uint32_t)(uintptr_t)(&Vs[(4 * fg + (fr >> 2)) * KLD + 4 * (fr & 3)]);
+#pragma unroll
+        for (int d4 = 0; d4 < ND; d4 += 4) {
+            uint2 lo[4], hi[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo[dt]) : "v"(vaddr), "n"((d4 + dt) * 32) : "memory");
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi[dt]) : "v"(vaddr), "n"((d4 + dt) * 32 + 16 * KLD * 2) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                uint4 va;
+                va.x = lo[dt].x; va.y = lo[dt].y; va.z = hi[dt].x; va.w = hi[dt].y;
+                o[d4 + dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, va), pf, o[d4 + dt], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the tile's reads are done before the next tile overwrites it
+    }
+
+    // merge the four waves: (m, l) per head and O^T through LDS (the tiles are idle), wave 0 finishes
+    __syncthreads();
+    float *mg = reinterpret_cast<float *>(smem);                 // [4 waves][64 lanes][2 + 32]
+    {
+        float *mp = mg + (wid * 64 + lane) * 34;
+        mp[0] = mrun;
+        mp[1] = lrun;
+#pragma unroll
+        for (int d = 0; d < ND; d++) {
+            mp[2 + 4 * d] = o[d][0]; mp[3 + 4 * d] = o[d][1]; mp[4 + 4 * d] = o[d][2]; mp[5 + 4 * d] = o[d][3];
+        }
+    }
+    __syncthreads();
+    if (wid == 0) {
+        float mall = mrun;
+#pragma unroll
+        for (int w = 1; w < 4; w++) mall = fmaxf(mall, mg[(w * 64 + lane) * 34]);
+        float lall = 0.0f;
+        f32x4 acc[ND];
+#pragma unroll
+        for (int d = 0; d < ND; d++) acc[d] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+            const float *mp = mg + (w * 64 + lane) * 34;
+            const float a = __builtin_amdgcn_exp2f((mp[0] - mall) * c1);
+            lall += mp[1] * a;
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+                acc[d][0] += mp[2 + 4 * d] * a; acc[d][1] += mp[3 + 4 * d] * a; acc[d][2] += mp[4 + 4 * d] * a; acc[d][3] += mp[5 + 4 * d] * a;
+            }
+        }
+        if (hok) {
+            const float inv = lall > 0.0f ? 1.0f / lall : 0.0f;
+            uint16_t *op = out + (int64_t)i * o_ts + (int64_t)h * HDT;
+#pragma unroll
+            for (int d = 0; d < ND; d++) {
+                uint2 pk;
+                pk.x = pack2(acc[d][0] * inv, acc[d][1] * inv);
+                pk.y = pack2(acc[d][2] * inv, acc[d][3] * inv);
+                *reinterpret_cast<uint2 *>(op + d * 16 + 4 * fg) = pk;
+            }
+        }
+    }
+}
+
 template <int G, int HDV>
 static void attn_gqa_launch(const ifh_gqa_desc *d, hipStream_t st, int gtot)
 {
@@ -578,6 +801,29 @@ extern "C" int ifh_attn_gqa_bf16(const ifh_gqa_desc *d, ifh_stream_t stream)
     // the fused rotary embedding + KV append: a decode step (one token per row) at head_dim 128, a 16-byte addressable table
     IFH_CHECK_ARG(!d->rope_cos_sin || (d->tokens_per_row == 1 && d->head_dim == 128 && (((uintptr_t)d->rope_cos_sin) & 15) == 0));
     hipStream_t st = as_stream(stream);
+    // a decode step at head_dim 128: one workgroup per (token, kv head), the group's heads as the query rows of the matrix-core layout
+    static const int dec_mfma = getenv("IFH_GQA_DECODE_MFMA") ? atoi(getenv("IFH_GQA_DECODE_MFMA")) : 1;       // tuning switch
+    if (dec_mfma && d->tokens_per_row == 1 && d->head_dim == 128) {
+        constexpr int bytes = 4 * 2 * 32 * 136 * 2;
+        static DeviceOnce attr_once;
+        int attr_dev = 0;
+        if (attr_once.needed(&attr_dev)) {
+            hipError_t e = hipFuncSetAttribute((const void *)k_attn_gqa_decode_mfma<true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *)k_attn_gqa_decode_mfma<false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return check_hip(e, "attn_gqa_decode lds attr");
+            attr_once.done(attr_dev);
+        }
+        const dim3 grid((unsigned)d->nkv, (unsigned)d->ntokens);
+        const int k_col = d->nheads * d->head_dim, v_col = (d->nheads + d->nkv) * d->head_dim;
+        if (d->rope_cos_sin)
+            hipLaunchKernelGGL(k_attn_gqa_decode_mfma<true>, grid, dim3(256), bytes, st, (const uint16_t *)d->q, d->q_ts, (uint16_t *)d->cache, d->cache_bs,
+                               d->cache_ts, d->v_off, (uint16_t *)d->out, d->o_ts, d->key_len, d->scale, G, d->rope_cos_sin, k_col, v_col);
+        else
+            hipLaunchKernelGGL(k_attn_gqa_decode_mfma<false>, grid, dim3(256), bytes, st, (const uint16_t *)d->q, d->q_ts, (uint16_t *)d->cache, d->cache_bs,
+                               d->cache_ts, d->v_off, (uint16_t *)d->out, d->o_ts, d->key_len, d->scale, G, (const float *)nullptr, 0, 0);
+        IFH_LAUNCH_CHECK("attn_gqa_decode");
+        return IFH_OK;
+    }
     // a prompt (16 or more tokens per row): the matrix-core kernel, 16 query tokens x G heads per workgroup
     static const int mfma_on = getenv("IFH_GQA_PREFILL_MFMA") ? atoi(getenv("IFH_GQA_PREFILL_MFMA")) : 1;       // tuning switch
     if (mfma_on && d->tokens_per_row >= 16 && d->ntokens % d->tokens_per_row == 0) {
