@@ -23,7 +23,7 @@
 
 namespace ifh {
 
-bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st);
+bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st, float *ws, int64_t ws_floats);
 
 struct GemmBigParams {
     const uint16_t *x;
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_big(const GemmBigParams p)
 }
 
 // true if it took the launch: plain matrix product, whole tiles, bf16 output, epilogue = bias / GELU or ReLU / residual
-bool try_launch_gemm_big(const IgemmParams &p, bool pre, hipStream_t st)
+bool try_launch_gemm_big(const IgemmParams &p, bool pre, hipStream_t st, float *ws, int64_t ws_floats)
 {
     static const int min_rows = getenv("IFH_GEMM_BIG_ROWS") ? atoi(getenv("IFH_GEMM_BIG_ROWS")) : 4096;        // tuning switch (0x7fffffff: off)
     const int64_t M = (int64_t)p.nbatch * p.T_out;
@@ -213,7 +213,7 @@ bool try_launch_gemm_big(const IgemmParams &p, bool pre, hipStream_t st)
         (p.bias && (((uintptr_t)p.bias) & 15)) || p.lda % 8 || p.ldc % 8 || (p.resid && p.resid_ld % 8))
         return false;
     if ((int64_t)M * p.lda * 2 >= (1ll << 32) || (int64_t)p.N * p.K * 2 >= (1ll << 32)) return false;      // 32-bit DMA offsets
-    if (try_launch_gemm_big8(p, M, st)) return true;         // whole 256 x 256 tiles: the eight-wave persistent form (gemm_big8.hip)
+    if (try_launch_gemm_big8(p, M, st, ws, ws_floats)) return true;         // whole 256 x 256 tiles: the eight-wave persistent form (gemm_big8.hip)
     GemmBigParams g;
     g.x = p.x; g.lda = p.lda; g.w = p.w; g.bias = p.bias; g.resid = p.resid; g.ldr = p.resid_ld;
     g.out = (uint16_t *)p.out; g.ldc = p.ldc; g.M = (int)M; g.N = p.N; g.K = p.K;

@@ -47,6 +47,8 @@ struct GemmBig8Params {
     int ldc;
     int M, N, K;
     int mtiles, ntiles;
+    float *split_ws;             // null, or: the tiles of the last (partial) round are cut into split_s parts of K, each part's raw f32
+    int split_s;                 // accumulators go to split_ws[tile - first leftover tile][part][256 rows][256 columns]; k_big8_split_finish follows
     long long *prof;             // tools builds: [0] K-loop clocks, [1] epilogue, [2] entry barrier, [3] tiles (wave 0 of every workgroup)
     int abl;                     // tools builds (GB_DEV_ABL, wrong results): 1 no DMA after a tile's first stage, 2 no MFMAs, 4 no epilogue, 16 no output stores
 };
@@ -82,9 +84,20 @@ __global__ __launch_bounds__(512, 2) void k_gemm_big8(const GemmBig8Params p)
     // tiles of this workgroup: round k takes tile k G + (b % 8) (G / 8) + b / 8 -- the workgroups of one XCD (equal b % 8) hold a
     // contiguous run of tiles, column tile fastest: the column tiles of the same rows of x run side by side on one L2
     const int total = p.mtiles * p.ntiles, G = gridDim.x;
-    const int nds = p.K / G8_DK;                       // stages per tile: even, >= 4; stage s lives in slot s % 2
-    int t = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
-    if (t >= total) return;
+    const int nds_full = p.K / G8_DK;                  // stages per tile: even, >= 4; stage s lives in slot s % 2
+    // The workgroup's items: tile first + k G of every full round k; then its item of the last, partial round -- a whole tile, or
+    // (split_ws) part j % S of tile R G + j / S, j = first: with 288 tiles on 256 CUs the 32 tiles of the second round would otherwise
+    // run alone on 32 CUs for a whole tile time.  A part is nds_full / S stages (even, >= 4) and leaves raw f32 accumulators.
+    const int first = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+    const int R = total / G, S = p.split_ws ? p.split_s : 1, nds_part = nds_full / S;
+    // item k of this workgroup -> tile (or -1) and part (-1: the whole K range)
+    auto item_tile = [&](int k) { return k < R ? first + k * G : (k > R ? -1 : (S > 1 ? (first < (total - R * G) * S ? R * G + first / S : -1)
+                                                                                  : (first + R * G < total ? first + R * G : -1))); };
+    auto item_part = [&](int k) { return (k == R && S > 1) ? first % S : -1; };
+    int kitem = 0;
+    int t = item_tile(0), tpart = item_part(0);
+    if (t < 0) return;
+    int nds = tpart < 0 ? nds_full : nds_part;
 
     // DMA: unit u of a stage (u < 32: rows n0 + 8 u .. of w; else rows m0 + 8 (u - 32) .. of x) is one wave-instruction: lane l fetches
     // the 16 bytes that belong at LDS position (row l / 8, chunk l % 8), i.e. source chunk (l % 8) ^ 2 (row / 2).  This wave's units:
@@ -95,11 +108,12 @@ __global__ __launch_bounds__(512, 2) void k_gemm_big8(const GemmBig8Params p)
     const unsigned lw = (unsigned)((drow * p.K) * 2 + dch * 16), lx = (unsigned)((drow * p.lda) * 2 + dch * 16);
     const int64_t wq = (int64_t)8 * p.K * 2, xq = (int64_t)8 * p.lda * 2;        // one unit on = 8 rows on
     struct Src { const unsigned char *w, *x, *b; };    // scalar: first w row / x row / bias value of this wave in a tile
-    auto tile_src = [&](int tile) {
+    auto tile_src = [&](int tile, int part) {
         const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+        const int64_t koff = part > 0 ? (int64_t)part * nds_part * (G8_DK * 2) : 0;      // a part starts at its own K offset
         Src r;
-        r.w = reinterpret_cast<const unsigned char *>(p.w) + (int64_t)(nt * G8_BN + wid * 32) * p.K * 2;
-        r.x = reinterpret_cast<const unsigned char *>(p.x) + (int64_t)(mt * G8_BM + wid * 32) * p.lda * 2;
+        r.w = reinterpret_cast<const unsigned char *>(p.w) + (int64_t)(nt * G8_BN + wid * 32) * p.K * 2 + koff;
+        r.x = reinterpret_cast<const unsigned char *>(p.x) + (int64_t)(mt * G8_BM + wid * 32) * p.lda * 2 + koff;
         // no bias: the pieces are fetched all the same (from w, never read) -- one instruction stream for both cases
         r.b = p.bias ? reinterpret_cast<const unsigned char *>(p.bias + nt * G8_BN + wn * 128) : reinterpret_cast<const unsigned char *>(p.w);
         return r;
@@ -136,7 +150,7 @@ __global__ __launch_bounds__(512, 2) void k_gemm_big8(const GemmBig8Params p)
     const unsigned char *b0 = lds + (32 + 8 * wm + (fr >> 3)) * 2048 + rr8 * 128 + ((fg ^ fsw) << 4);
     const unsigned char *b1 = lds + (32 + 8 * wm + (fr >> 3)) * 2048 + rr8 * 128 + (((4 + fg) ^ fsw) << 4);
 
-    Src cur = tile_src(t), nxt = cur;
+    Src cur = tile_src(t, tpart), nxt = cur;
     issue_bias(cur, 0);
 #pragma unroll
     for (int q = 0; q < 8; q++) issue_piece(cur, 0, 0, q);
@@ -209,9 +223,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_big8(const GemmBig8Params p)
     } while (0)
 
     for (;;) {
-        const int tnext = t + G;
-        const bool has_next = tnext < total;
-        if (has_next) nxt = tile_src(tnext);
+        const int tnext = item_tile(kitem + 1), pnext = item_part(kitem + 1);
+        const bool has_next = tnext >= 0;
+        if (has_next) nxt = tile_src(tnext, pnext);
 #pragma unroll
         for (int i = 0; i < 8; i++)
 #pragma unroll
@@ -272,14 +286,25 @@ __global__ __launch_bounds__(512, 2) void k_gemm_big8(const GemmBig8Params p)
             G8_DMA("global_load_lds_dwordx4", lres[it], rb, (((j & 1) ? 32 + 4 * wid : 4 * wid) + it) * 2048 + 1024);
         };
         G8_STAGE(1, g8_wait_vm<0>(), if (has_next) { if (q == 0) issue_bias(nxt, par ^ 1); issue_piece(nxt, 0, 0, 4 + q); },
-                 if (RESID) { if (q == 0) epi_geometry(); resid_dma(q >> 1, 2 * (q & 1)); resid_dma(q >> 1, 2 * (q & 1) + 1); }, false);
+                 if (RESID && tpart < 0) { if (q == 0) epi_geometry(); resid_dma(q >> 1, 2 * (q & 1)); resid_dma(q >> 1, 2 * (q & 1) + 1); }, false);
         G8_STAMP(pf_k);
 
         // ---- epilogue.  D[n][m]: a lane holds 4 consecutive columns n of row m = fr of accumulator tile (i, j).  Piece j = 16 rows x 128
         // columns of the wave's sub-tile goes through one of the wave's two 4 KB buffers (the slot-1 halves of its w units 4 wid .. + 3,
         // of its x units 32 + 4 wid .. + 3: row r in unit r / 4, 256 B, 16-byte chunk c at chunk c ^ r) and leaves as 256-byte row pieces,
         // 16 bytes per lane; the residual comes in the same way and is added in f32 before the one rounding, as k_igemm does.
-        if (!(abl & 4)) {
+        if (tpart >= 0) {
+            // a part of a tile of the last round: raw accumulators to the workspace, [row m][column n] f32 (k_big8_split_finish adds the
+            // parts in order and runs the epilogue)
+            int el2;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el2));
+            float *wp = p.split_ws + ((int64_t)(t - R * G) * S + tpart) * 65536 + (wm * 64 + (el2 & 15)) * 256 + wn * 128 + 4 * (el2 >> 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    *reinterpret_cast<float4 *>(wp + j * 16 * 256 + i * 16) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        } else if (!(abl & 4)) {
             if (!RESID) epi_geometry();
             const int efr = el & 15, efg = el >> 4, trow = el >> 4, tch = el & 15;
             unsigned char *const ebuf0 = lds + (4 * wid) * 2048 + 1024, *const ebuf1 = lds + (32 + 4 * wid) * 2048 + 1024;
@@ -363,6 +388,9 @@ __global__ __launch_bounds__(512, 2) void k_gemm_big8(const GemmBig8Params p)
         G8_STAMP(pf_e);
         if (!has_next) break;
         t = tnext;
+        tpart = pnext;
+        nds = tpart < 0 ? nds_full : nds_part;
+        kitem++;
         cur = nxt;
         par ^= 1;
     }
@@ -384,8 +412,44 @@ __global__ __launch_bounds__(512, 2) void k_gemm_big8(const GemmBig8Params p)
 #undef G8_MID_STAMP
 }
 
+// The parts of the last round's tiles added in part order + the epilogue of k_gemm_big8 (bias, activation, residual in f32, one
+// rounding): a thread = 4 consecutive columns of one row of one tile.
+__global__ __launch_bounds__(256) void k_big8_split_finish(const GemmBig8Params p, const int tile0, const int act)
+{
+    const int tl = blockIdx.x >> 6, m = (blockIdx.x & 63) * 4 + (threadIdx.x >> 6), n = (threadIdx.x & 63) * 4;
+    const int tile = tile0 + tl, mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const float *wp = p.split_ws + (int64_t)tl * p.split_s * 65536 + m * 256 + n;
+    float4 v = *reinterpret_cast<const float4 *>(wp);
+    for (int z = 1; z < p.split_s; z++) {
+        const float4 u = *reinterpret_cast<const float4 *>(wp + (int64_t)z * 65536);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    const int64_t row = (int64_t)mt * G8_BM + m;
+    const int col = nt * G8_BN + n;
+    if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4 *>(p.bias + col);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (act == ACT_SILU_GLU) {           // interleaved (gate, up) columns: two outputs of the half-width result (k_gemm_big8's arithmetic)
+        const float o0 = v.x / (1.0f + __expf(-v.x)) * v.y, o1 = v.z / (1.0f + __expf(-v.z)) * v.w;
+        *reinterpret_cast<uint32_t *>(p.out + row * p.ldc + (col >> 1)) = f32x2_to_bf16x2(o0, o1);
+        return;
+    }
+    if (act != ACT_NONE) {
+        v.x = apply_act(v.x, act, 0.0f); v.y = apply_act(v.y, act, 0.0f); v.z = apply_act(v.z, act, 0.0f); v.w = apply_act(v.w, act, 0.0f);
+    }
+    if (p.resid) {
+        const uint2 rv = *reinterpret_cast<const uint2 *>(p.resid + row * p.ldr + col);
+        v.x += __uint_as_float(rv.x << 16);
+        v.y += __uint_as_float(rv.x & 0xffff0000u);
+        v.z += __uint_as_float(rv.y << 16);
+        v.w += __uint_as_float(rv.y & 0xffff0000u);
+    }
+    *reinterpret_cast<uint2 *>(p.out + row * p.ldc + col) = make_uint2(f32x2_to_bf16x2(v.x, v.y), f32x2_to_bf16x2(v.z, v.w));
+}
+
 // true if it took the launch (try_launch_gemm_big has checked the epilogue and the views; here: whole 256 x 256 tiles, K in 128s)
-bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st)
+bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st, float *ws, int64_t ws_floats)
 {
     static const int on = getenv("IFH_GEMM_BIG8") ? atoi(getenv("IFH_GEMM_BIG8")) : 1;      // tuning switch: 0 = the 256 x 128 kernel
     if (!on || M % G8_BM || p.N % G8_BN || p.K % (2 * G8_DK) || p.K < 4 * G8_DK) return false;
@@ -394,6 +458,8 @@ bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st)
     g.out = (uint16_t *)p.out; g.ldc = p.ldc; g.M = (int)M; g.N = p.N; g.K = p.K;
     g.mtiles = (int)(M / G8_BM); g.ntiles = p.N / G8_BN;
     g.prof = nullptr;
+    g.split_ws = nullptr;
+    g.split_s = 1;
 #ifdef GB_DEV_ABL          /* tools builds only: ablations chosen by IFH_GEMM_BIG_ABL (wrong results; 8 = phase clocks, printed per launch) */
     g.abl = getenv("IFH_GEMM_BIG_ABL") ? atoi(getenv("IFH_GEMM_BIG_ABL")) : 0;
     static long long *prof_buf = nullptr;
@@ -422,10 +488,11 @@ bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st)
         attr_once.done(attr_dev);
     }
     const int total = g.mtiles * g.ntiles;
-    // one workgroup per CU of the device -- or of the budget the caller has set for persistent kernels (ifh_set_cu_budget);
-    // IFH_GEMM_BIG8_CUS (tuning switch): that many instead
+    // one workgroup per CU of the device: NOT of the budget a pipeline sets for its persistent vocoder kernels (ifh_set_cu_budget) -- the
+    // encoder and the LLM prompt need the whole chip (C3 measured the same at 160 / 208 / 256 workgroups; the C5 turn, whose LLM runs
+    // beside a pipeline's budget, lost a third of its prompt's CUs); IFH_GEMM_BIG8_CUS (tuning switch): that many instead
     static const int cus_env = getenv("IFH_GEMM_BIG8_CUS") ? atoi(getenv("IFH_GEMM_BIG8_CUS")) : 0;
-    int grid = (cus_env > 0 ? cus_env : device_cu_count()) & ~7;
+    int grid = (cus_env > 0 ? cus_env : device_cu_count_physical()) & ~7;
     if (grid < 8) grid = 8;
     if (grid > total) grid = total < 8 ? total : (total & ~7);
     // with fewer than 8 tiles the XCD interleave below degenerates: one workgroup per tile
@@ -434,7 +501,27 @@ bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st)
         // first = (b & 7) * (G >> 3) + (b >> 3) needs G >= 8; run as 8 workgroups, the surplus ones return at once
         grid = 8;
     }
-    const bool ok = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(512), args, G8_LDS, st) == hipSuccess;
+    // The last round: with L = total % grid tiles left for at most half of the workgroups, and a workspace of the caller's, those tiles
+    // are cut into S parts of K (S: the largest divisor of the stage count with an even part of >= 4 stages and L S <= grid) + a
+    // finishing pass; 288 tiles of the LLM prompt's down projection on 256 CUs: 2 tile times -> 1.14 + the pass.
+    int nleft = 0;
+    if (ws && (((uintptr_t)ws) & 15) == 0 && total > grid) {
+        static const int split_on = getenv("IFH_GEMM_BIG8_SPLIT") ? atoi(getenv("IFH_GEMM_BIG8_SPLIT")) : 1;      // tuning switch
+        const int L = total % grid, nst = g.K / G8_DK;
+        if (split_on && L > 0 && 2 * L <= grid) {
+            int S = 1;
+            for (int s_ = 2; s_ * L <= grid && s_ <= nst / 4; s_++)
+                if (nst % s_ == 0 && (nst / s_) % 2 == 0 && (int64_t)L * s_ * 65536 <= ws_floats) S = s_;
+            if (S > 2) {            // (two parts: the finishing pass costs what the half round saves)
+                g.split_ws = ws;
+                g.split_s = S;
+                nleft = L;
+            }
+        }
+    }
+    bool ok = hipLaunchKernel(fn, dim3((unsigned)grid), dim3(512), args, G8_LDS, st) == hipSuccess;
+    if (ok && nleft)
+        hipLaunchKernelGGL(k_big8_split_finish, dim3((unsigned)(nleft * 64)), dim3(256), 0, st, g, total - nleft, p.act);
 #ifdef GB_DEV_ABL
     if (ok && g.prof) {
         long long h[6] = {0, 0, 0, 0, 0, 0};

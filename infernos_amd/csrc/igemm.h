@@ -366,7 +366,7 @@ int step_record_gemm(const IgemmParams &p);
 // Returns true if it took the launch.
 bool try_launch_conv_direct(const IgemmParams &p, bool pre, hipStream_t st);
 // gemm_big.hip: DMA-ring matrix product for thousands of rows x whole 256 x 128 tiles.  Returns true if it took the launch.
-bool try_launch_gemm_big(const IgemmParams &p, bool pre, hipStream_t st);
+bool try_launch_gemm_big(const IgemmParams &p, bool pre, hipStream_t st, float *ws = nullptr, int64_t ws_floats = 0);
 bool try_launch_gemm_m64d(const IgemmParams &p, hipStream_t st);
 int try_launch_gemm_m64d_splitk(const IgemmParams &p, float *ws, int64_t ws_floats, hipStream_t st);
 

@@ -1182,7 +1182,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     if (glu && M > 64) {
         // thousands of rows (LLM prefill): the SiLU-gate epilogue exists in the DMA-ring kernel (gemm_big.hip) for whole 256 x 128 tiles
         IFH_CHECK_ARG(!ln_fold && !d->bias);
-        if (try_launch_gemm_big(p, pre, st)) {
+        if (try_launch_gemm_big(p, pre, st, (float *)d->splitk_ws, d->splitk_ws_floats)) {
             IFH_LAUNCH_CHECK("conv_bf16");
             return IFH_OK;
         }
@@ -1314,7 +1314,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
             hipLaunchKernelGGL((k_gemm_skinny<4, 12, 1>), grid, dim3(256), 0, st, p);
         else
             hipLaunchKernelGGL((k_gemm_skinny<2, 12, 1>), grid, dim3(128), 0, st, p);
-    } else if (try_launch_gemm_big(p, pre, st)) {
+    } else if (try_launch_gemm_big(p, pre, st, (float *)d->splitk_ws, d->splitk_ws_floats)) {
         // thousands of rows x whole 256 x 128 tiles: DMA ring, two workgroups per CU (gemm_big.hip)
     } else if (try_launch_conv_direct(p, pre, st)) {
         // residual-block shapes: input tile resident in LDS (conv.hip)

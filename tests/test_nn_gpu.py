@@ -534,6 +534,39 @@ def test_gemm_big_matches_torch_and_the_igemm_bits(dev, M, N, K, act, resid):
     assert torch.equal(out.view(torch.int16), wide[:, :N].contiguous().view(torch.int16)), (M, N, K)
 
 
+@pytest.mark.parametrize('M,N,K,act,resid', [(12288, 1536, 1536, 0, True), (12288, 1536, 8960, 0, True), (16384, 1280, 1024, 2, False)])
+def test_gemm_big8_split_last_round_matches_torch_and_the_unsplit_launch(dev, M, N, K, act, resid):
+    """With a workspace of the caller's (ifh_conv_desc.splitk_ws) the tiles of k_gemm_big8's last, partial round (288 or 320 tiles on
+    256 CUs: the LLM prompt's o and down projections, Cluster/InfernLLMWorker.py:103-119) are cut into parts of K that leave raw f32
+    accumulators, and k_big8_split_finish adds them in order and runs the epilogue: against fp32 torch, and against the same launch
+    without the workspace (whole tiles: the same values up to the rounding of a differently grouped sum)."""
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    x = bfr(torch.randn(M, K, generator=g) * 0.5)
+    w = bfr(torch.randn(N, K, generator=g) / K ** 0.5)
+    b = torch.randn(N, generator=g) * 0.1
+    r = bfr(torch.randn(M, N, generator=g)) if resid else None
+    xd, wd, bd = x.to(dev, BF), w.to(dev, BF), b.to(dev)
+    rd = r.to(dev, BF) if resid else None
+    ws = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=dev)
+    plain = torch.zeros(M, N, dtype=BF, device=dev)
+    ops.linear(xd, wd, bd, plain, rows=M, k=K, n=N, act=act, resid=rd)
+    split = torch.zeros(M, N, dtype=BF, device=dev)
+    ops.linear(xd, wd, bd, split, rows=M, k=K, n=N, act=act, resid=rd, splitk_ws=ws)
+    torch.cuda.synchronize()
+    ref = x @ w.t() + b
+    ref = F.gelu(ref) if act == 2 else ref
+    if resid:
+        ref = ref + r
+    assert rel_l2(split.float().cpu(), ref) < 4e-3
+    assert rel_l2(split.float().cpu(), plain.float().cpu()) < 3e-3
+    ntile = (M // 256) * (N // 256)
+    first_left = (ntile // 256) * 256                  # tiles of the full rounds are untouched by the split: the same bits
+    rows_full = (first_left // (N // 256)) * 256
+    assert torch.equal(split[:rows_full].view(torch.int16), plain[:rows_full].view(torch.int16))
+    assert not torch.equal(split.view(torch.int16), plain.view(torch.int16)) or ntile % 256 == 0
+
+
 def test_cu_range_stream_runs_kernels(dev):
     """ifh_stream_create_cu_range (include/infernos_hip.h): a stream confined to a CU range computes what an ordinary one does,
     and the persistent kernels follow ifh_set_cu_budget (a chain launch sized to 64 CUs on a 64-CU stream: same bits)."""
@@ -1430,6 +1463,25 @@ def test_splitk_chain_form_is_bit_identical_to_the_streaming_kernel(dev, M, N, K
         assert rel_l2(o.float().cpu(), outs[0].float().cpu()) < 3e-3
         if mode != 'plain':
             assert float((st[:M].double() - stats[0][:M].double()).abs().max()) <= 0.02 * float(stats[0][:M].double().abs().max())
+
+
+def test_gemm_big8_split_last_round_with_the_silu_gate_epilogue(dev):
+    """the SiLU-gate epilogue in the finishing pass of a split last round (gate|up of the LLM prompt: 3 360 tiles = 13 rounds + 32 tiles)"""
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(9)
+    M, K, F2 = 12288, 512, 1536                        # 48 x 6 = 288 tiles
+    x = bfr(torch.randn(M, K, generator=g)).to(dev, BF)
+    w = bfr(torch.randn(F2, K, generator=g) / K ** 0.5).to(dev, BF)
+    ws = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=dev)
+    out = torch.zeros(M, F2 // 2, dtype=BF, device=dev)
+    ops.linear(x, w, None, out, rows=M, k=K, n=F2, ldc=F2 // 2, act=ops.ACT_SILU_GLU, splitk_ws=ws)
+    plain = torch.zeros_like(out)
+    ops.linear(x, w, None, plain, rows=M, k=K, n=F2, ldc=F2 // 2, act=ops.ACT_SILU_GLU)
+    y = x.float() @ w.float().t()
+    ref = torch.nn.functional.silu(y[:, 0::2]) * y[:, 1::2]
+    assert rel_l2(out.float().cpu(), ref.cpu()) < 4e-3
+    assert rel_l2(out.float().cpu(), plain.float().cpu()) < 3e-3
+    assert torch.equal(out[:10240].view(torch.int16), plain[:10240].view(torch.int16))       # the full round's tiles: untouched
 
 
 def test_gemm_big_silu_gate_epilogue_matches_torch(dev):
