@@ -373,6 +373,10 @@ typedef struct ifh_conv_desc {
                             * arg-max).  Ties go to the lowest column.  Only where ifh_conv_argmax_supported says so (a wide f32-output
                             * matrix product of 17..64 rows without bias / activation / residual); ifh_argmax_keys_finish turns the
                             * keys into token ids and zeroes them again */
+    int32_t whole_chip;    /* 1: a persistent kernel taking this launch (the 256 x 256 GEMM) uses every CU even when ifh_set_cu_budget
+                            * reserves some for other stages -- for a caller that runs alone on the device for the moment (the LLM's
+                            * prompt pass of an AI-attendant turn); 0: the budget applies (inside the speech pipeline, where it measured
+                            * 1.7 % better) */
 } ifh_conv_desc;
 int ifh_conv_bf16(const ifh_conv_desc *desc, ifh_stream_t stream);
 /* 1 if a launch of this shape (rows x n x k matrix product, f32 output) fills ifh_conv_desc.argmax_keys */

@@ -79,7 +79,7 @@ class ConvDesc(ctypes.Structure):
                 ('aln_stats', _vp), ('aln_c1', _vp), ('rln_stats', _vp), ('rln_gamma', _vp), ('rln_beta', _vp),
                 ('stats_out', _vp), ('ln_dim', ctypes.c_int32), ('ln_eps', _f), ('ln_rms', ctypes.c_int32),
                 ('dyn_stride', ctypes.c_int32), ('decode_step', ctypes.c_int32), ('convt_cout', ctypes.c_int32),
-                ('splitk_ws', _vp), ('splitk_ws_floats', _i64), ('argmax_keys', _vp)]
+                ('splitk_ws', _vp), ('splitk_ws_floats', _i64), ('argmax_keys', _vp), ('whole_chip', ctypes.c_int32)]
 
 
 class ResblockDesc(ctypes.Structure):

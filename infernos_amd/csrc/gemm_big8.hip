@@ -488,11 +488,11 @@ bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st, float
         attr_once.done(attr_dev);
     }
     const int total = g.mtiles * g.ntiles;
-    // one workgroup per CU of the device: NOT of the budget a pipeline sets for its persistent vocoder kernels (ifh_set_cu_budget) -- the
-    // encoder and the LLM prompt need the whole chip (C3 measured the same at 160 / 208 / 256 workgroups; the C5 turn, whose LLM runs
-    // beside a pipeline's budget, lost a third of its prompt's CUs); IFH_GEMM_BIG8_CUS (tuning switch): that many instead
+    // one workgroup per CU of the budget the process has set for persistent kernels (ifh_set_cu_budget: inside the speech pipeline the
+    // encoder's products measured 1.7 % better on the vocoder's 160 than on all 256), or of the device if the caller says it runs alone
+    // (ifh_conv_desc.whole_chip: the LLM's prompt pass -- C5 share turn 129.6 -> 120 ms); IFH_GEMM_BIG8_CUS (tuning switch): that many
     static const int cus_env = getenv("IFH_GEMM_BIG8_CUS") ? atoi(getenv("IFH_GEMM_BIG8_CUS")) : 0;
-    int grid = (cus_env > 0 ? cus_env : device_cu_count_physical()) & ~7;
+    int grid = (cus_env > 0 ? cus_env : (p.whole_chip ? device_cu_count_physical() : device_cu_count())) & ~7;
     if (grid < 8) grid = 8;
     if (grid > total) grid = total < 8 ? total : (total & ~7);
     // with fewer than 8 tiles the XCD interleave below degenerates: one workgroup per tile

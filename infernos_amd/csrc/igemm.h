@@ -53,6 +53,7 @@ struct IgemmParams {
     float ln_eps;
     int ln_rms;               // RMSNorm instead of LayerNorm in the folded modes (mean term dropped)
     unsigned long long *amax_keys;   // k_gemm_m64: per-row arg-max keys (ifh_conv_desc.argmax_keys)
+    int whole_chip;           // ifh_conv_desc.whole_chip
     int zt_cout;              // > 0: fused ConvTranspose1d(k8,s4,p2) form (3 taps, 4*zt_cout columns): columns of phases 0-1 have an
                               // all-zero tap 2, of phases 2-3 an all-zero tap 0 -- a column tile inside one half skips those k-steps
 };

@@ -1162,6 +1162,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     }
     p.zt_cout = 0;
     p.amax_keys = (unsigned long long *)d->argmax_keys;
+    p.whole_chip = d->whole_chip;
     if (d->convt_cout) {
         IFH_CHECK_ARG(d->taps == 3 && d->n == 4 * d->convt_cout && d->cin % 32 == 0 && d->stride == 1 && d->dil == 1);
         p.zt_cout = d->convt_cout;

@@ -125,20 +125,20 @@ class Qwen2:
     def _layers(self, x, h, qkv, att, gu, ff, kv, rows, nrows, T, pos0, nvalid, key_len, max_keys):
         """the layer stack with explicit (unit-gamma) RMSNorm launches: prefill, and decode batches outside 17..64 rows"""
         d = self.d
-        pws = None
+        pws, big = None, rows >= 4096              # a prompt pass: the GEMMs take every CU (ifh_conv_desc.whole_chip) and a split workspace
         if rows >= 4096:
             if getattr(self, '_pws', None) is None:
                 self._pws = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=self.device)      # 64 MB, prompt passes only
             pws = self._pws
         for L, cache in zip(self.layers, kv):
             ops.rmsnorm(x, self.ones, h, rows, d, self.eps)
-            ops.linear(h, L['wqkv'], L['bqkv'], qkv, rows=rows, k=d, n=self.nq)
+            ops.linear(h, L['wqkv'], L['bqkv'], qkv, rows=rows, k=d, n=self.nq, whole_chip=big)
             ops.rope_append(qkv, self.cos_sin, cache, pos0, nvalid, nrows=nrows, tokens_per_row=T, nheads=self.nh, nkv=self.nkv,
                             head_dim=self.hd, max_pos=self.max_tokens)
             ops.attn_gqa(qkv, cache, att, key_len, ntokens=rows, tokens_per_row=T, nheads=self.nh, nkv=self.nkv,
                          head_dim=self.hd, max_pos=self.max_tokens, max_keys=max_keys)
             # (pws: a workspace for the last, partial round of tiles of the 256 x 256 GEMM -- 288 tiles of o / down on 256 CUs at 12 288 rows)
-            ops.linear(att, L['wo'], None, x, rows=rows, k=self.nh * self.hd, n=d, resid=x, splitk_ws=pws)
+            ops.linear(att, L['wo'], None, x, rows=rows, k=self.nh * self.hd, n=d, resid=x, splitk_ws=pws, whole_chip=big)
             ops.rmsnorm(x, self.ones, h, rows, d, self.eps)
             fused = self.glu_prefill and rows >= 4096 and rows % 128 == 0 and (2 * self.ff) % 256 == 0
             if fused:
@@ -146,13 +146,13 @@ class Qwen2:
                 # may decline the shape (its own row threshold IFH_GEMM_BIG_ROWS, view alignment, the 4 GiB DMA-offset limit): it says so
                 # before launching anything, and the two-launch form below takes over for good.
                 try:
-                    ops.linear(h, L['wgu'], None, ff, rows=rows, k=d, n=2 * self.ff, ldc=self.ff, act=ops.ACT_SILU_GLU, splitk_ws=pws)
+                    ops.linear(h, L['wgu'], None, ff, rows=rows, k=d, n=2 * self.ff, ldc=self.ff, act=ops.ACT_SILU_GLU, splitk_ws=pws, whole_chip=big)
                 except _lib.InfernosHipError:
                     self.glu_prefill = fused = False
             if not fused:
                 ops.linear(h, L['wgu'], None, gu, rows=rows, k=d, n=2 * self.ff)
                 ops.silu_mul(gu, ff, rows, self.ff, interleaved=True)
-            ops.linear(ff, L['wd'], None, x, rows=rows, k=self.ff, n=d, resid=x, splitk_ws=pws)
+            ops.linear(ff, L['wd'], None, x, rows=rows, k=self.ff, n=d, resid=x, splitk_ws=pws, whole_chip=big)
 
     def _layers_fused(self, st, B):
         """decode step at 17..64 rows: six launches per layer.  o-proj and down-proj leave the (sum, sum of squares) of the

@@ -24,7 +24,7 @@ def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=
          resid=None, resid_off=0, resid_ld=None, resid_bstride=None, scale=1.0, accumulate=False,
          out_off=0, ldc=None, out_bstride=None, ostride=1, ooff=0, dyn_pos=None, dyn_ooff_mul=0, dyn_resid_mul=0, dyn_stride=0, decode_step=False, convt_cout=0,
          n_split=0, out2=None, out2_bstride=0, ldc2=0, ooff2=0, dyn_ooff2_mul=0,
-         aln=None, rln=None, stats_out=None, stats_off=0, ln_dim=0, ln_eps=1e-5, ln_rms=False, splitk_ws=None, argmax_keys=None):
+         aln=None, rln=None, stats_out=None, stats_off=0, ln_dim=0, ln_eps=1e-5, ln_rms=False, splitk_ws=None, argmax_keys=None, whole_chip=False):
     # aln = (stats, stats_off, c1); rln = (stats, stats_off, gamma, beta); splitk_ws = f32 workspace of the caller's decode state;
     # argmax_keys = zeroed int64 [rows] (ifh_conv_desc.argmax_keys; argmax_supported(), argmax_keys_finish())
     """One implicit-GEMM launch (see ifh_conv_desc).  Strides default to dense [nbatch][t][c]."""
@@ -48,6 +48,7 @@ def conv(x, w, bias, out, *, nbatch, t_in, t_out, cin, n, taps=1, stride=1, dil=
     d.decode_step, d.convt_cout = int(decode_step), convt_cout
     d.splitk_ws, d.splitk_ws_floats = _addr(splitk_ws), (splitk_ws.numel() if splitk_ws is not None else 0)
     d.argmax_keys = _addr(argmax_keys)
+    d.whole_chip = int(whole_chip)
     d.n_split, d.out2, d.out2_bstride, d.ldc2, d.ooff2, d.dyn_ooff2_mul = n_split, _addr(out2), out2_bstride, ldc2, ooff2, dyn_ooff2_mul
     if aln is not None:
         d.aln_stats, d.aln_c1 = _addr(aln[0], aln[1]), _addr(aln[2])
