@@ -365,18 +365,23 @@ __global__ __launch_bounds__(512, 2) void k_gemm_big8(const GemmBig8Params p)
                             *reinterpret_cast<const uint4 *>(wbuf + it * 2048 + r8 * 128 + ((ch ^ r8) << 4));
                     }
                 } else {
-                    uint4 ov[4];
-#pragma unroll
-                    for (int it = 0; it < 4; it++) {
-                        const int row = it * 4 + trow;
-                        ov[it] = *reinterpret_cast<const uint4 *>(wbuf + it * 2048 + trow * 256 + ((tch ^ row) << 4));
-                    }
-                    if (RESID) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the piece is in registers: its buffer may be refilled
-#pragma unroll
-                    for (int it = 0; it < 4; it++) {
-                        const int row = it * 4 + trow;
-                        if (abl & 16) asm volatile("" ::"v"(ov[it].x), "v"(ov[it].y), "v"(ov[it].z), "v"(ov[it].w));
-                        else *reinterpret_cast<uint4 *>(p.out + (int64_t)(mrow0 + j * 16 + row) * p.ldc + ncol0 + tch * 8) = ov[it];
+                    // (native vectors: as `uint4` structs these four stayed a stack slot -- scratch stores and loads, each load behind an
+                    // s_waitcnt vmcnt(0) that also waited for the residual pieces in flight: 66 us of a 186 us launch)
+                    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                    u32x4_t ov0, ov1, ov2, ov3;
+                    ov0 = *reinterpret_cast<const u32x4_t *>(wbuf + 0 * 2048 + trow * 256 + ((tch ^ (0 * 4 + trow)) << 4));
+                    ov1 = *reinterpret_cast<const u32x4_t *>(wbuf + 1 * 2048 + trow * 256 + ((tch ^ (1 * 4 + trow)) << 4));
+                    ov2 = *reinterpret_cast<const u32x4_t *>(wbuf + 2 * 2048 + trow * 256 + ((tch ^ (2 * 4 + trow)) << 4));
+                    ov3 = *reinterpret_cast<const u32x4_t *>(wbuf + 3 * 2048 + trow * 256 + ((tch ^ (3 * 4 + trow)) << 4));
+                    if (RESID) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ov0), "+v"(ov1), "+v"(ov2), "+v"(ov3)::"memory");   // the piece is in registers: its buffer may be refilled
+                    if (abl & 16) {
+                        asm volatile("" ::"v"(ov0), "v"(ov1), "v"(ov2), "v"(ov3));
+                    } else {
+                        uint16_t *ob = p.out + (int64_t)(mrow0 + j * 16 + trow) * p.ldc + ncol0 + tch * 8;
+                        *reinterpret_cast<u32x4_t *>(ob) = ov0;
+                        *reinterpret_cast<u32x4_t *>(ob + (int64_t)4 * p.ldc) = ov1;
+                        *reinterpret_cast<u32x4_t *>(ob + (int64_t)8 * p.ldc) = ov2;
+                        *reinterpret_cast<u32x4_t *>(ob + (int64_t)12 * p.ldc) = ov3;
                     }
                 }
                 if (RESID && j < 2) {

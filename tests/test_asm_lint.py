@@ -32,3 +32,22 @@ def test_lint_finds_a_planted_hazard(tmp_path):
     lint = os.path.join(ROOT, 'tools', 'lint_asm_loads.py')
     assert subprocess.run([sys.executable, lint, str(bad)], capture_output=True).returncode == 1
     assert subprocess.run([sys.executable, lint, str(good)], capture_output=True).returncode == 0
+
+
+def test_dma_queue_kernels_use_no_scratch(tmp_path):
+    """The kernels that keep DMA pieces in flight behind counted `s_waitcnt vmcnt` (gemm_big8 / gemm_m64d / the attention kernels of
+    llm.hip) must not touch scratch: a scratch load or store is a vector-memory operation in the same in-order queue, and hipcc puts an
+    `s_waitcnt vmcnt(0)` behind every scratch load -- round 5: four `uint4` structs of k_gemm_big8's residual epilogue stayed a stack
+    slot (no register was spilled, `.vgpr_spill_count` read 0) and every launch with a residual waited 66 us of 186 on them.  Checked on
+    the compiled listing: no kernel of these files has a private segment or a scratch instruction."""
+    import re
+    from infernos_amd import build as b
+    flags = [f for f in b.FLAGS if f not in ('-fPIC', '-Wall')]
+    for name in ('gemm_big8', 'gemm_m64d', 'llm'):
+        out = str(tmp_path / (name + '.s'))
+        subprocess.check_call([b.HIPCC] + flags + ['-S', '--cuda-device-only', '-o', out, os.path.join(b.CSRC, name + '.hip')],
+                              stderr=subprocess.DEVNULL)
+        txt = open(out).read()
+        sizes = [int(v) for v in re.findall(r'^\s+\.private_segment_fixed_size:\s+(\d+)', txt, re.M)]
+        assert sizes and max(sizes) == 0, (name, sizes)
+        assert 'scratch_load' not in txt and 'scratch_store' not in txt, name
