@@ -258,7 +258,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_seq(const
     // wait, i.e. before the data had arrived -- tools/lint_asm_loads.py looks for exactly that in the listing.)
     auto bias_tile = [&](int q, int i, const f32x4 (&bv)[NT]) __attribute__((always_inline)) {
         if constexpr (BIAS_LDS) {
-            const int addr = BIAS_OFF + bvoff + q * C * 4 + i * 64;
+            // (the lane's base through an opaque copy: hipcc otherwise keeps base + constant for every (convolution, tile) it can see
+            // in a register of its own across the K loops -- nine of them -- and spills others for it: 45-66 spills per kernel, whose
+            // reloads at every pass start sat behind an s_waitcnt vmcnt(0), i.e. drained the weight ring)
+            int bb_ = bvoff;
+            asm volatile("" : "+v"(bb_));
+            const int addr = BIAS_OFF + bb_ + q * C * 4 + i * 64;
             f32x4 b;
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(b) : "v"(addr) : "memory");
             return b;
@@ -281,8 +286,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_seq(const
     auto advance = [&](int dd, int s) {
         nxt_enter = ks_in_unit == 0;
         const int tap = s / KSUB, cs = s - tap * KSUB;
-        nxt_a = ab + ring_read * UNITB + ks_in_unit * (FRAGS * 1024);
-        nxt_b = xb + (tap - H) * dd * SB + cs * 64;
+        int ab_ = ab, xb_ = xb;                            // (opaque copies: see bias_tile)
+        asm volatile("" : "+v"(ab_), "+v"(xb_));
+        nxt_a = ab_ + ring_read * UNITB + ks_in_unit * (FRAGS * 1024);
+        nxt_b = xb_ + (tap - H) * dd * SB + cs * 64;
         if (++ks_in_unit == UK) {
             ks_in_unit = 0;
             ring_read = (ring_read + 1 == NRING) ? 0 : ring_read + 1;
