@@ -22,8 +22,11 @@
 //     wave leaves it; outputs leave as whole 256-byte row pieces; the residual rows arrive by DMA in the same shape, one piece ahead
 //     (the first two under the tile's last sixteen MFMAs); the tile's bias comes by DMA as well (a register load in the epilogue
 //     would have to wait for every older operation in the queue, i.e. for the next tile's stage).
-// Measured (192 000 rows, tools/probe_gemm_abl.py, profiles/r05_gemm_big_pmc.md): q|k|v 1536 x 512 800 TF/s (k_gemm_big 610), fc2
-// 512 x 2048 1 040-1 120, fc1 + GELU 670, wo + residual 730.  Per tile of the q|k|v product wave 0 spends 30 k clocks in the K loop
+//   * with a workspace of the caller's the tiles of the last, partial round (288 tiles on 256 CUs: the LLM prompt) are cut into parts of
+//     K whose raw f32 accumulators k_big8_split_finish adds in order before the epilogue; the workgroup count follows the process-wide
+//     CU budget unless the launch says it runs alone (ifh_conv_desc.whole_chip).
+// Measured (192 000 rows, tools/probe_igemm_enc.py, profiles/r05_gemm_big_pmc.md): q|k|v 1536 x 512 830 TF/s (k_gemm_big 610), fc2
+// 512 x 2048 1 075-1 165, fc1 + GELU 680-700, wo + residual 680.  Per tile of the q|k|v product wave 0 spends 30 k clocks in the K loop
 // (16.4 k of MFMAs; 1 100 per stage in front of and inside the stage barrier: the 64 KB of a stage arrive at ~40 B/clk, the L2 -> LDS
 // rate of a CU with every CU fetching, and two slots cannot keep the fetch running through the barrier), 4 k in the epilogue, and the
 // stores of all workgroups fall together (without them 300 us instead of 380: started in phases it did not change).
