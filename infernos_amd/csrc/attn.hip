@@ -209,6 +209,237 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const AttnParams p)
     }
 }
 
+// k_attn_prefill2: the same arithmetic (bit for bit: the order of every sum is k_attn_prefill's) for long query sequences --
+// the Whisper encoder's 1500 x 1500 windows.  What k_attn_prefill pays per 64-key tile and wave -- sixteen MFMAs against eight
+// ds_read_b128 + sixteen transposed reads, four ds_write_b128 of the register-staged tile and two barriers -- is halved here:
+//   * 32 queries per wave (two 16-query blocks share every K / V fragment read), 128 per workgroup;
+//   * K / V tiles come by LDS-DMA (global_load_lds_dwordx4: a wave-instruction = 8 keys x 128 B) into two 16 KB buffers, tile
+//     kt + 1 in flight while tile kt is multiplied, ONE barrier per tile (own pieces landed -> barrier -> everyone's landed and
+//     the other buffer is free);
+//   * 128-byte LDS rows, 16-byte chunk c of key r at chunk c ^ 2 ((r / 2) % 4) (applied on the source side of the DMA): the
+//     permutation of gemm_big8.hip, conflict-free for the ds_read_b128 rows of K and for the ds_read_b64_tr_b16 blocks of V
+//     (it keeps 32-byte pairs together).  Keys past key_len are fetched from the last valid key and masked as before.
+constexpr int A2_BUF = 16384, A2_V = 8192;
+
+// the reductions over the four 16-lane rows of a wave (lane ^ 16, lane ^ 32) by row swaps instead of ds_bpermute: after
+// v_permlane16_swap of two copies one holds rows (0, 0, 2, 2), the other (1, 1, 3, 3); the sums are the __shfl_xor ones
+// with the operands of an addition exchanged on half of the lanes (same bits)
+typedef unsigned a2_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float a2_max_rows(float m)
+{
+    // (the builtins, not asm: a VALU write followed by a row swap of that register needs wait states hipcc only inserts for
+    // instructions it can see)
+    const unsigned u = __float_as_uint(m);
+    const a2_u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    float a;
+    asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(__uint_as_float(r.x)), "v"(__uint_as_float(r.y)));
+    const unsigned w = __float_as_uint(a);
+    const a2_u32x2 t = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    asm("v_max_f32 %0, %1, %2" : "=v"(a) : "v"(__uint_as_float(t.x)), "v"(__uint_as_float(t.y)));
+    return a;
+}
+__device__ __forceinline__ float a2_sum_rows(float l)
+{
+    const unsigned u = __float_as_uint(l);
+    const a2_u32x2 r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float a = __uint_as_float(r.x) + __uint_as_float(r.y);
+    const unsigned w = __float_as_uint(a);
+    const a2_u32x2 t = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return __uint_as_float(t.x) + __uint_as_float(t.y);
+}
+
+__global__ __launch_bounds__(256, 3) void k_attn_prefill2(const AttnParams p)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char lds2[2 * A2_BUF];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int qb0 = blockIdx.x * 128 + wid * 32 + fr;     // this lane's query rows: qb0, qb0 + 16
+    const int klen = p.key_len ? p.key_len[b] : p.Tk;
+    const unsigned lbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)lds2);
+
+    bf16x8_t qf[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int qi = qb0 + 16 * j;
+        const uint16_t *qp = p.q + (int64_t)b * p.q_bs + (int64_t)(qi < p.Tq ? qi : 0) * p.q_ts + h * HD;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (qi < p.Tq) t = *reinterpret_cast<const uint4 *>(qp + 32 * s + 8 * fg);
+            qf[j][s] = __builtin_bit_cast(bf16x8_t, t);
+        }
+    }
+    f32x4 o[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.0f, 0.0f};
+    const int ntile = (klen + KT - 1) / KT;
+
+    // DMA: this wave fetches keys 16 wid .. 16 wid + 15 of a tile (two pieces of K, two of V); lane l -> key l / 8 of the piece,
+    // LDS chunk l % 8 <- source chunk (l % 8) ^ 2 ((key / 2) % 4)
+    const int drow = lane >> 3, dch = (lane & 7) ^ (((drow >> 1) & 3) << 1);
+    const unsigned char *ksrc = reinterpret_cast<const unsigned char *>(p.k + (int64_t)b * p.k_bs + h * HD);
+    const unsigned char *vsrc = reinterpret_cast<const unsigned char *>(p.v + (int64_t)b * p.v_bs + h * HD);
+    const unsigned kts2 = (unsigned)p.k_ts * 2u, vts2 = (unsigned)p.v_ts * 2u;
+#define A2_DMA(VOFF, BASE, DST)                                                                                          \
+    do {                                                                                                                 \
+        unsigned keep_;                                                                                                  \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(VOFF), "s"(BASE), "s"(DST) : "memory");                                       \
+    } while (0)
+    auto issue_tile = [&](int kt) {
+        const unsigned dst = lbase + (unsigned)(kt & 1) * A2_BUF + (unsigned)wid * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            int key = kt * KT + wid * 16 + j * 8 + drow;
+            key = key < klen ? key : klen - 1;
+            const unsigned ko = (unsigned)key * kts2 + (unsigned)dch * 16u, vo = (unsigned)key * vts2 + (unsigned)dch * 16u;
+            A2_DMA(ko, ksrc, dst + j * 1024);
+            A2_DMA(vo, vsrc, dst + A2_V + j * 1024);
+        }
+    };
+    // fragment addresses (buffer 0; the other buffer, the key block c and the k step are immediates or one scalar add)
+    const int fsw = ((fr & 7) >> 1) << 1;
+    const unsigned ka0 = (unsigned)(fr * 128 + ((fg ^ fsw) << 4)), ka1 = (unsigned)(fr * 128 + (((4 + fg) ^ fsw) << 4));
+    unsigned va[4];
+    {
+        const int row = 4 * fg + (fr >> 2), sw = ((row >> 1) & 3) << 1;
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+            va[dt] = lbase + A2_V + (unsigned)(row * 128 + (((dt * 2 + ((fr & 3) >> 1)) ^ sw) << 4) + (fr & 1) * 8);
+    }
+
+    // the q loads are waited for HERE: left to hipcc, their s_waitcnt vmcnt(0) lands at the first MFMA inside the loop, right
+    // behind the next tile's DMA
+    asm volatile("" : : "v"(qf[0][0]), "v"(qf[0][1]), "v"(qf[1][0]), "v"(qf[1][1]));
+    if (ntile > 0) issue_tile(0);
+    for (int kt = 0; kt < ntile; kt++) {
+        const int kbase = kt * KT;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < ntile) issue_tile(kt + 1);
+        const unsigned bo = (unsigned)(kt & 1) * A2_BUF;
+        const unsigned char *kb = lds2 + bo;
+        // S^T tiles of both query blocks: 4 x (16 keys x 16 queries) each, every K fragment read once
+        f32x4 s[2][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            s[0][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            s[1][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bf16x8_t kf0 = *reinterpret_cast<const bf16x8_t *>(kb + c * 2048 + ka0);
+            const bf16x8_t kf1 = *reinterpret_cast<const bf16x8_t *>(kb + c * 2048 + ka1);
+            s[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[0][0], s[0][c], 0, 0, 0);
+            s[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[1][0], s[1][c], 0, 0, 0);
+            s[0][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[0][1], s[0][c], 0, 0, 0);
+            s[1][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[1][1], s[1][c], 0, 0, 0);
+        }
+        constexpr float kLog2e = 1.4426950408889634f;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            float mloc = -1e30f;
+            if (kbase + KT > klen) {       // wave-uniform: the last, partial tile
+                const int lim = klen - kbase - 4 * fg;      // key c * 16 + r of this lane is valid below lim
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) s[j][c][r] = (c * 16 + r < lim) ? s[j][c][r] : -1e30f;
+                }
+            }
+            // (asm: fmaxf on MFMA results costs a canonicalising v_max each under hipcc)
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mloc) : "v"(s[j][c][0]), "v"(s[j][c][1]));
+                asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mloc) : "v"(s[j][c][2]), "v"(s[j][c][3]));
+            }
+            mloc = a2_max_rows(mloc);
+            const float mnew = fmaxf(mrun[j], mloc);
+            const float mscaled = mnew * kLog2e;
+            const float alpha = __builtin_amdgcn_exp2f(mrun[j] * kLog2e - mscaled);
+            float lsum = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[j][c][r], kLog2e, -mscaled));
+                    s[j][c][r] = pv;
+                    lsum += pv;
+                }
+            }
+            lsum = a2_sum_rows(lsum);
+            lrun[j] = lrun[j] * alpha + lsum;
+            mrun[j] = mnew;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                o[j][i][0] *= alpha;
+                o[j][i][1] *= alpha;
+                o[j][i][2] *= alpha;
+                o[j][i][3] *= alpha;
+            }
+        }
+        // O^T += V^T . P^T: every transposed V fragment feeds both query blocks
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            bf16x8_t pf[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                uint4 pb;
+                pb.x = pack2(s[j][2 * ks][0], s[j][2 * ks][1]);
+                pb.y = pack2(s[j][2 * ks][2], s[j][2 * ks][3]);
+                pb.z = pack2(s[j][2 * ks + 1][0], s[j][2 * ks + 1][1]);
+                pb.w = pack2(s[j][2 * ks + 1][2], s[j][2 * ks + 1][3]);
+                pf[j] = __builtin_bit_cast(bf16x8_t, pb);
+            }
+            uint2 lo[4], hi[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                const unsigned a = va[dt] + bo;
+                if (ks == 0) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[dt]) : "v"(a) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(hi[dt]) : "v"(a) : "memory");
+                } else {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(lo[dt]) : "v"(a) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(hi[dt]) : "v"(a) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                uint4 vv;
+                vv.x = lo[dt].x;
+                vv.y = lo[dt].y;
+                vv.z = hi[dt].x;
+                vv.w = hi[dt].y;
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, vv);
+                o[0][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[0], o[0][dt], 0, 0, 0);
+                o[1][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[1], o[1][dt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int qi = qb0 + 16 * j;
+        if (qi < p.Tq) {
+            const float inv = lrun[j] > 0.0f ? 1.0f / lrun[j] : 0.0f;
+            uint16_t *op = p.out + (int64_t)b * p.o_bs + (int64_t)qi * p.o_ts + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                uint2 pk;
+                pk.x = pack2(o[j][dt][0] * inv, o[j][dt][1] * inv);
+                pk.y = pack2(o[j][dt][2] * inv, o[j][dt][3] * inv);
+                *reinterpret_cast<uint2 *>(op + dt * 16 + 4 * fg) = pk;
+            }
+        }
+    }
+#undef A2_DMA
+}
+
 // One query token per (batch, head) against a KV cache.  A wave is 8 key-groups x 8 lanes; a lane owns
 // 8 of the 64 head dims (one 16-byte load per key for K and for V, 128 B coalesced per key).
 // Every key-group runs its own online softmax over keys g, g+8*NW, ...; the groups (and the NW
@@ -485,8 +716,18 @@ extern "C" int ifh_attn_prefill_bf16(const ifh_attn_desc *d, ifh_stream_t stream
     p.key_len = d->key_len;
     p.relbias = d->relbias;
     p.nrel = d->nrel;
-    dim3 grid((d->tq + 63) / 64, d->nheads, d->nbatch);
-    hipLaunchKernelGGL(k_attn_prefill, grid, dim3(256), 0, as_stream(stream), p);
+    // long query sequences (the Whisper encoder) take the 128-query form; IFH_ATTN_PREFILL2 = 0 / 1 forces one of the two
+    // (read per call: the parity test compares the two forms in one process)
+    const char *env2 = getenv("IFH_ATTN_PREFILL2");
+    const int force2 = env2 && *env2 ? atoi(env2) : -1;
+    const bool fits2 = (int64_t)d->tk * d->k_ts * 2 < (int64_t(1) << 31) && (int64_t)d->tk * d->v_ts * 2 < (int64_t(1) << 31);
+    if (fits2 && !d->relbias && (force2 < 0 ? d->tq >= 256 : force2 > 0)) {
+        dim3 grid((d->tq + 127) / 128, d->nheads, d->nbatch);
+        hipLaunchKernelGGL(k_attn_prefill2, grid, dim3(256), 0, as_stream(stream), p);
+    } else {
+        dim3 grid((d->tq + 63) / 64, d->nheads, d->nbatch);
+        hipLaunchKernelGGL(k_attn_prefill, grid, dim3(256), 0, as_stream(stream), p);
+    }
     IFH_LAUNCH_CHECK("attn_prefill");
     return IFH_OK;
 }

@@ -113,7 +113,7 @@ __device__ __forceinline__ uint4 ld_stream16(const uint16_t *ptr)
 
 __device__ __forceinline__ uint32_t pack2(float a, float b)
 {
-    return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+    return f32x2_to_bf16x2(a, b);      // one v_cvt_pk_bf16_f32 (two conversions + shift + or before: same rounding)
 }
 
 }  // namespace ifh

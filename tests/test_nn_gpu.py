@@ -974,6 +974,46 @@ def test_attention_prefill_matches_torch(dev):
         assert rel_l2(got, ref) < 1e-2, (B, H, T, rel_l2(got, ref))
 
 
+@pytest.mark.parametrize('B,H,Tq,Tk,lens', [(2, 8, 1500, 1500, None), (3, 6, 300, 300, [300, 1, 191]), (2, 2, 129, 577, [64, 577]),
+                                            (1, 8, 256, 63, None), (2, 3, 640, 200, [0, 130])])
+def test_attention_prefill_128_query_form_is_bit_identical_to_the_64_query_form(dev, B, H, Tq, Tk, lens):
+    """k_attn_prefill2 (LDS-DMA tiles, 32 queries per wave; the Whisper encoder's windows) keeps k_attn_prefill's order of sums"""
+    import os
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(70 + Tq)
+    D = H * 64
+    q = bfr(torch.randn(B, Tq, D, generator=g) * 0.4).to(dev, BF)
+    kv = bfr(torch.randn(B, Tk, 2 * D, generator=g)).to(dev, BF)
+    kl = None if lens is None else torch.tensor(lens, dtype=torch.int32, device=dev)
+    outs = []
+    old = os.environ.get('IFH_ATTN_PREFILL2')
+    try:
+        for form in ('0', '1'):
+            os.environ['IFH_ATTN_PREFILL2'] = form
+            out = torch.full((B, Tq, D), 7.0, dtype=BF, device=dev)
+            ops.attn_prefill(q, kv, kv, out, nbatch=B, nheads=H, tq=Tq, tk=Tk, v_off=D, q_ts=D, k_ts=2 * D, v_ts=2 * D, o_ts=D,
+                             key_len=kl)
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+    finally:
+        if old is None:
+            os.environ.pop('IFH_ATTN_PREFILL2', None)
+        else:
+            os.environ['IFH_ATTN_PREFILL2'] = old
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    # and the value itself (a row with no keys is all zero)
+    for b in range(B):
+        n = Tk if lens is None else lens[b]
+        if n == 0:
+            assert not outs[1][b].any()
+            continue
+        qq = q[b].float().cpu().reshape(Tq, H, 64).transpose(0, 1)
+        kk = kv[b, :n, :D].float().cpu().reshape(n, H, 64).transpose(0, 1)
+        vv = kv[b, :n, D:].float().cpu().reshape(n, H, 64).transpose(0, 1)
+        ref = (torch.softmax(qq @ kk.transpose(-1, -2), -1) @ vv).transpose(0, 1).reshape(Tq, D)
+        assert rel_l2(outs[1][b].float(), ref) < 1e-2
+
+
 def test_attention_decode_matches_torch(dev):
     from infernos_amd import ops
     g = torch.Generator().manual_seed(8)
