@@ -942,67 +942,106 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? IFH_IGEMM_MINB : 2) void k_ige
 #undef IFH_IGEMM_EPI
 }
 
-// ---- LayerNorm: one wave per row, optional residual add first; D <= 256 * NCH (NCH = 4: 1024; 8: 2048 -- Whisper large-v3's 1280), D % 4 == 0
-template <int NCH>
+// ---- LayerNorm: RPW rows per wave, optional residual add first; D <= 256 * NCH (NCH = 4: 1024; 8: 2048 -- Whisper large-v3's 1280), D % 4 == 0.
+// Lane l holds elements 4 l .. 4 l + 3 of every 256-element chunk; every load of a wave's rows goes out before the first use (inside the
+// per-lane `if (e < D)` of the first form hipcc put each load in its own exec branch with an s_waitcnt vmcnt(0) behind it: 2-4 serial memory
+// latencies per launch, 3.7 TB/s on the encoder's 192 000 x 512 stream against 5.3 for a copy), lanes past D load element 0 and select
+// zeros.  RPW = 4 for long streams: the shuffle reductions of the rows interleave and gamma / beta are fetched once per wave.  The order of
+// every sum is the same for both RPW (same bits).
+template <int NCH, int RPW, bool RESID>
 __global__ __launch_bounds__(256) void k_layernorm(const uint16_t *__restrict__ x, const uint16_t *__restrict__ resid,
                                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                                    uint16_t *__restrict__ out, int rows, int D, float eps)
 {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
     const int lane = threadIdx.x & 63;
-    if (row >= rows) return;
-    const uint16_t *xr = x + (int64_t)row * D;
-    const uint16_t *rr = resid ? resid + (int64_t)row * D : nullptr;
-    float v[NCH][4];
-    float s = 0.0f;
+    if (row0 >= rows) return;
+    uint2 xa[RPW][NCH], xc[RPW][NCH];
+    float4 g[NCH], bt[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
         const int e = lane * 4 + 256 * i;
-        if (e < D) {
-            const uint2 a = *reinterpret_cast<const uint2 *>(xr + e);
-            v[i][0] = __uint_as_float(a.x << 16);
-            v[i][1] = __uint_as_float(a.x & 0xffff0000u);
-            v[i][2] = __uint_as_float(a.y << 16);
-            v[i][3] = __uint_as_float(a.y & 0xffff0000u);
-            if (rr) {
-                const uint2 c = *reinterpret_cast<const uint2 *>(rr + e);
-                v[i][0] += __uint_as_float(c.x << 16);
-                v[i][1] += __uint_as_float(c.x & 0xffff0000u);
-                v[i][2] += __uint_as_float(c.y << 16);
-                v[i][3] += __uint_as_float(c.y & 0xffff0000u);
-            }
-            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        } else {
-            v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.0f;
+        g[i] = *reinterpret_cast<const float4 *>(gamma + (e < D ? e : 0));
+        bt[i] = *reinterpret_cast<const float4 *>(beta + (e < D ? e : 0));
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; r++) {
+        const int row = row0 + r < rows ? row0 + r : rows - 1;      // (a clamped row is computed again, not stored)
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const int e = lane * 4 + 256 * i;
+            const int64_t off = (int64_t)row * D + (e < D ? e : 0);
+            xa[r][i] = *reinterpret_cast<const uint2 *>(x + off);
+            if (RESID) xc[r][i] = *reinterpret_cast<const uint2 *>(resid + off);
         }
     }
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.0f;
+    // (gamma / beta pinned up here: left alone hipcc sinks their loads behind the reductions, one more exposed latency)
 #pragma unroll
-    for (int i = 0; i < NCH; i++) {
-        const int e = lane * 4 + 256 * i;
-        if (e < D) {
+    for (int i = 0; i < NCH; i++)
+        asm volatile("" : "+v"(g[i].x), "+v"(g[i].y), "+v"(g[i].z), "+v"(g[i].w), "+v"(bt[i].x), "+v"(bt[i].y), "+v"(bt[i].z), "+v"(bt[i].w),
+                          "+v"(xa[0][0].x));       // (tied to the first row value: the statement cannot sink below the first sum)
+    float v[RPW][NCH][4];
+    float s[RPW];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const float d = v[i][r] - mean;
-                q += d * d;
+    for (int r = 0; r < RPW; r++) {
+        s[r] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const bool ok = lane * 4 + 256 * i < D;
+            v[r][i][0] = __uint_as_float(xa[r][i].x << 16);
+            v[r][i][1] = __uint_as_float(xa[r][i].x & 0xffff0000u);
+            v[r][i][2] = __uint_as_float(xa[r][i].y << 16);
+            v[r][i][3] = __uint_as_float(xa[r][i].y & 0xffff0000u);
+            if (RESID) {
+                v[r][i][0] += __uint_as_float(xc[r][i].x << 16);
+                v[r][i][1] += __uint_as_float(xc[r][i].x & 0xffff0000u);
+                v[r][i][2] += __uint_as_float(xc[r][i].y << 16);
+                v[r][i][3] += __uint_as_float(xc[r][i].y & 0xffff0000u);
             }
+            const float t = s[r] + ((v[r][i][0] + v[r][i][1]) + (v[r][i][2] + v[r][i][3]));
+            s[r] = ok ? t : s[r];
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-    uint16_t *orow = out + (int64_t)row * D;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < RPW; r++) s[r] += __shfl_xor(s[r], o, 64);
+    float mean[RPW], q[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; r++) {
+        mean[r] = s[r] / (float)D;
+        q[r] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NCH; i++) {
+            const bool ok = lane * 4 + 256 * i < D;
+            float t = q[r];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const float d = v[r][i][c] - mean[r];
+                t += d * d;
+            }
+            q[r] = ok ? t : q[r];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int r = 0; r < RPW; r++) q[r] += __shfl_xor(q[r], o, 64);
+    float rstd[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; r++) rstd[r] = rsqrtf(q[r] / (float)D + eps);
 #pragma unroll
     for (int i = 0; i < NCH; i++) {
         const int e = lane * 4 + 256 * i;
-        if (e < D) {
-            const float4 g = *reinterpret_cast<const float4 *>(gamma + e);
-            const float4 bt = *reinterpret_cast<const float4 *>(beta + e);
-            const float o0 = (v[i][0] - mean) * rstd * g.x + bt.x, o1 = (v[i][1] - mean) * rstd * g.y + bt.y;
-            const float o2 = (v[i][2] - mean) * rstd * g.z + bt.z, o3 = (v[i][3] - mean) * rstd * g.w + bt.w;
+        const bool ok = e < D;
+#pragma unroll
+        for (int r = 0; r < RPW; r++) {
+            const float o0 = (v[r][i][0] - mean[r]) * rstd[r] * g[i].x + bt[i].x, o1 = (v[r][i][1] - mean[r]) * rstd[r] * g[i].y + bt[i].y;
+            const float o2 = (v[r][i][2] - mean[r]) * rstd[r] * g[i].z + bt[i].z, o3 = (v[r][i][3] - mean[r]) * rstd[r] * g[i].w + bt[i].w;
             uint2 pk;
-            pk.x = (uint32_t)f32_to_bf16(o0) | ((uint32_t)f32_to_bf16(o1) << 16);
-            pk.y = (uint32_t)f32_to_bf16(o2) | ((uint32_t)f32_to_bf16(o3) << 16);
-            *reinterpret_cast<uint2 *>(orow + e) = pk;
+            pk.x = f32x2_to_bf16x2(o0, o1);
+            pk.y = f32x2_to_bf16x2(o2, o3);
+            if (ok && row0 + r < rows) *reinterpret_cast<uint2 *>(out + (int64_t)(row0 + r) * D + e) = pk;
         }
     }
 }
@@ -1358,12 +1397,29 @@ extern "C" int ifh_layernorm_bf16(const void *x, const void *resid, const float 
     IFH_CHECK_ARG(rows >= 0);
     if (rows == 0) return IFH_OK;
     IFH_CHECK_ARG(x && gamma && beta && out && dim > 0 && dim <= 2048 && dim % 4 == 0);
-    if (dim <= 1024)
-        hipLaunchKernelGGL(k_layernorm<4>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), (const uint16_t *)x,
-                       (const uint16_t *)resid, gamma, beta, (uint16_t *)out, rows, dim, eps);
-    else
-        hipLaunchKernelGGL(k_layernorm<8>, dim3((rows + 3) / 4), dim3(256), 0, as_stream(stream), (const uint16_t *)x,
-                       (const uint16_t *)resid, gamma, beta, (uint16_t *)out, rows, dim, eps);
+    // (IFH_LN_RPW = 1: one row per wave at every size; read per call for the parity test)
+    const char *rpw_env = getenv("IFH_LN_RPW");
+    const int rpw = rpw_env && *rpw_env ? atoi(rpw_env) : 4;
+    const bool many = rows >= 8192 && rpw == 4;
+#define IFH_LN(NCH, RPW, RESID)                                                                                                   \
+    hipLaunchKernelGGL((k_layernorm<NCH, RPW, RESID>), dim3((rows + 4 * RPW - 1) / (4 * RPW)), dim3(256), 0, as_stream(stream),  \
+                       (const uint16_t *)x, (const uint16_t *)resid, gamma, beta, (uint16_t *)out, rows, dim, eps)
+#define IFH_LN_R(NCH, RPW)                                                  \
+    do {                                                                    \
+        if (resid) IFH_LN(NCH, RPW, true); else IFH_LN(NCH, RPW, false);    \
+    } while (0)
+#define IFH_LN_N(NCH)                                                       \
+    do {                                                                    \
+        if (many) IFH_LN_R(NCH, 4); else IFH_LN_R(NCH, 1);                  \
+    } while (0)
+    // chunks of 256 elements per row: inactive chunks contribute nothing, so the count only decides how many dummy loads there are
+    if (dim <= 512) IFH_LN_N(2);
+    else if (dim <= 768) IFH_LN_N(3);
+    else if (dim <= 1024) IFH_LN_N(4);
+    else IFH_LN_R(8, 1);
+#undef IFH_LN_N
+#undef IFH_LN_R
+#undef IFH_LN
     IFH_LAUNCH_CHECK("layernorm");
     return IFH_OK;
 }

@@ -942,6 +942,34 @@ def test_layernorm_and_transpose(dev):
     assert torch.equal(o.cpu(), x.transpose(1, 2).to(BF))
 
 
+@pytest.mark.parametrize('rows,D,with_resid', [(20000, 512, False), (8193, 768, True), (12001, 384, True), (9000, 1024, False)])
+def test_layernorm_four_rows_per_wave_is_bit_identical_to_one(dev, rows, D, with_resid):
+    """k_layernorm_rows (many rows: the encoder's stream) keeps k_layernorm's element -> lane map and order of sums"""
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(rows)
+    x = bfr(torch.randn(rows, D, generator=g) * 2 + 0.3).to(dev, BF)
+    r = bfr(torch.randn(rows, D, generator=g)).to(dev, BF) if with_resid else None
+    gm, bt = (torch.rand(D, generator=g) + 0.5).to(dev), torch.randn(D, generator=g).to(dev)
+    outs = []
+    old = os.environ.get('IFH_LN_RPW')
+    try:
+        for form in ('1', '4'):
+            os.environ['IFH_LN_RPW'] = form
+            out = torch.zeros(rows, D, dtype=BF, device=dev)
+            ops.layernorm(x, gm, bt, out, rows, D, resid=r)
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        if old is None:
+            os.environ.pop('IFH_LN_RPW', None)
+        else:
+            os.environ['IFH_LN_RPW'] = old
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    xs = x.float() + (r.float() if with_resid else 0)
+    ref = F.layer_norm(xs, (D,), gm, bt, 1e-5)
+    assert rel_l2(outs[1].float().cpu(), ref.cpu()) < 5e-3
+
+
 # ---- attention -----------------------------------------------------------------------------------
 def test_attention_prefill_matches_torch(dev):
     from infernos_amd import ops
