@@ -82,14 +82,16 @@ __global__ __launch_bounds__(256) void k_beam_rowtop(const float *__restrict__ l
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const float *x = logits + (int64_t)row * ld;
     const float *bs = (begin_suppress && pos[0] == prompt_len) ? begin_suppress : nullptr;
-    const bool vec = ((reinterpret_cast<uintptr_t>(x) | (uintptr_t)(ld * 4)) & 15) == 0;
+    const bool vec = ((reinterpret_cast<uintptr_t>(x) | (uintptr_t)(ld * 4) | reinterpret_cast<uintptr_t>(suppress) |
+                       reinterpret_cast<uintptr_t>(begin_suppress)) & 15) == 0;
     const int V4 = vec ? (V >> 2) : 0;
     const float4 *x4 = reinterpret_cast<const float4 *>(x);
     if (tid == 0) l_n = 0;
     // ---- pass 1
     float m = -INFINITY, s = 0.0f, best = -INFINITY;
     int besti = 0x7fffffff;
-#define BEAM_P1(LV, IDX)                                          \
+    // (SV / BV: the suppress / begin-suppress addends of the element, already loaded)
+#define BEAM_P1(LV, IDX, SV, BV)                                  \
     {                                                             \
         const float lv_ = (LV);                                   \
         const int i_ = (IDX);                                     \
@@ -100,29 +102,41 @@ __global__ __launch_bounds__(256) void k_beam_rowtop(const float *__restrict__ l
             s += __expf(lv_ - m);                                 \
         }                                                         \
         float c_ = lv_;                                           \
-        if (suppress) c_ += suppress[i_];                         \
-        if (bs) c_ += bs[i_];                                     \
+        if (suppress) c_ += (SV);                                 \
+        if (bs) c_ += (BV);                                       \
         if (c_ > best) {                                          \
             best = c_;                                            \
             besti = i_;                                           \
         }                                                         \
     }
+    // a thread's four vectors of logits and of both tables go out together, from clamped addresses (as `j < V4 ? x4[j] : 0` and
+    // `if (suppress) c += suppress[i]` every load sat in its own exec branch with an s_waitcnt vmcnt(0) behind it: ~20 serial round
+    // trips per 4 096 logits); what a thread adds, and in which order, is unchanged
+    const float4 *sp4 = reinterpret_cast<const float4 *>(suppress), *bs4 = reinterpret_cast<const float4 *>(bs);
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#define BEAM_LOAD4()                                                                              \
+    float4 q[4], sq[4], bq[4];                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 4; u++) {                                               \
+        const int j = base + tid + 256 * u;                                                       \
+        const int jc = j < V4 ? j : V4 - 1;                                                       \
+        q[u] = x4[jc];                                                                            \
+        sq[u] = zero4;                                                                            \
+        bq[u] = zero4;                                                                            \
+        if (suppress) sq[u] = sp4[jc];                                                            \
+        if (bs) bq[u] = bs4[jc];                                                                  \
+    }
     for (int base = 0; base < V4; base += 256 * 4) {
-        float4 q[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = base + tid + 256 * u;
-            q[u] = j < V4 ? x4[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
+        BEAM_LOAD4()
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int j = base + tid + 256 * u;
             if (j < V4) {
-                BEAM_P1(q[u].x, 4 * j) BEAM_P1(q[u].y, 4 * j + 1) BEAM_P1(q[u].z, 4 * j + 2) BEAM_P1(q[u].w, 4 * j + 3)
+                BEAM_P1(q[u].x, 4 * j, sq[u].x, bq[u].x) BEAM_P1(q[u].y, 4 * j + 1, sq[u].y, bq[u].y)
+                BEAM_P1(q[u].z, 4 * j + 2, sq[u].z, bq[u].z) BEAM_P1(q[u].w, 4 * j + 3, sq[u].w, bq[u].w)
             }
         }
     }
-    for (int i = 4 * V4 + tid; i < V; i += 256) BEAM_P1(x[i], i)
+    for (int i = 4 * V4 + tid; i < V; i += 256) BEAM_P1(x[i], i, suppress[i], bs[i])
 #undef BEAM_P1
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -156,12 +170,12 @@ __global__ __launch_bounds__(256) void k_beam_rowtop(const float *__restrict__ l
         }
     }
     // ---- pass 2: candidates at or above the threshold (finite ones only)
-#define BEAM_P2(LV, IDX)                                          \
+#define BEAM_P2(LV, IDX, SV, BV)                                  \
     {                                                             \
         const int i_ = (IDX);                                     \
         float c_ = (LV);                                          \
-        if (suppress) c_ += suppress[i_];                         \
-        if (bs) c_ += bs[i_];                                     \
+        if (suppress) c_ += (SV);                                 \
+        if (bs) c_ += (BV);                                       \
         if (c_ >= thr && c_ > -INFINITY) {                        \
             const int at = atomicAdd(&l_n, 1);                    \
             if (at < BEAM_LIST) {                                 \
@@ -171,22 +185,19 @@ __global__ __launch_bounds__(256) void k_beam_rowtop(const float *__restrict__ l
         }                                                         \
     }
     for (int base = 0; base < V4; base += 256 * 4) {
-        float4 q[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int j = base + tid + 256 * u;
-            q[u] = j < V4 ? x4[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
+        BEAM_LOAD4()
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const int j = base + tid + 256 * u;
             if (j < V4) {
-                BEAM_P2(q[u].x, 4 * j) BEAM_P2(q[u].y, 4 * j + 1) BEAM_P2(q[u].z, 4 * j + 2) BEAM_P2(q[u].w, 4 * j + 3)
+                BEAM_P2(q[u].x, 4 * j, sq[u].x, bq[u].x) BEAM_P2(q[u].y, 4 * j + 1, sq[u].y, bq[u].y)
+                BEAM_P2(q[u].z, 4 * j + 2, sq[u].z, bq[u].z) BEAM_P2(q[u].w, 4 * j + 3, sq[u].w, bq[u].w)
             }
         }
     }
-    for (int i = 4 * V4 + tid; i < V; i += 256) BEAM_P2(x[i], i)
+    for (int i = 4 * V4 + tid; i < V; i += 256) BEAM_P2(x[i], i, suppress[i], bs[i])
 #undef BEAM_P2
+#undef BEAM_LOAD4
     __syncthreads();
     const int n = l_n;
     if (n <= BEAM_LIST) {
