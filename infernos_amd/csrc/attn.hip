@@ -59,7 +59,8 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const AttnParams p)
 #pragma unroll
     for (int i = 0; i < 4; i++) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float mrun = -1e30f, lrun = 0.0f;
-    const float *rb = p.relbias ? p.relbias + (((int64_t)b * p.Tq + (qi < p.Tq ? qi : 0)) * p.H + h) * p.nrel : nullptr;
+    const bool has_rb = p.relbias != nullptr;
+    const float *rb = has_rb ? p.relbias + (((int64_t)b * p.Tq + (qi < p.Tq ? qi : 0)) * p.H + h) * p.nrel : nullptr;
     const int half = p.nrel >> 1;
 
     const int ntile = (klen + KT - 1) / KT;
@@ -111,18 +112,29 @@ __global__ __launch_bounds__(256) void k_attn_prefill(const AttnParams p)
         // needs neither the relative-position bias nor the key-length mask -- every tile but the last of a Whisper window --
         // takes the short form: one max per score here, one fma + one exp2 below.
         float mloc = -1e30f;
-        if (rb || kbase + KT > klen) {
+        if (has_rb || kbase + KT > klen) {
+            // the 16 bias values of this lane's scores go out together under the wave-uniform flag (as `if (rb) val += rb[..]` on the
+            // per-lane pointer each load had its own exec branch and s_waitcnt vmcnt(0): 16 round trips in series per tile)
+            float rbv[4][4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    rbv[c][r] = 0.0f;
+                    if (has_rb) {
+                        int rel = qi - (kbase + c * 16 + 4 * fg + r);
+                        rel = rel < -half ? -half : (rel > half - 1 ? half - 1 : rel);
+                        rbv[c][r] = rb[rel + half];
+                    }
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 4; c++) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int kidx = kbase + c * 16 + 4 * fg + r;
                     float val = s[c][r];
-                    if (rb) {
-                        int rel = qi - kidx;
-                        rel = rel < -half ? -half : (rel > half - 1 ? half - 1 : rel);
-                        val += rb[rel + half];
-                    }
+                    if (has_rb) val += rbv[c][r];
                     val = (kidx < klen) ? val : -1e30f;
                     s[c][r] = val;
                     mloc = fmaxf(mloc, val);
