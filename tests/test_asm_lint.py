@@ -51,3 +51,34 @@ def test_dma_queue_kernels_use_no_scratch(tmp_path):
         sizes = [int(v) for v in re.findall(r'^\s+\.private_segment_fixed_size:\s+(\d+)', txt, re.M)]
         assert sizes and max(sizes) == 0, (name, sizes)
         assert 'scratch_load' not in txt and 'scratch_store' not in txt, name
+
+
+def test_batched_load_kernels_stay_batched(tmp_path):
+    """k_attn_prefill2 and k_beam_rowtop were rewritten so that their loads leave together (round 5: per-lane `if`s around loads had
+    made hipcc wait for each one separately; tools/scan_serial_loads.py).  On the compiled listings: at most a handful of
+    load + `s_waitcnt vmcnt(0)` pairs are left in k_beam_rowtop (71 before), k_attn_prefill's bias path has none of its sixteen, and
+    k_attn_prefill2 -- whose DMA queue a scratch access would drain -- has neither a private segment nor AGPR copies (hipcc used 32
+    AGPRs as spill space until the launch bounds said three waves per SIMD)."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from scan_serial_loads import scan
+    from infernos_amd import build as b
+    flags = [f for f in b.FLAGS if f not in ('-fPIC', '-Wall')]
+    outs = {}
+    for name in ('attn', 'beam'):
+        outs[name] = str(tmp_path / (name + '.s'))
+        subprocess.check_call([b.HIPCC] + flags + ['-S', '--cuda-device-only', '-o', outs[name], os.path.join(b.CSRC, name + '.hip')],
+                              stderr=subprocess.DEVNULL)
+    beam = {k: v for k, v in scan(outs['beam']).items() if 'k_beam_rowtop' in k}
+    assert beam and all(v[1] <= 10 for v in beam.values()), beam
+    attn = scan(outs['attn'])
+    v1 = [v for k, v in attn.items() if 'k_attn_prefillENS' in k]
+    assert v1 and v1[0][1] <= 4, v1
+    txt = open(outs['attn']).read()
+    body = txt[txt.index('_ZN3ifh15k_attn_prefill2'):]
+    body = body[:body.index('s_endpgm')]
+    assert 'v_accvgpr' not in body and 'scratch_' not in body
+    idx = [m.start() for m in re.finditer(r'\.name:\s+_ZN3ifh15k_attn_prefill2', txt)]
+    assert idx
+    m = re.search(r'\.private_segment_fixed_size:\s+(\d+)', txt[idx[0]:])       # (metadata keys are sorted: the size follows the name)
+    assert m is not None and int(m.group(1)) == 0

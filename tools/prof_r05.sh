@@ -41,6 +41,7 @@ for d in ('pmclm_sq', 'pmclm_sq2'):
 json.dump({k: res[k] / n[k] for k in res}, open(os.path.join(O, 'logmel_sq_counters.json'), 'w'), indent=1)
 print(json.dumps({k: res[k] / n[k] for k in res}))
 PY
+bash $R/tools/prof_encoder.sh > $O/prof_encoder.out 2>&1; tail -3 $O/prof_encoder.out
 find $O -name '*kernel_trace.csv' -delete   # the traces are large; only stats and counters travel back
 find $O -name '*agent_info.csv' -delete
 du -sh $O

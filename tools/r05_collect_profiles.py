@@ -18,6 +18,10 @@ for src, dst, cmd in (
         ('voc512_kernel_stats.csv', 'r05_vocoder512_kernel_stats', 'rocprofv3 --kernel-trace --stats -- python3 tools/probe_vocoder.py 10 512 (tools/prof_r05.sh)'),
         ('logmel_kernel_stats.csv', 'r05_logmel_kernel_stats', 'rocprofv3 --kernel-trace --stats -- python3 tools/probe_logmel.py 10 128 (tools/prof_r05.sh)')):
     subprocess.check_call(S + ['stats', os.path.join(O, src), os.path.join(P, dst + '.md'), cmd])
+if os.path.exists(os.path.join(O, 'encoder_kernel_stats.csv')):
+    subprocess.check_call(S + ['stats', os.path.join(O, 'encoder_kernel_stats.csv'), os.path.join(P, 'r05_encoder_kernel_stats.md'),
+                               'rocprofv3 --kernel-trace --stats -- python3 tools/probe_encoder.py 128 whisper_base (7 encoder passes of 128 windows: '
+                               'k_attn_prefill2, the k_gemm_big8 products, k_layernorm<2, 4, false>; tools/prof_encoder.sh)'])
 subprocess.check_call(['cp', os.path.join(O, 'voc1280_kernel_stats.csv'), os.path.join(P, 'r05_vocoder_kernel_stats.csv')])
 subprocess.check_call(S + ['pmc', os.path.join(O, 'pmc_FETCH_SIZE'), os.path.join(O, 'pmc_WRITE_SIZE'), '3', os.path.join(P, 'r05_vocoder_pmc.json'), '1280', 'vocoder'])
 subprocess.check_call(S + ['pmc', os.path.join(O, 'pmclm_FETCH_SIZE'), os.path.join(O, 'pmclm_WRITE_SIZE'), '3', os.path.join(P, 'r05_logmel_pmc.json'), '128', 'logmel'])
