@@ -22,6 +22,11 @@ if os.path.exists(os.path.join(O, 'encoder_kernel_stats.csv')):
     subprocess.check_call(S + ['stats', os.path.join(O, 'encoder_kernel_stats.csv'), os.path.join(P, 'r05_encoder_kernel_stats.md'),
                                'rocprofv3 --kernel-trace --stats -- python3 tools/probe_encoder.py 128 whisper_base (7 encoder passes of 128 windows: '
                                'k_attn_prefill2, the k_gemm_big8 products, k_layernorm<2, 4, false>; tools/prof_encoder.sh)'])
+    if os.path.exists(os.path.join(O, 'encoder_probe.txt')):
+        with open(os.path.join(P, 'r05_encoder_kernel_stats.md'), 'a') as f:
+            f.write('\nUnprofiled on the same box (tools/probe_encoder.py 128 whisper_base x 3; tools/probe_attn_prefill.py 128 8 1500: form 0 = '
+                    'k_attn_prefill, form 1 = k_attn_prefill2; tools/probe_layernorm.py: 192 000 x 512, IFH_LN_RPW = 1 / 4, and a copy of the same bytes):\n\n```\n'
+                    + open(os.path.join(O, 'encoder_probe.txt')).read() + '```\n')
 subprocess.check_call(['cp', os.path.join(O, 'voc1280_kernel_stats.csv'), os.path.join(P, 'r05_vocoder_kernel_stats.csv')])
 subprocess.check_call(S + ['pmc', os.path.join(O, 'pmc_FETCH_SIZE'), os.path.join(O, 'pmc_WRITE_SIZE'), '3', os.path.join(P, 'r05_vocoder_pmc.json'), '1280', 'vocoder'])
 subprocess.check_call(S + ['pmc', os.path.join(O, 'pmclm_FETCH_SIZE'), os.path.join(O, 'pmclm_WRITE_SIZE'), '3', os.path.join(P, 'r05_logmel_pmc.json'), '128', 'logmel'])
