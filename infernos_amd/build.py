@@ -15,6 +15,16 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
          '-mllvm', '-pragma-unroll-threshold=1000000']
 
 
+# per-file additions: attn.hip's one-wave kernel (k_attn_prefill_few: 48 KB of LDS per wave, so hipcc plans for one wave per SIMD and
+# 512 registers) got its MFMA results in AGPRs with a v_accvgpr copy around every vector instruction that touches them (144 in the tile
+# loop); the VGPR form of the MFMAs is selected for that file (no kernel in it keeps accumulators in AGPRs on purpose)
+EXTRA_FLAGS = {'attn.hip': ['-mllvm', '-amdgpu-mfma-vgpr-form']}
+
+
+def flags_for(src):
+    return FLAGS + EXTRA_FLAGS.get(os.path.basename(src), [])
+
+
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
 
@@ -50,7 +60,7 @@ def build(force=False, verbose=True, jobs=None):
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
             continue
-        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+        cmd = [HIPCC] + flags_for(src) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         procs.append((subprocess.Popen(cmd), src))

@@ -452,6 +452,187 @@ __global__ __launch_bounds__(256, 3) void k_attn_prefill2(const AttnParams p)
 #undef A2_DMA
 }
 
+// k_attn_prefill_few: at most 16 query rows per (batch, head) -- the beams of a Whisper utterance over its 1500 cross-attention keys
+// (5376 launches per bench cycle).  k_attn_prefill runs that as a 64-query block: three of its four waves multiply and exponentiate
+// padding rows, and the tile in flight is one.  Here ONE wave owns the (batch, head): the same per-tile arithmetic on its one
+// 16-query block (bit-identical to k_attn_prefill), K / V tiles by LDS-DMA into a wave-private ring of three 16 KB buffers (two tiles
+// in flight behind the one being multiplied), no barrier anywhere -- own-wave LDS reads behind an LDS-DMA are ordered by vmcnt alone.
+constexpr int AF_RING = 3;
+
+__global__ __launch_bounds__(64) void k_attn_prefill_few(const AttnParams p)
+{
+    __shared__ __attribute__((aligned(1024))) unsigned char ldsf[AF_RING * A2_BUF];
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int qi = fr;                                   // this lane's query row (Tq <= 16)
+    const int klen = p.key_len ? p.key_len[b] : p.Tk;
+    const unsigned lbase = (unsigned)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)ldsf);
+
+    bf16x8_t qf[2];
+    {
+        const uint16_t *qp = p.q + (int64_t)b * p.q_bs + (int64_t)(qi < p.Tq ? qi : 0) * p.q_ts + h * HD;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if (qi < p.Tq) t = *reinterpret_cast<const uint4 *>(qp + 32 * s + 8 * fg);
+            qf[s] = __builtin_bit_cast(bf16x8_t, t);
+        }
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun = -1e30f, lrun = 0.0f;
+    const int ntile = (klen + KT - 1) / KT;
+
+    // DMA: piece q of a tile = keys 8 q .. 8 q + 7 (eight pieces of K, eight of V); lane l -> key l / 8 of the piece, LDS chunk l % 8 <-
+    // source chunk (l % 8) ^ 2 ((key / 2) % 4): k_attn_prefill2's image
+    const int drow = lane >> 3, dch = (lane & 7) ^ (((drow >> 1) & 3) << 1);
+    const unsigned char *ksrc = reinterpret_cast<const unsigned char *>(p.k + (int64_t)b * p.k_bs + h * HD);
+    const unsigned char *vsrc = reinterpret_cast<const unsigned char *>(p.v + (int64_t)b * p.v_bs + h * HD);
+    const unsigned kts2 = (unsigned)p.k_ts * 2u, vts2 = (unsigned)p.v_ts * 2u;
+#define AF_DMA(VOFF, BASE, DST)                                                                                          \
+    do {                                                                                                                 \
+        unsigned keep_;                                                                                                  \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep_) : "v"(VOFF), "s"(BASE), "s"(DST) : "memory");                                       \
+    } while (0)
+    auto issue_tile = [&](int kt, int slot) {
+        const unsigned dst = lbase + (unsigned)slot * A2_BUF;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            int key = kt * KT + q * 8 + drow;
+            key = key < klen ? key : klen - 1;
+            const unsigned ko = (unsigned)key * kts2 + (unsigned)dch * 16u, vo = (unsigned)key * vts2 + (unsigned)dch * 16u;
+            AF_DMA(ko, ksrc, dst + q * 1024);
+            AF_DMA(vo, vsrc, dst + A2_V + q * 1024);
+        }
+    };
+    const int fsw = ((fr & 7) >> 1) << 1;
+    const unsigned ka0 = (unsigned)(fr * 128 + ((fg ^ fsw) << 4)), ka1 = (unsigned)(fr * 128 + (((4 + fg) ^ fsw) << 4));
+    unsigned va[4];
+    {
+        const int row = 4 * fg + (fr >> 2), sw = ((row >> 1) & 3) << 1;
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++)
+            va[dt] = lbase + A2_V + (unsigned)(row * 128 + (((dt * 2 + ((fr & 3) >> 1)) ^ sw) << 4) + (fr & 1) * 8);
+    }
+    asm volatile("" : : "v"(qf[0]), "v"(qf[1]));      // (the q loads are waited for here, not behind the first DMA)
+    if (ntile > 0) issue_tile(0, 0);
+    if (ntile > 1) issue_tile(1, 1);
+    int slot = 0;
+    for (int kt = 0; kt < ntile; kt++) {
+        const int kbase = kt * KT;
+        // tile kt + 2 goes into the buffer tile kt - 1 was multiplied from (its reads were waited for before its MFMAs); 16 DMA
+        // instructions per tile: tile kt has landed when at most the later tiles' are outstanding
+        if (kt + 2 < ntile) {
+            issue_tile(kt + 2, slot == 0 ? 2 : slot - 1);
+            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        } else if (kt + 1 < ntile) {
+            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        const unsigned bo = (unsigned)slot * A2_BUF;
+        const unsigned char *kb = ldsf + bo;
+        f32x4 s[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            s[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const bf16x8_t kf0 = *reinterpret_cast<const bf16x8_t *>(kb + c * 2048 + ka0);
+            const bf16x8_t kf1 = *reinterpret_cast<const bf16x8_t *>(kb + c * 2048 + ka1);
+            s[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf0, qf[0], s[c], 0, 0, 0);
+            s[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf1, qf[1], s[c], 0, 0, 0);
+        }
+        constexpr float kLog2e = 1.4426950408889634f;
+        float mloc = -1e30f;
+        if (kbase + KT > klen) {       // wave-uniform: the last, partial tile
+            const int lim = klen - kbase - 4 * fg;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) s[c][r] = (c * 16 + r < lim) ? s[c][r] : -1e30f;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mloc) : "v"(s[c][0]), "v"(s[c][1]));
+            asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mloc) : "v"(s[c][2]), "v"(s[c][3]));
+        }
+        mloc = a2_max_rows(mloc);
+        const float mnew = fmaxf(mrun, mloc);
+        const float mscaled = mnew * kLog2e;
+        const float alpha = __builtin_amdgcn_exp2f(mrun * kLog2e - mscaled);
+        float lsum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[c][r], kLog2e, -mscaled));
+                s[c][r] = pv;
+                lsum += pv;
+            }
+        }
+        lsum = a2_sum_rows(lsum);
+        lrun = lrun * alpha + lsum;
+        mrun = mnew;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            o[i][0] *= alpha;
+            o[i][1] *= alpha;
+            o[i][2] *= alpha;
+            o[i][3] *= alpha;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            uint4 pb;
+            pb.x = pack2(s[2 * ks][0], s[2 * ks][1]);
+            pb.y = pack2(s[2 * ks][2], s[2 * ks][3]);
+            pb.z = pack2(s[2 * ks + 1][0], s[2 * ks + 1][1]);
+            pb.w = pack2(s[2 * ks + 1][2], s[2 * ks + 1][3]);
+            const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pb);
+            uint2 lo[4], hi[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                const unsigned a = va[dt] + bo;
+                if (ks == 0) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[dt]) : "v"(a) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(hi[dt]) : "v"(a) : "memory");
+                } else {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:4096" : "=v"(lo[dt]) : "v"(a) : "memory");
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:6144" : "=v"(hi[dt]) : "v"(a) : "memory");
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])
+                         :
+                         : "memory");
+#pragma unroll
+            for (int dt = 0; dt < 4; dt++) {
+                uint4 vv;
+                vv.x = lo[dt].x;
+                vv.y = lo[dt].y;
+                vv.z = hi[dt].x;
+                vv.w = hi[dt].y;
+                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, vv), pf, o[dt], 0, 0, 0);
+            }
+        }
+        slot = slot == AF_RING - 1 ? 0 : slot + 1;
+    }
+    if (qi < p.Tq) {
+        const float inv = lrun > 0.0f ? 1.0f / lrun : 0.0f;
+        uint16_t *op = p.out + (int64_t)b * p.o_bs + (int64_t)qi * p.o_ts + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 4; dt++) {
+            uint2 pk;
+            pk.x = pack2(o[dt][0] * inv, o[dt][1] * inv);
+            pk.y = pack2(o[dt][2] * inv, o[dt][3] * inv);
+            *reinterpret_cast<uint2 *>(op + dt * 16 + 4 * fg) = pk;
+        }
+    }
+#undef AF_DMA
+}
+
 // One query token per (batch, head) against a KV cache.  A wave is 8 key-groups x 8 lanes; a lane owns
 // 8 of the 64 head dims (one 16-byte load per key for K and for V, 128 B coalesced per key).
 // Every key-group runs its own online softmax over keys g, g+8*NW, ...; the groups (and the NW
@@ -733,7 +914,12 @@ extern "C" int ifh_attn_prefill_bf16(const ifh_attn_desc *d, ifh_stream_t stream
     const char *env2 = getenv("IFH_ATTN_PREFILL2");
     const int force2 = env2 && *env2 ? atoi(env2) : -1;
     const bool fits2 = (int64_t)d->tk * d->k_ts * 2 < (int64_t(1) << 31) && (int64_t)d->tk * d->v_ts * 2 < (int64_t(1) << 31);
-    if (fits2 && !d->relbias && (force2 < 0 ? d->tq >= 256 : force2 > 0)) {
+    // at most 16 query rows (the beams of an utterance over its cross-attention keys): one wave per (batch, head); IFH_ATTN_FEW = 0 / 1
+    const char *envf = getenv("IFH_ATTN_FEW");
+    const int forcef = envf && *envf ? atoi(envf) : -1;
+    if (fits2 && !d->relbias && d->tq <= 16 && (forcef < 0 ? d->tk >= 256 : forcef > 0)) {
+        hipLaunchKernelGGL(k_attn_prefill_few, dim3(1, d->nheads, d->nbatch), dim3(64), 0, as_stream(stream), p);
+    } else if (fits2 && !d->relbias && (force2 < 0 ? d->tq >= 256 : force2 > 0)) {
         dim3 grid((d->tq + 127) / 128, d->nheads, d->nbatch);
         hipLaunchKernelGGL(k_attn_prefill2, grid, dim3(256), 0, as_stream(stream), p);
     } else {

@@ -63,10 +63,10 @@ def test_batched_load_kernels_stay_batched(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     from scan_serial_loads import scan
     from infernos_amd import build as b
-    flags = [f for f in b.FLAGS if f not in ('-fPIC', '-Wall')]
     outs = {}
     for name in ('attn', 'beam'):
         outs[name] = str(tmp_path / (name + '.s'))
+        flags = [f for f in b.flags_for(name + '.hip') if f not in ('-fPIC', '-Wall')]
         subprocess.check_call([b.HIPCC] + flags + ['-S', '--cuda-device-only', '-o', outs[name], os.path.join(b.CSRC, name + '.hip')],
                               stderr=subprocess.DEVNULL)
     beam = {k: v for k, v in scan(outs['beam']).items() if 'k_beam_rowtop' in k}
@@ -78,6 +78,9 @@ def test_batched_load_kernels_stay_batched(tmp_path):
     body = txt[txt.index('_ZN3ifh15k_attn_prefill2'):]
     body = body[:body.index('s_endpgm')]
     assert 'v_accvgpr' not in body and 'scratch_' not in body
+    few = txt[txt.index('_ZN3ifh18k_attn_prefill_few'):]
+    few = few[:few.index('s_endpgm')]
+    assert 'v_accvgpr' not in few and 'scratch_' not in few        # (the one-wave kernel: build.EXTRA_FLAGS selects the MFMAs' VGPR form)
     idx = [m.start() for m in re.finditer(r'\.name:\s+_ZN3ifh15k_attn_prefill2', txt)]
     assert idx
     m = re.search(r'\.private_segment_fixed_size:\s+(\d+)', txt[idx[0]:])       # (metadata keys are sorted: the size follows the name)

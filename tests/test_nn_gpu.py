@@ -1042,6 +1042,45 @@ def test_attention_prefill_128_query_form_is_bit_identical_to_the_64_query_form(
         assert rel_l2(outs[1][b].float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize('B,H,Tq,Tk,lens', [(4, 8, 5, 1500, None), (3, 6, 16, 700, [700, 1, 333]), (2, 8, 1, 257, None),
+                                            (2, 4, 5, 1500, [1500, 0])])
+def test_attention_prefill_one_wave_form_is_bit_identical_for_few_query_rows(dev, B, H, Tq, Tk, lens):
+    """k_attn_prefill_few (the beams' cross-attention: <= 16 query rows, one wave per (batch, head), wave-private DMA ring) keeps
+    k_attn_prefill's arithmetic; K / V read through cache-shaped strides (heads side by side in a row)"""
+    from infernos_amd import ops
+    g = torch.Generator().manual_seed(90 + Tk)
+    D = H * 64
+    q = bfr(torch.randn(B, Tq, D, generator=g) * 0.4).to(dev, BF)
+    kv = bfr(torch.randn(B, Tk, 2 * D, generator=g)).to(dev, BF)
+    kl = None if lens is None else torch.tensor(lens, dtype=torch.int32, device=dev)
+    outs = []
+    old = os.environ.get('IFH_ATTN_FEW')
+    try:
+        for form in ('0', '1'):
+            os.environ['IFH_ATTN_FEW'] = form
+            out = torch.full((B, Tq, D), 7.0, dtype=BF, device=dev)
+            ops.attn_prefill(q, kv, kv, out, nbatch=B, nheads=H, tq=Tq, tk=Tk, v_off=D, q_ts=D, k_ts=2 * D, v_ts=2 * D, o_ts=D,
+                             key_len=kl)
+            torch.cuda.synchronize()
+            outs.append(out.cpu())
+    finally:
+        if old is None:
+            os.environ.pop('IFH_ATTN_FEW', None)
+        else:
+            os.environ['IFH_ATTN_FEW'] = old
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    for b in range(B):
+        n = Tk if lens is None else lens[b]
+        if n == 0:
+            assert not outs[1][b].any()
+            continue
+        qq = q[b].float().cpu().reshape(Tq, H, 64).transpose(0, 1)
+        kk = kv[b, :n, :D].float().cpu().reshape(n, H, 64).transpose(0, 1)
+        vv = kv[b, :n, D:].float().cpu().reshape(n, H, 64).transpose(0, 1)
+        ref = (torch.softmax(qq @ kk.transpose(-1, -2), -1) @ vv).transpose(0, 1).reshape(Tq, D)
+        assert rel_l2(outs[1][b].float(), ref) < 1e-2
+
+
 def test_attention_decode_matches_torch(dev):
     from infernos_amd import ops
     g = torch.Generator().manual_seed(8)

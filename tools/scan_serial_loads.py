@@ -40,8 +40,8 @@ def main():
     from infernos_amd import build as b
     files = sys.argv[1:]
     if not files:
-        flags = [f for f in b.FLAGS if f not in ('-fPIC', '-Wall')]
         for src in sorted(glob.glob(os.path.join(b.CSRC, '*.hip'))):
+            flags = [f for f in b.flags_for(src) if f not in ('-fPIC', '-Wall')]
             out = '/tmp/scan_' + os.path.basename(src) + '.s'
             if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
                 subprocess.run([b.HIPCC] + flags + ['-S', '--cuda-device-only', src, '-o', out], stderr=subprocess.DEVNULL)
