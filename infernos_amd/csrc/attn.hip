@@ -455,10 +455,9 @@ __global__ __launch_bounds__(256, 3) void k_attn_prefill2(const AttnParams p)
 // k_attn_prefill_few: at most 16 query rows per (batch, head) -- the beams of a Whisper utterance over its 1500 cross-attention keys
 // (5376 launches per bench cycle).  k_attn_prefill runs that as a 64-query block: three of its four waves multiply and exponentiate
 // padding rows, and the tile in flight is one.  Here ONE wave owns the (batch, head): the same per-tile arithmetic on its one
-// 16-query block (bit-identical to k_attn_prefill), K / V tiles by LDS-DMA into a wave-private ring of three 16 KB buffers (two tiles
-// in flight behind the one being multiplied), no barrier anywhere -- own-wave LDS reads behind an LDS-DMA are ordered by vmcnt alone.
-constexpr int AF_RING = 3;
-
+// 16-query block (bit-identical to k_attn_prefill), K / V tiles by LDS-DMA into a wave-private ring of AF_RING 16 KB buffers (AF_RING - 1
+// tiles in flight behind the one being multiplied; four by default), no barrier anywhere -- own-wave LDS reads behind an LDS-DMA are ordered by vmcnt alone.
+template <int AF_RING>
 __global__ __launch_bounds__(64) void k_attn_prefill_few(const AttnParams p)
 {
     __shared__ __attribute__((aligned(1024))) unsigned char ldsf[AF_RING * A2_BUF];
@@ -518,20 +517,24 @@ __global__ __launch_bounds__(64) void k_attn_prefill_few(const AttnParams p)
             va[dt] = lbase + A2_V + (unsigned)(row * 128 + (((dt * 2 + ((fr & 3) >> 1)) ^ sw) << 4) + (fr & 1) * 8);
     }
     asm volatile("" : : "v"(qf[0]), "v"(qf[1]));      // (the q loads are waited for here, not behind the first DMA)
-    if (ntile > 0) issue_tile(0, 0);
-    if (ntile > 1) issue_tile(1, 1);
+#pragma unroll
+    for (int t = 0; t < AF_RING - 1; t++)
+        if (t < ntile) issue_tile(t, t);
     int slot = 0;
     for (int kt = 0; kt < ntile; kt++) {
         const int kbase = kt * KT;
-        // tile kt + 2 goes into the buffer tile kt - 1 was multiplied from (its reads were waited for before its MFMAs); 16 DMA
-        // instructions per tile: tile kt has landed when at most the later tiles' are outstanding
-        if (kt + 2 < ntile) {
-            issue_tile(kt + 2, slot == 0 ? 2 : slot - 1);
-            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        } else if (kt + 1 < ntile) {
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        // tile kt + AF_RING - 1 goes into the buffer tile kt - 1 was multiplied from (its reads were waited for before its MFMAs); 16
+        // DMA instructions per tile: tile kt has landed when at most the later tiles' are outstanding
+        if (kt + AF_RING - 1 < ntile) {
+            issue_tile(kt + AF_RING - 1, slot == 0 ? AF_RING - 1 : slot - 1);
+            if (AF_RING == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (AF_RING == 3) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            if (AF_RING == 4) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int later = ntile - 1 - kt;           // tiles requested and not yet needed: 0 .. AF_RING - 2
+            if (later >= 2) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         const unsigned bo = (unsigned)slot * A2_BUF;
         const unsigned char *kb = ldsf + bo;
@@ -918,7 +921,13 @@ extern "C" int ifh_attn_prefill_bf16(const ifh_attn_desc *d, ifh_stream_t stream
     const char *envf = getenv("IFH_ATTN_FEW");
     const int forcef = envf && *envf ? atoi(envf) : -1;
     if (fits2 && !d->relbias && d->tq <= 16 && (forcef < 0 ? d->tk >= 256 : forcef > 0)) {
-        hipLaunchKernelGGL(k_attn_prefill_few, dim3(1, d->nheads, d->nbatch), dim3(64), 0, as_stream(stream), p);
+        // (IFH_ATTN_FEW_RING: buffers per wave, 2 .. 4; tuning switch)
+        const char *envr = getenv("IFH_ATTN_FEW_RING");
+        const int ring = envr && *envr ? atoi(envr) : 4;        // alone: 2 -> 76 us, 3 -> 91 (768 slots for 1 024 workgroups), 4 -> 77; C3: NOTES
+        const dim3 gridf(1, d->nheads, d->nbatch);
+        if (ring == 2) hipLaunchKernelGGL(k_attn_prefill_few<2>, gridf, dim3(64), 0, as_stream(stream), p);
+        else if (ring == 4) hipLaunchKernelGGL(k_attn_prefill_few<4>, gridf, dim3(64), 0, as_stream(stream), p);
+        else hipLaunchKernelGGL(k_attn_prefill_few<3>, gridf, dim3(64), 0, as_stream(stream), p);
     } else if (fits2 && !d->relbias && (force2 < 0 ? d->tq >= 256 : force2 > 0)) {
         dim3 grid((d->tq + 127) / 128, d->nheads, d->nbatch);
         hipLaunchKernelGGL(k_attn_prefill2, grid, dim3(256), 0, as_stream(stream), p);

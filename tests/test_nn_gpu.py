@@ -1044,7 +1044,8 @@ def test_attention_prefill_128_query_form_is_bit_identical_to_the_64_query_form(
 
 @pytest.mark.parametrize('B,H,Tq,Tk,lens', [(4, 8, 5, 1500, None), (3, 6, 16, 700, [700, 1, 333]), (2, 8, 1, 257, None),
                                             (2, 4, 5, 1500, [1500, 0])])
-def test_attention_prefill_one_wave_form_is_bit_identical_for_few_query_rows(dev, B, H, Tq, Tk, lens):
+@pytest.mark.parametrize('ring', ['2', '3', '4'])
+def test_attention_prefill_one_wave_form_is_bit_identical_for_few_query_rows(dev, B, H, Tq, Tk, lens, ring):
     """k_attn_prefill_few (the beams' cross-attention: <= 16 query rows, one wave per (batch, head), wave-private DMA ring) keeps
     k_attn_prefill's arithmetic; K / V read through cache-shaped strides (heads side by side in a row)"""
     from infernos_amd import ops
@@ -1054,8 +1055,9 @@ def test_attention_prefill_one_wave_form_is_bit_identical_for_few_query_rows(dev
     kv = bfr(torch.randn(B, Tk, 2 * D, generator=g)).to(dev, BF)
     kl = None if lens is None else torch.tensor(lens, dtype=torch.int32, device=dev)
     outs = []
-    old = os.environ.get('IFH_ATTN_FEW')
+    old, old_ring = os.environ.get('IFH_ATTN_FEW'), os.environ.get('IFH_ATTN_FEW_RING')
     try:
+        os.environ['IFH_ATTN_FEW_RING'] = ring          # buffers of the wave's DMA ring: every depth gives the same bits
         for form in ('0', '1'):
             os.environ['IFH_ATTN_FEW'] = form
             out = torch.full((B, Tq, D), 7.0, dtype=BF, device=dev)
@@ -1064,10 +1066,11 @@ def test_attention_prefill_one_wave_form_is_bit_identical_for_few_query_rows(dev
             torch.cuda.synchronize()
             outs.append(out.cpu())
     finally:
-        if old is None:
-            os.environ.pop('IFH_ATTN_FEW', None)
-        else:
-            os.environ['IFH_ATTN_FEW'] = old
+        for name, val in (('IFH_ATTN_FEW', old), ('IFH_ATTN_FEW_RING', old_ring)):
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val
     assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
     for b in range(B):
         n = Tk if lens is None else lens[b]
