@@ -461,8 +461,7 @@ def main():
         raise SystemExit('WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
+    ge.build()        # every rank: one compiles under build/.lock, the others wait for it (infernos_amd/build.py)
     # IFH_DRYRUN_ONE_GPU=1: every rank uses cuda:0 and the collectives run over gloo (host-staged) -- lets the
     # N>1 code path (sharding, collective order, stage threads) be exercised on a single-GPU box
     dry = os.environ.get('IFH_DRYRUN_ONE_GPU') == '1'

@@ -166,24 +166,6 @@ int ifh_rtpjb_push_batch(ifh_rtpjb_t h, const uint8_t *buf, const int32_t *off, 
 int ifh_rtpjb_pop_tick(ifh_rtpjb_t h, uint8_t *frames, int32_t *slots, int cap, int *n_out);
 int ifh_rtpjb_stats(ifh_rtpjb_t h, int stream, int64_t *stats /* [IFH_RTP_NSTATS] */);
 
-/* RTP egress: header synthesis for the [n][plen] payload matrix ifh_mux_encode_f32_u8 produces -- the reference's
- * `rsynth = RtpSynth(codec.crate, out_ft)` / `rsynth.next_pkt(out_psize, out_pt, pload=packet)` / `rsynth.skip(1)`
- * (RTP/RTPOutputWorker.py:88,104,136; third-party rtpsynth, PARITY UNPINNED: RFC 3550 header, sequence +1 and timestamp
- * +ts_step per packet, timestamp +ts_step per skipped frame, marker bit on the first packet and on the first one after a skip).
- * ifh_rtpsynth_create   ts_step = clock rate x ptime / 1000 (160); SSRC, first sequence number and timestamp of every call
- *                       are derived from seed (ifh_rtpsynth_set overrides them).
- * ifh_rtpsynth_next_batch  n calls (slots[i], or i when slots is NULL): has[i] == 0 -> the call sends nothing this tick and,
- *                       once it has started, its clock skips one frame; otherwise out[i] = 12-byte header + payload[i]
- *                       and out_len[i] = 12 + plen.  out is [n][12 + plen]. */
-typedef void *ifh_rtpsynth_t;
-int ifh_rtpsynth_create(int n_streams, int ts_step, uint64_t seed, ifh_rtpsynth_t *out);
-int ifh_rtpsynth_destroy(ifh_rtpsynth_t h);
-int ifh_rtpsynth_set(ifh_rtpsynth_t h, int stream, uint32_t ssrc, uint32_t seq, uint32_t ts, int marker);
-int ifh_rtpsynth_get(ifh_rtpsynth_t h, int stream, uint32_t *ssrc, uint32_t *seq, uint32_t *ts, int64_t *sent, int64_t *skipped);
-int ifh_rtpsynth_skip(ifh_rtpsynth_t h, int stream, int nframes);
-int ifh_rtpsynth_next_batch(ifh_rtpsynth_t h, const uint8_t *payload, const uint8_t *has, const int32_t *slots, int n,
-                            int plen, int pt, uint8_t *out, int32_t *out_len);
-
 /* ---------------------------------------------------------------------------------
  * Output mix + encode    replaces Core/OutputMuxer.py:75-85 (OutputMTMuxer.idle mix: zero-pad,
  *                        sum in track order, divide by the number of tracks) + G711Codec.encode, for n calls at once.
@@ -371,7 +353,8 @@ typedef struct ifh_conv_desc {
                             * (order-preserving bits of the largest value << 32) | (0xffffffff - its column) -- the greedy pick of a
                             * vocabulary head without a second pass over the logits (Cluster/InfernLLMWorker.py:103-119: generate()'s
                             * arg-max).  Ties go to the lowest column.  Only where ifh_conv_argmax_supported says so (a wide f32-output
-                            * matrix product of 17..64 rows without bias / activation / residual); ifh_argmax_keys_finish turns the
+                            * matrix product of 17..64 rows without bias / activation / residual; a folded normalisation of the A rows
+                            * (aln_stats) must be the RMS form, ln_rms = 1 -- IFH_EINVAL otherwise); ifh_argmax_keys_finish turns the
                             * keys into token ids and zeroes them again */
     int32_t whole_chip;    /* 1: a persistent kernel taking this launch (the 256 x 256 GEMM) uses every CU even when ifh_set_cu_budget
                             * reserves some for other stages -- for a caller that runs alone on the device for the moment (the LLM's
@@ -707,32 +690,6 @@ int ifh_stream_destroy(ifh_stream_t stream);
 /* persistent kernels (one workgroup per CU: ifh_resblock_chain_bf16, ifh_conv_ring256_bf16) size their grids to n CUs instead of
  * the device's count; 0 restores the device's count.  Process-wide. */
 int ifh_set_cu_budget(int n);
-
-/* ---- resident decode step (step.hip) ----
- * One launch per SpeechT5 decoder step (HelloSippyTTSRT/HelloSippyRTPipe.py:196-229 loops 16 of them per infer() call) instead of
- * the ~55 dependent launches of the step's GEMMs, attentions and stop rule.  The step is RECORDED once: between
- * ifh_step_record_begin(stat_rows) and ifh_step_record_end() the calling thread's ifh_conv_bf16 / ifh_attn_decode_bf16 /
- * ifh_tts_stop_advance_rows calls are appended to a phase table instead of being launched (stat_rows = rows per slot of the
- * LayerNorm statistics array the stop rule clears).  ifh_step_run() then runs the table: row blocks of 32 rows, each walked through
- * all phases by a cluster of `cw` workgroups that synchronise through arrival flags of the context (no grid-wide barrier: every
- * operation of the step is row-local).  Same bits as the launch chain.  A context serves one decode state on one stream. */
-typedef void *ifh_step_prog_t;
-typedef void *ifh_step_ctx_t;
-int ifh_step_record_begin(int stat_rows);
-int ifh_step_record_abort(void);
-int ifh_step_record_end(ifh_step_prog_t *prog_out, int *nphase_out);
-int ifh_step_prog_destroy(ifh_step_prog_t prog);
-int ifh_step_ctx_create(int max_rows, ifh_step_ctx_t *ctx_out);
-int ifh_step_ctx_destroy(ifh_step_ctx_t ctx);
-/* synchronises the device; *err_out = 1 when a cluster wait ran into its 2 s bound (the clusters were not co-resident: results of
- * that launch are garbage; the counters are cleared); xcc_out (optional, n_xcc ints) = the XCC id each workgroup of the last
- * launch with debug_xcc ran on */
-int ifh_step_ctx_status(ifh_step_ctx_t ctx, int *err_out, int *xcc_out, int n_xcc);
-/* cw = workgroups per cluster (1..32).  debug bit 0: record the XCC ids; bit 1: accumulate cluster 0's per-phase clock ticks (read
- * and cleared by ifh_step_ctx_prof: out256[2 ph] = 100 MHz ticks spent waiting for the cluster in front of phase ph,
- * out256[2 ph + 1] = in the phase); bit 2: write-through hand-offs even when the cluster shares one XCD (test of that path) */
-int ifh_step_run(ifh_step_prog_t prog, ifh_step_ctx_t ctx, int cw, int debug, ifh_stream_t stream);
-int ifh_step_ctx_prof(ifh_step_ctx_t ctx, unsigned long long *out256);
 
 #ifdef __cplusplus
 }

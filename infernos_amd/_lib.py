@@ -38,12 +38,6 @@ SIGNATURES = {
     'ifh_rtpjb_push_batch': (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     'ifh_rtpjb_pop_tick': (_i, [_vp, _vp, _vp, _i, c_i32p]),
     'ifh_rtpjb_stats': (_i, [_vp, _i, _vp]),
-    'ifh_rtpsynth_create': (_i, [_i, _i, ctypes.c_uint64, ctypes.POINTER(_vp)]),
-    'ifh_rtpsynth_destroy': (_i, [_vp]),
-    'ifh_rtpsynth_set': (_i, [_vp, _i, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, _i]),
-    'ifh_rtpsynth_get': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
-    'ifh_rtpsynth_skip': (_i, [_vp, _i, _i]),
-    'ifh_rtpsynth_next_batch': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'ifh_vad_energy_prob': (_i, [_vp, _vp, _i, _vp, _vp]),
     'ifh_vadnet_weight_floats': (_i, []),
     'ifh_vadnet_prob': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -207,15 +201,6 @@ SIGNATURES.update({
     'ifh_stream_create_cu_range': (_i, [_i, _i, ctypes.POINTER(ctypes.c_void_p)]),
     'ifh_stream_destroy': (_i, [_vp]),
     'ifh_set_cu_budget': (_i, [_i]),
-    'ifh_step_record_begin': (_i, [_i]),
-    'ifh_step_record_abort': (_i, []),
-    'ifh_step_record_end': (_i, [ctypes.POINTER(ctypes.c_void_p), c_i32p]),
-    'ifh_step_prog_destroy': (_i, [_vp]),
-    'ifh_step_ctx_create': (_i, [_i, ctypes.POINTER(ctypes.c_void_p)]),
-    'ifh_step_ctx_destroy': (_i, [_vp]),
-    'ifh_step_ctx_status': (_i, [_vp, c_i32p, c_i32p, _i]),
-    'ifh_step_run': (_i, [_vp, _vp, _i, _i, _vp]),
-    'ifh_step_ctx_prof': (_i, [_vp, ctypes.POINTER(ctypes.c_uint64)]),
 })
 
 _lib = None
@@ -223,7 +208,7 @@ _lock = threading.Lock()
 # Statistic: calls into stream-taking entry points (~ kernel launches issued through the C ABI), including those replayed from
 # captured hipGraphs (CountedGraph); bench.py reports it per utterance cycle.
 CALLS = [0]
-_HOST_ONLY = ('ifh_g711_tables_host', 'ifh_step_prog_destroy', 'ifh_step_ctx_destroy')
+_HOST_ONLY = ('ifh_g711_tables_host',)
 
 
 _tls = threading.local()
@@ -241,6 +226,29 @@ def _counted(fn):
     return call
 
 
+# Captures and graph destruction never overlap: torch's ~CUDAGraph ends with a device-wide synchronisation (ROCm >= 6.2), which HIP
+# refuses while a stream of the process is capturing -- inside a destructor that is std::terminate, i.e. abort() of the whole serving
+# process, with no message (round 6: a dead pipeline's graphs reached the garbage collector on the main thread while an engine
+# thread of the live one was capturing a decoder step; found under rocgdb).  So a CountedGraph never lets its graph die where the
+# collector happens to find it: __del__ parks it, and parked graphs are destroyed under the lock every capture takes.
+_graph_lock = threading.RLock()
+_graveyard = []
+
+
+def _drain_graveyard():
+    """destroy parked graphs; the caller holds _graph_lock"""
+    while _graveyard:
+        g = _graveyard.pop()
+        del g
+
+
+def release_graphs():
+    """Destroy the hipGraphs of CountedGraph objects that are no longer referenced (SpeechPipeline.close() calls this).  Blocks while
+    another thread captures."""
+    with _graph_lock:
+        _drain_graveyard()
+
+
 class CountedGraph:
     """hipGraph of the launches `fn` issues on the current stream (thread-local capture), remembering how many C-ABI calls
     it holds so that replays keep the CALLS statistic meaningful.  The count is this thread's own: launches other threads
@@ -250,25 +258,43 @@ class CountedGraph:
 
     def __init__(self, fn):
         import torch
-        CountedGraph.captures[0] += 1
-        torch.cuda.synchronize()
-        self.g = torch.cuda.CUDAGraph()
-        prev, cap = getattr(_tls, 'cap', None), [0]
-        _tls.cap = cap
-        try:
-            with torch.cuda.graph(self.g, capture_error_mode='thread_local'):      # records the launches; nothing executes until replay
-                fn()
-        finally:
-            _tls.cap = prev
-        self.n = cap[0]
+        with _graph_lock:
+            _drain_graveyard()
+            CountedGraph.captures[0] += 1
+            torch.cuda.synchronize()
+            self.g = torch.cuda.CUDAGraph()
+            prev, cap = getattr(_tls, 'cap', None), [0]
+            _tls.cap = cap
+            try:
+                with torch.cuda.graph(self.g, capture_error_mode='thread_local'):      # records the launches; nothing executes until replay
+                    fn()
+            finally:
+                _tls.cap = prev
+            self.n = cap[0]
 
     def replay(self):
         self.g.replay()
         CALLS[0] += self.n
 
+    def __del__(self):
+        try:
+            g = self.__dict__.pop('g', None)
+            if g is not None:
+                _graveyard.append(g)
+        except Exception:           # interpreter shutdown: the module's globals may be gone
+            pass
+
 
 class InfernosHipError(RuntimeError):
-    pass
+    """A failed library call.  `code` is the entry point's return value (IFH_EINVAL = -1: the call was declined before anything was
+    launched; IFH_EHIP = -2: a HIP error), None where no call was made."""
+
+    def __init__(self, msg, code=None):
+        super().__init__(msg)
+        self.code = code
+
+
+IFH_EINVAL, IFH_EHIP = -1, -2
 
 
 def lib():
@@ -299,7 +325,7 @@ def lib():
 def check(rc, what=''):
     if rc != 0:
         msg = lib().ifh_last_error()
-        raise InfernosHipError('%s failed (%d): %s' % (what or 'libinfernos_hip', rc, (msg or b'').decode()))
+        raise InfernosHipError('%s failed (%d): %s' % (what or 'libinfernos_hip', rc, (msg or b'').decode()), code=rc)
     return rc
 
 

@@ -38,11 +38,36 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _flags_stamp():
+    """the compile flags of every file as text: a changed flag (EXTRA_FLAGS, FLAGS) rebuilds, not only a changed source"""
+    return '\n'.join('%s: %s' % (os.path.basename(s), ' '.join(flags_for(s))) for s in sources()) + '\n'
+
+
 def build(force=False, verbose=True, jobs=None):
-    if not force and not needs_build():
-        return OUT
+    """Compile what is out of date and link.  Safe to call from several processes at once (the ranks of a multi-GPU job all call
+    it): one holds build/.lock and compiles, the others wait for it and find the library up to date."""
+    import fcntl
     objdir = os.path.join(HERE, 'build')
     os.makedirs(objdir, exist_ok=True)
+    with open(os.path.join(objdir, '.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose, jobs, objdir)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose, jobs, objdir):
+    stamp_path = os.path.join(objdir, 'flags.txt')
+    stamp = _flags_stamp()
+    old_stamp = open(stamp_path).read() if os.path.exists(stamp_path) else None
+    if old_stamp != stamp:
+        # built with other flags: only on a tree whose objects are older than this check (no stamp yet) are they trusted
+        force = force or old_stamp is not None
+    if not force and not needs_build():
+        if old_stamp is None:
+            open(stamp_path, 'w').write(stamp)
+        return OUT
     procs = []
     objs = []
     jobs = jobs or min(6, os.cpu_count() or 1)
@@ -70,6 +95,7 @@ def build(force=False, verbose=True, jobs=None):
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
+    open(stamp_path, 'w').write(stamp)
     return OUT
 
 

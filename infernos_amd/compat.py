@@ -31,7 +31,6 @@ MAP = {
     'safetorch.InfernTorcher': ('infernos_amd.torcher', ['InfernTorcher', 'InfernTorcherDeadlock', 'rc_filter']),
     'config.InfernGlobals': ('infernos_amd.torcher', ['InfernGlobals']),
     'rtpsynth.RtpJBuf': ('infernos_amd.rtp', ['RtpJBuf', 'RTPFrameType', 'RTPParseError']),
-    'rtpsynth.RtpSynth': ('infernos_amd.rtp', ['RtpSynth']),
 }
 
 

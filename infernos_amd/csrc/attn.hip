@@ -923,7 +923,9 @@ extern "C" int ifh_attn_prefill_bf16(const ifh_attn_desc *d, ifh_stream_t stream
     if (fits2 && !d->relbias && d->tq <= 16 && (forcef < 0 ? d->tk >= 256 : forcef > 0)) {
         // (IFH_ATTN_FEW_RING: buffers per wave, 2 .. 4; tuning switch)
         const char *envr = getenv("IFH_ATTN_FEW_RING");
-        const int ring = envr && *envr ? atoi(envr) : 4;        // alone: 2 -> 76 us, 3 -> 91 (768 slots for 1 024 workgroups), 4 -> 77; C3: NOTES
+        // alone: 2 -> 76 us, 3 -> 91 (768 slots for 1 024 workgroups), 4 -> 77 (its fourth tile makes 64 LDS-DMA pieces outstanding
+        // against a 6-bit vmcnt: never fully ahead); C3 equal within the spread for all three: the smallest ring, 32 KB per wave
+        const int ring = envr && *envr ? atoi(envr) : 2;
         const dim3 gridf(1, d->nheads, d->nbatch);
         if (ring == 2) hipLaunchKernelGGL(k_attn_prefill_few<2>, gridf, dim3(64), 0, as_stream(stream), p);
         else if (ring == 4) hipLaunchKernelGGL(k_attn_prefill_few<4>, gridf, dim3(64), 0, as_stream(stream), p);
@@ -948,8 +950,6 @@ static int attn_decode_launch(const void *q, int64_t q_bs, const void *k, const 
     IFH_CHECK_ARG(q && k && v && out && nheads > 0 && head_dim == HD && max_keys >= 1 && kv_group >= 1);
     IFH_CHECK_ARG(q_bs % 8 == 0 && kv_bs % 8 == 0 && kv_ts % 8 == 0 && o_bs % 8 == 0 && nbatch < 65536);
     IFH_CHECK_ARG(kv_group == 1 || !key_len);       // per-row key counts belong to query rows, not to shared cache rows
-    if (step_recording())
-        return step_record_attn(q, q_bs, k, v, kv_bs, kv_ts, out, o_bs, key_len, max_keys, nbatch, nheads, dyn_len, dyn_add, kv_group);
     dim3 grid(nheads, nbatch);
     // 4 waves per (batch, head) for long caches (measured faster from ~160 keys up) -- and for EVERY growing cache (a decode
     // loop's self-attention: dyn_len, or per-row positions key_len + dyn_add): the waves' partial softmaxes are merged in a

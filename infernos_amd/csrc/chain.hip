@@ -732,7 +732,7 @@ extern "C" int ifh_conv_ring256_bf16(const ifh_ring256_desc *d, ifh_stream_t str
     const int ncu = device_cu_count();
     if (ncu <= 0) return fail(IFH_EHIP, "conv_ring256: device query");
     const int reach = (d->taps - 1) / 2 * d->dil;
-    static const bool no3 = getenv("IFH_RING256_NO3") != nullptr;            // tuning switch
+    constexpr bool no3 = false;            // fixed by measurement (profiles/NOTES.md)
     if (reach <= 8 && !no3 && d->nbatch >= 3 * ncu) {
         constexpr size_t bytes = (size_t)(160 + 16) * 544 + 4 * 16384 + 256 * sizeof(float);
         static_assert(bytes <= 160 * 1024, "ring256 tile");

@@ -71,14 +71,6 @@ static inline int device_cu_count_physical()
     return prop.multiProcessorCount;
 }
 
-// step.hip: while the calling thread records a resident decode step (ifh_step_record_begin), decode-step launches are appended
-// to its phase table instead of being launched.  step_recording() is false everywhere else.
-bool step_recording();
-int step_record_attn(const void *q, int64_t q_bs, const void *k, const void *v, int64_t kv_bs, int64_t kv_ts, void *out, int64_t o_bs,
-                     const int32_t *key_len, int max_keys, int nbatch, int nheads, const int32_t *dyn_len, int dyn_add, int kv_group);
-int step_record_stop(const float *prob_logits, int64_t *ends_at, int n, float threshold, int ends_inc, int32_t *pos,
-                     const uint8_t *active, const int32_t *minmax, int logits_ld, void *zero_buf, int64_t zero_bytes);
-
 // vadnet.hip: one recurrent-VAD window step for n calls (window rows by slot, state rows [2][n][64] by call index, updated in place)
 void launch_vadnet_slots(const float *win, const int32_t *slot, int n, const float *weights, float *h, float *c, float *prob, hipStream_t st);
 

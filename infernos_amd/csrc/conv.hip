@@ -236,19 +236,19 @@ bool try_launch_conv_direct(const IgemmParams &p_, bool pre, hipStream_t st)
 {
     IgemmParams p = p_;
     if (p.dyn && p.dyn_stride != 0) return false;          // per-row dynamic offsets: the generic kernels (nn.hip)
-    static const bool no16 = getenv("IFH_CONV_NO_STORE16") != nullptr;      // tuning switch
+    constexpr bool no16 = false;      // fixed by measurement (profiles/NOTES.md)
     p.store16 = !no16 && !p.out_f32 && (reinterpret_cast<uintptr_t>(p.out) & 15) == 0 && p.ldc % 8 == 0 &&
                 p.out_bstride % 8 == 0 && ((int64_t)p.ooff * p.ldc) % 8 == 0 && ((int64_t)p.ostride * p.ldc) % 8 == 0 &&
                 (p.dyn == nullptr || ((int64_t)p.dyn_ooff_mul * p.ldc) % 8 == 0);
     (void)pre;
-    static const int mask = getenv("IFH_DIRECT_CONV_MASK") ? atoi(getenv("IFH_DIRECT_CONV_MASK")) : 15;   // tuning switch
+    constexpr int mask = 15;   // fixed by measurement (profiles/NOTES.md)
     if (!((p.Cin == 256 && (mask & 1)) || (p.Cin == 128 && (mask & 2)) || (p.Cin == 64 && (mask & 4)) || (p.Cin == 32 && (mask & 8))))
         return false;
     if (p.stride != 1 || p.taps < 2 || p.N != p.Cin || p.n_split != 0 || !p.fast_epi) return false;
     if (p.T_out != p.T_in + 2 * p.pad - (p.taps - 1) * p.dil) return false;
     if (p.nbatch >= 65536) return false;
-    static const int epb = getenv("IFH_CONV_EPB") ? atoi(getenv("IFH_CONV_EPB")) : 2;       // tuning switch
-    static const int kc = getenv("IFH_DIRECT_KC") ? atoi(getenv("IFH_DIRECT_KC")) : 64;      // tuning switch
+    constexpr int epb = 2;       // fixed by measurement (profiles/NOTES.md)
+    constexpr int kc = 64;      // fixed by measurement (profiles/NOTES.md)
     switch (p.Cin) {
     case 256:                                                                        // BM 48  x BN 256
         if (p.T_out < 32) return false;

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_big(const GemmBigParams p)
 // true if it took the launch: plain matrix product, whole tiles, bf16 output, epilogue = bias / GELU or ReLU / residual
 bool try_launch_gemm_big(const IgemmParams &p, bool pre, hipStream_t st, float *ws, int64_t ws_floats)
 {
-    static const int min_rows = getenv("IFH_GEMM_BIG_ROWS") ? atoi(getenv("IFH_GEMM_BIG_ROWS")) : 4096;        // tuning switch (0x7fffffff: off)
+    constexpr int min_rows = 4096;        // fixed by measurement (profiles/NOTES.md) (0x7fffffff: off)
     const int64_t M = (int64_t)p.nbatch * p.T_out;
     if (pre || p.taps != 1 || p.stride != 1 || p.pad != 0 || p.T_out != p.T_in || M < min_rows || M % GB_BM || p.N % GB_BN || p.K % GB_BK ||
         p.K < 2 * GB_BK)
@@ -225,7 +225,7 @@ bool try_launch_gemm_big(const IgemmParams &p, bool pre, hipStream_t st, float *
 #endif
     // IFH_GEMM_BIG_LDS (tuning switch): request that many bytes of LDS instead -- above 80 KB a CU holds ONE workgroup of this kernel
     // and half of its registers stay free for the decode chains' workgroups
-    static const size_t lds_req = getenv("IFH_GEMM_BIG_LDS") ? (size_t)atoll(getenv("IFH_GEMM_BIG_LDS")) : 0;
+    constexpr size_t lds_req = 0;
     const size_t bytes = lds_req > (size_t)GB_STAGES * GB_STAGE_BYTES ? lds_req : (size_t)GB_STAGES * GB_STAGE_BYTES;
     static DeviceOnce attr_once;
     int attr_dev = 0;

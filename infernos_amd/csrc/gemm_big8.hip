@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void k_big8_split_finish(const GemmBig8Params 
 // true if it took the launch (try_launch_gemm_big has checked the epilogue and the views; here: whole 256 x 256 tiles, K in 128s)
 bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st, float *ws, int64_t ws_floats)
 {
-    static const int on = getenv("IFH_GEMM_BIG8") ? atoi(getenv("IFH_GEMM_BIG8")) : 1;      // tuning switch: 0 = the 256 x 128 kernel
+    constexpr int on = 1;      // fixed by measurement (profiles/NOTES.md): 0 = the 256 x 128 kernel
     if (!on || M % G8_BM || p.N % G8_BN || p.K % (2 * G8_DK) || p.K < 4 * G8_DK) return false;
     GemmBig8Params g;
     g.x = p.x; g.lda = p.lda; g.w = p.w; g.bias = p.bias; g.resid = p.resid; g.ldr = p.resid_ld;
@@ -499,7 +499,7 @@ bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st, float
     // one workgroup per CU of the budget the process has set for persistent kernels (ifh_set_cu_budget: inside the speech pipeline the
     // encoder's products measured 1.7 % better on the vocoder's 160 than on all 256), or of the device if the caller says it runs alone
     // (ifh_conv_desc.whole_chip: the LLM's prompt pass -- C5 share turn 129.6 -> 120 ms); IFH_GEMM_BIG8_CUS (tuning switch): that many
-    static const int cus_env = getenv("IFH_GEMM_BIG8_CUS") ? atoi(getenv("IFH_GEMM_BIG8_CUS")) : 0;
+    constexpr int cus_env = 0;
     int grid = (cus_env > 0 ? cus_env : (p.whole_chip ? device_cu_count_physical() : device_cu_count())) & ~7;
     if (grid < 8) grid = 8;
     if (grid > total) grid = total < 8 ? total : (total & ~7);
@@ -514,7 +514,7 @@ bool try_launch_gemm_big8(const IgemmParams &p, int64_t M, hipStream_t st, float
     // finishing pass; 288 tiles of the LLM prompt's down projection on 256 CUs: 2 tile times -> 1.14 + the pass.
     int nleft = 0;
     if (ws && (((uintptr_t)ws) & 15) == 0 && total > grid) {
-        static const int split_on = getenv("IFH_GEMM_BIG8_SPLIT") ? atoi(getenv("IFH_GEMM_BIG8_SPLIT")) : 1;      // tuning switch
+        constexpr int split_on = 1;      // fixed by measurement (profiles/NOTES.md)
         const int L = total % grid, nst = g.K / G8_DK;
         if (split_on && L > 0 && 2 * L <= grid) {
             int S = 1;

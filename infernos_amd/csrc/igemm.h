@@ -360,8 +360,6 @@ __device__ __forceinline__ void ln_epi4(const IgemmParams &p, int m, int n, bool
     }
 }
 
-// step.hip (see common.h: step_recording): a decode-step GEMM is appended to the phase table being recorded
-int step_record_gemm(const IgemmParams &p);
 
 // conv.hip: LDS-resident-input convolution for the stride-1 residual-block shapes.
 // Returns true if it took the launch.

@@ -813,7 +813,7 @@ extern "C" int ifh_attn_gqa_bf16(const ifh_gqa_desc *d, ifh_stream_t stream)
     IFH_CHECK_ARG(!d->rope_cos_sin || (d->tokens_per_row == 1 && d->head_dim == 128 && (((uintptr_t)d->rope_cos_sin) & 15) == 0));
     hipStream_t st = as_stream(stream);
     // a decode step at head_dim 128: one workgroup per (token, kv head), the group's heads as the query rows of the matrix-core layout
-    static const int dec_mfma = getenv("IFH_GQA_DECODE_MFMA") ? atoi(getenv("IFH_GQA_DECODE_MFMA")) : 1;       // tuning switch
+    constexpr int dec_mfma = 1;       // fixed by measurement (profiles/NOTES.md)
     if (dec_mfma && d->tokens_per_row == 1 && d->head_dim == 128) {
         constexpr int bytes = 4 * 2 * 32 * 136 * 2;
         static DeviceOnce attr_once;
@@ -836,7 +836,7 @@ extern "C" int ifh_attn_gqa_bf16(const ifh_gqa_desc *d, ifh_stream_t stream)
         return IFH_OK;
     }
     // a prompt (16 or more tokens per row): the matrix-core kernel, 16 query tokens x G heads per workgroup
-    static const int mfma_on = getenv("IFH_GQA_PREFILL_MFMA") ? atoi(getenv("IFH_GQA_PREFILL_MFMA")) : 1;       // tuning switch
+    constexpr int mfma_on = 1;       // fixed by measurement (profiles/NOTES.md)
     if (mfma_on && d->tokens_per_row >= 16 && d->ntokens % d->tokens_per_row == 0) {
         const dim3 grid((unsigned)((d->tokens_per_row + 15) / 16), (unsigned)d->nkv, (unsigned)(d->ntokens / d->tokens_per_row));
         if (d->head_dim == 128)
@@ -850,7 +850,7 @@ extern "C" int ifh_attn_gqa_bf16(const ifh_gqa_desc *d, ifh_stream_t stream)
     }
     // query heads per workgroup: the whole group while that fills the chip twice over, else the largest divisor of G that does (a
     // decode step: few tokens); IFH_GQA_GS overrides (tuning switch)
-    static const int gs_env = getenv("IFH_GQA_GS") ? atoi(getenv("IFH_GQA_GS")) : 0;
+    constexpr int gs_env = 0;
     int gs = G;
     if (gs_env > 0 && G % gs_env == 0)
         gs = gs_env;

@@ -378,8 +378,6 @@ extern "C" int ifh_tts_stop_advance_rows(const float *prob_logits, int64_t *ends
     IFH_CHECK_ARG(n >= 0 && prob_logits && ends_at && pos && active && minmax && logits_ld >= 2);
     IFH_CHECK_ARG(zero_bytes >= 0 && zero_bytes % 16 == 0 && zero_bytes < (1ll << 30) && (zero_bytes == 0 || zero_buf));
     IFH_CHECK_ARG((((uintptr_t)zero_buf) & 15) == 0);
-    if (step_recording())
-        return step_record_stop(prob_logits, ends_at, n, threshold, ends_inc, pos, active, minmax, logits_ld, zero_buf, zero_bytes);
     // a few blocks: the statistics of a 1024-row step are 300 KB to clear
     hipLaunchKernelGGL(k_tts_stop_advance_rows, dim3(zero_bytes > 65536 ? 8 : 1), dim3(256), 0, as_stream(stream), prob_logits,
                        ends_at, n, threshold, ends_inc, pos, active, minmax, logits_ld, (uint4 *)zero_buf, (int)(zero_bytes / 16));

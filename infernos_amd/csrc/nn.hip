@@ -642,7 +642,8 @@ __global__ __launch_bounds__(256) void k_gemm_m64(const IgemmParams p)
         for (int w = 0; w < NW; w++) s += *reinterpret_cast<const f32x4 *>(&red[w][tile][lane][0]);
         const int m = 16 * (tile % MT) + fr, n = n0 + 16 * (tile / MT) + 4 * fg;
         if (p.amax_keys && m < M) {
-            // (the launcher admits no bias / activation / residual / scale here: s is what igemm_store4 stores)
+            // (the launcher admits no bias / activation / residual / scale here, and of the folded normalisations only the RMS form: s is
+            // what igemm_store4 stores up to a positive factor per row, so its order is the stored values' order)
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 if (n + e < p.N) {
@@ -1076,7 +1077,7 @@ static int launch_igemm(const IgemmParams &p, bool pre, hipStream_t st)
     const int M = p.nbatch * p.T_out;
     const int64_t tiles = (int64_t)((M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
     dim3 grid((unsigned)(((tiles + 7) / 8) * 8));          // 1-D, a multiple of 8: see the tile map at the top of k_igemm
-    static const bool no_plain = getenv("IFH_IGEMM_NO_PLAIN") != nullptr;     // tuning switch
+    constexpr bool no_plain = false;     // fixed by measurement (profiles/NOTES.md)
     const bool plain = p.fast_epi && !pre && p.taps == 1 && p.stride == 1 && p.pad == 0 && p.K % KT == 0 && p.T_out <= p.T_in && !p.zt_cout;
     if (p.aln_stats) {                       // the caller (ifh_conv_bf16) has checked `plain` and the tile shape
         if (BM == 128 && BN == 128 && NWV == 4 && KT == 32)
@@ -1106,7 +1107,7 @@ using namespace ifh;
 
 static int igemm_aln_rows()
 {
-    static const int v = getenv("IFH_IGEMM_ALN_ROWS") ? atoi(getenv("IFH_IGEMM_ALN_ROWS")) : 256;      // tuning switch
+    constexpr int v = 256;      // fixed by measurement (profiles/NOTES.md)
     return v;
 }
 
@@ -1215,7 +1216,6 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
     const int64_t M = (int64_t)d->nbatch * d->t_out;
     IFH_CHECK_ARG(M < (1ll << 31));
     hipStream_t st = as_stream(stream);
-    if (step_recording()) return step_record_gemm(p);        // resident decode step (step.hip): a phase, not a launch
     const bool ln_fold = d->aln_stats || d->rln_stats || d->stats_out;
     const bool aln_only = d->aln_stats && !d->rln_stats && !d->stats_out;     // k_gemm_m64 can consume row statistics, not produce them
     const bool glu = d->act == IFH_ACT_SILU_GLU;
@@ -1234,9 +1234,12 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
                       d->out_scale == 1.0f && !d->rln_stats && !d->stats_out && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre);
     const bool wide_m64 = M <= 64 && M > 16 && d->taps == 1 && d->stride == 1 && d->pad == 0 && !pre && (!ln_fold || aln_only) && d->n >= 8192 &&
                           ((int64_t)d->n * p.K >= (int64_t)4096 * 1024 || glu);
-    if (d->argmax_keys)       // arg-max keys exist in k_gemm_m64's epilogue only, on the values as stored (ifh_conv_argmax_supported)
+    if (d->argmax_keys)       // arg-max keys exist in k_gemm_m64's epilogue only, on the values as stored (ifh_conv_argmax_supported).  A folded
+                              // normalisation must be the RMS form: k_gemm_m64 takes the keys from the raw sums, which a positive per-row
+                              // scale leaves in order and a LayerNorm fold's per-column mean term does not (k_gemm_m64d keys the stored values)
         IFH_CHECK_ARG(wide_m64 && !glu && d->out_f32 && !d->bias && !d->resid && !d->accumulate && !d->colmask && d->act == IFH_ACT_NONE &&
-                      d->out_scale == 1.0f && d->n_split == 0 && d->nbatch == 1 && (((uintptr_t)d->argmax_keys) & 7) == 0);
+                      d->out_scale == 1.0f && d->n_split == 0 && d->nbatch == 1 && (((uintptr_t)d->argmax_keys) & 7) == 0 &&
+                      (!d->aln_stats || d->ln_rms));
     if (wide_m64) {
         // LLM-sized wide layer at decode batch (gate|up 17920 x 1536, the vocabulary head): every weight byte once
         // (k_gemm_m64).  Narrow deep layers (down 1536 x 8960: 96 column tiles) stay with the 16 x 16-tile kernel below:
@@ -1267,15 +1270,15 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         // flight (SpeechPipeline TTS lanes) fewer, longer waves beat 4/8 short ones by ~6 % end to end; alone the
         // launch takes the same time either way.  Above 64 rows a block takes two row tiles per weight fragment
         // (same K split, hence the same bits): the step time grows by the L2 re-reads of W per 16-row tile.
-        static const bool one_tile = getenv("IFH_SKINNY_MT1") != nullptr;              // tuning switch
+        constexpr bool one_tile = false;              // fixed by measurement (profiles/NOTES.md)
         // From a few hundred rows up the step is no longer launch-bound and the streaming kernel's L2 traffic (all of W per 32
         // rows) is what a launch costs: the LDS-tiled kernel with the same accumulation chains takes over (same bits).
-        static const int dec_rows = getenv("IFH_GEMM_DEC_ROWS") ? atoi(getenv("IFH_GEMM_DEC_ROWS")) : 128;   // tuning switch
+        constexpr int dec_rows = 128;   // fixed by measurement (profiles/NOTES.md)
         // a deep narrow layer at decode batch (the LLM's down projection: 1536 x 8960 at 64 rows) is 96 x 4 workgroups of the
         // streaming kernel re-reading 4 x the weights and 96 x the activations from L2 (34 us for 27.5 MB of weights): the LDS-tiled
         // kernel with one of the four accumulation chains per workgroup (blockIdx.z) + a finishing pass -- the same chains added in
         // the same order, hence the same bits
-        static const int splitk_on = getenv("IFH_GEMM_SPLITK") ? atoi(getenv("IFH_GEMM_SPLITK")) : 1;        // tuning switch
+        constexpr int splitk_on = 1;        // fixed by measurement (profiles/NOTES.md)
         if (splitk_on && M > 16 && M <= 64 && p.K >= 4096 && p.K % 32 == 0 && d->n % 32 == 0 && d->n >= 512 && p.vec_ok && !glu) {
             // whole-line DMA form (gemm_m64d.hip): as many K parts as the caller's workspace holds, one chain each, added in part order
             // by the same finishing pass (its sums differ in the last bits from the four-chain forms below)
@@ -1322,7 +1325,7 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
                 IFH_LAUNCH_CHECK("conv_bf16");
                 return IFH_OK;
             }
-            static const int64_t bm32_max = getenv("IFH_GEMM_DEC_BM32") ? atoll(getenv("IFH_GEMM_DEC_BM32")) : 200;   // tuning switch: 32-row tiles up to this many 64 x 32 workgroups (pipelined C3, three alternating runs each: 0 -> 10 006 x, 100 -> 10 001, 150 -> 10 177-10 279, 200 -> 10 313-10 326, 300 -> 10 194, 500 -> 10 101)
+            constexpr int64_t bm32_max = 200;   // fixed by measurement (profiles/NOTES.md): 32-row tiles up to this many 64 x 32 workgroups (pipelined C3, three alternating runs each: 0 -> 10 006 x, 100 -> 10 001, 150 -> 10 177-10 279, 200 -> 10 313-10 326, 300 -> 10 194, 500 -> 10 101)
             if (t64 >= 200)
                 hipLaunchKernelGGL((k_gemm_dec<64>), dim3((M + 63) / 64, (d->n + 63) / 64), dim3(256), 0, st, p, ksplit);
             else if (((M + 63) / 64) * ((d->n + 31) / 32) <= bm32_max)
@@ -1335,8 +1338,8 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
             // co-resident at 200 registers) take the half-depth load batch: 128 registers, twice the blocks per CU --
             // ff1 20.2 -> 15.4 us, qkv 14.6 -> 13.1 us at 256 rows, same bits (the k order of a wave is unchanged).
             // Measured without effect on the deep-K GEMM (ff2, 19 us at 256 rows): 8 waves, one row tile, shallower batches.
-            static const bool u6 = getenv("IFH_SKINNY_U6") ? atoi(getenv("IFH_SKINNY_U6")) != 0 : true;      // tuning switch
-            static const int nt2 = getenv("IFH_SKINNY_NT2") ? atoi(getenv("IFH_SKINNY_NT2")) : 3;            // tuning switch: bit 0 deep K, bit 1 big grids
+            constexpr bool u6 = true;      // fixed by measurement (profiles/NOTES.md)
+            constexpr int nt2 = 3;            // fixed by measurement (profiles/NOTES.md): bit 0 deep K, bit 1 big grids
             const bool big = (int64_t)grid2.x * grid2.y > 1024;
             const dim3 grid3((d->n + 31) / 32, (unsigned)((M + 31) / 32));
             if (p.K >= 2048) {
@@ -1371,12 +1374,12 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
         const int64_t mt = (M + 127) / 128;
         // thousands of row tiles (encoders, prefill): the 256 x 128 tile of eight waves moves a quarter fewer operand bytes per
         // FLOP through L2 -> CU, which is what these GEMMs wait for at K = 512..2048 (same k order per element: same bits)
-        static const int big_rows = getenv("IFH_IGEMM_256_ROWS") ? atoi(getenv("IFH_IGEMM_256_ROWS")) : 0x7fffffff;   // tuning switch: measured SLOWER (encoder 30.0 vs 28.2 ms), off
+        constexpr int big_rows = 0x7fffffff;   // fixed by measurement (profiles/NOTES.md): measured SLOWER (encoder 30.0 vs 28.2 ms), off
         if (M >= big_rows && (mt / 2) * ((d->n + 127) / 128) >= 512)
             launch_igemm<256, 128, 4, 8>(p, pre, st);
         else if (mt * ((d->n + 127) / 128) >= 256) {
             // three or more tiles per workgroup slot: 128-byte row pieces (KT = 64), +9-12 % at the Whisper-base encoder shapes
-            static const int kt64_rows = getenv("IFH_IGEMM_KT64_ROWS") ? atoi(getenv("IFH_IGEMM_KT64_ROWS")) : 0;
+            constexpr int kt64_rows = 0;
             if (M >= kt64_rows && p.Cin % 64 == 0 && mt * ((d->n + 127) / 128) >= 3 * 768)
                 launch_igemm<128, 128, 2, 4, 64>(p, pre, st);
             else

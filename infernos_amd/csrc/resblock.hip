@@ -413,9 +413,9 @@ extern "C" int ifh_resblock_pair_bf16(const ifh_resblock_desc *d, ifh_stream_t s
     p.out = (uint16_t *)d->out;
     p.out_bstride = d->out_bstride;
     hipStream_t st = as_stream(stream);
-    static const int nwv8 = getenv("IFH_PAIR_NWV8") ? atoi(getenv("IFH_PAIR_NWV8")) : 1;      // tuning switch: 8-wave blocks at C = 128
-    static const int c64v = getenv("IFH_PAIR_C64V") ? atoi(getenv("IFH_PAIR_C64V")) : 1;      // tuning switch
-    static const int c32v = getenv("IFH_PAIR_C32V") ? atoi(getenv("IFH_PAIR_C32V")) : 1;      // tuning switch
+    constexpr int nwv8 = 1;      // fixed by measurement (profiles/NOTES.md): 8-wave blocks at C = 128
+    constexpr int c64v = 1;      // fixed by measurement (profiles/NOTES.md)
+    constexpr int c32v = 1;      // fixed by measurement (profiles/NOTES.md)
     int rc;
     switch (d->c) {                                                                // <C, WGM, MT1, NT, resident W, entries/block, residual rows in LDS>
     case 256: rc = launch_pair<256, 1, 4, 4, false, 1, true, 128>(p, st); break;   // conv1 64 rows, out 48; 128-wide weight chunks

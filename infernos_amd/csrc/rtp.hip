@@ -211,50 +211,6 @@ int push_one(RtpTable *t, int stream, const uint8_t *pkt, int len, Sink *out)
 
 RtpTable *as_table(ifh_rtpjb_t h) { return reinterpret_cast<RtpTable *>(h); }
 
-// ---- egress: RTP header synthesis per call (the reference's `RtpSynth(crate, ptime).next_pkt(...)`, RTPOutputWorker.py:88,136) ----
-struct SynthStream {
-    uint32_t ssrc = 0, ts = 0;
-    uint16_t seq = 0;
-    bool marker = true;         // first packet of a talkspurt
-    int64_t sent = 0, skipped = 0;
-};
-
-struct SynthTable {
-    int n = 0, ts_step = 0;
-    std::vector<SynthStream> st;
-};
-
-inline uint32_t mix32(uint64_t x)          // splitmix64 finaliser: per-call SSRC / initial sequence / timestamp from a seed
-{
-    x += 0x9e3779b97f4a7c15ull;
-    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
-    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
-    return (uint32_t)((x ^ (x >> 31)) >> 16);
-}
-
-inline void write_packet(SynthStream &ss, int ts_step, int pt, const uint8_t *payload, int plen, uint8_t *out)
-{
-    out[0] = 0x80;
-    out[1] = (uint8_t)((ss.marker ? 0x80 : 0) | (pt & 0x7f));
-    out[2] = (uint8_t)(ss.seq >> 8);
-    out[3] = (uint8_t)ss.seq;
-    out[4] = (uint8_t)(ss.ts >> 24);
-    out[5] = (uint8_t)(ss.ts >> 16);
-    out[6] = (uint8_t)(ss.ts >> 8);
-    out[7] = (uint8_t)ss.ts;
-    out[8] = (uint8_t)(ss.ssrc >> 24);
-    out[9] = (uint8_t)(ss.ssrc >> 16);
-    out[10] = (uint8_t)(ss.ssrc >> 8);
-    out[11] = (uint8_t)ss.ssrc;
-    if (payload) memcpy(out + 12, payload, (size_t)plen);
-    else memset(out + 12, 0, (size_t)plen);
-    ss.seq++;
-    ss.ts += (uint32_t)ts_step;
-    ss.marker = false;
-    ss.sent++;
-}
-
-SynthTable *as_synth(ifh_rtpsynth_t h) { return reinterpret_cast<SynthTable *>(h); }
 
 
 }  // namespace
@@ -403,98 +359,6 @@ int ifh_rtpjb_stats(ifh_rtpjb_t h, int stream, int64_t *stats)
     stats[IFH_RTP_STAT_FIFO_BYTES] = js.count;
     stats[IFH_RTP_STAT_HELD] = (int64_t)js.held.size();
     stats[IFH_RTP_STAT_LAST_LSEQ] = js.have_out ? js.last_lseq : -1;
-    return 0;
-}
-
-
-int ifh_rtpsynth_create(int n_streams, int ts_step, uint64_t seed, ifh_rtpsynth_t *out)
-{
-    IFH_CHECK_ARG(out != nullptr && n_streams >= 1 && ts_step >= 1);
-    SynthTable *t = new (std::nothrow) SynthTable();
-    if (!t) return fail(IFH_ENOMEM, "ifh_rtpsynth_create: out of host memory");
-    try {
-        t->n = n_streams;
-        t->ts_step = ts_step;
-        t->st.resize(n_streams);
-    } catch (const std::bad_alloc &) {
-        delete t;
-        return fail(IFH_ENOMEM, "ifh_rtpsynth_create: out of host memory");
-    }
-    for (int i = 0; i < n_streams; ++i) {
-        SynthStream &ss = t->st[i];
-        ss.ssrc = mix32(seed * 3 + (uint64_t)i * 0x10001ull);
-        ss.seq = (uint16_t)mix32(seed * 5 + (uint64_t)i * 0x10003ull + 1);
-        ss.ts = mix32(seed * 7 + (uint64_t)i * 0x10007ull + 2);
-    }
-    *out = t;
-    return 0;
-}
-
-int ifh_rtpsynth_destroy(ifh_rtpsynth_t h)
-{
-    delete as_synth(h);
-    return 0;
-}
-
-int ifh_rtpsynth_set(ifh_rtpsynth_t h, int stream, uint32_t ssrc, uint32_t seq, uint32_t ts, int marker)
-{
-    SynthTable *t = as_synth(h);
-    IFH_CHECK_ARG(t != nullptr && stream >= 0 && stream < t->n);
-    SynthStream &ss = t->st[stream];
-    ss.ssrc = ssrc;
-    ss.seq = (uint16_t)seq;
-    ss.ts = ts;
-    ss.marker = marker != 0;
-    return 0;
-}
-
-int ifh_rtpsynth_get(ifh_rtpsynth_t h, int stream, uint32_t *ssrc, uint32_t *seq, uint32_t *ts, int64_t *sent, int64_t *skipped)
-{
-    SynthTable *t = as_synth(h);
-    IFH_CHECK_ARG(t != nullptr && stream >= 0 && stream < t->n);
-    const SynthStream &ss = t->st[stream];
-    if (ssrc) *ssrc = ss.ssrc;
-    if (seq) *seq = ss.seq;
-    if (ts) *ts = ss.ts;
-    if (sent) *sent = ss.sent;
-    if (skipped) *skipped = ss.skipped;
-    return 0;
-}
-
-int ifh_rtpsynth_skip(ifh_rtpsynth_t h, int stream, int nframes)
-{
-    SynthTable *t = as_synth(h);
-    IFH_CHECK_ARG(t != nullptr && stream >= 0 && stream < t->n && nframes >= 0);
-    SynthStream &ss = t->st[stream];
-    ss.ts += (uint32_t)nframes * (uint32_t)t->ts_step;
-    ss.skipped += nframes;
-    if (nframes > 0) ss.marker = true;           // the next packet starts a talkspurt
-    return 0;
-}
-
-int ifh_rtpsynth_next_batch(ifh_rtpsynth_t h, const uint8_t *payload, const uint8_t *has, const int32_t *slots, int n,
-                            int plen, int pt, uint8_t *out, int32_t *out_len)
-{
-    SynthTable *t = as_synth(h);
-    IFH_CHECK_ARG(t != nullptr && n >= 0 && plen >= 0 && plen <= IFH_RTP_MAX_PAYLOAD && pt >= 0 && pt <= 127);
-    IFH_CHECK_ARG(n == 0 || (out != nullptr && out_len != nullptr));
-    const size_t ostride = 12 + (size_t)plen;
-    for (int i = 0; i < n; ++i) {
-        const int s = slots ? slots[i] : i;
-        IFH_CHECK_ARG(s >= 0 && s < t->n);
-        SynthStream &ss = t->st[s];
-        if (has && !has[i]) {                   // nothing to send for this call this tick (RTPOutputWorker.py:104: rsynth.skip(1))
-            if (ss.sent > 0) {                  // before its first packet a call has no clock to keep (:98-105, stime is None)
-                ss.ts += (uint32_t)t->ts_step;
-                ss.skipped++;
-                ss.marker = true;
-            }
-            out_len[i] = 0;
-            continue;
-        }
-        write_packet(ss, t->ts_step, pt, payload ? payload + (size_t)i * plen : nullptr, plen, out + (size_t)i * ostride);
-        out_len[i] = (int32_t)ostride;
-    }
     return 0;
 }
 

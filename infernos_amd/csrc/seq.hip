@@ -659,7 +659,7 @@ extern "C" int ifh_resblock_seq_bf16(const ifh_seq_desc *d, ifh_stream_t stream)
     SEQ_CASE(128, 3, 192, 2, 8, 2, 4, 6, 1, false, 4, 8192)
     // C = 256: two 48-row sequences per workgroup, four waves (512 registers) of both sequences x 64 channels, a half-step per
     // sequence; a k-step of weights is one 16 KB unit
-    static const int nh256 = getenv("IFH_SEQ256_NH") ? atoi(getenv("IFH_SEQ256_NH")) : 2;     // tuning switch: half-steps (a sequence each) or full steps
+    constexpr int nh256 = 2;     // fixed by measurement (profiles/NOTES.md): half-steps (a sequence each) or full steps
     if (nh256 == 2) {
         SEQ_CASE(256, 11, 48, 2, 4, 4, 4, 6, 2, true, 4, 16384)
         SEQ_CASE(256, 7, 48, 2, 4, 4, 4, 6, 2, true, 4, 16384)

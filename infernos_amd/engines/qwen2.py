@@ -10,7 +10,6 @@ over the padded [B, T] token block with per-token key counts (causal) and paddin
 advances all rows by one token at their own positions -- the per-token launch sequence is identical for every step, so it
 is captured into a hipGraph after the first eager step and replayed.
 """
-import os
 
 import torch
 
@@ -91,7 +90,7 @@ class Qwen2:
         fr = torch.arange(self.max_tokens).float()[:, None] * inv[None, :]
         self.cos_sin = torch.stack([fr.cos(), fr.sin()], -1).contiguous().to(dev)
         self._bufs = {}
-        self.fuse = os.environ.get('IFH_LLM_NO_FUSE') is None      # tuning switch: explicit RMSNorm / SiLU launches instead
+        self.fuse = True       # False: explicit RMSNorm / SiLU launches (tests/test_llm_gpu.py compares the two)
         self.glu_prefill = True                                      # prefill's gate|up with the SiLU-gate epilogue, until the library declines it
         self.bucket_batches = True
 
@@ -127,9 +126,14 @@ class Qwen2:
         d = self.d
         pws, big = None, rows >= 4096              # a prompt pass: the GEMMs take every CU (ifh_conv_desc.whole_chip) and a split workspace
         if rows >= 4096:
-            if getattr(self, '_pws', None) is None:
-                self._pws = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=self.device)      # 64 MB, prompt passes only
-            pws = self._pws
+            # 64 MB, prompt passes only; one per STREAM (include/infernos_hip.h: a split workspace belongs to one stream / graph):
+            # two prompt passes of this model on different streams must not share the partial tiles
+            key = torch.cuda.current_stream(self.device).cuda_stream
+            if not hasattr(self, '_pws'):
+                self._pws = {}
+            if key not in self._pws:
+                self._pws[key] = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=self.device)
+            pws = self._pws[key]
         for L, cache in zip(self.layers, kv):
             ops.rmsnorm(x, self.ones, h, rows, d, self.eps)
             ops.linear(h, L['wqkv'], L['bqkv'], qkv, rows=rows, k=d, n=self.nq, whole_chip=big)
@@ -147,7 +151,9 @@ class Qwen2:
                 # before launching anything, and the two-launch form below takes over for good.
                 try:
                     ops.linear(h, L['wgu'], None, ff, rows=rows, k=d, n=2 * self.ff, ldc=self.ff, act=ops.ACT_SILU_GLU, splitk_ws=pws, whole_chip=big)
-                except _lib.InfernosHipError:
+                except _lib.InfernosHipError as e:
+                    if e.code != _lib.IFH_EINVAL:        # a HIP error is an error, not a declined shape
+                        raise
                     self.glu_prefill = fused = False
             if not fused:
                 ops.linear(h, L['wgu'], None, gu, rows=rows, k=d, n=2 * self.ff)

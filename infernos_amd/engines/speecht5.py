@@ -35,10 +35,6 @@ class SpeechT5:
         self.device = dev = _lib.require_device(device)
         self.max_steps = max_steps
         self.use_graphs = True
-        # resident decode step (csrc/step.hip): one launch per step for the ragged batch; workgroups per 32-row cluster
-        self.resident_step = os.environ.get('IFH_TTS_RESIDENT', '0') == '1'
-        self.resident_cw = int(os.environ.get('IFH_TTS_RESIDENT_CW', '16'))
-        self.resident_wt = os.environ.get('IFH_TTS_RESIDENT_WT', '0') == '1'       # test switch: write-through hand-offs even when a cluster shares one XCD
         self._states = {}
         E = 'speecht5.encoder.'
         alpha_e = float(sd[E + 'prenet.encode_positions.alpha'])
@@ -437,7 +433,6 @@ class TTSRaggedState:
         self.stats = z(3 * len(model.dec_layers), self.stat_rows, 2, dt=torch.int64)
         self.pn = [z(R, 32, 256), z(R, 32, 256)]
         self.graphs, self.eager = {}, {}
-        self.progs, self.step_ctx = {}, None                        # resident decode step: phase tables, cluster counters
         self.ncalls = 0
 
 
@@ -498,7 +493,7 @@ def _decoder_step_ragged(model: 'SpeechT5', st: TTSRaggedState, s: int, threshol
 
 
 def ragged_decoder_steps(model: 'SpeechT5', st: TTSRaggedState, masks: torch.Tensor, n: int, nsteps=16, threshold=0.5,
-                         use_graphs=None, sync_every=0, resident=None):
+                         use_graphs=None, sync_every=0):
     """One infer() call's decoder steps (HelloSippyRTPipe.py:195-229) for the first n row slots of a ragged state.
     The same [nsteps,2,256] dropout keep-masks serve every row of the step, as the reference shares one mask across
     its batch (modeling_speecht5.py:671-674).  One hipGraph per (in-call step, frame-buffer parity, n)."""
@@ -509,22 +504,8 @@ def ragged_decoder_steps(model: 'SpeechT5', st: TTSRaggedState, masks: torch.Ten
     _lib.check(_lib.lib().ifh_tts_carry_rows_bf16(ops._addr(st.spec[1 - par]), ops._addr(st.spec[par]), ops._addr(st.pos), n, 33,
                                                   _lib.stream_ptr(model.device)), 'ifh_tts_carry_rows_bf16')
     use_graphs = use_graphs and st.eager.get(n, 0) >= 1            # the first call at a row count runs eagerly (loads kernels)
-    resident = model.resident_step if resident is None else resident
     for s in range(nsteps):
-        if resident:
-            # ONE launch per step (csrc/step.hip): the step's launches are recorded once per (in-call step, parity, n) and run by
-            # clusters of workgroups that each walk a block of 32 rows through every phase
-            key = (s, threshold, par, n)
-            prog = st.progs.get(key)
-            if prog is None:
-                prog = st.progs[key] = ops.StepProgram(lambda: _decoder_step_ragged(model, st, s, threshold, par, n),
-                                                       st.stat_rows, model.device)
-            if st.step_ctx is None:
-                st.step_ctx = ops.StepContext(st.R, model.device)
-            prog.run(st.step_ctx, cw=model.resident_cw, write_through=model.resident_wt)
-            if sync_every and (s + 1) % sync_every == 0 and s + 1 < nsteps:
-                torch.cuda.current_stream(model.device).synchronize()
-        elif not use_graphs:
+        if not use_graphs:
             _decoder_step_ragged(model, st, s, threshold, par, n)
         else:
             key = (s, threshold, par, n)
@@ -536,7 +517,7 @@ def ragged_decoder_steps(model: 'SpeechT5', st: TTSRaggedState, masks: torch.Ten
             # same hardware queue (16 steps = ~900 kernels); waiting every few steps keeps that to a handful of milliseconds
             if sync_every and (s + 1) % sync_every == 0 and s + 1 < nsteps:
                 torch.cuda.current_stream(model.device).synchronize()
-    if not use_graphs and not resident:
+    if not use_graphs:
         st.eager[n] = st.eager.get(n, 0) + 1
     st.ncalls += 1
     return par

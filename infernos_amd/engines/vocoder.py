@@ -8,8 +8,6 @@ bias/residual/3-way-mean fused in the epilogue: the residual pairs (conv k,d -> 
 ifh_resblock_pair_bf16 launch each with the intermediate held in LDS, the rest one ifh_conv_bf16 launch
 each; the transposed convolutions run as 4 two-tap phases.
 """
-import os
-
 import torch
 
 from .. import _lib, ops
@@ -25,7 +23,7 @@ class HifiGan:
         self.up = [(ops.w_convT_phases(sd['upsampler.%d.weight' % i], dev), ops.w_bias(sd['upsampler.%d.bias' % i], dev))
                    for i in range(4)]
         self.upf = [ops.w_convT_fused(sd['upsampler.%d.weight' % i], sd['upsampler.%d.bias' % i], dev) for i in range(4)]
-        self.fused_up = os.environ.get('IFH_NO_FUSED_UP') is None        # tuning switch
+        self.fused_up = True             # (attributes: the unfused forms are what the parity tests compare against)
         self.res = []
         for i in range(4):
             lvl = []
@@ -38,9 +36,9 @@ class HifiGan:
         # whole residual blocks as one launch each (csrc/chain.hip) where the channel count allows: the six convolutions'
         # weights as one pre-packed fragment stream per block
         self.chain = {}
-        self.fused_chain = os.environ.get('IFH_NO_CHAIN') is None           # tuning switch
+        self.fused_chain = True
         # the C = 32 level: its three residual blocks as ONE launch with the weights stationary in registers (csrc/level.hip)
-        self.fused_level = os.environ.get('IFH_NO_LEVEL') is None           # tuning switch
+        self.fused_level = True
         for i in range(1, 4):
             for j, k in enumerate((3, 7, 11)):
                 R = 'resblocks.%d.' % (i * 3 + j)
@@ -50,10 +48,10 @@ class HifiGan:
                     convs.append((sd[R + 'convs2.%d.weight' % d], sd[R + 'convs2.%d.bias' % d]))
                 self.chain[(i, j)] = ops.w_chain_pack(convs, dev)
         # whole-sequence blocks (csrc/seq.hip: one LDS image overwritten in place, nothing recomputed) where the level's shape is one
-        # of (c, t) = (256, 48), (128, 192), (64, 768); IFH_SEQ_LEVELS = the channel counts that take it (tuning switch; default 64 and
+        # of (c, t) = (256, 48), (128, 192), (64, 768); seq_levels = the channel counts that take it (64 and
         # 256: at C = 128 the chain kernel's one-chunk tiles measure faster, 943 against 1 095 us per level at 1 280 chunks)
         self.seq = {}
-        self.seq_levels = tuple(int(v) for v in os.environ.get('IFH_SEQ_LEVELS', '64,256').split(',') if v)
+        self.seq_levels = (64, 256)
         for i, c in ((0, 256), (1, 128), (2, 64)):
             for j, k in enumerate((3, 7, 11)):
                 if ops.seq_unit_bytes(c) == 8192:
@@ -67,7 +65,7 @@ class HifiGan:
                     self.seq[(i, j)] = ops.w_chain_pack(convs, dev, unit_bytes=ops.seq_unit_bytes(c))
         # the C = 256 level: every convolution as its own fragment stream for ifh_conv_ring256_bf16 (two chunks per workgroup)
         self.ring = {}
-        self.fused_ring = os.environ.get('IFH_NO_RING256') is None          # tuning switch
+        self.fused_ring = True
         for j in range(3):
             R = 'resblocks.%d.' % j
             for d in range(3):
@@ -78,7 +76,7 @@ class HifiGan:
         self.post_w = sd['conv_post.weight'].float()[0].t().contiguous().to(dev)     # [7][32]
         self.post_b = float(sd['conv_post.bias'].float()[0])
         self._bufs = {}
-        self.fused_pairs = os.environ.get('IFH_NO_FUSED_PAIR') is None      # tuning switch
+        self.fused_pairs = True
 
     def _buffers(self, n, t0, cache=None):
         """Activation buffers of one batch shape.  `cache` is a dict owned by the caller (a TTS batch state, so that

@@ -32,7 +32,7 @@ class Whisper:
         self.ff = sd[E + 'layers.0.fc1.weight'].shape[0]
         self.vocab = sd[Dc + 'embed_tokens.weight'].shape[0]
         self.max_tokens = min(max_tokens, sd[Dc + 'embed_positions.weight'].shape[0])
-        self.beam_cross_mfma = os.environ.get('IFH_BEAM_CROSS_VALU') is None     # tuning switch: the beams' cross-attention on k_attn_prefill
+        self.beam_cross_mfma = True       # the beams' cross-attention on k_attn_prefill (False: k_attn_decode_shared; tests/test_beam_gpu.py runs both)
         self.c1 = (ops.w_conv(sd[E + 'conv1.weight'], dev), ops.w_bias(sd[E + 'conv1.bias'], dev))
         self.c2 = (ops.w_conv(sd[E + 'conv2.weight'], dev), ops.w_bias(sd[E + 'conv2.bias'], dev))
         self.enc_pos = sd[E + 'embed_positions.weight'].to(BF16).contiguous().to(dev)
@@ -273,7 +273,7 @@ class Whisper:
         return bufs['logits']
 
     def _step(self, bufs, Bn, argmax, use_graphs):
-        if self.fold_ln and Bn <= int(os.environ.get('IFH_FOLD_MAX_ROWS', '1024')):
+        if self.fold_ln and Bn <= 1024:
             step = self.decoder_step_folded
         else:
             step = self.decoder_step

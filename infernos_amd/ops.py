@@ -412,78 +412,3 @@ def w_convT_phases(w, device):
         wr = torch.stack([w[:, :, k0].t(), w[:, :, k1].t()], dim=1)     # [Cout][2][Cin]
         phases.append((wr.to(BF16).contiguous().to(device), pad))
     return phases
-
-
-# ---- resident decode step (csrc/step.hip) ----------------------------------------------------------------------------------------
-class StepContext:
-    """Arrival counters of the resident decode step's clusters (ifh_step_ctx_*).  One per decode batch state and stream."""
-
-    def __init__(self, max_rows: int, device):
-        import ctypes
-        import torch
-        self.device = device
-        h = ctypes.c_void_p()
-        with torch.cuda.device(device):
-            _lib.check(_lib.lib().ifh_step_ctx_create(int(max_rows), ctypes.byref(h)), 'ifh_step_ctx_create')
-        self.h = h
-
-    def status(self, n_xcc: int = 0):
-        """(error word, XCC id per workgroup of the last debug launch); synchronises the device"""
-        import ctypes
-        import torch
-        err = ctypes.c_int32(0)
-        xcc = (ctypes.c_int32 * max(1, n_xcc))()
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().ifh_step_ctx_status(self.h, ctypes.byref(err), xcc, int(n_xcc)), 'ifh_step_ctx_status')
-        return err.value, list(xcc)[:n_xcc]
-
-    def prof(self):
-        """per-phase (wait us, work us) of cluster 0 accumulated by run(prof=True) launches since the last call"""
-        import ctypes
-        import torch
-        out = (ctypes.c_uint64 * 256)()
-        with torch.cuda.device(self.device):
-            _lib.check(_lib.lib().ifh_step_ctx_prof(self.h, out), 'ifh_step_ctx_prof')
-        self.gemm_breakdown = [out[200 + i] / 100.0 for i in range(6)] + [int(out[206])]
-        return [(out[2 * i] / 100.0, out[2 * i + 1] / 100.0) for i in range(100)]
-
-    def __del__(self):
-        try:
-            if self.h:
-                _lib.lib().ifh_step_ctx_destroy(self.h)
-                self.h = None
-        except Exception:
-            pass
-
-
-class StepProgram:
-    """The phase table of one decoder step: `fn` issues the step's launches once on the calling thread, and instead of running
-    they are recorded (ifh_step_record_begin / _end).  run() then executes the whole step as ONE launch."""
-
-    def __init__(self, fn, stat_rows: int, device):
-        import ctypes
-        import torch
-        self.device = device
-        L = _lib.lib()
-        with torch.cuda.device(device):
-            _lib.check(L.ifh_step_record_begin(int(stat_rows)), 'ifh_step_record_begin')
-            try:
-                fn()
-            except BaseException:
-                L.ifh_step_record_abort()
-                raise
-            h, n = ctypes.c_void_p(), ctypes.c_int32(0)
-            _lib.check(L.ifh_step_record_end(ctypes.byref(h), ctypes.byref(n)), 'ifh_step_record_end')
-        self.h, self.nphase = h, n.value
-
-    def run(self, ctx: StepContext, cw: int = 16, debug_xcc: bool = False, prof: bool = False, write_through: bool = False):
-        dbg = int(debug_xcc) | (2 if prof else 0) | (4 if write_through else 0)
-        _lib.check(_lib.lib().ifh_step_run(self.h, ctx.h, int(cw), dbg, _lib.stream_ptr(self.device)), 'ifh_step_run')
-
-    def __del__(self):
-        try:
-            if self.h:
-                _lib.lib().ifh_step_prog_destroy(self.h)
-                self.h = None
-        except Exception:
-            pass

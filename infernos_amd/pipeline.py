@@ -15,9 +15,9 @@ Stages of one utterance cycle (`step`):
            mu-law encoded -> [N, bytes] for the RTP side.
 """
 import ctypes
-from typing import List
-
 import os
+import threading
+from typing import List
 
 import torch
 
@@ -79,6 +79,27 @@ class BatchedVAD:
         return out
 
 
+# ifh_set_cu_budget is process-wide: the pipelines that reserved CUs, in construction order.  The budget in force is the newest
+# live pipeline's; closing one brings back the one before it (or "all CUs" when none is left).
+_budget_lock = threading.Lock()
+_budget_holders = []
+
+
+def _budget_push(owner, ncus):
+    with _budget_lock:
+        _budget_holders.append((id(owner), int(ncus)))
+        _lib.check(_lib.lib().ifh_set_cu_budget(int(ncus)), 'ifh_set_cu_budget')
+
+
+def _budget_pop(owner):
+    with _budget_lock:
+        for i, (oid, _) in enumerate(_budget_holders):
+            if oid == id(owner):
+                del _budget_holders[i]
+                break
+        _lib.check(_lib.lib().ifh_set_cu_budget(_budget_holders[-1][1] if _budget_holders else 0), 'ifh_set_cu_budget')
+
+
 class SpeechPipeline:
     def __init__(self, ncalls: int, device=None, whisper_family='whisper_tiny', seed=0, n_text=64, n_infer=10,
                  n_new_tokens=32, tts_output_sr=8000, weights=None, tts_lanes=2, tts_overlap=True, tts_group=1,
@@ -100,19 +121,20 @@ class SpeechPipeline:
         ncu = torch.cuda.get_device_properties(dev).multi_processor_count
         self._budget_set = False
         if int(os.environ.get('IFH_BIG_CUS', '0')) <= 0:          # (that switch masks the throughput streams and sets the budget itself)
-            _lib.check(_lib.lib().ifh_set_cu_budget(max(32, ncu - self.cu_reserve) if self.cu_reserve else 0), 'ifh_set_cu_budget')
-            self._budget_set = bool(self.cu_reserve)              # process-wide: close() gives the CUs back
+            if self.cu_reserve:                                   # process-wide: close() gives the CUs back
+                _budget_push(self, max(32, ncu - self.cu_reserve))
+                self._budget_set = True
         self.tts_overlap = tts_overlap      # render of chunk c on a second stream while chunk c+1 decodes (within a lane)
         self.tts_group = max(1, tts_group)  # utterance cycles synthesised as one TTS batch (rows = group * ncalls)
-        self.block_ingest = os.environ.get('IFH_TICK_INGEST') is None
+        self.block_ingest = True           # False: one ifh_ingest_tick per tick (what the block form is tested against)
         # The probability model of the VAD step (Core/VAD/SileroVAD.py:78-80 runs its network on every 768-sample window of every call):
         # None / 'energy' = the stateless energy rule (ifh_vad_energy_prob); 'recurrent' = the conv + 2 x LSTM(64) network of
         # csrc/vadnet.hip with the distilled weights and the per-call [2,N,64] x 2 state, driven window by window from
         # ifh_ingest_block_net; or a factory `f(device) -> model(x, sr)` (any other model takes the per-tick path).
-        self.vad_model = os.environ.get('IFH_VAD_MODEL', vad_model) if not callable(vad_model) else vad_model
+        self.vad_model = vad_model
         assert self.vad_model in (None, 'energy', 'recurrent') or callable(self.vad_model)
         self.stt_beam = int(stt_beam)      # 1: greedy (the reference's torch engine); 5: its default engine's beam search
-        self.stt_dec_prio = os.environ.get('IFH_STT_DEC_PRIO', '0') != '0'
+        self.stt_dec_prio = False
         with torch.cuda.device(dev):
             self.calls = CallTable(ncalls, dev)
             self.vad = BatchedVAD(ncalls, dev, model=self._new_vad_model())
@@ -137,9 +159,9 @@ class SpeechPipeline:
             from .tts import ContinuousTTS
             bucket = -(-ncalls * self.tts_group // 16) * 16
             # (+1 batch of head-room: a finished batch frees its rows one engine call after its last audio was queued)
-            # IFH_TTS_ENGINES (tuning switch, default 1): that many ragged batches, each with its own state, graphs, streams and
-            # thread; utterance cycle c joins engine c % n.  Rows are independent, so the audio does not depend on the engine.
-            ne = max(1, int(os.environ.get('IFH_TTS_ENGINES', '1')))
+            # ne ragged batches, each with its own state, graphs, streams and thread; utterance cycle c joins engine c % ne.  Rows
+            # are independent, so the audio does not depend on the engine (one engine: two measured 4 % slower, profiles/NOTES.md)
+            ne = 1
             per_engine = -(-(max(1, tts_lanes) + 1) // ne) + (1 if ne > 1 else 0)
             self.ctts_all = [ContinuousTTS(self.tts if e == 0 else self.tts.clone_for_lane(),
                                            max_rows=min(1024, bucket * per_engine), max_text=n_text, row_bucket=bucket).start()
@@ -163,12 +185,12 @@ class SpeechPipeline:
         # copies over the same weights, so that ingest+STT of consecutive cycles can overlap too (run_steps)
         self.front_lanes = [_FrontLane(self, first=True)] + [_FrontLane(self) for _ in range(max(1, front_lanes) - 1)]
         # In continuous mode the lanes' submit work (SpeechT5 text encoder, cross K|V: ~1 ms per batch) shares ONE stream.
-        if tts_mode == 'continuous' and os.environ.get('IFH_ONE_SUBMIT_STREAM', '1') != '0':
+        if tts_mode == 'continuous':
             self._lane_streams = [self._lane_streams[0]] * len(self._lane_streams)
         # The process's streams are dealt over four hardware queues when they are first used; first use from several threads made
         # the dealing -- and with it the cycle time, 109 or 118 ms -- a matter of thread timing.  Every stream is used once here, in
-        # a fixed order (IFH_STREAM_ORDER: F = front lanes, M / S = TTS decode / render, L = submit), from this thread.
-        order = os.environ.get('IFH_STREAM_ORDER', 'S,F,L,M')
+        # a fixed order (F = front lanes, M / S = TTS decode / render, L = submit), from this thread.
+        order = 'S,F,L,M'
         named = {'F': [fl.stream for fl in self.front_lanes], 'L': list(dict.fromkeys(self._lane_streams)),
                  'M': [e.main for e in getattr(self, 'ctts_all', [])], 'S': [e.side for e in getattr(self, 'ctts_all', [])]}
         scratch = torch.zeros(64, device=dev)
@@ -502,17 +524,18 @@ class SpeechPipeline:
     def close(self):
         """stop the continuous TTS engine thread (its state holds the KV caches of every row slot) and give back the CUs the
         persistent kernels were kept off (the budget is process-wide: a pipeline that set it restores "all CUs")"""
-        if getattr(self, '_budget_set', False):
-            _lib.check(_lib.lib().ifh_set_cu_budget(0), 'ifh_set_cu_budget')
-            self._budget_set = False
         if self.ctts is not None:
             for eng in self.ctts_all:
                 eng.stop()
             self.ctts, self.ctts_all = None, []
+        if getattr(self, '_budget_set', False):        # behind the engines' last launches; another live pipeline's budget comes back
+            _budget_pop(self)
+            self._budget_set = False
         for name in ('_pool', '_tts_pool'):
             if hasattr(self, name):
                 getattr(self, name).shutdown(wait=True)
                 delattr(self, name)
+        _lib.release_graphs()          # graphs of states already dropped: destroyed here, not wherever the collector finds them
 
     def step(self, frames: torch.Tensor):
         chunks = self.ingest(frames)

@@ -7,8 +7,8 @@ UNPINNED).  The reference's own RTP/InfernRTPIngest.py (per-packet 
 mirrored here: it runs unchanged on top of these names once `compat.install()` has aliased `rtpsynth.RtpJBuf`,
 `Core.VAD.SileroVAD` and `Core.Codecs.G711` (INTEGRATION.md).
 
-`RtpSynth` / `RTPEgressTable` are the egress counterpart (`rtpsynth.RtpSynth`, RTP/RTPOutputWorker.py:88,104,136) over
-`ifh_rtpsynth_*`.  `RTPIngestTable` is the batched form the MI355X path uses: datagrams of all calls are pushed into one table and
+(RTP egress -- header synthesis, `rtpsynth.RtpSynth` -- is outside SURVEY.md section 8 and not part of this library.)
+`RTPIngestTable` is the batched form the MI355X path uses: datagrams of all calls are pushed into one table and
 `pop_tick()` hands `CallTable.tick` / `ifh_ingest_block` the `[n,160]` frame matrix and slot list of the calls
 that have a whole 20 ms frame, instead of one Python `VADChannel.ingest` call per packet per call.
 """
@@ -180,81 +180,3 @@ class RTPIngestTable(_Table):
                                                  ctypes.byref(self._n)), 'ifh_rtpjb_pop_tick')
         n = self._n.value
         return self.frames[:n], self.slots[:n]
-
-
-class _SynthTable:
-    """Owner of one ifh_rtpsynth_t handle."""
-
-    def __init__(self, n_streams, ts_step, seed=None):
-        import os
-        self.n_streams, self.ts_step = n_streams, ts_step
-        if seed is None:
-            seed = int.from_bytes(os.urandom(8), 'little')          # RFC 3550 8.1: random SSRC / initial sequence / timestamp
-        h = ctypes.c_void_p()
-        _lib.check(_lib.lib().ifh_rtpsynth_create(n_streams, ts_step, seed, ctypes.byref(h)), 'ifh_rtpsynth_create')
-        self._h = h
-
-    def __del__(self):
-        h, self._h = getattr(self, '_h', None), None
-        if h:
-            _lib.lib().ifh_rtpsynth_destroy(h)
-
-    def set(self, stream, ssrc, seq, ts, marker=True):
-        _lib.check(_lib.lib().ifh_rtpsynth_set(self._h, stream, ssrc, seq, ts, int(marker)), 'ifh_rtpsynth_set')
-
-    def get(self, stream) -> dict:
-        u = [ctypes.c_uint32() for _ in range(3)]
-        q = [ctypes.c_int64() for _ in range(2)]
-        _lib.check(_lib.lib().ifh_rtpsynth_get(self._h, stream, *[ctypes.byref(x) for x in u + q]), 'ifh_rtpsynth_get')
-        return dict(ssrc=u[0].value, seq=u[1].value, ts=u[2].value, sent=q[0].value, skipped=q[1].value)
-
-    def skip(self, stream, nframes):
-        _lib.check(_lib.lib().ifh_rtpsynth_skip(self._h, stream, nframes), 'ifh_rtpsynth_skip')
-
-
-class RtpSynth:
-    """`rtpsynth.RtpSynth.RtpSynth(srate, ptime)` as used at RTPOutputWorker.py:88,104,136: `next_pkt(plen, pt, pload=bytes)`
-    returns the datagram, `skip(n)` lets n frame times pass without a packet."""
-
-    def __init__(self, srate: int, ptime: int, seed=None):
-        self._t = _SynthTable(1, srate * ptime // 1000, seed)
-        self._len = ctypes.c_int32()
-
-    def next_pkt(self, plen: int, pt: int, pload: Optional[bytes] = None) -> bytes:
-        if pload is not None:
-            assert len(pload) == plen
-            src = (ctypes.c_uint8 * max(plen, 1)).from_buffer_copy(pload or b'\0')
-        else:
-            src = None
-        out = (ctypes.c_uint8 * (12 + plen))()
-        _lib.check(_lib.lib().ifh_rtpsynth_next_batch(self._t._h, src, None, None, 1, plen, pt, out, ctypes.byref(self._len)),
-                   'ifh_rtpsynth_next_batch')
-        return bytes(out)
-
-    def skip(self, npkts: int):
-        self._t.skip(0, npkts)
-
-    def state(self):
-        return self._t.get(0)
-
-
-class RTPEgressTable(_SynthTable):
-    """All calls of one output thread: the [n, plen] payload matrix of `frontend.mux_encode` (host copy) -> n datagrams."""
-
-    def __init__(self, n_streams, ts_step=160, pt=0, seed=None):
-        super().__init__(n_streams, ts_step, seed)
-        self.pt = pt
-
-    def next_batch(self, payload, has=None, slots=None):
-        """payload: uint8 tensor/array [n, plen] on the host; has: uint8 [n] (0 = nothing to send this tick) or None;
-        slots: int32 [n] call indices or None (= 0..n-1).  -> list of n datagrams (bytes, b'' where nothing is sent)."""
-        pl = np.ascontiguousarray(payload.numpy() if hasattr(payload, 'numpy') else payload, np.uint8)
-        n, plen = pl.shape
-        vp = lambda a: None if a is None else a.ctypes.data_as(ctypes.c_void_p)
-        hs = None if has is None else np.ascontiguousarray(has.numpy() if hasattr(has, 'numpy') else has, np.uint8)
-        sl = None if slots is None else np.ascontiguousarray(slots.numpy() if hasattr(slots, 'numpy') else slots, np.int32)
-        out = np.empty((n, 12 + plen), np.uint8)
-        ln = np.empty(n, np.int32)
-        _lib.check(_lib.lib().ifh_rtpsynth_next_batch(self._h, vp(pl), vp(hs), vp(sl), n, plen, self.pt, vp(out), vp(ln)),
-                   'ifh_rtpsynth_next_batch')
-        return [out[i, :ln[i]].tobytes() for i in range(n)]

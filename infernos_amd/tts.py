@@ -7,7 +7,6 @@ postnet, carry+chunking, HiFi-GAN, AmendmentNetwork1, optional 16k->8k resample)
 kernels; `unbatch_and_dispatch()` reproduces the reference's offset arithmetic and hands each
 live session a 1-D CPU tensor, then None at the end of the utterance.
 """
-import os
 import uuid
 import weakref
 from functools import partial
@@ -286,16 +285,15 @@ class ContinuousTTS:
         dev = pp.device
         assert max_text <= 256, 'cross-attention over > 256 keys takes the 4-wave kernel: such texts go through the frozen-batch path'
         self.row_bucket = row_bucket
-        self.host_wait = os.environ.get('IFH_TTS_HOST_WAIT', '0') == '1'      # tuning switch (see step()): measured without effect, off
-        self.admit_ready = os.environ.get('IFH_TTS_ADMIT_READY', '0') == '1'  # tuning switch (see _admit()): measured without effect, off
-        self.sync_every = int(os.environ.get('IFH_TTS_SYNC_EVERY', '8'))         # decoder steps queued at a time (0: all 16); 8: +2 % and a steadier tick p99 at C3
+        self.host_wait = False        # (see step()): measured without effect, off
+        self.admit_ready = False      # (see _admit()): measured without effect, off
+        self.sync_every = 8           # decoder steps queued at a time (0: all 16); 8: +2 % and a steadier tick p99 at C3
         with torch.cuda.device(dev):
             self.st = TTSRaggedState(pp.model, max_rows, max_text)
             # the decode chain is one latency-bound sequence of small dependent launches for ALL in-flight rows: on an ordinary
             # queue each of them waits for CU slots behind whatever long throughput kernels other stages have resident (the
-            # Whisper encoder's GEMMs), serially; a high-priority queue lets them through (tuning switch IFH_TTS_PRIO)
-            prio = int(os.environ.get('IFH_TTS_PRIO', '-1'))
-            self.main = torch.cuda.Stream(device=dev, priority=prio)
+            # Whisper encoder's GEMMs), serially; a high-priority queue lets them through
+            self.main = torch.cuda.Stream(device=dev, priority=-1)
             self.side = _lib.throughput_stream(dev)          # postnet + HiFi-GAN + amendment passes
         R = self.st.R
         self.free = list(range(R))                       # row slots, lowest first

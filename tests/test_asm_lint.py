@@ -7,7 +7,17 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _hipcc_missing():
+    from infernos_amd import build as b
+    return not os.path.exists(b.HIPCC)
+
+
+pytestmark = pytest.mark.skipif(_hipcc_missing(), reason='hipcc is not installed here: nothing to compile the listings with')
 
 
 def test_seq_kernels_do_not_touch_asm_read_destinations_early(tmp_path):

@@ -189,7 +189,10 @@ def _pipelined_worker(rank, world, port, n_total, nsteps, group, lanes, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,n_total,nsteps,group,lanes', [(2, 6, 9, 1, 3), (3, 7, 10, 2, 2), (4, 8, 7, 1, 4)])
+@pytest.mark.parametrize('world,n_total,nsteps,group,lanes', [
+    (2, 6, 9, 1, 3), (3, 7, 10, 2, 2), (4, 8, 7, 1, 4),
+    (8, 2051, 4, 1, 3),       # BASELINE config 4's world: 8 ranks, 2 048 calls + 3 (ragged shards of 257 / 256 rows)
+])
 def test_pipelined_collective_order_gloo(world, n_total, nsteps, group, lanes):
     """The N > 1 bench path: every rank issues the scatters of the ingress communicator and the gathers of the egress
     communicator in the same order although its stage threads run at their own pace (ragged shards included) --
