@@ -465,8 +465,19 @@ typedef struct ifh_level_desc {
     void *out;
     int64_t out_bstride;
     void *debug_prof;       /* NULL (diagnostic builds: device uint64[16], shader-clock sums per phase of a convolution) */
+    /* Optional: the vocoder's last convolution folded in (SpeechT5HifiGan.forward: conv_post, 7 taps, 32 -> 1 channel, behind
+     * LeakyReLU(post_slope), then tanh -- what ifh_hifigan_post_bf16 computes from `out`, with the same order of sums: same bits).
+     * post_w f32 [7][32] != NULL: nblocks = 3, accumulate = 0; the level's mean stays on the chip (`out` is not written and may be
+     * NULL), audio bf16 [nbatch][t] is; mean_ws is scratch of the caller's (one per stream / captured graph that may run
+     * concurrently), mean_ws_bytes >= ifh_level_ws_bytes(): the blocks' running mean of the tile a workgroup is working on. */
+    const float *post_w;
+    float post_bias, post_slope;
+    void *audio;
+    void *mean_ws;
+    int64_t mean_ws_bytes;
 } ifh_level_desc;
 int ifh_resblock_level_bf16(const ifh_level_desc *desc, ifh_stream_t stream);
+int64_t ifh_level_ws_bytes(void);
 
 /* One stride-1 "same" convolution with 256 input and 256 output channels on short sequences (t <= 48: the first
  * HiFi-GAN level), two sequences per workgroup, weights DMA'd as pre-packed fragments (the stream layout of

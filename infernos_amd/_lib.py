@@ -102,7 +102,8 @@ class LevelDesc(ctypes.Structure):
     _fields_ = [('x', _vp), ('x_bstride', _i64), ('c', ctypes.c_int32), ('t', ctypes.c_int32), ('nbatch', ctypes.c_int32),
                 ('nblocks', ctypes.c_int32), ('taps', ctypes.c_int32 * 3), ('accumulate', ctypes.c_int32),
                 ('wstream', _vp * 3), ('bias', _vp * 3), ('slope', _f), ('out_scale', _f), ('out', _vp), ('out_bstride', _i64),
-                ('debug_prof', _vp)]
+                ('debug_prof', _vp), ('post_w', _vp), ('post_bias', _f), ('post_slope', _f), ('audio', _vp), ('mean_ws', _vp),
+                ('mean_ws_bytes', _i64)]
 
 
 class Ring256Desc(ctypes.Structure):
@@ -167,6 +168,7 @@ SIGNATURES.update({
     'ifh_resblock_seq_supported': (_i, [_i, _i, _i]),
     'ifh_conv_ring256_bf16': (_i, [ctypes.POINTER(Ring256Desc), _vp]),
     'ifh_resblock_level_bf16': (_i, [ctypes.POINTER(LevelDesc), _vp]),
+    'ifh_level_ws_bytes': (_i64, []),
     'ifh_layernorm_bf16': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     'ifh_transpose_to_bf16': (_i, [_vp, _i, _vp, _i, _i, _i, _vp]),
     'ifh_attn_prefill_bf16': (_i, [ctypes.POINTER(AttnDesc), _vp]),

@@ -22,6 +22,11 @@ struct LevelParams {
     float slope, out_scale;
     int accumulate;              // the first block adds to `out` as well
     unsigned long long *prof;    // ABL & 16 builds: shader-clock sums of wave 0 of every workgroup, per phase of a convolution
+    // POST instantiations (ifh_level_desc.post_w): the folded conv_post
+    const float *post_w;         // [7][32]
+    float post_bias, post_slope;
+    uint16_t *audio;             // bf16 [nbatch][T]
+    uint16_t *mean_ws;           // per workgroup: the running mean of the tile being worked on, [grid][RT][C] bf16
 };
 
 template <int... I, class F>

@@ -28,7 +28,10 @@ namespace ifh {
 // tiles); HC rows computed on either side of the R = WGM*MTB*16 - 2*HC stored rows; PF = fragment reads in flight;
 // B0, B1, B2 = taps of the blocks run back to back (0 = none); ACC0: the first block adds to `out` too;
 // ABL (tools builds only, wrong results): 1 = no fragment reloads, 2 = no epilogue pieces, 4 = no activation reads, 8 = no MFMAs
-template <int C, int NW, int WGM, int WGN, int MTB, int HC, int PF, int B0, int B1, int B2, bool ACC0, int ABL = 0>
+// POST: the 7-tap 32 -> 1 channel convolution + tanh behind the level (SpeechT5HifiGan.forward's conv_post, what k_conv_post of
+// misc.hip computes, in its order of sums) runs on the tile's final mean while it is still in LDS: the level's output never crosses
+// HBM, the running mean of the blocks lives in a workspace slab of the workgroup's own (L2-resident), the kernel writes audio.
+template <int C, int NW, int WGM, int WGN, int MTB, int HC, int PF, int B0, int B1, int B2, bool ACC0, int ABL = 0, bool POST = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(const LevelParams p)
 {
     constexpr int NT = 2;
@@ -48,7 +51,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
     constexpr int WB_OFF = IMG_BYTES, WBYTES = KSMAX * FR * 1024;       // two buffers of one convolution's fragments each
     constexpr int NB = PF + 2;                         // fragment registers: a read lands PF k-steps ahead, its slot was last used 2 steps back
     constexpr int NP = 4 * NT;                         // epilogue pieces per row block
-    static_assert(HC >= 6 * (BMAX - 1) || HC == 0, "margin covers the chain: (1+3+5 dilated + 3 plain) * (taps-1)/2 rows");
+    static_assert(HC >= 6 * (BMAX - 1) + (POST ? 3 : 0) || HC == 0, "margin covers the chain: (1+3+5 dilated + 3 plain) * (taps-1)/2 rows (+ conv_post's 3)");
+    static_assert(!POST || (C == 32 && B2 > 0 && !ACC0), "the folded conv_post is the C = 32 level's: three blocks, nothing to add to");
     static_assert(PF >= 1 && PF <= 3, "prefetch depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -177,7 +181,18 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
         const int tq = ti * R - HC;                                      // time of tile row 0
         const bool inside = tq >= 0 && tq + RT <= T;                     // no row of this tile is zero padding
         const int tile_next = tile + (int)gridDim.x < p.ntiles ? tile + (int)gridDim.x : tile;
-        const __amdgpu_buffer_rsrc_t outs = srd(p.out + (int64_t)b * p.out_bstride);
+        // POST: the running mean of this tile's rows in the workgroup's own slab (every row of the tile, margins included: the last
+        // block needs the mean three rows beyond the stored ones); else in `out`
+        const __amdgpu_buffer_rsrc_t outs = POST ? srd(p.mean_ws + (size_t)blockIdx.x * RT * C) : srd(p.out + (int64_t)b * p.out_bstride);
+        auto ld_prev = [&](int tqo_, int rb, int coff) __attribute__((always_inline)) {          // rows of the running mean for row block rb
+            if constexpr (POST) {
+                // (tqo_ carries this lane's slab offset here: an opaque per-convolution copy, or hipcc keeps one address register per
+                // row block and tile alive through all eighteen convolutions; the row block's part goes into the scalar offset)
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(outs, tqo_, rb * 16 * RB + coff, 0);
+                return make_uint2(v.x, v.y);
+            } else
+                return ld_row(outs, tqo_ + r0 + rb * 16, coff);
+        };
         // per lane: bit rb = its row of row block rb lies inside the sequence (okbits) / is one of the tile's stored rows too (stbits)
         uint32_t okbits = 0, stbits = 0;
 #pragma unroll
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
         // and the residual registers are refilled with the raw rows the NEXT block (or tile) starts from.
         // KC >= 0: the kind is a compile-time constant (row blocks 0 .. MTB-2 of a convolution: three instantiations chosen by one
         // branch per convolution); KC < 0: run-time kind (the last row block, which also refills W -- one body for all kinds).
-        auto piece = [&](auto kc_c, auto acc_c, auto rbp_c, auto p_c, int kind, int tqo, int wdst0, int wdst1, __amdgpu_buffer_rsrc_t xnext, int tnext)
+        auto piece = [&](auto kc_c, auto acc_c, auto last_c, auto rbp_c, auto p_c, int kind, int tqo, int wso, int wdst0, int wdst1, __amdgpu_buffer_rsrc_t xnext, int tnext)
                          __attribute__((always_inline)) {
             constexpr int KC = decltype(kc_c)::value, RBP = decltype(rbp_c)::value, P = decltype(p_c)::value;
             constexpr bool ACC = decltype(acc_c)::value;
@@ -243,8 +258,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
                     const uint32_t okm = (uint32_t)((int32_t)(okbits << (31 - RBP)) >> 31);      // all ones / zero: one v_bfe_i32
                     LV_STORE((i == 0 ? wdst0 : wdst1), RBP * 16 * RB, make_uint2(tpk[i].x & okm, tpk[i].y & okm))
                 } else {
-                    if ((stbits >> RBP) & 1u)
-                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){tpk[i].x, tpk[i].y}, outs, (tqo + r0 + RBP * 16) * RB + lane_col + i * 32, 0, 0);
+                    if constexpr (POST) {
+                        if constexpr (decltype(last_c)::value)             // the level's mean of this row: into the (free) x image, for the conv_post phase
+                            LV_STORE((i == 0 ? xw[0] : xw[1]), RBP * 16 * RB, tpk[i])
+                        else                                               // the running mean: every row of the tile, to the workgroup's slab
+                            __builtin_amdgcn_raw_buffer_store_b64((u32x2){tpk[i].x, tpk[i].y}, outs, wso, RBP * 16 * RB + i * 32, 0);
+                    } else {
+                        if ((stbits >> RBP) & 1u)
+                            __builtin_amdgcn_raw_buffer_store_b64((u32x2){tpk[i].x, tpk[i].y}, outs, (tqo + r0 + RBP * 16) * RB + lane_col + i * 32, 0, 0);
+                    }
                     xr[RBP][i] = ld_row(xnext, tnext + RBP * 16, i * 32);
                 }
             }
@@ -254,7 +276,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
         // Convolution q of a block: over the image at src_off (guard G rows) with dilation d, results to the image behind wdst0/1
         // (kinds 0, 1).  (w2base, w2off, w2nfr): the convolution TWO ahead, whose fragments this one's start sends on their way to LDS;
         // NKS: k-steps of the convolution that follows a block's last one (kind 2); xnext/tnext: kind 2's refill of the residual registers.
-        auto conv = [&](auto taps_c, auto acc_c, auto nks_c, int kind, int src_off, int G, int d, int wdst0, int wdst1, __amdgpu_buffer_rsrc_t bsrd,
+        auto conv = [&](auto taps_c, auto acc_c, auto nks_c, auto last_c, int kind, int src_off, int G, int d, int wdst0, int wdst1, __amdgpu_buffer_rsrc_t bsrd,
                         int boff, const uint16_t *w2base, int w2off, int w2nfr, __amdgpu_buffer_rsrc_t xnext, int tnext) __attribute__((always_inline)) {
             constexpr int TAPS = decltype(taps_c)::value, NKS = decltype(nks_c)::value;
             constexpr bool ACC = decltype(acc_c)::value;
@@ -271,6 +293,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
             int tqo = __builtin_amdgcn_readfirstlane(tq), dd = __builtin_amdgcn_readfirstlane(d);
             asm volatile("" : "+s"(tqo), "+s"(dd));
             asm volatile("" : "+v"(tnext));
+            int wso = r0 * RB + lane_col;              // POST: this lane's byte offset in the workgroup's slab (row block 0), opaque per convolution
+            asm volatile("" : "+v"(wso));
             d = dd;
             // This wave's pieces of the DMA issued as the previous convolution started have landed (nothing else of its vector memory
             // traffic is pending here: dilated / plain convolutions have none, and a block's top drains what its predecessor's last one left)
@@ -282,7 +306,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
                 rbase[s] = img_addr(src_off, G + r0 + (tap - H) * d, cs * 4 + g);
             });
             if constexpr (ACC)                         // rows of `out` for row block 0 (the others: one row block before their block)
-                if (kind == 2) lv_static_for<NT>([&](auto ic) { pvb[0][ic] = ld_row(outs, tqo + r0, ic * 32); });
+                if (kind == 2) lv_static_for<NT>([&](auto ic) { pvb[0][ic] = ld_prev(POST ? wso : tqo, 0, ic * 32); });
             const int wrd = lane_w + ((cpar + 1) & 1) * WBYTES;          // where the next convolution's fragments are read from
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             LV_STAMP(0)                                // [0] set-up
@@ -318,13 +342,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
                 }
                 // (slot (rb + 1) % 3 held row block rb - 2, whose epilogue ran during row block rb - 1; this load is consumed during rb + 2)
                 if constexpr (ACC && s == 0 && rb + 1 < MTB)
-                    if (kd == 2) lv_static_for<NT>([&](auto ic) { pvb[(rb + 1) % 3][ic] = ld_row(outs, tqo + r0 + (rb + 1) * 16, ic * 32); });
+                    if (kd == 2) lv_static_for<NT>([&](auto ic) { pvb[(rb + 1) % 3][ic] = ld_prev(POST ? wso : tqo, rb + 1, ic * 32); });
                 // (pieces start behind step 1: the first one reads accumulators that the previous row block's last MFMAs are still
                 // writing when step 0 issues -- nine wait states)
                 if constexpr (rb > 0 && !(ABL & 2))
                     lv_static_for<NP>([&](auto pc) {
                         if constexpr (1 + (decltype(pc)::value * (KS - 1)) / NP == s)
-                            piece(kc_c, acc_c, std::integral_constant<int, rb - 1>{}, pc, kind, tqo, wdst0, wdst1, xnext, tnext);
+                            piece(kc_c, acc_c, last_c, std::integral_constant<int, rb - 1>{}, pc, kind, tqo, wso, wdst0, wdst1, xnext, tnext);
                     });
                 __builtin_amdgcn_sched_barrier(0);
             };
@@ -353,7 +377,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
             lv_static_for<KS>([&](auto sc) { step(any_kind, std::integral_constant<int, MTB - 1>{}, sc); });
             LV_STAMP(4)                                // [4] last row block (+ fragment copies)
             if constexpr (!(ABL & 2))
-                lv_static_for<NP>([&](auto pc) { piece(any_kind, acc_c, std::integral_constant<int, MTB - 1>{}, pc, kind, tqo, wdst0, wdst1, xnext, tnext); });
+                lv_static_for<NP>([&](auto pc) { piece(any_kind, acc_c, last_c, std::integral_constant<int, MTB - 1>{}, pc, kind, tqo, wso, wdst0, wdst1, xnext, tnext); });
             // the next convolution's fragments are in W before this body is left (the loop's back edge is a join too)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             lv_static_for<KSMAX>([&](auto sc) { lv_static_for<NT>([&](auto ic) { bf16x8_t d_ = W[sc][ic]; asm volatile("" : "+v"(d_)); W[sc][ic] = d_; }); });
@@ -366,7 +390,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
 
         // one residual block: xr holds the tile's raw input rows, W the fragments of its first convolution, the LDS buffer of the
         // current parity those of its second one
-        auto block = [&](auto taps_c, auto nks_c, auto acc_c, const uint16_t *wb, const float *bb, const uint16_t *wnext_block,
+        auto block = [&](auto taps_c, auto nks_c, auto acc_c, auto last_c, const uint16_t *wb, const float *bb, const uint16_t *wnext_block,
                          int tile_nx) __attribute__((always_inline)) {
             constexpr int TAPS = decltype(taps_c)::value, KS = TAPS * KSUB, NKS = decltype(nks_c)::value;
             const unsigned long long tblk = (ABL & 16) ? __builtin_amdgcn_s_memtime() : 0;
@@ -391,20 +415,57 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
 #pragma unroll 1
             for (int q = 0; q < 6; q++) {
                 const bool dil = (q & 1) == 0, last = q == 5, own2 = q < 4;      // own2: the convolution two ahead is this block's
-                conv(taps_c, acc_c, nks_c, last ? 2 : (q & 1), dil ? X_OFF : M_OFF, dil ? GX : GM, dil ? q + 1 : 1, dil ? mw[0] : xw[0], dil ? mw[1] : xw[1],
+                conv(taps_c, acc_c, nks_c, last_c, last ? 2 : (q & 1), dil ? X_OFF : M_OFF, dil ? GX : GM, dil ? q + 1 : 1, dil ? mw[0] : xw[0], dil ? mw[1] : xw[1],
                      bsb, q * C * 4, own2 ? wb : wnext_block, own2 ? (q + 2) * CB : (q - 4) * NKS * FR * 1024, own2 ? KS * FR : NKS * FR, xnext, tnext);
             }
         };
 
         constexpr int NBLK = (B0 > 0) + (B1 > 0) + (B2 > 0);
         // the block after the last one of this tile is the first one of the next tile
-        block(std::integral_constant<int, B0>{}, std::integral_constant<int, (NBLK > 1 ? B1 : B0) * KSUB>{}, std::integral_constant<bool, ACC0>{}, p.w[0], p.bias[0],
+        block(std::integral_constant<int, B0>{}, std::integral_constant<int, (NBLK > 1 ? B1 : B0) * KSUB>{}, std::integral_constant<bool, ACC0>{}, std::integral_constant<bool, NBLK == 1>{}, p.w[0], p.bias[0],
               NBLK > 1 ? p.w[1] : p.w[0], NBLK > 1 ? tile : tile_next);
         if constexpr (B1 > 0)
-            block(std::integral_constant<int, B1>{}, std::integral_constant<int, (NBLK > 2 ? B2 : B0) * KSUB>{}, std::true_type{}, p.w[1], p.bias[1],
+            block(std::integral_constant<int, B1>{}, std::integral_constant<int, (NBLK > 2 ? B2 : B0) * KSUB>{}, std::true_type{}, std::integral_constant<bool, NBLK == 2>{}, p.w[1], p.bias[1],
                   NBLK > 2 ? p.w[2] : p.w[0], NBLK > 2 ? tile : tile_next);
         if constexpr (B2 > 0)
-            block(std::integral_constant<int, B2>{}, std::integral_constant<int, B0 * KSUB>{}, std::true_type{}, p.w[2], p.bias[2], p.w[0], tile_next);
+            block(std::integral_constant<int, B2>{}, std::integral_constant<int, B0 * KSUB>{}, std::true_type{}, std::true_type{}, p.w[2], p.bias[2], p.w[0], tile_next);
+        if constexpr (POST) {
+            // conv_post + tanh on the tile's mean, now in the x image (raw bf16 rows, stored rows +-3): the 7 x 32 products of an output
+            // row added in k_conv_post's order (tap-major, channels ascending, one fma chain from the bias), taps beyond the sequence
+            // skipped as there.  (The lanes of a wave read different rows of one slot: bank conflicts on every read -- a few per cent of a tile.)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            uint16_t *arow = p.audio + (int64_t)b * T;
+            const float pslope = p.post_slope;
+            // one output row per thread and pass.  (Two adjacent rows per thread, so that a row's LeakyReLU is taken twice instead of
+            // seven times, measured SLOWER: 1 511 against 1 449 us per 1 280 chunks -- six busy waves and rows 128 bytes apart.)
+            for (int j = tid; j < R; j += NW * 64) {
+                const int t = tq + HC + j;
+                if (t >= T) break;
+                float acc = p.post_bias;
+#pragma unroll 1
+                for (int k = 0; k < 7; k++) {
+                    const int tt = t + k - 3;
+                    if (tt < 0 || tt >= T) continue;
+                    const int row = GX + HC + j + k - 3;
+#pragma unroll
+                    for (int q = 0; q < SPR; q++) {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(lds + img_addr(X_OFF, row, q));
+                        const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            float lo = __uint_as_float(u[e] << 16), hi = __uint_as_float(u[e] & 0xffff0000u);
+                            lo = lo > 0.0f ? lo : lo * pslope;
+                            hi = hi > 0.0f ? hi : hi * pslope;
+                            acc = __fmaf_rn(p.post_w[k * 32 + q * 8 + 2 * e], lo, acc);
+                            acc = __fmaf_rn(p.post_w[k * 32 + q * 8 + 2 * e + 1], hi, acc);
+                        }
+                    }
+                }
+                arow[t] = f32_to_bf16(tanhf(acc));
+            }
+            __builtin_amdgcn_s_barrier();              // the next tile's first block refills the x image
+        }
     }
     if constexpr ((ABL & 16) != 0) {
         if (tid == 0)
@@ -416,14 +477,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
 #undef LV_STORE
 }
 
-template <int C, int NW, int WGM, int WGN, int MTB, int HC, int PF, int B0, int B1, int B2, bool ACC0, int ABL = 0>
-static int launch_level(LevelParams &p, hipStream_t st)
+template <int C, int NW, int WGM, int WGN, int MTB, int HC, int PF, int B0, int B1, int B2, bool ACC0, int ABL = 0, bool POST = false>
+static int launch_level(LevelParams &p, hipStream_t st, int64_t ws_bytes = 0)
 {
     constexpr int RT = WGM * MTB * 16, R = RT - 2 * HC;
     constexpr int BMAX = B0 > B1 ? (B0 > B2 ? B0 : B2) : (B1 > B2 ? B1 : B2);
     constexpr size_t bytes = (size_t)(RT + 50 + RT + 10) * C * 2 + 2 * (size_t)BMAX * (C / 32) * (C / 16) * 1024;
     static_assert(bytes <= 160 * 1024, "tile does not fit in LDS");
-    auto kern = k_resblock_level<C, NW, WGM, WGN, MTB, HC, PF, B0, B1, B2, ACC0, ABL>;
+    auto kern = k_resblock_level<C, NW, WGM, WGN, MTB, HC, PF, B0, B1, B2, ACC0, ABL, POST>;
     static DeviceOnce attr_once;
     int attr_dev = 0;
     if (attr_once.needed(&attr_dev)) {
@@ -436,18 +497,26 @@ static int launch_level(LevelParams &p, hipStream_t st)
     const int ncu = device_cu_count();
     if (ncu <= 0) return fail(IFH_EHIP, "resblock_level: device query");
     const int grid = p.ntiles < ncu ? p.ntiles : ncu;
+    if (POST && ws_bytes < (int64_t)grid * RT * C * 2) return fail(IFH_EINVAL, "resblock_level: mean_ws is smaller than ifh_level_ws_bytes()");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), bytes, st, p);
     return IFH_OK;
 }
 
 }  // namespace ifh
 
+// bytes of ifh_level_desc.mean_ws: one tile of running-mean rows (896 x 32 bf16) per workgroup, a workgroup per CU
+extern "C" int64_t ifh_level_ws_bytes(void)
+{
+    const int ncu = ifh::device_cu_count_physical();
+    return ncu > 0 ? (int64_t)ncu * 896 * 32 * 2 : -1;
+}
+
 using namespace ifh;
 
 extern "C" int ifh_resblock_level_bf16(const ifh_level_desc *d, ifh_stream_t stream)
 {
     IFH_CHECK_ARG(d);
-    IFH_CHECK_ARG(d->x && d->out && d->nblocks >= 1 && d->nblocks <= 3);
+    IFH_CHECK_ARG(d->x && (d->out || d->post_w) && d->nblocks >= 1 && d->nblocks <= 3);
     IFH_CHECK_ARG(d->nbatch >= 0 && d->t >= 0);
     if (d->nbatch == 0 || d->t == 0) return IFH_OK;
     IFH_CHECK_ARG(d->c == 32);
@@ -469,6 +538,16 @@ extern "C" int ifh_resblock_level_bf16(const ifh_level_desc *d, ifh_stream_t str
     p.out_scale = d->out_scale;
     p.accumulate = d->accumulate;
     p.prof = (unsigned long long *)d->debug_prof;
+    p.post_w = d->post_w;
+    p.post_bias = d->post_bias;
+    p.post_slope = d->post_slope;
+    p.audio = (uint16_t *)d->audio;
+    p.mean_ws = (uint16_t *)d->mean_ws;
+    if (d->post_w) {
+        // conv_post folded in: the three-block C = 32 level only, nothing to add to; `out` is not touched
+        IFH_CHECK_ARG(d->audio && d->mean_ws && d->nblocks == 3 && !d->accumulate && d->post_slope > 0.0f && d->post_slope <= 1.0f);
+        IFH_CHECK_ARG((((uintptr_t)d->mean_ws) & 15) == 0 && (((uintptr_t)d->post_w) & 3) == 0 && (((uintptr_t)d->audio) & 1) == 0);
+    }
     hipStream_t st = as_stream(stream);
     int rc = IFH_EINVAL;
     const int t0 = d->taps[0], t1 = d->nblocks > 1 ? d->taps[1] : 0, t2 = d->nblocks > 2 ? d->taps[2] : 0;
@@ -497,6 +576,9 @@ extern "C" int ifh_resblock_level_bf16(const ifh_level_desc *d, ifh_stream_t str
 #ifdef LV_DEV_ONLY
         LEVEL_CASE(LV_DEV_ONLY, 0, 0)
 #else
+        if (d->post_w) {
+            if (t0 == 3 && t1 == 7 && t2 == 11) rc = launch_level<32, 8, 8, 1, 7, 64, 3, 3, 7, 11, false, 0, true>(p, st, d->mean_ws_bytes);
+        } else
         LEVEL_CASE(3, 7, 11)
         LEVEL_CASE(3, 0, 0)
         LEVEL_CASE(7, 0, 0)

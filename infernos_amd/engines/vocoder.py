@@ -39,6 +39,7 @@ class HifiGan:
         self.fused_chain = True
         # the C = 32 level: its three residual blocks as ONE launch with the weights stationary in registers (csrc/level.hip)
         self.fused_level = True
+        self.fused_post = True           # conv_post + tanh inside that launch: the level's [n, t, 32] mean never crosses HBM
         for i in range(1, 4):
             for j, k in enumerate((3, 7, 11)):
                 R = 'resblocks.%d.' % (i * 3 + j)
@@ -99,15 +100,22 @@ class HifiGan:
             for nm in ('u', 'h', 'r0', 'r1', 'xn'):
                 b['%s%d' % (nm, i)] = torch.empty((n, t, c), dtype=BF16, device=dev)
         b['audio'] = torch.empty((n, t), dtype=BF16, device=dev)
+        # the C = 32 level's running mean, one tile per workgroup (ifh_level_desc.mean_ws: scratch of this buffer set, so of one stream / graph)
+        b['lvl_ws'] = torch.empty(ops.level_ws_bytes(), dtype=torch.uint8, device=dev)
         return b
 
-    def level(self, i, u, B, n, t, c):
-        """The three residual blocks (k = 3, 7, 11) of upsampling level i over u bf16 [n, t, c] -> their mean (B['xn%d' % i])."""
+    def level(self, i, u, B, n, t, c, post=False):
+        """The three residual blocks (k = 3, 7, 11) of upsampling level i over u bf16 [n, t, c] -> their mean (B['xn%d' % i]);
+        post (the last level, on the level kernel): -> conv_post + tanh of that mean, B['audio'], with the mean left on the chip."""
         h, xn = B['h%d' % i], B['xn%d' % i]
         rbuf = (B['r0%d' % i], B['r1%d' % i])
         if self.fused_level and self.fused_chain and c == 32:
-            ops.resblock_level(u, [(k, self.chain[(i, j)][0], self.chain[(i, j)][2]) for j, k in enumerate((3, 7, 11))], xn,
-                               nbatch=n, t=t, c=c, slope=0.1, scale=1.0 / 3.0)
+            blocks = [(k, self.chain[(i, j)][0], self.chain[(i, j)][2]) for j, k in enumerate((3, 7, 11))]
+            if post:
+                ops.resblock_level(u, blocks, None, nbatch=n, t=t, c=c, slope=0.1, scale=1.0 / 3.0,
+                                   post=(self.post_w, self.post_b, 0.01, B['audio'], B['lvl_ws']))
+                return B['audio']
+            ops.resblock_level(u, blocks, xn, nbatch=n, t=t, c=c, slope=0.1, scale=1.0 / 3.0)
             return xn
         for j, k in enumerate((3, 7, 11)):
             cur = u
@@ -169,8 +177,11 @@ class HifiGan:
                     ops.conv(prev, w, ub, u, nbatch=n, t_in=t, t_out=t, cin=c, n=c // 2, taps=2, pad=pad, pre_slope=0.1,
                              ostride=4, ooff=r)
             t, c = t * 4, c // 2
-            prev = self.level(i, u, B, n, t, c)
+            post = i == 3 and c == 32 and self.fused_post and self.fused_level and self.fused_chain
+            prev = self.level(i, u, B, n, t, c, post=post)
         audio = B['audio']
+        if post:
+            return audio
         _lib.check(_lib.lib().ifh_hifigan_post_bf16(ops._addr(prev), ops._addr(self.post_w), self.post_b, ops._addr(audio),
                                                     n, t, 0.01, _lib.stream_ptr(self.device)), 'ifh_hifigan_post_bf16')
         return audio

@@ -108,18 +108,29 @@ def seq_supported(c, t, taps):
     return bool(_lib.lib().ifh_resblock_seq_supported(int(c), int(t), int(taps)))
 
 
-def resblock_level(x, blocks, out, *, nbatch, t, c, slope=0.1, scale=1.0, accumulate=False, prof=None):
+def level_ws_bytes():
+    """bytes of the `ws` a resblock_level(post=...) launch needs (ifh_level_ws_bytes)"""
+    return int(_lib.lib().ifh_level_ws_bytes())
+
+
+def resblock_level(x, blocks, out, *, nbatch, t, c, slope=0.1, scale=1.0, accumulate=False, prof=None, post=None):
     """out = sum_j chain_j(x) * scale (+ out): the residual blocks of one HiFi-GAN level in ONE launch (ifh_resblock_level_bf16,
     weights stationary in registers), bit-identical to len(blocks) resblock_chain launches with accumulate.
-    blocks = [(taps, wstream, bias), ...] with wstream/bias from w_chain_pack."""
+    blocks = [(taps, wstream, bias), ...] with wstream/bias from w_chain_pack.
+    post = (w f32 [7][32], bias, slope, audio bf16 [nbatch][t], ws uint8 [level_ws_bytes()]): conv_post + tanh folded in -- the
+    level's mean is not written (`out` may be None), audio is; the bits of hifigan_post on the unfolded launch's `out`."""
     d = _lib.LevelDesc()
+    if post is not None:
+        pw, pb, ps, audio, ws = post
+        d.post_w, d.post_bias, d.post_slope, d.audio = _addr(pw), float(pb), float(ps), _addr(audio)
+        d.mean_ws, d.mean_ws_bytes = _addr(ws), ws.numel() * ws.element_size()
     d.x, d.x_bstride = _addr(x), t * c
     d.c, d.t, d.nbatch, d.nblocks = c, t, nbatch, len(blocks)
     for j, (taps, ws, bias) in enumerate(blocks):
         d.taps[j], d.wstream[j], d.bias[j] = taps, _addr(ws), _addr(bias)
     d.slope, d.out_scale, d.accumulate = slope, scale, int(accumulate)
     d.out, d.out_bstride, d.debug_prof = _addr(out), t * c, _addr(prof)
-    _lib.check(_lib.lib().ifh_resblock_level_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_resblock_level_bf16')
+    _lib.check(_lib.lib().ifh_resblock_level_bf16(ctypes.byref(d), _lib.stream_ptr(x.device)), 'ifh_resblock_level_bf16')
     return out
 
 

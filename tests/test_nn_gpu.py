@@ -889,6 +889,45 @@ def test_resblock_level_is_bit_identical_to_chain_launches(dev, case):
         assert e < 1.5e-2, (case, e)            # six bf16 roundings of the stream per block, three blocks
 
 
+@pytest.mark.parametrize('B,T', [(3, 3072), (2, 1000), (5, 48), (300, 768), (90, 3072), (1, 5)])
+def test_level_with_conv_post_folded_in_is_bit_identical_to_the_two_launches(dev, B, T):
+    """ifh_resblock_level_bf16 with ifh_level_desc.post_w (round 6: SpeechT5HifiGan.forward's conv_post + tanh on the tile's mean
+    while it is in LDS, the blocks' running mean in a per-workgroup workspace slab, `out` never written) against the launches it
+    replaces -- the level into `out`, then ifh_hifigan_post_bf16 on it: the same audio bit for bit, at whole tiles, ragged and tiny
+    sequences, several tiles per sequence and more tiles than CUs; and against fp32 torch."""
+    from infernos_amd import _lib, ops
+    c = 32
+    g = torch.Generator().manual_seed(B * 7 + T)
+    x = bfr(torch.randn(B, T, c, generator=g))
+    blocks, convs_all = [], []
+    for k in (3, 7, 11):
+        convs = [(bfr(torch.randn(c, c, k, generator=g) / (c * k) ** 0.5), torch.randn(c, generator=g) * 0.1) for _ in range(6)]
+        ws, nu, bias = ops.w_chain_pack(convs, dev)
+        blocks.append((k, ws, bias))
+        convs_all.append(convs)
+    pw = (torch.randn(7, 32, generator=g) / 15).contiguous()
+    pb = 0.03
+    xd = x.to(dev, BF)
+    mean = torch.empty(B, T, c, dtype=BF, device=dev)
+    ops.resblock_level(xd, blocks, mean, nbatch=B, t=T, c=c, scale=1 / 3)
+    ref = torch.empty(B, T, dtype=BF, device=dev)
+    _lib.check(_lib.lib().ifh_hifigan_post_bf16(ops._addr(mean), ops._addr(pw.to(dev)), pb, ops._addr(ref), B, T, 0.01,
+                                                _lib.stream_ptr(dev)), 'ifh_hifigan_post_bf16')
+    out = torch.full((B, T), 7.0, dtype=BF, device=dev)
+    wsb = torch.empty(ops.level_ws_bytes(), dtype=torch.uint8, device=dev)
+    ops.resblock_level(xd, blocks, None, nbatch=B, t=T, c=c, scale=1 / 3, post=(pw.to(dev), pb, 0.01, out, wsb))
+    torch.cuda.synchronize()
+    if not torch.equal(out.view(torch.int16), ref.view(torch.int16)):
+        diff = (out.float() - ref.float()).abs()
+        bad = torch.nonzero(diff > 0)
+        raise AssertionError('folded conv_post differs: max abs %g at %d samples, first (batch,row) %s' % (
+            float(diff.max()), bad.size(0), bad[:8].tolist()))
+    if B <= 8:
+        m = sum(_torch_resblock(x, cv) for cv in convs_all) / 3
+        want = torch.tanh(F.conv1d(F.leaky_relu(m.transpose(1, 2), 0.01), pw.t()[None], torch.tensor([pb]), padding=3))[:, 0]
+        assert float((out.float().cpu() - want).abs().max()) < 3e-2
+
+
 @pytest.mark.parametrize('case', [
     dict(B=4, T=48, k=3, d=1), dict(B=5, T=48, k=7, d=3, resid=True), dict(B=7, T=48, k=11, d=5, resid=True, scale=1 / 3, acc=True),
     dict(B=1, T=48, k=11, d=1), dict(B=3, T=37, k=7, d=5, resid=True), dict(B=600, T=48, k=11, d=3, resid=True),

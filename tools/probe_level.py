@@ -54,6 +54,21 @@ def main():
         tl = ev_time(lambda: ops.resblock_level(x, [(k, ws, bias)], out, nbatch=n, t=T, c=c, scale=1 / 3))
         print('C=%d k=%2d: chain %7.1f us = %6.1f TF/s   level %7.1f us = %6.1f TF/s   x%.2f' % (
             c, k, tc * 1e6, fl(k) / tc / 1e12, tl * 1e6, fl(k) / tl / 1e12, tc / tl))
+    # round 6: conv_post + tanh folded into the level launch against level + ifh_hifigan_post_bf16
+    pw = (torch.randn(7, 32, generator=g) / 15).to(dev)
+    audio, audio2 = torch.empty(n, T, dtype=BF, device=dev), torch.empty(n, T, dtype=BF, device=dev)
+    wsb = torch.empty(ops.level_ws_bytes(), dtype=torch.uint8, device=dev)
+
+    def level_then_post():
+        level_all()
+        _lib.check(_lib.lib().ifh_hifigan_post_bf16(ops._addr(out), ops._addr(pw), 0.03, ops._addr(audio), n, T, 0.01, _lib.stream_ptr(dev)), 'post')
+
+    def level_post():
+        ops.resblock_level(x, [(k, ws, bias) for k, ws, nu, bias in blocks], None, nbatch=n, t=T, c=c, scale=1 / 3, post=(pw, 0.03, 0.01, audio2, wsb))
+    level_then_post(); level_post(); torch.cuda.synchronize()
+    print('folded conv_post bits equal:', bool(torch.equal(audio.view(torch.int16), audio2.view(torch.int16))))
+    t2, t1 = ev_time(level_then_post), ev_time(level_post)
+    print('C=%d level + conv_post: two launches %7.1f us   folded %7.1f us   x%.2f' % (c, t2 * 1e6, t1 * 1e6, t2 / t1))
     tc, tl = ev_time(chain_all), ev_time(level_all)
     ft = sum(fl(k) for k in (3, 7, 11))
     print('C=%d level (3 blocks): chain launches %7.1f us = %6.1f TF/s   one level launch %7.1f us = %6.1f TF/s   x%.2f' % (
