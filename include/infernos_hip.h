@@ -575,10 +575,11 @@ typedef struct ifh_beam_desc {
     void *scratch;
 } ifh_beam_desc;
 int ifh_beam_step(const ifh_beam_desc *desc, ifh_stream_t stream);
-/* dst[row] = src[row_src[row]] for the first min(len[0], max_len) tokens of a KV cache laid out [nrows][max_len][tok_elems]
- * bf16 (row_stride elements between rows); src != dst (ping-pong).  tok_elems % 8 == 0. */
+/* dst[l][row] = src[l][row_src[row]] for the first min(len[0], max_len) tokens of nlayers KV caches laid out
+ * [nlayers][nrows][max_len][tok_elems] bf16 (row_stride elements between rows, layer_stride between layers: the decoder's
+ * layers in ONE launch per search step); src != dst (ping-pong).  tok_elems % 8 == 0. */
 int ifh_kv_gather_bf16(const void *src, void *dst, const int32_t *row_src, const int32_t *len, int max_len, int nrows,
-                       int64_t row_stride, int tok_elems, ifh_stream_t stream);
+                       int64_t row_stride, int tok_elems, int nlayers, int64_t layer_stride, ifh_stream_t stream);
 
 /* out[i] = table[ids[i]] + pos_table[pos0 + i % seq_len] (pos_table may be NULL); bf16, dim % 8 == 0.
  * dyn_pos (device scalar, optional): pos0 += dyn_pos[0], ids += dyn_pos[0]*dyn_ids_mul */

@@ -177,7 +177,7 @@ SIGNATURES.update({
     'ifh_add_i32': (_i, [_vp, _i, _vp, _i64, _vp]),
     'ifh_attn_decode_shared_bf16': (_i, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i, _i, _i, _i, _i, _vp]),
     'ifh_beam_step': (_i, [ctypes.POINTER(BeamDesc), _vp]),
-    'ifh_kv_gather_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _vp]),
+    'ifh_kv_gather_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i, _i, _i64, _vp]),
     'ifh_rmsnorm_bf16': (_i, [_vp, _vp, _vp, _i, _i, _f, _vp]),
     'ifh_rope_append_bf16': (_i, [_vp, _i64, _vp, _i, _vp, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     'ifh_attn_gqa_bf16': (_i, [ctypes.POINTER(GqaDesc), _vp]),

@@ -480,12 +480,12 @@ __global__ __launch_bounds__(64) void k_beam_update(BeamParams p)
 __global__ __launch_bounds__(256) void k_kv_gather(const uint4 *__restrict__ src, uint4 *__restrict__ dst,
                                                    const int32_t *__restrict__ row_src,
                                                    const int32_t *__restrict__ len, int max_len, int64_t row_u4,
-                                                   int tok_u4)
+                                                   int tok_u4, int64_t layer_u4)
 {
     const int row = blockIdx.y;
     const int n = min(len[0], max_len) * tok_u4;
-    const uint4 *s = src + (int64_t)row_src[row] * row_u4;
-    uint4 *d = dst + (int64_t)row * row_u4;
+    const uint4 *s = src + (int64_t)blockIdx.z * layer_u4 + (int64_t)row_src[row] * row_u4;
+    uint4 *d = dst + (int64_t)blockIdx.z * layer_u4 + (int64_t)row * row_u4;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] = s[i];
 }
 
@@ -537,15 +537,16 @@ extern "C" int ifh_beam_step(const ifh_beam_desc *d, ifh_stream_t stream)
 }
 
 extern "C" int ifh_kv_gather_bf16(const void *src, void *dst, const int32_t *row_src, const int32_t *len, int max_len,
-                                  int nrows, int64_t row_stride, int tok_elems, ifh_stream_t stream)
+                                  int nrows, int64_t row_stride, int tok_elems, int nlayers, int64_t layer_stride, ifh_stream_t stream)
 {
-    IFH_CHECK_ARG(nrows >= 0);
-    if (nrows == 0) return IFH_OK;
-    IFH_CHECK_ARG(src && dst && src != dst && row_src && len && max_len >= 1 && nrows < 65536);
+    IFH_CHECK_ARG(nrows >= 0 && nlayers >= 0);
+    if (nrows == 0 || nlayers == 0) return IFH_OK;
+    IFH_CHECK_ARG(src && dst && src != dst && row_src && len && max_len >= 1 && nrows < 65536 && nlayers < 65536);
     IFH_CHECK_ARG(tok_elems > 0 && tok_elems % 8 == 0 && row_stride % 8 == 0 && row_stride >= (int64_t)max_len * tok_elems);
+    IFH_CHECK_ARG(layer_stride % 8 == 0 && (nlayers == 1 || layer_stride >= (int64_t)nrows * row_stride));
     IFH_CHECK_ARG(((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0);
-    hipLaunchKernelGGL(k_kv_gather, dim3(8, nrows), dim3(256), 0, as_stream(stream), (const uint4 *)src, (uint4 *)dst,
-                       row_src, len, max_len, row_stride / 8, tok_elems / 8);
+    hipLaunchKernelGGL(k_kv_gather, dim3(8, nrows, nlayers), dim3(256), 0, as_stream(stream), (const uint4 *)src, (uint4 *)dst,
+                       row_src, len, max_len, row_stride / 8, tok_elems / 8, layer_stride / 8);
     IFH_LAUNCH_CHECK("kv_gather");
     return IFH_OK;
 }

@@ -10,7 +10,6 @@ Only the last time row of the prenet is computed per step: rows are independent 
 mask row, so this equals the reference's prenet-over-history followed by [:, -1:].
 """
 import math
-import os
 
 import torch
 
@@ -95,7 +94,7 @@ class SpeechT5:
         # ---- LayerNorm-folded variants for the decode loop (ifh_conv_desc.aln_*/rln_*): the three LayerNorm
         # launches per layer disappear; gamma goes into the consumer's weights, mean/rstd are applied in its
         # epilogue from row statistics the producer's epilogue accumulated.
-        self.fold_ln = os.environ.get('IFH_FOLD_LN', '1') != '0'      # tuning switch
+        self.fold_ln = True            # LayerNorms folded around the decode GEMMs (False: explicit launches)
         lnp = lambda name: (sd[name + '.weight'].float(), sd[name + '.bias'].float())
         self.dec_fold = []
         for i in range(self.n_dec_layers):

@@ -7,7 +7,6 @@ KV-cached decoder, tied output projection, greedy argmax and the no-speech proba
 Architecture per transformers modeling_whisper.py (v5.15.0).  The decode loop runs entirely
 on the device (argmax feeds the next embedding lookup; no host sync per token).
 """
-import os
 
 import torch
 
@@ -80,7 +79,7 @@ class Whisper:
         # LayerNorm folded around the decode-step GEMMs (ifh_conv_desc.aln_* / stats_out; same scheme as the SpeechT5
         # decoder): 13 of the 49 launches per token disappear.  The vocabulary projection is padded to a multiple of
         # 16 rows; the padded logits are pinned to -1e30 through the folded bias so that argmax never picks them.
-        self.fold_ln = os.environ.get('IFH_FOLD_LN', '1') != '0'      # tuning switch
+        self.fold_ln = True            # LayerNorms folded around the decode GEMMs (False: explicit launches, decoder_step)
         self.vpad = -(-self.vocab // 16) * 16
         self.dec_fold = []
         nl = len(self.dec_layers)
@@ -149,7 +148,7 @@ class Whisper:
                 self._dec_bufs.pop(next(iter(self._dec_bufs)))
             self._dec_bufs[key] = dict(
                 cross=[e(Bn // max(1, beams) * N_CTX, 2 * d) for _ in self.dec_layers],
-                kv=[torch.zeros((Bn, self.max_tokens, 2 * d), dtype=BF16, device=dev) for _ in self.dec_layers],
+                kv_all=torch.zeros((len(self.dec_layers), Bn, self.max_tokens, 2 * d), dtype=BF16, device=dev),
                 x=e(Bn, d), hn=e(Bn, d), q=e(Bn, d), att=e(Bn, d), ff=e(Bn, self.ff),
                 logits_full=e(Bn, self.vpad, dt=torch.float32),
                 stats=torch.zeros((3 * len(self.dec_layers), max(64, -(-Bn // 16) * 16), 2), dtype=torch.int64, device=dev),
@@ -157,9 +156,11 @@ class Whisper:
                 pos=torch.zeros(1, dtype=torch.int32, device=dev), graphs={}, eager_runs=0)
             b = self._dec_bufs[key]
             b['logits'] = b['logits_full'][:, :self.vocab]         # [Bn, vocab] view, row stride vpad
+            b['kv'] = list(b['kv_all'].unbind(0))                  # per-layer views of one allocation (the beam gather moves all layers in one launch)
             if beams >= 1:
                 b['cross_group'] = beams
-                b['kv2'] = [torch.zeros_like(t) for t in b['kv']]
+                b['kv2_all'] = torch.zeros_like(b['kv_all'])
+                b['kv2'] = list(b['kv2_all'].unbind(0))
         return self._dec_bufs[key]
 
     def _cross_attn(self, bufs, li, Bn):
@@ -187,9 +188,9 @@ class Whisper:
         ops.beam_step(bufs['logits_full'], bm['state'], bufs['toks'], bufs['pos'], vocab=self.vocab, ld=self.vpad,
                       prompt_len=bm['P'], max_length=bm['max_length'], eos_id=bm['eos'], length_penalty=bm['lp'],
                       suppress=bm['suppress'], begin_suppress=bm['begin_suppress'])
-        src, dst = (bufs['kv'], bufs['kv2']) if mode[1] == 0 else (bufs['kv2'], bufs['kv'])
-        for a, b in zip(src, dst):
-            ops.kv_gather(a, b, bm['state'].beam_src, bufs['pos'], nrows=Bn, max_len=self.max_tokens, tok_elems=2 * self.d)
+        src, dst = (bufs['kv_all'], bufs['kv2_all']) if mode[1] == 0 else (bufs['kv2_all'], bufs['kv_all'])
+        ops.kv_gather(src, dst, bm['state'].beam_src, bufs['pos'], nrows=Bn, max_len=self.max_tokens, tok_elems=2 * self.d,
+                      nlayers=len(self.dec_layers))
 
     @staticmethod
     def _kvsel(bufs, mode):

@@ -71,7 +71,7 @@ class TickEgress:
     inside the tick's own hardware queue (round 4: eleven alternating runs, p99 40-57 ms without the marker, 3.6-7.2 ms with it;
     the queue reaches the tick's first packet at once, the stall sits between its last kernel and the completion signal of the
     copy).  What the extra packet changes in the queue processor is not understood; it is kept where every per-tick caller gets it --
-    bench.py's tick probe calls this class (IFH_TICK_MARKER=0 takes it out, for measurements)."""
+    bench.py's tick probe calls this class (`marker = False` takes the event out, for measurements)."""
 
     def __init__(self, n: int, L: int = 160, device=None):
         self.device = _lib.require_device(device)

@@ -291,10 +291,11 @@ def beam_step(logits, st: BeamState, toks, pos, *, vocab, ld, prompt_len, max_le
     _lib.check(_lib.lib().ifh_beam_step(ctypes.byref(d), _lib.stream_ptr(logits.device)), 'ifh_beam_step')
 
 
-def kv_gather(src, dst, row_src, length, *, nrows, max_len, tok_elems):
-    """dst[row] = src[row_src[row]] for the first length[0] tokens of a [nrows, max_len, tok_elems] bf16 cache"""
+def kv_gather(src, dst, row_src, length, *, nrows, max_len, tok_elems, nlayers=1):
+    """dst[l][row] = src[l][row_src[row]] for the first length[0] tokens of a [nlayers, nrows, max_len, tok_elems] bf16 cache"""
     _lib.check(_lib.lib().ifh_kv_gather_bf16(_addr(src), _addr(dst), _addr(row_src), _addr(length), max_len, nrows,
-                                             max_len * tok_elems, tok_elems, _lib.stream_ptr(dst.device)),
+                                             max_len * tok_elems, tok_elems, nlayers, nrows * max_len * tok_elems,
+                                             _lib.stream_ptr(dst.device)),
                'ifh_kv_gather_bf16')
 
 

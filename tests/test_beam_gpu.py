@@ -194,6 +194,14 @@ def test_kv_gather_exact(dev):
         m = min(n, max_len)
         assert torch.equal(dst[:, :m], src[idx.long(), :m])
         assert torch.equal(dst[:, m:], dst0[:, m:])
+    # the decoder's layers in one launch (round 6): [layers, rows, max_len, tok]
+    L = 3
+    src = torch.randn(L, rows, max_len, tok, generator=g).to(dev, BF)
+    dst0 = torch.randn(L, rows, max_len, tok, generator=g).to(dev, BF)
+    dst = dst0.clone()
+    ops.kv_gather(src, dst, idx, torch.tensor([17], dtype=torch.int32, device=dev), nrows=rows, max_len=max_len, tok_elems=tok, nlayers=L)
+    assert torch.equal(dst[:, :, :17], src[:, idx.long(), :17])
+    assert torch.equal(dst[:, :, 17:], dst0[:, :, 17:])
 
 
 @pytest.mark.parametrize('keys', [200, 1500])

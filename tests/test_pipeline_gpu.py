@@ -72,7 +72,7 @@ def test_pipeline_cycle_small(built_lib):
     assert np.isfinite(audio).all() and 1e-4 < np.abs(audio).mean() < 0.5
 
 
-@pytest.mark.parametrize('lanes,group,fronts', [(2, 1, 1), (2, 2, 1), (1, 3, 1), (3, 2, 2)])
+@pytest.mark.parametrize('lanes,group,fronts', [(2, 1, 1), (3, 2, 2)])      # (round 6: (2, 2, 1) and (1, 3, 1) ran the same code paths)
 def test_pipelined_tts_lanes_match_sequential(built_lib, lanes, group, fronts):
     """run_steps with the front-end thread, overlapping TTS lanes and grouped TTS batches (the utterances of
     `group` consecutive cycles synthesised as one batch) returns, cycle by cycle and in order, the bytes of the
@@ -339,8 +339,9 @@ class _RecMasks:
         return m.to(self.dev)
 
 
-@pytest.mark.parametrize('name,N,family,nheads,stt_beam,tts_mode', [('C3', 128, 'whisper_base', 8, 1, 'lanes'),
-                                                                   ('C3-as-benched', 128, 'whisper_base', 8, 5, 'continuous'),
+# (round 6: the third case of rounds 2-5, C3 with greedy decode and the lane schedule, ran Whisper-base as 'C3-as-benched' does and
+# greedy + lanes as 'C4-share' does; dropped for the suite's time limit)
+@pytest.mark.parametrize('name,N,family,nheads,stt_beam,tts_mode', [('C3-as-benched', 128, 'whisper_base', 8, 5, 'continuous'),
                                                                    ('C4-share', 256, 'whisper_tiny', 6, 1, 'lanes')])
 def test_baseline_config_full_cycle(built_lib, name, N, family, nheads, stt_beam, tts_mode):
     """BASELINE config 3 (128 calls, Whisper-base STT -> T2T stub -> TTS) and the per-GPU share of config 4 (256 calls):

@@ -1,7 +1,7 @@
-# per-kernel stats of the Whisper-base encoder at 128 windows:  bash tools/prof_encoder.sh  -> gpurun_out/r05p/encoder_kernel_stats.csv
+# per-kernel stats of the Whisper-base encoder at 128 windows:  bash tools/prof_encoder.sh  -> gpurun_out/r06p/encoder_kernel_stats.csv
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r05p
+O=$R/gpurun_out/${PROF_DIR:-r06p}
 mkdir -p $O
 rm -rf $O/prof_enc
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_enc -- python3 $R/tools/probe_encoder.py 128 whisper_base > $O/prof_enc.log 2>&1
