@@ -251,6 +251,8 @@ def time_steps(pipe, frames_for, nsteps, warmup, world, pipelined, egress, dry, 
     g0 = _lib.CountedGraph.captures[0]
     e0 = (sum(e.calls_run for e in pipe.ctts_all), sum(e.rows_run for e in pipe.ctts_all)) if pipe.ctts is not None else None
     p0 = [dict(e.prof) for e in pipe.ctts_all] if pipe.ctts is not None else []
+    if pipe.ctts is not None:
+        pipe.ctts.st.replay_prof = [0.0, 0]
     t0 = time.perf_counter()
     res = pipe.run_steps(frames_for, nsteps, pipelined=pipelined, on_cycle=egress)
     torch.cuda.synchronize()
@@ -263,6 +265,9 @@ def time_steps(pipe, frames_for, nsteps, warmup, world, pipelined, egress, dry, 
     time_steps.launches_per_step = (_lib.CALLS[0] - c0) / max(1, nsteps)
     time_steps.graph_captures = _lib.CountedGraph.captures[0] - g0
     time_steps.engine_prof = None if e0 is None else {k: round(sum(e.prof.get(k, 0.0) - q.get(k, 0.0) for e, q in zip(pipe.ctts_all, p0)), 4) for k in ('admit', 'steps', 'render', 'ends_wait', 'book')}
+    time_steps.replay_prof = None if e0 is None else list(pipe.ctts.st.replay_prof)
+    if pipe.ctts is not None:
+        pipe.ctts.st.replay_prof = None
     time_steps.engine = None if e0 is None else (sum(e.calls_run for e in pipe.ctts_all) - e0[0], sum(e.rows_run for e in pipe.ctts_all) - e0[1])
     if probe is not None:
         probe.stop()
@@ -624,9 +629,9 @@ def main():
             return json.load(open(f)).get(key)
         voc_pmc, lm_pmc = os.path.relpath(latest('vocoder_pmc.json'), ROOT), os.path.relpath(latest('logmel_pmc.json'), ROOT)
         # the TTS decode chain (the chain that sets the cycle): a decoder step of the continuous engine at the rows it ran with, inside
-        # the timed region (host seconds the engine thread spent in its step calls / steps; the calls wait for the device every 8
-        # steps, so this is the chain's device time under load) and alone on the idle GPU (16 steps on the engine's own state and
-        # stream, nothing live: every row is computed, none advances)
+        # the timed region (host seconds the engine thread spent waiting for its 16-step calls -- it waits for the device after step 8,
+        # 'steps', and for the end flags after step 16, 'ends_wait' -- per step: the chain's device time under load) and alone on the
+        # idle GPU (16 steps on the engine's own state and stream, nothing live: every row is computed, none advances)
         step_ms = None
         if engine is not None and engine[0] and getattr(time_steps, 'engine_prof', None):
             from infernos_amd.engines.speecht5 import ragged_decoder_steps
@@ -644,9 +649,12 @@ def main():
                     ragged_decoder_steps(eng.pp.model, eng.st, masks, nrows, nsteps=16, threshold=eng.pp.threshold)
                 eng.main.synchronize()
                 idle = (time.perf_counter() - ta) / 64 * 1e3
-            step_ms = {'in_pipeline': round(time_steps.engine_prof['steps'] / (engine[0] * 16) * 1e3, 3), 'idle_gpu': round(idle, 3),
+            step_ms = {'in_pipeline': round((time_steps.engine_prof['steps'] + time_steps.engine_prof['ends_wait']) / (engine[0] * 16) * 1e3, 3),
+                       'idle_gpu': round(idle, 3),
                        'rows_idle_measurement': nrows, 'steps_per_cycle': round(engine[0] * 16 / max(1, args.steps), 1),
-                       'launches_per_step': 55}
+                       'launches_per_step': 55,
+                       'host_ms_in_graph_launch_per_step': (round(time_steps.replay_prof[0] / max(1, time_steps.replay_prof[1]) * 1e3, 3)
+                                                            if getattr(time_steps, 'replay_prof', None) else None)}
         lat = np.array(probe.lat) if probe is not None and probe.lat else None
         out = {
             'metric': 'real-time-factor x concurrent calls (STT+TTS on 20 ms G.711 frames)',

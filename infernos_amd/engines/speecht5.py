@@ -428,6 +428,7 @@ class TTSRaggedState:
         self.x0, self.q, self.att, self.t1, self.t2, self.t3 = (z(R, self.DP) for _ in range(6))
         self.ff = z(R, self.FP)
         self.plog16 = z(R, 16, dt=torch.float32)
+        self.replay_prof = None          # [seconds, launches] of the step graphs' replays when a caller wants them (bench.py)
         self.stat_rows = max(64, R)
         self.stats = z(3 * len(model.dec_layers), self.stat_rows, 2, dt=torch.int64)
         self.pn = [z(R, 32, 256), z(R, 32, 256)]
@@ -511,7 +512,14 @@ def ragged_decoder_steps(model: 'SpeechT5', st: TTSRaggedState, masks: torch.Ten
             g = st.graphs.get(key)
             if g is None:
                 g = st.graphs[key] = _lib.CountedGraph(lambda: _decoder_step_ragged(model, st, s, threshold, par, n))
-            g.replay()
+            if st.replay_prof is not None:          # (statistics: host seconds inside hipGraphLaunch, and launches)
+                import time as _t
+                _a = _t.perf_counter()
+                g.replay()
+                st.replay_prof[0] += _t.perf_counter() - _a
+                st.replay_prof[1] += 1
+            else:
+                g.replay()
             # bounded queue depth: whatever this stream has queued stands in front of a real-time tick whose launches land on the
             # same hardware queue (16 steps = ~900 kernels); waiting every few steps keeps that to a handful of milliseconds
             if sync_every and (s + 1) % sync_every == 0 and s + 1 < nsteps:

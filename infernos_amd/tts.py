@@ -244,7 +244,9 @@ class TTSGroup:
         self.dispatch = list(dispatch) if dispatch is not None else None
         self.want_ulaw = want_ulaw
         self.slots = None
-        self.idx = self.calls = 0
+        self.idx = self.calls = 0               # decoder steps / infer() calls whose results have been taken
+        self.q_idx = self.q_calls = 0           # ... that have been queued (ContinuousTTS looks one call ahead)
+        self._finished = False
         self.ulaw = self.valid = None
         self.spans = []
         self.done, self.done_event, self.error = threading.Event(), None, None
@@ -302,6 +304,14 @@ class ContinuousTTS:
         self.ren_done = [None, None]
         self.h_active = torch.zeros(R, dtype=torch.uint8).pin_memory()
         self.h_fresh = [torch.zeros(R, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self.h_ends = [torch.zeros(R, dtype=torch.int64).pin_memory() for _ in range(3)]      # end flags of the calls in flight
+        self.h_audio = {}                                # pinned audio of a call for the dispatch callbacks, by (shape, call % 3)
+        # queue call c + 1 before taking call c's results (step()).  Off by default: it closes the ~2.9 ms the decode chain stands empty
+        # at every call boundary (per-step time in the pipelined C3 cycle 2.27 -> 2.08 ms) but C3's throughput does not move -- the GPU is
+        # bound by the sum of the stages' work, not by this chain's latency (round 6, profiles/NOTES.md) -- and a session would hear
+        # every chunk half a call later
+        self.lookahead = False
+        self._inflight = None
         self.render_bufs = {}
         self.thread, self.halt = None, False
         self.failed = None                               # the exception that killed the engine thread (submit() then raises)
@@ -414,7 +424,31 @@ class ContinuousTTS:
         return min(self.st.R, -(-hi // self.row_bucket) * self.row_bucket)
 
     def step(self) -> bool:
-        """One infer() call over every live row.  Returns False when nothing is live or pending."""
+        """One infer() call over every live row: its 16 decoder steps and its render pass are QUEUED, then the results of the call
+        before it are taken (end flags, dispatch, groups that finished) -- `lookahead`: the host work between two calls (waiting
+        for the end flags, bookkeeping, admission, the next call's launches) used to leave the decode chain empty for ~2.9 ms per
+        call, 8-10 % of a C3 cycle (tools/trace_gaps.py).  A group whose last call is known when it is queued (max_calls, or the
+        KV cache's capacity) gives its row slots back at once; one that ends by the stop rule is computed for one call more than it
+        needed (its rows are independent of the others: nothing changes for them).  Returns False when nothing is live, pending or
+        in flight."""
+        ctx = self._queue_call()
+        if not self.lookahead:
+            if ctx is None:
+                return False
+            self._finish_call(ctx)
+            return True
+        prev, self._inflight = self._inflight, ctx
+        if prev is not None:
+            self._finish_call(prev)
+        return ctx is not None or prev is not None
+
+    def _close(self, grp, par):
+        """the group's row slots go back (the engine thread owns them; a later admission writes them behind everything queued)"""
+        self.live.remove(grp)
+        with self.cv:
+            self.free.extend(grp.slots)
+
+    def _queue_call(self):
         pp, st, dev = self.pp, self.st, self.device
         import time as _time
         prof = self.prof
@@ -422,7 +456,7 @@ class ContinuousTTS:
         with torch.cuda.device(dev), torch.cuda.stream(self.main):
             self._admit()
             if not self.live:
-                return False
+                return None
             t_b = _time.perf_counter()
             n = self._bucket()
             par = st.ncalls & 1
@@ -445,6 +479,11 @@ class ContinuousTTS:
             st.fresh[par].copy_(self.h_fresh[par], non_blocking=True)
             masks = pp.mask_source(16).to(dev).contiguous()
             ragged_decoder_steps(pp.model, st, masks, n, nsteps=16, threshold=pp.threshold, sync_every=self.sync_every)
+            # this call's end flags, as they stand behind its 16 steps (a later call's admissions write behind this copy)
+            k = self.calls_run % len(self.h_ends)
+            ends_host, ends_ev = self.h_ends[k], torch.cuda.Event()
+            ends_host[:n].copy_(st.ends_at[:n], non_blocking=True)
+            ends_ev.record(self.main)
             t_c = _time.perf_counter()
             dec_done = torch.cuda.Event()
             dec_done.record(self.main)
@@ -466,27 +505,57 @@ class ContinuousTTS:
                         if grp.ulaw is None:
                             grp.ulaw = torch.empty((grp.n, (grp.max_calls or 64) * A), dtype=torch.uint8, device=dev)
                             grp.valid = torch.zeros(grp.n, dtype=torch.int64)
-                        c = grp.calls
+                        c = grp.q_calls
                         if (c + 1) * A > grp.ulaw.size(1):
                             grp.ulaw = torch.cat([grp.ulaw, torch.empty_like(grp.ulaw)], 1)
                         grp.ulaw[:, c * A:(c + 1) * A] = ul.index_select(0, grp._slots_dev)
                 host_audio = None
                 if any(grp.dispatch is not None for grp in self.live):
-                    host_audio = (audio if audio.dtype == torch.bfloat16 else audio.to(torch.bfloat16))
-                    host_audio = host_audio.to('cpu', non_blocking=False)          # as unbatch_and_dispatch: one D2H of the batch
+                    # as unbatch_and_dispatch: one D2H of the batch -- into pinned memory, waited for when the call's results are taken
+                    dev_audio = (audio if audio.dtype == torch.bfloat16 else audio.to(torch.bfloat16))
+                    key = (tuple(dev_audio.shape), self.calls_run % 3)
+                    host_audio = self.h_audio.get(key)
+                    if host_audio is None:
+                        host_audio = self.h_audio[key] = torch.empty(dev_audio.shape, dtype=torch.bfloat16).pin_memory()
+                    host_audio.copy_(dev_audio, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.side)
                 self.ren_done[par] = ev
             t_d = _time.perf_counter()
-            ends_all = st.ends_at[:n].cpu().numpy()              # waits for this call's decoder steps (the reference's .item())
-            t_e = _time.perf_counter()
         self.calls_run += 1
         self.rows_run += n
+        groups = []
+        for grp in list(self.live):
+            grp.q_idx += 16
+            grp.q_calls += 1
+            # known now: this was the group's last call (its call budget, or the KV cache is full) -> its slots are free for the
+            # next admission, which is queued behind everything above
+            last = (grp.max_calls is not None and grp.q_calls >= grp.max_calls) or (grp.q_idx + 16 > st.smax)
+            groups.append((grp, grp.q_idx, grp.q_calls, last, grp.q_idx + 16 > st.smax))
+            if last:
+                self._close(grp, par)
+        for k_, v in (('admit', t_b - t_a), ('steps', t_c - t_b), ('render', t_d - t_c)):
+            prof[k_] = prof.get(k_, 0.0) + v
+        return dict(par=par, n=n, groups=groups, ends_host=ends_host, ends_ev=ends_ev, host_audio=host_audio, ren_ev=ev, A=A, stepsize=stepsize)
+
+    def _finish_call(self, ctx):
+        """take the results of a queued call: per group the dispatch offsets of HelloSippyRTPipe.py:242-259 and the end of the utterance"""
+        import time as _time
+        st, dev = self.st, self.device
+        A, stepsize, par = ctx['A'], ctx['stepsize'], ctx['par']
+        t_d = _time.perf_counter()
+        ctx['ends_ev'].synchronize()                 # waits for this call's decoder steps (the reference's .item())
+        ends_all = ctx['ends_host'].numpy()
+        host_audio = ctx['host_audio']
+        if host_audio is not None:
+            ctx['ren_ev'].synchronize()
+        t_e = _time.perf_counter()
         finished = []
-        for grp in self.live:
-            grp.idx += 16
-            grp.calls += 1
-            idx, end_idx = grp.idx, grp.idx - 1
+        for grp, idx, calls, last, out_of_cache in ctx['groups']:
+            if grp._finished:                        # ended by the stop rule in the call before: this one was computed for nothing
+                continue
+            grp.idx, grp.calls = idx, calls
+            end_idx = idx - 1
             e = ends_all[grp.slots]
             s_off = max(0, A - (idx - 1) * stepsize)                        # starts_at = post_nframes // 2 = 1 for every row
             e_off = np.where(e >= 0, np.minimum(A, A - (idx - e) * stepsize), A)
@@ -505,35 +574,33 @@ class ContinuousTTS:
                         d(None)
                         grp.dispatch[i] = None
             ended = bool(np.all((e >= 0) & (e <= end_idx)))
-            out_of_cache = grp.idx + 16 > st.smax
             if out_of_cache and not ended and grp.dispatch is not None:
                 for i, d in enumerate(grp.dispatch):      # the KV cache is full: the utterance is cut here, the session is told
                     if d is not None:
                         d(None)
                         grp.dispatch[i] = None
-            if ended or (grp.max_calls is not None and grp.calls >= grp.max_calls) or out_of_cache:
-                finished.append(grp)
-        for grp in finished:
-            self.live.remove(grp)
-            with self.cv:
-                self.free.extend(grp.slots)
-            grp.done_event = self.ren_done[par]
+            if ended or last:
+                finished.append((grp, last))
+        for grp, last in finished:
+            grp._finished = True
+            if grp in self.live:                          # (a group closed when its last call was queued has given its slots back)
+                self._close(grp, par)
+            grp.done_event = ctx['ren_ev']
             if grp.ulaw is not None:
                 # [n, max_calls*A] as the lanes path returns it: calls the group did not take (it ended early) are mu-law
                 # silence (0xFF), `valid`/`spans` say what is audio; without max_calls the width is what was produced
                 if grp.max_calls is not None and grp.calls < grp.max_calls:
-                    with torch.cuda.stream(self.side):
+                    with torch.cuda.device(dev), torch.cuda.stream(self.side):
                         grp.ulaw[:, grp.calls * A:grp.max_calls * A] = 0xFF
                         grp.done_event = torch.cuda.Event()
                         grp.done_event.record(self.side)
                 grp.ulaw = grp.ulaw[:, :(grp.max_calls or grp.calls) * A]
             grp.done.set()
         t_f = _time.perf_counter()
-        # host wall seconds of this call by phase: admission, queueing the 16 decoder steps (incl. the bounded-queue waits), queueing
-        # the render pass, waiting for the steps' end flags, per-group bookkeeping / dispatch
-        for k, v in (('admit', t_b - t_a), ('steps', t_c - t_b), ('render', t_d - t_c), ('ends_wait', t_e - t_d), ('book', t_f - t_e)):
-            prof[k] = prof.get(k, 0.0) + v
-        return True
+        # host wall seconds by phase: admission, queueing the 16 decoder steps (incl. the bounded-queue waits), queueing the render
+        # pass (_queue_call); waiting for a call's end flags, per-group bookkeeping / dispatch (here)
+        for k, v in (('ends_wait', t_e - t_d), ('book', t_f - t_e)):
+            self.prof[k] = self.prof.get(k, 0.0) + v
 
     def _render(self, par, n):
         """postnet -> carry + 4 overlapped chunks -> HiFi-GAN -> AmendmentNetwork1 over the first n row slots; one
@@ -595,9 +662,9 @@ class ContinuousTTS:
             torch.cuda.set_device(self.device)
             while True:
                 with self.cv:
-                    while not self.halt and not self.pending and not self.live:
+                    while not self.halt and not self.pending and not self.live and self._inflight is None:
                         self.cv.wait()
-                    if self.halt and not self.pending and not self.live:
+                    if self.halt and not self.pending and not self.live and self._inflight is None:
                         return
                 try:
                     self.step()

@@ -101,9 +101,12 @@ def test_ragged_rows_get_the_audio_of_their_own_batch(built_lib):
     assert sorted(eng.free) == list(range(16))
 
 
-def test_ragged_natural_stop_and_slot_reuse(built_lib):
+@pytest.mark.parametrize('lookahead', [False, True])
+def test_ragged_natural_stop_and_slot_reuse(built_lib, lookahead):
     """Seeded weights with the stop head live: rows of one batch end at different steps (sigmoid arm of the rule); a
-    second batch takes over the slots of the first.  Same bytes as each batch alone."""
+    second batch takes over the slots of the first.  Same bytes as each batch alone -- also with the engine queueing call c + 1
+    before it takes call c's results (`lookahead`: a batch that ends by the stop rule is then computed for one call more than it
+    needed; nothing changes for any row)."""
     from infernos_amd import _lib
     from infernos_amd.tts import ContinuousTTS
     dev = _lib.require_device('cuda:0')
@@ -114,6 +117,7 @@ def test_ragged_natural_stop_and_slot_reuse(built_lib):
         batches.append((torch.randint(4, 80, (n, T), generator=g, dtype=torch.int32), torch.randn(n, 512, generator=g)))
     ref = [_per_batch(pp, ids, spk) for ids, spk in batches]
     eng = ContinuousTTS(pp, max_rows=16, max_text=16, row_bucket=16)
+    eng.lookahead = lookahead
     out = []
     for k, (ids, spk) in enumerate(batches):
         s = _Sink(ids.size(0))

@@ -14,7 +14,7 @@ S = [sys.executable, os.path.join(ROOT, 'tools', 'summarize_profiles.py')]
 
 for src, dst, cmd in (
         ('voc1280_kernel_stats.csv', 'r06_vocoder_kernel_stats', 'rocprofv3 --kernel-trace --stats -- python3 tools/probe_vocoder.py 10 1280 (10 HiFi-GAN passes of 1280 chunks x 12 frames; tools/prof_r06.sh)'),
-        ('voc2048_kernel_stats.csv', 'r06_vocoder2048_kernel_stats', 'rocprofv3 --kernel-trace --stats -- python3 tools/probe_vocoder.py 10 2048 (10 passes at the render-group size the bench line quotes; tools/prof_r06.sh)'),
+        ('voc2560_kernel_stats.csv', 'r06_vocoder2560_kernel_stats', 'rocprofv3 --kernel-trace --stats -- python3 tools/probe_vocoder.py 10 2560 (10 passes at the render-group size the bench line quotes; tools/prof_r06.sh)'),
         ('voc512_kernel_stats.csv', 'r06_vocoder512_kernel_stats', 'rocprofv3 --kernel-trace --stats -- python3 tools/probe_vocoder.py 10 512 (tools/prof_r06.sh)'),
         ('logmel_kernel_stats.csv', 'r06_logmel_kernel_stats', 'rocprofv3 --kernel-trace --stats -- python3 tools/probe_logmel.py 10 128 (tools/prof_r06.sh)')):
     subprocess.check_call(S + ['stats', os.path.join(O, src), os.path.join(P, dst + '.md'), cmd])
