@@ -437,127 +437,6 @@ __global__ __launch_bounds__(64) void k_splitk_finish(const IgemmParams p, const
     }
 }
 
-// ---- k_gemm_dec for deep K (K >= 2048: SpeechT5 fc2 at 3072, Whisper fc2 at 2048), 32 x 32 tiles ----
-// A decode-step launch is a serial walk over K in 256-wide chunks whose cost is per chunk, not per byte (profiles/NOTES.md: fc2 spent
-// 35 000 of its 47 000 shader clocks in 12 chunks).  Here the workgroup is TWO groups of four waves: group h walks the half
-// [h K/2, (h + 1) K/2) -- exactly the two accumulation chains 2h, 2h + 1 of the four the streaming kernel splits a deep K into -- through
-// its own LDS image, so a launch is half as many chunk steps.  Group 1 hands its two chain tiles to group 0 through LDS, which adds
-// the four chains in chain order (c0, + c1, + c2, + c3: the streaming kernel's order) and runs the shared epilogue: same bits.
-__global__ __launch_bounds__(512, 1) void k_gemm_dec_deep(const IgemmParams p, const int cph /* chains per half: 1 or 2 */)
-{
-    constexpr int BM = 32, BN = 32, KC = 256, LDK = KC + 8;
-    constexpr int AV = BM * (KC / 8) / 256, BV = BN * (KC / 8) / 256;      // 4 + 4 16-byte vectors per thread per chunk
-    extern __shared__ __attribute__((aligned(16))) unsigned char deep_lds[];
-    const int tid = threadIdx.x, half = tid >> 8, ltid = tid & 255, lane = tid & 63, wid = (tid >> 6) & 3;
-    uint16_t *As = reinterpret_cast<uint16_t *>(deep_lds) + half * (BM + BN) * LDK, *Bs = As + BM * LDK;
-    const int wm = wid & 1, wn = wid >> 1;                       // 2 x 2 waves, one 16 x 16 tile each
-    const int fr = lane & 15, fg = lane >> 4;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int M = p.nbatch * p.T_out;
-    const int lrow = ltid >> 5, lcol = (ltid & 31) * 8;
-    const int khalf = p.K >> 1;                                  // host: K % 64 == 0 (the last chunk of a half may be short)
-    const uint16_t *arow[AV], *brow[BV];
-    const bool t1 = p.T_out == 1;
-#pragma unroll
-    for (int i = 0; i < AV; i++) {
-        const int mm = min(m0 + lrow + 8 * i, M - 1);
-        const int b = t1 ? mm : mm / p.T_out, t = mm - b * p.T_out;
-        arow[i] = p.x + (int64_t)b * p.x_bstride + (int64_t)t * p.lda + lcol + half * khalf;
-    }
-#pragma unroll
-    for (int i = 0; i < BV; i++) brow[i] = p.w + (int64_t)min(n0 + lrow + 8 * i, p.N - 1) * p.K + lcol + half * khalf;
-    uint4 ra[AV], rb[BV];
-    const bool whole = khalf % KC == 0;
-#define IFH_DEEP_LOAD(K0)                                                                                      \
-    if (whole) {                                                                                               \
-        _Pragma("unroll") for (int i = 0; i < AV; i++) ra[i] = ld_u32x4(arow[i] + (K0));                       \
-        _Pragma("unroll") for (int i = 0; i < BV; i++) rb[i] = ld_u32x4(brow[i] + (K0));                       \
-    } else {                                                                                                   \
-        const bool kin_ = (K0) + lcol < khalf;                                                                 \
-        _Pragma("unroll") for (int i = 0; i < AV; i++) ra[i] = kin_ ? ld_u32x4(arow[i] + (K0)) : make_uint4(0, 0, 0, 0); \
-        _Pragma("unroll") for (int i = 0; i < BV; i++) rb[i] = kin_ ? ld_u32x4(brow[i] + (K0)) : make_uint4(0, 0, 0, 0); \
-    }
-    IFH_DEEP_LOAD(0)
-    // epilogue operands (group 0 only: it runs the epilogue), requested behind the first chunk
-    const bool ln_mode = p.aln_stats || p.rln_stats || p.stats_out;
-    const int em = m0 + wm * 16 + fr;
-    const bool exok = em < M;
-    const int n = n0 + wn * 16 + 4 * fg;
-    int edyn = 0;
-    longlong2 st_a = make_longlong2(0, 0), st_r = make_longlong2(0, 0);
-    float4 pc1 = make_float4(0.f, 0.f, 0.f, 0.f), pbias = pc1, pgam = pc1, pbeta = pc1;
-    uint2 presid = make_uint2(0, 0);
-    if (half == 0) {
-        edyn = dyn_value(p, exok ? em : 0);
-        if (exok) {
-            if (p.aln_stats) st_a = reinterpret_cast<const longlong2 *>(p.aln_stats)[em];
-            if (p.rln_stats) st_r = reinterpret_cast<const longlong2 *>(p.rln_stats)[em];
-        }
-        if (ln_mode && n < p.N) {
-            if (p.aln_stats && !p.ln_rms) pc1 = *reinterpret_cast<const float4 *>(p.aln_c1 + n);
-            if (p.bias) pbias = *reinterpret_cast<const float4 *>(p.bias + n);
-            if (p.resid && p.rln_stats) {
-                pgam = *reinterpret_cast<const float4 *>(p.rln_gamma + n);
-                pbeta = *reinterpret_cast<const float4 *>(p.rln_beta + n);
-            }
-            if (p.resid && exok) presid = *reinterpret_cast<const uint2 *>(p.resid + epi_row(p, em, n, edyn).rbase + n);
-        }
-    }
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, part0 = acc, part1 = acc;
-    const int nkh = khalf / 32, per = nkh / cph;                 // k-steps of this half; per chain (host: nk % (2 cph) == 0)
-    const int nchunk = (khalf + KC - 1) / KC;
-    for (int c = 0; c < nchunk; c++) {
-#pragma unroll
-        for (int i = 0; i < AV; i++) *reinterpret_cast<uint4 *>(&As[(lrow + 8 * i) * LDK + lcol]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BV; i++) *reinterpret_cast<uint4 *>(&Bs[(lrow + 8 * i) * LDK + lcol]) = rb[i];
-        __syncthreads();
-        if (c + 1 < nchunk) {
-            IFH_DEEP_LOAD((c + 1) * KC)
-        }
-        const int ks1 = min(KC / 32, nkh - c * (KC / 32));
-        for (int ks = 0; ks < ks1; ks++) {
-            const bf16x8_t fa = *reinterpret_cast<const bf16x8_t *>(&Bs[(wn * 16 + fr) * LDK + ks * 32 + fg * 8]);
-            const bf16x8_t fb = *reinterpret_cast<const bf16x8_t *>(&As[(wm * 16 + fr) * LDK + ks * 32 + fg * 8]);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb, acc, 0, 0, 0);
-            const int kt1 = c * (KC / 32) + ks + 1;
-            if (cph == 2 && kt1 == per) {                        // end of this half's first chain
-                part0 = acc;
-                acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        __syncthreads();
-    }
-#undef IFH_DEEP_LOAD
-    part1 = acc;
-    // group 1 -> group 0: its two chain tiles, lane for lane (both groups map waves and lanes to the tile the same way)
-    f32x4 *xch = reinterpret_cast<f32x4 *>(deep_lds);            // 2 x 4 waves x 64 lanes x 16 B = 8 KB over the dead images
-    if (half == 1) {
-        xch[(0 * 4 + wid) * 64 + lane] = part0;
-        xch[(1 * 4 + wid) * 64 + lane] = part1;
-    }
-    __syncthreads();
-    if (half == 1) return;
-    f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (cph == 2) {                                              // chain order: c0, c1 (this group), c2, c3 (the other)
-        sum += part0;
-        sum += part1;
-        sum += xch[(0 * 4 + wid) * 64 + lane];
-        sum += xch[(1 * 4 + wid) * 64 + lane];
-    } else {                                                     // two chains: c0 (this group), c1 (the other)
-        sum += part1;
-        sum += xch[(1 * 4 + wid) * 64 + lane];
-    }
-    if (ln_mode) {
-        ln_epi4(p, em, n, exok, sum, edyn, ln_row(p, st_a, st_r), pc1, pbias, pgam, pbeta, presid, fg);
-    } else if (exok && n < p.N) {
-        if (p.fast_epi)
-            igemm_store4<true>(p, em, n, sum, edyn);
-        else
-            igemm_store4<false>(p, em, n, sum, edyn);
-    }
-}
-
 // ---- weight-streaming GEMM for decode steps of LLM-sized layers (M <= 64 rows, N x K in the tens of MB) ----
 // k_gemm_skinny gives every 16 x 16 output tile its own block: at M = 64 a weight fragment is fetched by four blocks and an
 // activation fragment by N/16 of them, fine for 768-wide speech decoders whose weights live in L2, ~1 TB/s of weight
@@ -1306,25 +1185,8 @@ extern "C" int ifh_conv_bf16(const ifh_conv_desc *d, ifh_stream_t stream)
             const int ksplit = p.K >= 2048 ? 4 : 2;
             // 64 x 64 tiles; 64 x 32 where that is what it takes to give every CU a workgroup
             const int64_t t64 = ((M + 63) / 64) * ((d->n + 63) / 64);
-            static const int deep_on = getenv("IFH_GEMM_DEC_DEEP") ? atoi(getenv("IFH_GEMM_DEC_DEEP")) : 0;        // tuning switch (see below: default off)
-            // deep_on: 1 = deep K only (two chains per half), 2 = also K < 2048 (one chain per half).  A latency switch: a stage
-            // running alone gets 2.5-5 % faster (TTS stage 125.1 -> 119.0 ms, fc2 17.1 -> 12.3 us at 256 rows), but the fully
-            // pipelined C3 cycle, which is bound by the SUM of the kernels' work, loses 2 % to the doubled waves per launch
-            // (10 340 x off, 10 085 x on, three alternating runs each): off by default.
-            if (((deep_on >= 1 && ksplit == 4) || (deep_on >= 2 && ksplit == 2)) && p.K % 64 == 0 && (p.K / 32) % ksplit == 0 &&
-                ((M + 63) / 64) * ((d->n + 31) / 32) <= 200) {
-                constexpr size_t bytes = 2 * (32 + 32) * (256 + 8) * 2;
-                static DeviceOnce attr_once;
-                int attr_dev = 0;
-                if (attr_once.needed(&attr_dev)) {
-                    hipError_t e = hipFuncSetAttribute((const void *)k_gemm_dec_deep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-                    if (e != hipSuccess) return check_hip(e, "gemm_dec_deep lds attr");
-                    attr_once.done(attr_dev);
-                }
-                hipLaunchKernelGGL(k_gemm_dec_deep, dim3((M + 31) / 32, (d->n + 31) / 32), dim3(512), bytes, st, p, ksplit / 2);
-                IFH_LAUNCH_CHECK("conv_bf16");
-                return IFH_OK;
-            }
+            // (k_gemm_dec_deep -- the two halves of K in two wave groups of one workgroup: a stage alone 2.5-5 % faster, the pipelined
+            // cycle 2 % slower -- was a switch of rounds 3-5, off by default; removed in round 6, profiles/NOTES.md "Round 3, late")
             constexpr int64_t bm32_max = 200;   // fixed by measurement (profiles/NOTES.md): 32-row tiles up to this many 64 x 32 workgroups (pipelined C3, three alternating runs each: 0 -> 10 006 x, 100 -> 10 001, 150 -> 10 177-10 279, 200 -> 10 313-10 326, 300 -> 10 194, 500 -> 10 101)
             if (t64 >= 200)
                 hipLaunchKernelGGL((k_gemm_dec<64>), dim3((M + 63) / 64, (d->n + 63) / 64), dim3(256), 0, st, p, ksplit);

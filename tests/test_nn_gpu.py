@@ -301,20 +301,6 @@ def test_wide_ln_folded_head_on_the_large_gemm_kernel(dev, M, D, NV):
     assert rel_l2(got, pieces.cpu()) < 1e-4, rel_l2(got, pieces.cpu())
 
 
-def test_gemm_dec_split_kernel_is_bit_identical(built_lib):
-    """k_gemm_dec_deep (csrc/nn.hip; the two halves of K in two wave groups of one workgroup, chains added in the streaming kernel's
-    order) is a latency switch, off by default (IFH_GEMM_DEC_DEEP): the bit-identity test of the decode kernels re-run in a child
-    process with it on for deep K (1) and for every K (2)."""
-    import subprocess
-    import sys
-    for mode in ('1', '2'):
-        env = dict(os.environ, IFH_GEMM_DEC_DEEP=mode)
-        r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-m', 'gpu', '-x', '-k',
-                            'test_gemm_dec_is_bit_identical_to_skinny or test_skinny_gemm_variants_match_torch'],
-                           env=env, capture_output=True, text=True, timeout=1200)
-        assert r.returncode == 0, (mode, r.stdout[-2000:], r.stderr[-1000:])
-
-
 @pytest.mark.parametrize('M', [128, 192, 257, 512, 1000])
 def test_gemm_dec_is_bit_identical_to_skinny(dev, M):
     """From 128 rows up the decode-step launches take the LDS-tiled k_gemm_dec instead of the weight-streaming k_gemm_skinny
