@@ -519,14 +519,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_seq(const
             constexpr int PD = 8;                                        // tiles of `out` requested ahead (16 registers)
             static_assert(PD <= MT * NT, "prefetch distance");
             uint2 pv[PD];
+            // Row tile outer, channel tile inner (round 6; the other epilogues walk channel tile outer): the NT pieces of a row -- 32 bytes
+            // each, one store instruction each -- then leave back to back and meet in L2 as whole 64-byte sectors.  Channel tile outer they
+            // left MT tiles apart, the L2s wrote the half-filled lines back in between, and the launch wrote 1.75-2.1 x its output
+            // (TCC_EA0_WRREQ: 28 % of the write requests 32-byte ones; k_resblock_chain, whose pieces leave together: none).
+            auto tj = [](int t) constexpr { return t / NT; };
+            auto ti = [](int t) constexpr { return t % NT; };
             if constexpr (ACCUM) {
 #pragma unroll
-                for (int t = 0; t < PD; t++) pv[t] = ld_row(os, t % MT, t / MT);
+                for (int t = 0; t < PD; t++) pv[t] = ld_row(os, tj(t), ti(t));
             }
-            f32x4 bt;
+            f32x4 bts[NT];
+#pragma unroll
+            for (int i = 0; i < NT; i++) bts[i] = bias_tile(5, i, bv);
             seq_static_for<MT * NT>([&](auto tc) __attribute__((always_inline)) {
-                constexpr int t = decltype(tc)::value, i = t / MT, j = t % MT;
-                if constexpr (j == 0) bt = bias_tile(5, i, bv);
+                constexpr int t = decltype(tc)::value, i = t % NT, j = t / NT;
+                const f32x4 bt = bts[i];
                 SEQ_ACC_HERE(acc[i][j])
                 f32x4 a = acc[i][j];
                 const uint2 rv = xr[j][i];
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_seq(const
                     a[1] += __uint_as_float(q2.x & 0xffff0000u);
                     a[2] += __uint_as_float(q2.y << 16);
                     a[3] += __uint_as_float(q2.y & 0xffff0000u);
-                    if constexpr (t + PD < MT * NT) pv[t % PD] = ld_row(os, (t + PD) % MT, (t + PD) / MT);
+                    if constexpr (t + PD < MT * NT) pv[t % PD] = ld_row(os, (t + PD) / NT, (t + PD) % NT);
                 }
                 st_row(os, j, i, make_uint2(f32x2_to_bf16x2(a[0], a[1]), f32x2_to_bf16x2(a[2], a[3])));
                 __builtin_amdgcn_sched_barrier(0);
