@@ -417,6 +417,9 @@ typedef struct ifh_chain_desc {
     void *debug_prof;       /* NULL, or device uint64[16] (zeroed by the caller): diagnostic shader-clock sums of wave 0 of every
                              * workgroup -- [0] tile set-up, [1+2q] K loop / [2+2q] epilogue+barrier of convolution q, [13] tiles,
                              * [14] workgroup lifetime, [15] workgroups (tools/probe_chain.py) */
+    float post_slope;       /* LeakyReLU applied to what is stored, (0, 1]; 0 or 1 = none.  With the slope the CONSUMER would apply on load
+                             * (the next upsampler's 0.1) the stored tensor is what that consumer multiplies, so it can run as a plain matrix
+                             * product (round 6: the vocoder's upsamplers over guard rows); same bits either way */
 } ifh_chain_desc;
 int ifh_resblock_chain_bf16(const ifh_chain_desc *desc, ifh_stream_t stream);
 /* The same residual block over WHOLE sequences held in ONE LDS image that every convolution overwrites in place (csrc/seq.hip):
@@ -440,6 +443,7 @@ typedef struct ifh_seq_desc {
     void *debug_prof;       /* NULL, or device uint64[8] (zeroed by the caller): diagnostic shader-clock sums of wave 0 of every workgroup --
                              * [0] tile top, [1] K loops, [2] waiting for the other waves behind a K loop, [3] conv1 / [4] conv2 epilogues,
                              * [5] last epilogue, [6] tiles, [7] workgroup lifetime (tools/probe_seq.py) */
+    float post_slope;       /* as ifh_chain_desc.post_slope */
 } ifh_seq_desc;
 int ifh_resblock_seq_unit_bytes(int c);
 int ifh_resblock_seq_supported(int c, int t, int taps);       /* 1 if ifh_resblock_seq_bf16 serves this shape */

@@ -87,14 +87,16 @@ class ChainDesc(ctypes.Structure):
     """ifh_chain_desc (include/infernos_hip.h)"""
     _fields_ = [('x', _vp), ('x_bstride', _i64), ('c', ctypes.c_int32), ('taps', ctypes.c_int32), ('t', ctypes.c_int32),
                 ('nbatch', ctypes.c_int32), ('wstream', _vp), ('nunits', ctypes.c_int32), ('bias', _vp), ('slope', _f),
-                ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp), ('out_bstride', _i64), ('debug_prof', _vp)]
+                ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp), ('out_bstride', _i64), ('debug_prof', _vp),
+                ('post_slope', _f)]
 
 
 class SeqDesc(ctypes.Structure):
     """ifh_seq_desc (include/infernos_hip.h)"""
     _fields_ = [('x', _vp), ('x_bstride', _i64), ('c', ctypes.c_int32), ('taps', ctypes.c_int32), ('t', ctypes.c_int32),
                 ('nbatch', ctypes.c_int32), ('wstream', _vp), ('nunits', ctypes.c_int32), ('bias', _vp), ('slope', _f),
-                ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp), ('out_bstride', _i64), ('debug_prof', _vp)]
+                ('out_scale', _f), ('accumulate', ctypes.c_int32), ('out', _vp), ('out_bstride', _i64), ('debug_prof', _vp),
+                ('post_slope', _f)]
 
 
 class LevelDesc(ctypes.Structure):

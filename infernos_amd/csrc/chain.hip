@@ -48,6 +48,7 @@ struct ChainParams {
     int tiles_per_seq, ntiles;
     int nunits;                  // units in the stream (one pass of the chain)
     float slope, out_scale;
+    float post_slope;            // LeakyReLU on what is stored (1 = none): ifh_chain_desc.post_slope
     int accumulate;
     uint16_t *out;
     int64_t out_bstride;
@@ -342,11 +343,12 @@ __global__ __launch_bounds__(512, 2) void k_resblock_chain(const ChainParams p)
                             v3 += __uint_as_float(q2.y & 0xffff0000u);
                         }
                     }
-                    const uint2 pk = make_uint2(f32x2_to_bf16x2(v0, v1), f32x2_to_bf16x2(v2, v3));
+                    uint2 pk = make_uint2(f32x2_to_bf16x2(v0, v1), f32x2_to_bf16x2(v2, v3));
                     if (!LAST) {
                         xr[j][i] = pk;
                         CHAIN_LDS_STORE(xw, j * 16 * SB + i * 32, ok ? chain_lrelu4(pk, p.slope) : make_uint2(0, 0))
                     } else if (ok && qrow >= HC && qrow < HC + R) {
+                        if (p.post_slope != 1.0f) pk = chain_lrelu4(pk, p.post_slope);    // (the consumer's LeakyReLU-on-load, taken here: same bits)
                         *reinterpret_cast<uint2 *>(p.out + (int64_t)b * p.out_bstride + (int64_t)t * C + (wn * NT + i) * 16 + 4 * fg) = pk;
                     }
                 }
@@ -671,6 +673,8 @@ extern "C" int ifh_resblock_chain_bf16(const ifh_chain_desc *d, ifh_stream_t str
     p.nunits = d->nunits;
     p.slope = d->slope;
     p.out_scale = d->out_scale;
+    IFH_CHECK_ARG(d->post_slope >= 0.0f && d->post_slope <= 1.0f);
+    p.post_slope = d->post_slope > 0.0f ? d->post_slope : 1.0f;      // (0 = a zeroed descriptor: none)
     p.accumulate = d->accumulate;
     p.out = (uint16_t *)d->out;
     p.out_bstride = d->out_bstride;

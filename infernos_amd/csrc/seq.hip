@@ -35,6 +35,7 @@ struct SeqParams {
     const float *bias;           // [6][C]
     int nbatch, ntiles, nunits;
     float slope, out_scale;
+    float post_slope;            // LeakyReLU on what is stored (1 = none): ifh_seq_desc.post_slope
     int accumulate;
     uint16_t *out;
     int64_t out_bstride;
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_seq(const
     const int ab = RING_OFF + wn * NT * 1024 + lane * 16;                // A-fragment base inside a k-step of the ring
     const int cw = (wn * NT * 16 + 4 * fg) * 2;                          // byte offset of this lane's 4 channels in a row (tile 0)
     const int xw = (GX + sq0 * SROWS + srow) * SB + cw;                  // store base of this lane
-    const float slope = p.slope, out_scale = p.out_scale;
+    const float slope = p.slope, out_scale = p.out_scale, post_slope = p.post_slope;
 
     uint2 xr[MT][NT];                                  // residual stream of the owned elements, packed bf16 (accumulator layout)
     f32x4 acc[NT][MT];
@@ -551,7 +552,12 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_seq(const
                     a[3] += __uint_as_float(q2.y & 0xffff0000u);
                     if constexpr (t + PD < MT * NT) pv[t % PD] = ld_row(os, (t + PD) / NT, (t + PD) % NT);
                 }
-                st_row(os, j, i, make_uint2(f32x2_to_bf16x2(a[0], a[1]), f32x2_to_bf16x2(a[2], a[3])));
+                uint2 pk = make_uint2(f32x2_to_bf16x2(a[0], a[1]), f32x2_to_bf16x2(a[2], a[3]));
+                if (post_slope != 1.0f) {              // the consumer's LeakyReLU-on-load, taken here (same bits); a wave-uniform branch
+                    asm volatile("" ::: "memory");
+                    pk = chain_lrelu4(pk, post_slope);
+                }
+                st_row(os, j, i, pk);
                 __builtin_amdgcn_sched_barrier(0);
             });
         }
@@ -647,6 +653,8 @@ extern "C" int ifh_resblock_seq_bf16(const ifh_seq_desc *d, ifh_stream_t stream)
     p.nunits = d->nunits;
     p.slope = d->slope;
     p.out_scale = d->out_scale;
+    IFH_CHECK_ARG(d->post_slope >= 0.0f && d->post_slope <= 1.0f);
+    p.post_slope = d->post_slope > 0.0f ? d->post_slope : 1.0f;      // (0 = a zeroed descriptor: none)
     p.accumulate = d->accumulate;
     p.out = (uint16_t *)d->out;
     p.out_bstride = d->out_bstride;

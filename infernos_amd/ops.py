@@ -72,29 +72,34 @@ def resblock_pair(x, w1, b1, w2, b2, out, *, nbatch, t, c, taps, dil, slope=0.1,
     return out
 
 
-def resblock_chain(x, wstream, nunits, bias, out, *, nbatch, t, c, taps, slope=0.1, scale=1.0, accumulate=False, prof=None):
+def resblock_chain(x, wstream, nunits, bias, out, *, nbatch, t, c, taps, slope=0.1, scale=1.0, accumulate=False, prof=None,
+                   x_bstride=None, out_bstride=None, post_slope=1.0):
     """out = chain(x) * scale (+ out): the three dilation pairs (1, 3, 5) of one HiFi-GAN residual block in ONE launch
-    (ifh_resblock_chain_bf16), bit-identical to three resblock_pair launches.  wstream/nunits/bias from w_chain_pack."""
+    (ifh_resblock_chain_bf16), bit-identical to three resblock_pair launches.  wstream/nunits/bias from w_chain_pack.
+    x_bstride / out_bstride: elements between sequences (default t * c); post_slope: LeakyReLU on what is stored."""
     d = _lib.ChainDesc()
-    d.x, d.x_bstride = _addr(x), t * c
+    d.post_slope = post_slope
+    d.x, d.x_bstride = _addr(x), (t * c if x_bstride is None else x_bstride)
     d.c, d.taps, d.t, d.nbatch = c, taps, t, nbatch
     d.wstream, d.nunits, d.bias = _addr(wstream), nunits, _addr(bias)
     d.slope, d.out_scale, d.accumulate = slope, scale, int(accumulate)
-    d.out, d.out_bstride, d.debug_prof = _addr(out), t * c, _addr(prof)
+    d.out, d.out_bstride, d.debug_prof = _addr(out), (t * c if out_bstride is None else out_bstride), _addr(prof)
     _lib.check(_lib.lib().ifh_resblock_chain_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_resblock_chain_bf16')
     return out
 
 
-def resblock_seq(x, wstream, nunits, bias, out, *, nbatch, t, c, taps, slope=0.1, scale=1.0, accumulate=False, prof=None):
+def resblock_seq(x, wstream, nunits, bias, out, *, nbatch, t, c, taps, slope=0.1, scale=1.0, accumulate=False, prof=None,
+                 x_bstride=None, out_bstride=None, post_slope=1.0):
     """out = chain(x) * scale (+ out) like resblock_chain, over whole sequences in one LDS image overwritten in place
     (ifh_resblock_seq_bf16: (c, t) = (64, 768), (128, 192), (256, 48)); bit-identical to resblock_chain.  wstream/nunits/bias from
     w_chain_pack(convs, dev, unit_bytes=seq_unit_bytes(c))."""
     d = _lib.SeqDesc()
-    d.x, d.x_bstride = _addr(x), t * c
+    d.post_slope = post_slope
+    d.x, d.x_bstride = _addr(x), (t * c if x_bstride is None else x_bstride)
     d.c, d.taps, d.t, d.nbatch = c, taps, t, nbatch
     d.wstream, d.nunits, d.bias = _addr(wstream), nunits, _addr(bias)
     d.slope, d.out_scale, d.accumulate = slope, scale, int(accumulate)
-    d.out, d.out_bstride = _addr(out), t * c
+    d.out, d.out_bstride = _addr(out), (t * c if out_bstride is None else out_bstride)
     d.debug_prof = _addr(prof)
     _lib.check(_lib.lib().ifh_resblock_seq_bf16(ctypes.byref(d), _lib.stream_ptr(out.device)), 'ifh_resblock_seq_bf16')
     return out
@@ -113,7 +118,7 @@ def level_ws_bytes():
     return int(_lib.lib().ifh_level_ws_bytes())
 
 
-def resblock_level(x, blocks, out, *, nbatch, t, c, slope=0.1, scale=1.0, accumulate=False, prof=None, post=None):
+def resblock_level(x, blocks, out, *, nbatch, t, c, slope=0.1, scale=1.0, accumulate=False, prof=None, post=None, x_bstride=None):
     """out = sum_j chain_j(x) * scale (+ out): the residual blocks of one HiFi-GAN level in ONE launch (ifh_resblock_level_bf16,
     weights stationary in registers), bit-identical to len(blocks) resblock_chain launches with accumulate.
     blocks = [(taps, wstream, bias), ...] with wstream/bias from w_chain_pack.
@@ -124,7 +129,7 @@ def resblock_level(x, blocks, out, *, nbatch, t, c, slope=0.1, scale=1.0, accumu
         pw, pb, ps, audio, ws = post
         d.post_w, d.post_bias, d.post_slope, d.audio = _addr(pw), float(pb), float(ps), _addr(audio)
         d.mean_ws, d.mean_ws_bytes = _addr(ws), ws.numel() * ws.element_size()
-    d.x, d.x_bstride = _addr(x), t * c
+    d.x, d.x_bstride = _addr(x), (t * c if x_bstride is None else x_bstride)
     d.c, d.t, d.nbatch, d.nblocks = c, t, nbatch, len(blocks)
     for j, (taps, ws, bias) in enumerate(blocks):
         d.taps[j], d.wstream[j], d.bias[j] = taps, _addr(ws), _addr(bias)

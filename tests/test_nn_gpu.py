@@ -1170,6 +1170,33 @@ def test_hifigan_and_amendment_match_oracle(dev):
     print('hifigan rel_l2 %.3e, amended rel_l2 %.3e' % (e_voc, e_out))
 
 
+@pytest.mark.parametrize('nchunks', [5, 300, 1025])
+def test_hifigan_plain_upsamplers_over_guard_rows_give_the_same_audio(dev, nchunks):
+    """The vocoder pass of round 6 -- upsamplers 1-3 as plain matrix products over buffers with a zero guard row between sequences
+    (K = 3 Cin contiguous at row stride Cin), the LeakyReLU in front of each taken by the producing level's last launch
+    (ifh_chain_desc / ifh_seq_desc.post_slope), the residual-block kernels reading and writing the guard-row layout through their
+    batch strides, conv_post inside the last level's launch -- against the pass of round 5 (3-tap convolutions with LeakyReLU on the
+    operand load, contiguous buffers, a separate conv_post launch): the same audio bit for bit; twice over the same buffers."""
+    from infernos_amd.engines.vocoder import HifiGan
+    from infernos_amd.weights import synth_state_dict
+    sd_v = synth_state_dict('hifigan', 0)
+    g = torch.Generator().manual_seed(nchunks)
+    chunks = bfr(torch.randn(nchunks, 12, 80, generator=g) * 0.8)
+    voc_in = ((chunks - sd_v['mean']) / sd_v['scale']).to(BF).to(dev)
+    voc = HifiGan(sd_v, dev)
+    assert voc.plain_up and voc.fused_post
+    a = voc(voc_in).clone()
+    a2 = voc(voc_in).clone()
+    voc.plain_up = voc.fused_post = False
+    b = voc(voc_in)
+    torch.cuda.synchronize()
+    assert torch.equal(a.view(torch.int16), a2.view(torch.int16))
+    if not torch.equal(a.view(torch.int16), b.view(torch.int16)):
+        d = (a.float() - b.float()).abs()
+        bad = torch.nonzero(d > 0)
+        raise AssertionError('plain-upsampler pass differs: max abs %g at %d samples, first (chunk, sample) %s' % (float(d.max()), bad.size(0), bad[:8].tolist()))
+
+
 @pytest.mark.parametrize('nchunks', [1024, 513])
 def test_hifigan_at_bench_group_size_matches_oracle(dev, nchunks):
     """The vocoder pass at the launch-group size of the timed region (1024 chunks: two-launch C = 256 path, two chunks per
