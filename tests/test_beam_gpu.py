@@ -365,12 +365,13 @@ def test_whisper_base_beam_at_bench_batch_128(dev, golden_dir):
           sup[50257:] = float('-inf')
           sup[c['eos']] = 0.0
           runs = []
-          for use_graphs in (False, True, True):                  # eager, capture, replay
+          # eager, capture, replay on the default (MFMA) cross-attention; the VALU kernel (not the default) runs eagerly once
+          for use_graphs in ((False, True, True) if mfma else (False,)):
               runs.append(model.generate_beam(enc, prompt, c['n_new'], beams=K, eos_id=c['eos'], length_penalty=c['lp'],
                                               suppress=sup, no_speech_id=50362, check_every=8, use_graphs=use_graphs))
-          for a, b_ in zip(runs[0][:3], runs[2][:3]):
+          for a, b_ in zip(runs[0][:3], runs[-1][:3]):
               assert torch.equal(a, b_), 'graph replay differs from the eager search'
-          toks, lens, scores, nsp = (t.cpu() for t in runs[2])
+          toks, lens, scores, nsp = (t.cpu() for t in runs[-1])
           assert torch.equal(toks[:64], toks[64:]) and torch.equal(lens[:64], lens[64:]) and torch.equal(scores[:64], scores[64:])
           assert torch.equal(nsp[:64], nsp[64:])
           glen = g['base_len%d' % ci]
