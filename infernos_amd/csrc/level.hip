@@ -53,7 +53,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 1) void k_resblock_level(con
     constexpr int NP = 4 * NT;                         // epilogue pieces per row block
     static_assert(HC >= 6 * (BMAX - 1) + (POST ? 3 : 0) || HC == 0, "margin covers the chain: (1+3+5 dilated + 3 plain) * (taps-1)/2 rows (+ conv_post's 3)");
     static_assert(!POST || (C == 32 && B2 > 0 && !ACC0), "the folded conv_post is the C = 32 level's: three blocks, nothing to add to");
-    static_assert(PF >= 1 && PF <= 3, "prefetch depth");
+    static_assert(PF >= 1 && PF <= 6, "prefetch depth");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     // ABL & 16: phase clocks of wave 0, summed locally and added to p.prof once as the workgroup ends (an atomic per stamp -- a vector
@@ -552,9 +552,19 @@ extern "C" int ifh_resblock_level_bf16(const ifh_level_desc *d, ifh_stream_t str
     int rc = IFH_EINVAL;
     const int t0 = d->taps[0], t1 = d->nblocks > 1 ? d->taps[1] : 0, t2 = d->nblocks > 2 ? d->taps[2] : 0;
     //                <C, NW, WGM, WGN, MTB, HC, PF, B0, B1, B2>
+    // (tools builds may pick another wave count / prefetch depth: -DLV_NW=4 -DLV_WGM=4 -DLV_MTB=14 -DLV_PF=..; the tile stays 896 rows)
+#ifndef LV_NW
+#define LV_NW 8
+#define LV_WGM 8
+#define LV_MTB 7
+#endif
+#ifndef LV_PF
+#define LV_PF 3
+#endif
+#define LV_SHAPE 32, LV_NW, LV_WGM, 1, LV_MTB, 64, LV_PF
 #define LEVEL_CASE(A, B, C_)                                                                                    \
     if (t0 == A && t1 == B && t2 == C_)                                                                         \
-        rc = d->accumulate ? launch_level<32, 8, 8, 1, 7, 64, 3, A, B, C_, true>(p, st) : launch_level<32, 8, 8, 1, 7, 64, 3, A, B, C_, false>(p, st);
+        rc = d->accumulate ? launch_level<LV_SHAPE, A, B, C_, true>(p, st) : launch_level<LV_SHAPE, A, B, C_, false>(p, st);
 #ifdef LV_WITH_PIPE        /* tools/mb/level_bench builds: the software-pipelined form of tools/exp/level_pipe.hip unless IFH_LEVEL_BARRIER is set */
     if (d->c == 32 && getenv("IFH_LEVEL_BARRIER") == nullptr) {
         rc = launch_level_pipe(p, t0, t1, t2, st);
@@ -567,17 +577,17 @@ extern "C" int ifh_resblock_level_bf16(const ifh_level_desc *d, ifh_stream_t str
     if (d->c == 32) {
 #ifdef LV_DEV_ABL          /* tools builds: ablations of the k = 11 block, chosen by IFH_LEVEL_ABL (wrong results) */
         const int abl = getenv("IFH_LEVEL_ABL") ? atoi(getenv("IFH_LEVEL_ABL")) : 0;
-#define LEVEL_ABL(V) if (abl == V && t0 == 11 && t1 == 0) return launch_level<32, 8, 8, 1, 7, 64, 3, 11, 0, 0, false, V>(p, st);
+#define LEVEL_ABL(V) if (abl == V && t0 == 11 && t1 == 0) return launch_level<LV_SHAPE, 11, 0, 0, false, V>(p, st);
         LEVEL_ABL(1) LEVEL_ABL(4) LEVEL_ABL(8) LEVEL_ABL(12) LEVEL_ABL(13) LEVEL_ABL(16)
-        if (abl == 16 && t1 == 0 && t0 == 3) return launch_level<32, 8, 8, 1, 7, 64, 3, 3, 0, 0, false, 16>(p, st);
-        if (abl == 16 && t1 == 0 && t0 == 7) return launch_level<32, 8, 8, 1, 7, 64, 3, 7, 0, 0, false, 16>(p, st);
+        if (abl == 16 && t1 == 0 && t0 == 3) return launch_level<LV_SHAPE, 3, 0, 0, false, 16>(p, st);
+        if (abl == 16 && t1 == 0 && t0 == 7) return launch_level<LV_SHAPE, 7, 0, 0, false, 16>(p, st);
 #undef LEVEL_ABL
 #endif
 #ifdef LV_DEV_ONLY
         LEVEL_CASE(LV_DEV_ONLY, 0, 0)
 #else
         if (d->post_w) {
-            if (t0 == 3 && t1 == 7 && t2 == 11) rc = launch_level<32, 8, 8, 1, 7, 64, 3, 3, 7, 11, false, 0, true>(p, st, d->mean_ws_bytes);
+            if (t0 == 3 && t1 == 7 && t2 == 11) rc = launch_level<LV_SHAPE, 3, 7, 11, false, 0, true>(p, st, d->mean_ws_bytes);
         } else
         LEVEL_CASE(3, 7, 11)
         LEVEL_CASE(3, 0, 0)
