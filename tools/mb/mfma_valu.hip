@@ -48,6 +48,30 @@ __global__ __launch_bounds__(512) void k_mix(float *out, unsigned long long *clk
                 if (KIND == 1) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(f[j]) : "v"(c2));
                 if (KIND == 2) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(u[j]) : "v"(f[j].x), "v"(f[j].y));
                 if (KIND == 3) asm volatile("v_and_b32 %0, %1, %0" : "+v"(u[j]) : "v"(0xfffffff7u + v));
+                // kinds 4 / 5 / 6: NV plain ops, then TWO packed ones (does a packed op pay its 12 extra clocks when plain ops sit between
+                // it and the MFMA?); kind 7: two packed ones FIRST, then NV plain ops
+                if (KIND >= 4 && KIND <= 6) asm volatile("v_and_b32 %0, %1, %0" : "+v"(u[j]) : "v"(0xfffffff7u + v));
+                if (KIND == 7 && v == 0) {
+                    asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(f[0]) : "v"(c2));
+                    asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(f[1]) : "v"(c2));
+                }
+                if (KIND == 7) asm volatile("v_and_b32 %0, %1, %0" : "+v"(u[j]) : "v"(0xfffffff7u + v));
+                if (KIND >= 4 && KIND <= 6 && v == NV - 1) {
+                    if (KIND == 4) {
+                        asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(f[0]) : "v"(c2));
+                        asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(f[1]) : "v"(c2));
+                    }
+                    if (KIND == 5) {
+                        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(f[0]) : "v"(c2));
+                        asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(f[1]) : "v"(c2));
+                    }
+                    if (KIND == 6) {       // the same arithmetic as four plain multiplies
+                        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[0].x) : "v"(c));
+                        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[0].y) : "v"(c));
+                        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[1].x) : "v"(c));
+                        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[1].y) : "v"(c));
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -95,12 +119,20 @@ static void run(int waves, float *out, unsigned long long *clk, const char *knam
         run<8, KIND, NACC>(w, out, clk, NAME);             \
     }
 
-int main()
+int main(int argc, char **argv)
 {
+    (void)argv;
     float *out;
     unsigned long long *clk;
     hipMalloc(&out, 4);
     hipMalloc(&clk, 8);
+    if (argc > 1) {          // the second table: packed ops behind NV plain ones
+        RUN_ALL(4, "NV and + 2 pk_mul", 16)
+        RUN_ALL(5, "NV and + 2 pk_add", 16)
+        RUN_ALL(6, "NV and + 4 mul", 16)
+        RUN_ALL(7, "2 pk_mul + NV and", 16)
+        return 0;
+    }
     RUN_ALL(0, "v_add_f32", 16)
     RUN_ALL(0, "v_add_f32", 2)
     RUN_ALL(1, "v_pk_mul_f32", 16)
