@@ -1197,6 +1197,27 @@ def test_hifigan_plain_upsamplers_over_guard_rows_give_the_same_audio(dev, nchun
         raise AssertionError('plain-upsampler pass differs: max abs %g at %d samples, first (chunk, sample) %s' % (float(d.max()), bad.size(0), bad[:8].tolist()))
 
 
+def test_hifigan_audio_of_a_chunk_does_not_depend_on_the_launch(dev):
+    """A size-independent property at the bench line's render-group size: the 3 072 samples of a chunk are the same bits whether it is
+    vocoded alone, among 7, among 300 or among the 2 560 chunks of a launch group of the timed region -- every kernel of the pass keeps
+    a chunk's sums in one order whatever the batch (the upsamplers' matrix products never fall to the decode-step kernels: _plain_rows),
+    and no chunk reads a neighbour's rows through the guard rows."""
+    from infernos_amd.engines.vocoder import HifiGan
+    from infernos_amd.weights import synth_state_dict
+    sd_v = synth_state_dict('hifigan', 0)
+    g = torch.Generator().manual_seed(77)
+    n = 2560
+    chunks = bfr(torch.randn(n, 12, 80, generator=g) * 0.8)
+    voc_in = ((chunks - sd_v['mean']) / sd_v['scale']).to(BF).to(dev)
+    voc = HifiGan(sd_v, dev)
+    full = voc(voc_in).clone()
+    assert full.shape == (n, 3072) and bool(torch.isfinite(full.float()).all())
+    for lo, m in ((0, 1), (n - 1, 1), (1279, 7), (2000, 300), (0, 1025)):
+        part = voc(voc_in[lo:lo + m].contiguous())
+        torch.cuda.synchronize()
+        assert torch.equal(part.view(torch.int16), full[lo:lo + m].view(torch.int16)), (lo, m)
+
+
 @pytest.mark.parametrize('nchunks', [1024, 513])
 def test_hifigan_at_bench_group_size_matches_oracle(dev, nchunks):
     """The vocoder pass at the launch-group size of the timed region (1024 chunks: two-launch C = 256 path, two chunks per
