@@ -436,6 +436,31 @@ def test_logmel_edge_cases(dev):
     assert np.abs(o128[0] - odsp.logmel(xb[0, :160000], n_mel=128)).max() < 1e-3
 
 
+def test_logmel_of_a_window_does_not_depend_on_the_batch(dev):
+    """A size-independent property at the bench configuration's batch (128 windows of 30 s, ragged lengths): the [80, 3000] plane of a
+    window -- and the raw plane + window maximum the STT stage consumes -- is the same bits alone, among 3 and among 128."""
+    from infernos_amd.features import WhisperLogMel
+    lm = WhisperLogMel(80, dev)
+    rng = np.random.default_rng(5)
+    n = 128
+    x = (0.1 * rng.standard_normal((n, 480000))).astype(np.float32)
+    lens_np = rng.integers(1, 480001, size=n).astype(np.int32)
+    lens_np[:4] = (480000, 160000, 1, 0)
+    for i in range(n):
+        x[i, lens_np[i]:] = 0.0
+    xb, lens = torch.from_numpy(x).to(dev), torch.from_numpy(lens_np)
+    full = lm(xb, lens=lens).clone()
+    raw_full, wmax_full = lm.raw(xb, lens=lens)
+    raw_full, wmax_full = raw_full.clone(), wmax_full.clone()
+    assert bool(torch.isfinite(full).all())
+    for lo, m in ((0, 1), (2, 1), (3, 1), (n - 1, 1), (60, 3), (0, 64)):
+        part = lm(xb[lo:lo + m].contiguous(), lens=lens[lo:lo + m])
+        assert torch.equal(part.view(torch.int32), full[lo:lo + m].view(torch.int32)), (lo, m)
+        raw, wm = lm.raw(xb[lo:lo + m].contiguous(), lens=lens[lo:lo + m])
+        assert torch.equal(raw.view(torch.int32), raw_full[lo:lo + m].view(torch.int32)), ('raw', lo, m)
+        assert torch.equal(wm, wmax_full[lo:lo + m]), ('max', lo, m)
+
+
 # ---- output mix + encode (8f-1) ---------------------------------------------------------------------
 def test_mux_encode_matches_oracle(dev):
     from infernos_amd.frontend import mux_encode

@@ -1481,6 +1481,28 @@ def test_whisper_base_config3_matches_oracle(dev, golden_dir):
             assert int(toks[b, 0]) == int(o_toks[b, 0])
 
 
+def test_whisper_base_encoder_of_a_window_does_not_depend_on_the_batch(dev):
+    """A size-independent property at BASELINE config 3's batch: the [1500, 512] encoder states of a 30 s window are the same bits
+    among the 128 windows of a bench cycle (256 x 256 persistent tiles, the 128-query attention kernel, four rows per wave in the
+    LayerNorm) and in batches of 1, 2 and 32 -- whichever of k_igemm / k_gemm_big / k_gemm_big8 and k_attn_prefill / k_attn_prefill2 a
+    batch size selects, an output element is one ascending chain of the same MFMA steps and the same epilogue."""
+    from infernos_amd.engines.whisper import Whisper
+    from infernos_amd.weights import synth_state_dict
+    model = Whisper(synth_state_dict('whisper_base', 1), dev)
+    g = torch.Generator().manual_seed(9)
+    n = 128
+    mel = (torch.randn(n, 80, 3000, generator=g) * 0.5).clamp_(-1.0, 1.5).to(dev)
+    full = model.encode(mel).clone()
+    assert full.shape == (n, 1500, 512) and bool(torch.isfinite(full.float()).all())
+    for lo, m in ((0, 1), (n - 1, 1), (63, 2), (32, 32)):
+        part = model.encode(mel[lo:lo + m].contiguous())
+        torch.cuda.synchronize()
+        same = torch.equal(part.view(torch.int16), full[lo:lo + m].view(torch.int16))
+        if not same:
+            d = (part.float() - full[lo:lo + m].float()).abs()
+            raise AssertionError('encoder states differ at batch (%d, %d): max abs %g, %d elements' % (lo, m, float(d.max()), int((d > 0).sum())))
+
+
 def test_whisper_engine_at_large_v3_layer_shapes_matches_oracle(dev, golden_dir):
     """The reference's DEFAULT STT model is openai/whisper-large-v3 (Cluster/InfernSTTWorker.py:25: 128 mel bins, d = 1280, 20 heads,
     ffn 5120, vocabulary 51 866, 32 + 32 layers); BASELINE names tiny / base, so the bench never builds it.  Its layer shapes with two
