@@ -404,6 +404,37 @@ def test_whisper_base_beam_at_bench_batch_128(dev, golden_dir):
     assert abs(em - ev) <= 2, (em, ev, total)
 
 
+def test_whisper_base_beam_hypotheses_do_not_depend_on_the_batch(dev):
+    """A size-independent property of the 5-beam decode at the bench batch: an utterance's best hypothesis (tokens, length) is the same
+    searched among the 128 utterances of a cycle (640 decode rows: k_gemm_dec tiles, the vocabulary head on the large-GEMM kernel) and
+    alone, in a pair, among 16 or among 64 (skinny decode kernels, other head tiles); its score and no-speech probability agree to the
+    f32 rounding of a different tile's summation order (2e-6), bit for bit where the row count selects the same kernels (64 vs 128)."""
+    from infernos_amd.engines.whisper import Whisper
+    from infernos_amd.weights import synth_state_dict
+    model = Whisper(synth_state_dict('whisper_base', 1), dev)
+    g = torch.Generator().manual_seed(4)
+    n = 128
+    mel = (torch.randn(n, 80, 3000, generator=g) * 0.5).clamp_(-1.0, 1.5).to(dev)
+    enc = model.encode(mel).clone()
+    prompt = torch.tensor([[50258, 50259, 50359, 50363]] * n, dtype=torch.int32)
+    sup = torch.zeros(51865)
+    sup[50257:] = float('-inf')
+    sup[50257] = 0.0
+
+    def run(lo, m):
+        r = model.generate_beam(enc[lo:lo + m].contiguous(), prompt[:m], 16, beams=5, eos_id=50257, length_penalty=1.0, suppress=sup,
+                                no_speech_id=50362, check_every=8)
+        return [t.cpu().clone() for t in r]
+    toks, lens, scores, nsp = run(0, n)
+    assert toks.shape[0] == n and bool(torch.isfinite(scores).all())
+    for lo, m in ((0, 1), (127, 1), (60, 2), (32, 16), (0, 64)):
+        t, l, sc, ns = run(lo, m)
+        assert torch.equal(t, toks[lo:lo + m]) and torch.equal(l, lens[lo:lo + m]), (lo, m)
+        assert float((sc - scores[lo:lo + m]).abs().max()) < 2e-6 and float((ns - nsp[lo:lo + m]).abs().max()) < 2e-6, (lo, m)
+        if m == 64:
+            assert torch.equal(sc, scores[lo:lo + m]) and torch.equal(ns, nsp[lo:lo + m])
+
+
 def test_whisper_generate_beam_one_beam_is_greedy(dev):
     """beams=1 walks the greedy path: same tokens as generate() up to the first eos."""
     from infernos_amd.engines.whisper import Whisper
